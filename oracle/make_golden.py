@@ -1,0 +1,132 @@
+"""TEST INFRASTRUCTURE ONLY.  Regenerate tests/golden/*.npz by running the REAL reference
+(/root/reference, imported via oracle.ref_loader) on seeded synthetic inputs in the build container.
+
+    python -m oracle.make_golden
+
+The fixtures pin oracle/seg_oracle.py (and through it the HIP engine) to the reference's actual
+outputs; /root/reference itself does not exist on the GPU box.  Sizes are tiny so the files stay
+small (a few hundred KB in total)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_loader
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def make_losses(nets, losses, metric):
+    # SURVEY.md §8(c) recipe — order of draws matters
+    torch.manual_seed(0)
+    z = torch.randn(2, 1, 8, 8, 8)
+    y = (torch.rand(2, 8, 8, 8) > 0.7).long()
+    z4 = torch.randn(2, 4, 8, 8, 8)
+    y4 = torch.randint(0, 4, (2, 8, 8, 8))
+    a = torch.ones(4)
+    out = dict(z=_np(z), y=_np(y), z4=_np(z4), y4=_np(y4))
+    for name, f, args in (
+            ("BinaryDiceLoss", losses.BinaryDiceLoss(), (z, y)),
+            ("BinaryCrossEntropyLoss", losses.BinaryCrossEntropyLoss(), (z, y)),
+            ("BinaryFocalLoss", losses.BinaryFocalLoss(), (z, y)),
+            ("BinaryCrossEntropyDiceLoss", losses.BinaryCrossEntropyDiceLoss(), (z, y)),
+            ("MutilDiceLoss", losses.MutilDiceLoss(a), (z4, y4)),
+            ("MutilCrossEntropyLoss", losses.MutilCrossEntropyLoss(a), (z4, y4)),
+            ("MutilFocalLoss_g2", losses.MutilFocalLoss(a, gamma=2), (z4, y4)),
+            ("MutilFocalLoss_g3", losses.MutilFocalLoss(a, gamma=3), (z4, y4))):
+        zz = args[0].clone().requires_grad_(True)
+        val = f(zz, args[1])
+        val.backward()
+        out["loss_" + name] = _np(val)
+        out["grad_" + name] = _np(zz.grad)
+    out["dice_coeff"] = _np(metric.dice_coeff(torch.sigmoid(z), y))
+    out["iou_coeff"] = _np(metric.iou_coeff(torch.sigmoid(z), y))
+    out["multiclass_dice_coeff"] = _np(metric.multiclass_dice_coeff(torch.softmax(z4, 1), y4))
+    np.savez_compressed(os.path.join(OUT, "losses_metrics.npz"), **out)
+    print("losses:", {k: float(v) for k, v in out.items() if k.startswith("loss_")})
+
+
+def grad_summary(g):
+    """Compact, order-sensitive fingerprint of one gradient tensor: sum, L2 norm, and 16 entries
+    at fixed pseudo-random flat positions."""
+    f = g.detach().double().reshape(-1)
+    idx = (torch.arange(16, dtype=torch.int64) * 2654435761 + 12345) % f.numel()
+    return np.concatenate([[float(f.sum()), float(f.norm())], f[idx].numpy()])
+
+
+def make_net(nets, losses, seg, tag, kind, ndim, ctor, shape, numclass, loss_mod):
+    """eval-mode fwd+bwd (dropout off) and a train-mode fwd with the recorded dropout masks.
+    Weights come from oracle.seg_oracle.init_params/perturb_params (seeded, reproducible on the GPU
+    box) and are loaded into the REAL reference module with load_state_dict, so only outputs and
+    gradient fingerprints need to be stored."""
+    m = ctor()
+    params = seg.perturb_params(seg.init_params(kind, ndim, shape[1], numclass, seed=0), seed=7)
+    missing = m.load_state_dict(params, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    x, y = seg.synthetic_batch(shape[0], shape[2:], shape[1], numclass, seed=1)
+    out = dict(x_sum=np.float64(x.double().sum()), y_sum=np.int64(y.sum()))
+    m.eval()
+    logits, probs = m(x)
+    loss = loss_mod(logits, y)
+    m.zero_grad()
+    loss.backward()
+    out["eval_logits"], out["eval_loss"] = _np(logits), _np(loss)
+    out["eval_probs_sum"] = np.float64(probs.double().sum())
+    names = [k for k, _ in m.named_parameters()]
+    out["grad_names"] = np.array(names)
+    out["grad_summary"] = np.stack([grad_summary(p.grad) for _, p in m.named_parameters()])
+    # train mode: record per-call dropout multipliers (peek the CPU generator before each call)
+    masks = []
+
+    def pre(mod, inp):
+        xin = inp[0]
+        n, c = xin.shape[:2]
+        state = torch.get_rng_state()
+        mk = torch.empty((n, c) + (1,) * (xin.dim() - 2)).bernoulli_(0.8).div_(0.8)
+        torch.set_rng_state(state)           # peek only: the module then consumes the same draws
+        masks.append(mk.reshape(n, c).clone())
+
+    hs = [mod.register_forward_pre_hook(pre) for mod in m.modules()
+          if isinstance(mod, (torch.nn.Dropout3d, torch.nn.Dropout2d))]
+    m.train()
+    torch.manual_seed(99)
+    logits_t, _ = m(x)
+    loss_t = loss_mod(logits_t, y)
+    m.zero_grad()
+    loss_t.backward()
+    for h in hs:
+        h.remove()
+    out["train_logits"], out["train_loss"] = _np(logits_t), _np(loss_t)
+    out["train_grad_summary"] = np.stack([grad_summary(p.grad) for _, p in m.named_parameters()])
+    out["train_masks"] = np.stack([np.pad(_np(k), ((0, 0), (0, 256 - k.shape[1]))) for k in masks]).astype(np.float16)
+    out["train_mask_channels"] = np.array([k.shape[1] for k in masks])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
+    print(tag, "logits.sum", float(logits.sum()), "loss", float(loss), "train loss", float(loss_t), "n_masks", len(masks))
+
+
+def main():
+    if not ref_loader.available():
+        sys.exit("reference tree not available; golden fixtures can only be regenerated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    nets, losses, metric = ref_loader.load()
+    torch.set_num_threads(1)
+    make_losses(nets, losses, metric)
+    from . import seg_oracle as seg
+    a4 = torch.ones(4)
+    make_net(nets, losses, seg, "vnet3d_bin_16", "vnet", 3, lambda: nets.VNet3d(1, 1), (2, 1, 16, 16, 16), 1,
+             losses.BinaryDiceLoss())
+    make_net(nets, losses, seg, "unet3d_mc4_16", "unet", 3, lambda: nets.UNet3d(1, 4), (1, 1, 16, 16, 16), 4,
+             losses.MutilDiceLoss(a4))
+    make_net(nets, losses, seg, "vnet2d_mc2_32", "vnet", 2, lambda: nets.VNet2d(1, 2), (2, 1, 32, 32), 2,
+             losses.MutilCrossEntropyLoss(torch.ones(2)))
+    make_net(nets, losses, seg, "unet2d_bin_32", "unet", 2, lambda: nets.UNet2d(1, 1), (2, 1, 32, 32), 1,
+             losses.BinaryCrossEntropyDiceLoss())
+
+
+if __name__ == "__main__":
+    main()

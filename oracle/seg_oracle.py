@@ -1,0 +1,463 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement of the reference segmentation hot path.
+
+Plain PyTorch (CPU, fp32 or fp64) restatement of what junqiangchen/PytorchDeepLearing computes on
+the path named by BASELINE.json: VNet/UNet (2-D and 3-D) forward, the seven losses reachable from
+the model wrappers, the Dice/IoU metrics and one optimiser step.  It is *functional* (weights are
+a dict keyed exactly like the reference ``state_dict``) so that the same code checks the HIP engine
+on the GPU box, where ``/root/reference`` does not exist.
+
+The arithmetic itself lives in PyTorch/ATen (third-party, un-pinned by the reference; README.md:13
+says "pytorch1.10.0").  Anchors: the reference call sites cited per function below.  The reference
+has no tests/golden vectors: this file is pinned against outputs of the real
+reference run in the build container (tests/golden/*.npz via oracle/make_golden.py) and against the
+live reference whenever /root/reference is importable (tests/test_oracle.py).
+
+Never imported by the product package (pytorchdeeplearing_amd, model, networks).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+GN_GROUPS = 8          # networks/VNet3d.py:9,30,50,66 ; networks/Unet3d.py:73,82
+DROP_P = 0.2           # networks/VNet3d.py:115-125 ; networks/Unet3d.py:65
+GN_EPS = 1e-5          # torch.nn.GroupNorm default
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter tables (names/shapes == reference state_dict)
+# ----------------------------------------------------------------------------------------------
+def _k(ndim, k):
+    return (k,) * ndim
+
+
+def vnet_param_shapes(ndim, image_channel, numclass, feat=16):
+    """state_dict layout of networks/VNet3d.py:102-127 (VNet2d.py mirrors it)."""
+    P = OrderedDict()
+
+    def conv(name, cin, cout, k):
+        P[name + ".weight"] = (cout, cin) + _k(ndim, k)
+        P[name + ".bias"] = (cout,)
+
+    def convT(name, cin, cout, k):
+        P[name + ".weight"] = (cin, cout) + _k(ndim, k)
+        P[name + ".bias"] = (cout,)
+
+    def gn(name, c):
+        P[name + ".weight"] = (c,)
+        P[name + ".bias"] = (c,)
+
+    conv("in_tr.conv1", image_channel, feat, 3)
+    conv("in_tr.conv2", image_channel, feat, 1)
+    gn("in_tr.bn1", feat)
+    for cin, cout, n in ((feat, 2 * feat, 2), (2 * feat, 4 * feat, 3), (4 * feat, 8 * feat, 3),
+                         (8 * feat, 16 * feat, 3)):
+        pre = "down_tr%d" % (cout * 16 // feat)
+        conv(pre + ".down_conv", cin, cout, 2)
+        gn(pre + ".bn1", cout)
+        for i in range(n):
+            conv("%s.ops.%d.conv1" % (pre, i), cout, cout, 3)
+            gn("%s.ops.%d.bn1" % (pre, i), cout)
+    for cin, cout, n in ((16 * feat, 8 * feat, 3), (8 * feat, 4 * feat, 3), (4 * feat, 2 * feat, 2),
+                         (2 * feat, feat, 1)):
+        pre = "up_tr%d" % (cin * 16 // feat)
+        convT(pre + ".up_conv", cin, cout, 2)
+        gn(pre + ".bn", cout)
+        for i in range(n):
+            conv("%s.ops.%d.conv1" % (pre, i), cout, cout, 3)
+            gn("%s.ops.%d.bn1" % (pre, i), cout)
+        conv(pre + ".conv", cin, cout, 1)
+    conv("out_tr.conv", feat, numclass, 1)
+    return P
+
+
+def unet_param_shapes(ndim, in_channels, out_channels, feat=16):
+    """state_dict layout of networks/Unet3d.py:11-34,64-86 (block convs have bias=False)."""
+    P = OrderedDict()
+
+    def block(mod, name, cin, c):
+        P["%s.%sconv1.weight" % (mod, name)] = (c, cin) + _k(ndim, 3)
+        P["%s.%snorm1.weight" % (mod, name)] = (c,)
+        P["%s.%snorm1.bias" % (mod, name)] = (c,)
+        P["%s.%sconv2.weight" % (mod, name)] = (c, c) + _k(ndim, 3)
+        P["%s.%snorm2.weight" % (mod, name)] = (c,)
+        P["%s.%snorm2.bias" % (mod, name)] = (c,)
+
+    block("encoder1", "enc1", in_channels, feat)
+    block("encoder2", "enc2", feat, 2 * feat)
+    block("encoder3", "enc3", 2 * feat, 4 * feat)
+    block("encoder4", "enc4", 4 * feat, 8 * feat)
+    block("bottleneck", "bottleneck", 8 * feat, 16 * feat)
+    for lvl, c in ((4, 8 * feat), (3, 4 * feat), (2, 2 * feat), (1, feat)):
+        P["upconv%d.weight" % lvl] = (2 * c, c) + _k(ndim, 2)
+        P["upconv%d.bias" % lvl] = (c,)
+        block("decoder%d" % lvl, "dec%d" % lvl, 2 * c, c)
+    P["conv.weight"] = (out_channels, feat) + _k(ndim, 1)
+    P["conv.bias"] = (out_channels,)
+    return P
+
+
+def param_shapes(kind, ndim, in_ch, numclass, feat=16):
+    return (vnet_param_shapes if kind == "vnet" else unet_param_shapes)(ndim, in_ch, numclass, feat)
+
+
+def init_params(kind, ndim, in_ch, numclass, feat=16, seed=0, dtype=torch.float32):
+    """Same distribution as networks/__init__.py:11-26 (`initialize_weights`): conv/convT weights
+    kaiming_normal_(relu) — std = sqrt(2 / (weight.size(1) * prod(kernel))), so ConvTranspose uses
+    C_out·k^d as fan-in — biases 0, GroupNorm gamma 1 / beta 0.  (Distribution-equal, not
+    RNG-stream-equal; parity tests copy the tensors into both sides.)"""
+    g = torch.Generator().manual_seed(seed)
+    out = OrderedDict()
+    for name, shp in param_shapes(kind, ndim, in_ch, numclass, feat).items():
+        if len(shp) > 1:
+            fan_in = shp[1]
+            for k in shp[2:]:
+                fan_in *= k
+            out[name] = (torch.randn(shp, generator=g, dtype=torch.float64) * (2.0 / fan_in) ** 0.5).to(dtype)
+        elif name.endswith("weight"):
+            out[name] = torch.ones(shp, dtype=dtype)
+        else:
+            out[name] = torch.zeros(shp, dtype=dtype)
+    return out
+
+
+def perturb_params(params, seed=1, scale=0.1):
+    """Make biases / GroupNorm affine non-trivial so tests exercise them (init leaves them 0/1)."""
+    g = torch.Generator().manual_seed(seed)
+    out = OrderedDict()
+    for k, v in params.items():
+        if v.dim() == 1:
+            out[k] = v + scale * torch.randn(v.shape, generator=g, dtype=torch.float64).to(v.dtype)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# forward
+# ----------------------------------------------------------------------------------------------
+class _Masks:
+    """Channel-dropout multipliers in forward-call order.  nn.Dropout3d/2d zero whole (n, c)
+    feature maps and scale survivors by 1/(1-p) (networks/VNet3d.py:11,31,51,67).  ``masks`` is
+    None (eval: identity) or a list of (N, C) tensors consumed in call order — 34 per VNet
+    forward, 18 per UNet forward."""
+
+    def __init__(self, masks):
+        self.masks = masks
+        self.i = 0
+
+    def __call__(self, x):
+        if self.masks is None:
+            return x
+        m = self.masks[self.i].to(x.dtype)
+        self.i += 1
+        return x * m.reshape(m.shape + (1,) * (x.dim() - 2))
+
+
+def draw_masks(kind, n, feat=16, p=DROP_P, generator=None):
+    """Pre-draw the dropout multipliers exactly like the reference modules consume the CPU
+    generator: one `empty(N,C,1,..).bernoulli_(1-p).div_(1-p)` per Dropout call, forward order."""
+    chans = dropout_channels(kind, feat)
+    out = []
+    for c in chans:
+        m = torch.empty(n, c).bernoulli_(1 - p, generator=generator).div_(1 - p)
+        out.append(m)
+    return out
+
+
+def dropout_channels(kind, feat=16):
+    if kind == "vnet":
+        ch = [feat, feat]
+        for c, n in ((2 * feat, 2), (4 * feat, 3), (8 * feat, 3), (16 * feat, 3)):
+            ch += [c] * (1 + n)
+        for c, n in ((8 * feat, 3), (4 * feat, 3), (2 * feat, 2), (feat, 1)):
+            ch += [c] * (2 + n)
+        return ch
+    ch = []
+    for c in (feat, 2 * feat, 4 * feat, 8 * feat, 16 * feat, 8 * feat, 4 * feat, 2 * feat, feat):
+        ch += [c, c]
+    return ch
+
+
+def _conv(ndim):
+    return F.conv3d if ndim == 3 else F.conv2d
+
+
+def _convT(ndim):
+    return F.conv_transpose3d if ndim == 3 else F.conv_transpose2d
+
+
+def _gn_drop_relu(x, w, b, drop):
+    # relu(dropout(groupnorm(x)))  — networks/VNet3d.py:14 ; Unet3d.py:73-75
+    return F.relu(drop(F.group_norm(x, GN_GROUPS, w, b, GN_EPS)))
+
+
+def _head(logits):
+    # networks/VNet3d.py:94-99 ; Unet3d.py:57-62
+    if logits.shape[1] == 1:
+        return logits, torch.sigmoid(logits)
+    return logits, torch.softmax(logits, dim=1)
+
+
+def vnet_forward(P, x, masks=None):
+    """networks/VNet3d.py:129-158 (2-D: VNet2d.py:129-160).  Returns (logits, probs)."""
+    ndim = x.dim() - 2
+    conv, convT = _conv(ndim), _convT(ndim)
+    drop = _Masks(masks)
+
+    def lu(pre, t):                                   # LUConv: VNet3d.py:13-15
+        return _gn_drop_relu(conv(t, P[pre + ".conv1.weight"], P[pre + ".conv1.bias"], padding=1),
+                             P[pre + ".bn1.weight"], P[pre + ".bn1.bias"], drop)
+
+    def nops(pre):
+        n = 0
+        while "%s.ops.%d.conv1.weight" % (pre, n) in P:
+            n += 1
+        return n
+
+    # InputTransition: VNet3d.py:34-43 — ONE GroupNorm (bn1) applied to both branches
+    gw, gb = P["in_tr.bn1.weight"], P["in_tr.bn1.bias"]
+    a = _gn_drop_relu(conv(x, P["in_tr.conv1.weight"], P["in_tr.conv1.bias"], padding=1), gw, gb, drop)
+    b = _gn_drop_relu(conv(x, P["in_tr.conv2.weight"], P["in_tr.conv2.bias"]), gw, gb, drop)
+    out = a + b
+    skips = [out]
+    for pre in ("down_tr32", "down_tr64", "down_tr128", "down_tr256"):   # DownTransition: VNet3d.py:55-59
+        down = _gn_drop_relu(conv(out, P[pre + ".down_conv.weight"], P[pre + ".down_conv.bias"], stride=2),
+                             P[pre + ".bn1.weight"], P[pre + ".bn1.bias"], drop)
+        t = down
+        for i in range(nops(pre)):
+            t = lu("%s.ops.%d" % (pre, i), t)
+        out = t + down
+        skips.append(out)
+    skips.pop()                                       # out256 is not a skip
+    for pre in ("up_tr256", "up_tr128", "up_tr64", "up_tr32"):   # UpTransition: VNet3d.py:72-80
+        skip = skips.pop()
+        gw, gb = P[pre + ".bn.weight"], P[pre + ".bn.bias"]   # ONE GroupNorm used twice (:73,:75)
+        u = _gn_drop_relu(convT(out, P[pre + ".up_conv.weight"], P[pre + ".up_conv.bias"], stride=2), gw, gb, drop)
+        xcat = torch.cat((u, skip), 1)
+        xcat = _gn_drop_relu(conv(xcat, P[pre + ".conv.weight"], P[pre + ".conv.bias"]), gw, gb, drop)
+        t = xcat
+        for i in range(nops(pre)):
+            t = lu("%s.ops.%d" % (pre, i), t)
+        out = t + xcat
+    return _head(conv(out, P["out_tr.conv.weight"], P["out_tr.conv.bias"]))
+
+
+def unet_forward(P, x, masks=None):
+    """networks/Unet3d.py:36-62 with `_block` :64-86 (2-D: Unet2d.py)."""
+    ndim = x.dim() - 2
+    conv, convT = _conv(ndim), _convT(ndim)
+    pool = F.max_pool3d if ndim == 3 else F.max_pool2d
+    drop = _Masks(masks)
+
+    def block(mod, name, t):
+        for j in (1, 2):
+            t = conv(t, P["%s.%sconv%d.weight" % (mod, name, j)], None, padding=1)
+            t = _gn_drop_relu(t, P["%s.%snorm%d.weight" % (mod, name, j)],
+                              P["%s.%snorm%d.bias" % (mod, name, j)], drop)
+        return t
+
+    enc = []
+    t = x
+    for lvl in (1, 2, 3, 4):
+        t = block("encoder%d" % lvl, "enc%d" % lvl, t)
+        enc.append(t)
+        t = pool(t, 2, 2)
+    t = block("bottleneck", "bottleneck", t)
+    for lvl in (4, 3, 2, 1):
+        t = convT(t, P["upconv%d.weight" % lvl], P["upconv%d.bias" % lvl], stride=2)
+        t = torch.cat((t, enc[lvl - 1]), dim=1)
+        t = block("decoder%d" % lvl, "dec%d" % lvl, t)
+    return _head(conv(t, P["conv.weight"], P["conv.bias"]))
+
+
+def net_forward(kind, P, x, masks=None):
+    return vnet_forward(P, x, masks) if kind == "vnet" else unet_forward(P, x, masks)
+
+
+# ----------------------------------------------------------------------------------------------
+# losses (model/losses.py) — logits (N,C,...) ; binary target (N,...) or (N,1,...) in {0,1};
+# multi-class target (N,...) integer class ids
+# ----------------------------------------------------------------------------------------------
+def _flat2(logits, y):
+    bs, nc = y.shape[0], logits.shape[1]
+    return logits.float().reshape(bs, nc, -1), y.float().reshape(bs, nc, -1)
+
+
+def binary_dice_loss(logits, y, smooth=1e-5, eps=1e-7):
+    """model/losses.py:43-53 — sums run over the WHOLE batch."""
+    p, t = _flat2(torch.sigmoid(logits), y)
+    inter = (p * t).sum()
+    dsc = (2.0 * inter + smooth) / (p.sum() + t.sum() + smooth).clamp_min(eps)
+    return 1.0 - dsc
+
+
+def binary_ce_loss(logits, y):
+    """model/losses.py:141-147"""
+    z, t = _flat2(logits, y)
+    return F.binary_cross_entropy_with_logits(z, t)
+
+
+def binary_focal_loss(logits, y, alpha=0.25, gamma=2):
+    """model/losses.py:160-181 (alpha/gamma = ctor defaults; wrappers never forward theirs)."""
+    z, t = _flat2(logits, y)
+    bce = F.binary_cross_entropy_with_logits(z, t, reduction="none")
+    pt = torch.exp(-bce)
+    return (alpha * (1 - pt) ** gamma * bce).mean()
+
+
+def binary_ce_dice_loss(logits, y):
+    """model/losses.py:192-197"""
+    return binary_ce_loss(logits, y) + binary_dice_loss(logits, y)
+
+
+def _mc_flat(logits, y):
+    n, c = logits.shape[0], logits.shape[1]
+    return logits.float().reshape(n, c, -1), y.long().reshape(n, -1)
+
+
+def multi_ce_loss(logits, y, alpha=None):
+    """model/losses.py:252-260 — class weight = 'class present in batch'; every target voxel's
+    class is present, so this equals plain mean CE.  alpha is unused there."""
+    z, t = _mc_flat(logits, y)
+    present = (F.one_hot(t, z.shape[1]).sum((0, 1)) > 0).to(z.dtype)
+    return F.cross_entropy(z, t, weight=present)
+
+
+def multi_focal_loss(logits, y, alpha=None, gamma=2):
+    """model/losses.py:273-285"""
+    z, t = _mc_flat(logits, y)
+    present = (F.one_hot(t, z.shape[1]).sum((0, 1)) > 0).to(z.dtype)
+    logpt = F.cross_entropy(z, t, weight=present, reduction="none")
+    pt = torch.exp(-logpt)
+    return (((1 - pt) ** gamma) * logpt).mean()
+
+
+def multi_dice_loss(logits, y, alpha):
+    """model/losses.py:301-325 — negative-valued; per-class sums over (batch, voxels)."""
+    z, t = _mc_flat(logits, y)
+    p = torch.softmax(z, dim=1)
+    oh = F.one_hot(t, z.shape[1]).permute(0, 2, 1)
+    inter = torch.sum(oh * p, dim=(0, 2))
+    den = torch.sum(oh + p, dim=(0, 2))
+    dice = ((2.0 * inter + 1e-5) / (den + 1e-5)).clamp_min(1e-7)
+    mask = oh.sum((0, 2)) > 0
+    loss = -dice * mask.to(dice.dtype)
+    return (loss * alpha.to(loss.dtype)).sum() / torch.count_nonzero(mask)
+
+
+LOSSES = {
+    "BinaryDiceLoss": binary_dice_loss,
+    "BinaryCrossEntropyLoss": binary_ce_loss,
+    "BinaryFocalLoss": binary_focal_loss,
+    "BinaryCrossEntropyDiceLoss": binary_ce_dice_loss,
+    "MutilCrossEntropyLoss": multi_ce_loss,
+    "MutilFocalLoss": multi_focal_loss,
+    "MutilDiceLoss": multi_dice_loss,
+}
+
+
+def loss_fn(name, alpha=None, gamma=None):
+    f = LOSSES[name]
+    if name == "MutilDiceLoss":
+        return lambda z, y: f(z, y, alpha)
+    if name == "MutilFocalLoss":
+        return lambda z, y: f(z, y, alpha, 2 if gamma is None else gamma)
+    if name == "MutilCrossEntropyLoss":
+        return lambda z, y: f(z, y, alpha)
+    return f
+
+
+# ----------------------------------------------------------------------------------------------
+# metrics (model/metric.py)
+# ----------------------------------------------------------------------------------------------
+def dice_coeff(probs, target):
+    """model/metric.py:146-155 — threshold 0.5, per-sample, mean over batch."""
+    m = (probs > 0.5).float()
+    n = target.shape[0]
+    m = m.reshape(n, -1)
+    t = target.reshape(n, -1).float()
+    inter = (m * t).sum(1)
+    return ((2.0 * inter + 1e-5) / (m.sum(1) + t.sum(1) + 1e-5)).sum() / n
+
+
+def iou_coeff(probs, target):
+    """model/metric.py:158-167"""
+    m = (probs > 0.5).float()
+    n = target.shape[0]
+    m = m.reshape(n, -1)
+    t = target.reshape(n, -1).float()
+    inter = (m * t).sum(1)
+    return ((inter + 1e-5) / (m.sum(1) + t.sum(1) - inter + 1e-5)).sum() / n
+
+
+def multiclass_dice_coeff(probs, target):
+    """model/metric.py:170-181 — background excluded; thresholds softmax prob > 0.5."""
+    n, c = probs.shape[0], probs.shape[1]
+    p = probs.float().reshape(n, c, -1)
+    oh = F.one_hot(target.long().reshape(n, -1), c).permute(0, 2, 1)
+    d = 0
+    for ch in range(1, c):
+        d = d + dice_coeff(p[:, ch], oh[:, ch])
+    return d / (c - 1)
+
+
+def multiclass_iou_coeff(probs, target):
+    """model/metric.py:204-215 restated for index labels (the reference's size assert at :210
+    only passes for one-hot targets; the arithmetic below is its loop body)."""
+    n, c = probs.shape[0], probs.shape[1]
+    p = probs.float().reshape(n, c, -1)
+    oh = F.one_hot(target.long().reshape(n, -1), c).permute(0, 2, 1)
+    d = 0
+    for ch in range(1, c):
+        d = d + iou_coeff(p[:, ch], oh[:, ch])
+    return d / (c - 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# one optimisation step (model/modelVNet.py:570-596 ; modelUnet.py:870-895)
+# ----------------------------------------------------------------------------------------------
+def forward_backward(kind, params, x, y, loss_name, masks=None, alpha=None, gamma=None):
+    """fwd -> loss -> backward.  Returns dict(loss, logits, probs, grads{name: tensor})."""
+    P = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in params.items())
+    logits, probs = net_forward(kind, P, x, masks)
+    loss = loss_fn(loss_name, alpha, gamma)(logits, y)
+    loss.backward()
+    return dict(loss=loss.detach(), logits=logits.detach(), probs=probs.detach(),
+                grads=OrderedDict((k, v.grad) for k, v in P.items()))
+
+
+def adamw_step(params, grads, state, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
+               decoupled=True):
+    """torch.optim.AdamW (modelVNet.py:548) / torch.optim.Adam (modelUnet.py:849) single step,
+    restated on dicts.  state = {"step": int, "m": {..}, "v": {..}}."""
+    state["step"] = state.get("step", 0) + 1
+    t = state["step"]
+    b1, b2 = betas
+    out = OrderedDict()
+    for k, p in params.items():
+        g = grads[k]
+        m = state.setdefault("m", {}).get(k, torch.zeros_like(p))
+        v = state.setdefault("v", {}).get(k, torch.zeros_like(p))
+        if decoupled:
+            p = p * (1 - lr * weight_decay)
+        elif weight_decay != 0:
+            g = g + weight_decay * p
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        denom = v.sqrt() / (bc2 ** 0.5) + eps
+        out[k] = p - (lr / bc1) * m / denom
+        state["m"][k], state["v"][k] = m, v
+    return out
+
+
+def synthetic_batch(n, spatial, in_ch=1, numclass=1, seed=1234):
+    """BASELINE.md §3.1 synthetic inputs (no dataset ships with the reference)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((n, in_ch) + tuple(spatial), generator=g)
+    if numclass == 1:
+        y = (torch.rand((n,) + tuple(spatial), generator=g) > 0.8).long()
+    else:
+        y = torch.randint(0, numclass, (n,) + tuple(spatial), generator=g)
+    return x, y
