@@ -1,0 +1,172 @@
+/* libsegengine — C-ABI of the MI355X (gfx950) segmentation engine.
+ *
+ * Drop-in boundary for the hot path of junqiangchen/PytorchDeepLearing.  The
+ * reference has no FFI of its own — its boundary is Python duck typing — so every entry point
+ * cites the reference interface it stands behind.  Plain pointers and sizes only; no torch types.
+ *
+ * Ownership: the caller allocates and owns every buffer (parameters, gradients, optimiser state,
+ * workspace, inputs, outputs); the engine keeps views plus small host-side descriptors.
+ * Errors: every function returns 0 on success, <0 on failure; seg_last_error() gives the message.
+ * Threading: calls are stream-ordered and asynchronous; a handle is not thread-safe.
+ * All device pointers must be 256-byte aligned.  `stream` is a hipStream_t.
+ */
+#ifndef SEGENGINE_H
+#define SEGENGINE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct seg_engine* seg_handle;
+
+enum { SEG_NET_VNET = 0, SEG_NET_UNET = 1 };
+enum { SEG_F32 = 0, SEG_F16 = 1, SEG_BF16 = 2 };
+enum { SEG_LABEL_U8 = 0, SEG_LABEL_I32 = 1, SEG_LABEL_I64 = 2, SEG_LABEL_F32 = 3 };
+/* loss_name strings of model/modelVNet.py:68-76,513-521,750-756 */
+enum {
+    SEG_LOSS_BINARY_DICE = 0,     /* model/losses.py:33-53   BinaryDiceLoss */
+    SEG_LOSS_BINARY_CE = 1,       /* model/losses.py:129-147 BinaryCrossEntropyLoss */
+    SEG_LOSS_BINARY_FOCAL = 2,    /* model/losses.py:150-181 BinaryFocalLoss */
+    SEG_LOSS_BINARY_CE_DICE = 3,  /* model/losses.py:184-197 BinaryCrossEntropyDiceLoss */
+    SEG_LOSS_MULTI_CE = 4,        /* model/losses.py:247-260 MutilCrossEntropyLoss */
+    SEG_LOSS_MULTI_FOCAL = 5,     /* model/losses.py:263-285 MutilFocalLoss */
+    SEG_LOSS_MULTI_DICE = 6       /* model/losses.py:288-325 MutilDiceLoss */
+};
+enum { SEG_MASKS_EVAL = 0, SEG_MASKS_GIVEN = 1, SEG_MASKS_RANDOM = 2 };
+
+/* networks/VNet3d.py:109 VNet3d(image_channel, numclass, init_features=16), networks/VNet2d.py:109,
+ * networks/Unet3d.py:11 UNet3d(in_channels, out_channels, init_features=16), networks/Unet2d.py:11.
+ * ndim = 2 or 3. */
+int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_features, int dtype,
+               seg_handle* out);
+void seg_destroy(seg_handle h);
+
+/* Parameter table in reference state_dict order: name, PyTorch shape, and the
+ * offset (in floats) of the tensor inside the flat fp32 parameter / gradient buffers. */
+int seg_param_count(seg_handle h);
+int seg_param_info(seg_handle h, int index, char* name, int name_cap, int* shape8, int* ndim,
+                   long long* offset);
+long long seg_param_numel(seg_handle h);
+
+/* Number of channel-dropout calls per forward (34 VNet / 18 UNet) and the row stride of the
+ * multiplier table [calls][N][ld] used by SEG_MASKS_GIVEN (networks/VNet3d.py:11,31,51,67). */
+int seg_dropout_calls(seg_handle h);
+int seg_dropout_ld(seg_handle h);
+int seg_dropout_channels(seg_handle h, int call);
+
+/* Fix the batch shape (N, D, H, W; D ignored for ndim 2) and size the workspace. */
+int seg_plan(seg_handle h, int n, int d, int hgt, int wid);
+long long seg_workspace_bytes(seg_handle h);
+
+/* Bind caller-owned buffers: flat fp32 params / grads (seg_param_numel floats each) + workspace. */
+int seg_bind(seg_handle h, float* params, float* grads, void* workspace);
+
+/* Re-layout the fp32 master weights into the run-dtype GEMM layouts (call after every update). */
+int seg_pack_weights(seg_handle h, void* stream);
+
+/* forward(x) -> (logits, probs): x is fp32 NC[D]HW like the reference datasets deliver
+ * (model/dataset.py:107), logits/probs are fp32 NC[D]HW (networks/VNet3d.py:90-99,129-158).
+ * mask_mode: SEG_MASKS_EVAL = model.eval(); SEG_MASKS_GIVEN = `masks` holds the per-call (n,c)
+ * dropout multipliers; SEG_MASKS_RANDOM = engine draws them from (seed, internal step). */
+int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks,
+                unsigned long long seed, float* logits, float* probs, void* stream);
+
+/* backward of the last forward given d(loss)/d(logits) (fp32 NC[D]HW, already multiplied by
+ * seg_get_loss_scale); parameter gradients (times the loss scale) are ACCUMULATED into the bound
+ * flat gradient buffer (zero_grads != 0 clears it first — `opt.zero_grad()` of
+ * model/modelVNet.py:593). */
+int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* stream);
+
+int seg_set_loss_scale(seg_handle h, float scale);
+float seg_get_loss_scale(seg_handle h);
+
+/* Losses and metrics on planar fp32 logits [N][C][V] (model/losses.py, model/metric.py:146-215).
+ * out3 = {loss, dice metric, iou metric}.  `ws` needs seg_loss_ws_bytes(N, C) bytes; it carries
+ * the reduction results from seg_loss_forward to seg_loss_backward. */
+long long seg_loss_ws_bytes(int n, int c);
+int seg_loss_forward(const float* logits, const void* target, int label_type, int n, int c,
+                     long long v, int loss_kind, float focal_alpha, float focal_gamma,
+                     const float* class_alpha, void* ws, float* out3, void* stream);
+int seg_loss_backward(const float* logits, const void* target, int label_type, int n, int c,
+                      long long v, int loss_kind, float focal_alpha, float focal_gamma, void* ws,
+                      float grad_scale, float* dlogits, void* stream);
+/* dice_coeff / iou_coeff / multiclass_* on probabilities (model/metric.py:146-215): out2 = {dice, iou} */
+int seg_metric(const float* probs, const void* target, int label_type, int n, int c, long long v,
+               void* ws, float* out2, void* stream);
+
+/* torch.optim.AdamW (model/modelVNet.py:548) / Adam (model/modelUnet.py:849) over flat buffers.
+ * `state` = int[2] on the device: {step, found_inf}.  Gradients are multiplied by inv_scale first;
+ * with check_finite the update is skipped (and state[1] set) when any gradient is inf/nan. */
+int seg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                  long long numel, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int decoupled, float inv_scale, int check_finite, int* state, void* stream);
+
+/* ---- operator-level entry points (what torch.nn.functional.conv3d / conv_transpose3d and their
+ * autograd weight-gradients are to the reference: networks/VNet3d.py:8,28,29,49,65,70,88).  The
+ * network-level calls above are built from exactly these launches; they are exported so each
+ * kernel can be checked in isolation.  All tensors channels-last [N][D][H][W][C] in `dtype`. */
+typedef struct seg_taps {
+    int n;
+    signed char d[27], h[27], w[27];
+} seg_taps;
+
+/* implicit-GEMM convolution: out[m][co] = sum_{tap,ci} in[vox(m,tap)][ci] * w[co][tap*Cin+ci] (+bias).
+ * gather mode (scatter=0): rows m = output voxels (N,OD,OH,OW), input voxel = o*stride + tap.
+ * scatter mode (scatter=1): rows m = input voxels, K = Cin, GEMM columns = (tap, co), column block
+ * of tap a goes to fine voxel i*up + a (ConvTranspose k2 s2 / data-gradient of conv k2 s2).
+ * The reduction input may be a virtual channel concat of in0 (C0 ch) and in1 (C1 ch). */
+typedef struct seg_conv_args {
+    const void* in0;
+    const void* in1;
+    int C0, C1;
+    const void* w;      /* packed [Ngemm][Kpad] in dtype, zero padded */
+    const float* bias;  /* [Cout] or null */
+    void* out;
+    double* stats;      /* [N][Cout][2] sum / sum of squares (+=) or null */
+    int N, ID, IH, IW;  /* gather source dims */
+    int OD, OH, OW;     /* row-space dims */
+    int FD, FH, FW;     /* scatter: fine output dims */
+    int Cout, Ngemm, K, Kpad;
+    int sd, sh, sw;     /* gather: input stride; scatter: up-sampling factor */
+    int scatter;
+    seg_taps taps;
+} seg_conv_args;
+int seg_op_conv(const seg_conv_args* a, int dtype, void* stream);
+
+/* weight gradient dW[p][tap][q] += sum_m dR[m][p] * X[vox(m,tap)][q], written to
+ * dw[p*sP + q*sQ + tap*sT] (fp32).  stem=1: X is [N][V][C0] with tiny C0 and q enumerates (tap,ci). */
+typedef struct seg_wgrad_args {
+    const void* dr;
+    const void* x0;
+    const void* x1;
+    int C0, C1;
+    float* dw;
+    int P, Q;
+    int N, ID, IH, IW, OD, OH, OW;
+    int sd, sh, sw;
+    seg_taps taps;
+    long long sP, sQ, sT;
+    int stem;
+} seg_wgrad_args;
+int seg_op_wgrad(const seg_wgrad_args* a, int dtype, void* stream);
+
+/* weight re-layout: dst[r1][r2][t][c] (dtype, row length Kpad, zero padded) = src[r1*s1+r2*s2+t'*sT+c*sC],
+ * t' = flipT ? T-1-t : t.  `descs` is a DEVICE array. */
+typedef struct seg_pack_desc {
+    const float* src;
+    void* dst;
+    int R1, R2, T, Cc;
+    int Kpad;
+    long long s1, s2, sT, sC;
+    int flipT;
+} seg_pack_desc;
+int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int dtype, void* stream);
+/* sizeof of the structs above as compiled into the library: 0 conv, 1 wgrad, 2 pack */
+int seg_abi_sizeof(int which);
+
+const char* seg_last_error(void);
+const char* seg_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""ctypes binding of the C-ABI in include/segengine.h.
+
+The product library is the in-tree gfx950 build (pytorchdeeplearing_amd/lib/libsegengine.so).
+There is NO CPU implementation: tensors that are not on an AMD GPU raise.  `inject_library` exists
+only so the repo's CPU test-suite can hand in the host-side kernel-logic checker build
+(tests/emu); nothing in the package calls it."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsegengine.so")
+
+NET_KIND = {"vnet": 0, "unet": 1}
+DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "bf16": 2, "bfloat16": 2}
+LABEL_TYPES = {"torch.uint8": 0, "torch.int32": 1, "torch.int64": 2, "torch.float32": 3}
+LOSS_KIND = {
+    "BinaryDiceLoss": 0, "BinaryCrossEntropyLoss": 1, "BinaryFocalLoss": 2, "BinaryCrossEntropyDiceLoss": 3,
+    "MutilCrossEntropyLoss": 4, "MutilFocalLoss": 5, "MutilDiceLoss": 6,
+}
+MASKS_EVAL, MASKS_GIVEN, MASKS_RANDOM = 0, 1, 2
+
+_vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+SIGNATURES = {
+    "seg_create": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "seg_destroy": (None, [_vp]),
+    "seg_param_count": (_i, [_vp]),
+    "seg_param_info": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)]),
+    "seg_param_numel": (_ll, [_vp]),
+    "seg_dropout_calls": (_i, [_vp]),
+    "seg_dropout_ld": (_i, [_vp]),
+    "seg_dropout_channels": (_i, [_vp, _i]),
+    "seg_plan": (_i, [_vp, _i, _i, _i, _i]),
+    "seg_workspace_bytes": (_ll, [_vp]),
+    "seg_bind": (_i, [_vp, _vp, _vp, _vp]),
+    "seg_pack_weights": (_i, [_vp, _vp]),
+    "seg_forward": (_i, [_vp, _vp, _i, _vp, C.c_ulonglong, _vp, _vp, _vp]),
+    "seg_backward": (_i, [_vp, _vp, _i, _vp]),
+    "seg_set_loss_scale": (_i, [_vp, _f]),
+    "seg_get_loss_scale": (_f, [_vp]),
+    "seg_loss_ws_bytes": (_ll, [_i, _i]),
+    "seg_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    "seg_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _f, _vp, _vp]),
+    "seg_metric": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp]),
+    "seg_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _i, _vp, _vp]),
+    "seg_last_error": (C.c_char_p, []),
+    "seg_build_info": (C.c_char_p, []),
+}
+
+
+class SegLib:
+    def __init__(self, path):
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.dll, name)     # raises AttributeError when the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def check(self, rc, what=""):
+        if rc is not None and rc < 0:
+            raise RuntimeError("segengine %s failed: %s" % (what, self.seg_last_error().decode()))
+
+    def build_info(self):
+        return self.seg_build_info().decode()
+
+
+_product = None
+_injected = None
+
+
+def inject_library(lib):
+    """TEST-ONLY: route *CPU* tensors to the given library (host-side checker build)."""
+    global _injected
+    _injected = lib
+
+
+def product_library():
+    global _product
+    if _product is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libsegengine.so (gfx950) is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python -m pytorchdeeplearing_amd.build`. There is no CPU fallback.")
+        _product = SegLib(LIB_PATH)
+    return _product
+
+
+def lib_for(device):
+    import torch
+    device = torch.device(device)
+    if device.type == "cuda":
+        return product_library()
+    if _injected is not None:
+        return _injected
+    raise RuntimeError("the segmentation engine runs on AMD MI355X (gfx950) only; got a %s tensor" % device.type)
+
+
+def stream_for(device):
+    import torch
+    device = torch.device(device)
+    if device.type == "cuda":
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return C.c_void_p(0)

@@ -1,0 +1,47 @@
+"""Build libsegengine.so for gfx950 with hipcc (in-tree, so it travels to the GPU box)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libsegengine.so")
+SRCS = ["conv.hip", "wgrad.hip", "norm.hip", "misc.hip", "engine.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+
+
+def _deps():
+    d = [os.path.join(CSRC, f) for f in SRCS + ["common.h", "kernels.h"]]
+    d.append(os.path.join(os.path.dirname(HERE), "include", "segengine.h"))
+    return d
+
+
+def up_to_date():
+    return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps())
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for s in SRCS:
+        o = os.path.join(objdir, s + ".o")
+        objs.append(o)
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out = p.communicate()[0].decode()
+        if p.returncode:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (s, out))
+        if verbose and out.strip():
+            print(out)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="-f" in sys.argv, verbose=True))

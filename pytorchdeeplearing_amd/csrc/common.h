@@ -1,0 +1,96 @@
+// Shared device helpers for the gfx950 segmentation engine (wave64, MFMA 16x16, NDHWC tensors).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace seg {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+template <class T, int N>
+using vec = T __attribute__((ext_vector_type(N)));
+typedef vec<float, 4> f32x4;
+typedef vec<short, 4> s16x4;
+
+enum DType { DT_F32 = 0, DT_F16 = 1, DT_BF16 = 2 };
+template <class T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int v = DT_F32; };
+template <> struct dtype_of<f16> { static constexpr int v = DT_F16; };
+template <> struct dtype_of<bf16> { static constexpr int v = DT_BF16; };
+
+constexpr int kWave = 64;
+constexpr int GN_GROUPS = 8;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// One K-step of the implicit GEMMs is 32 reduction elements; every lane owns 8 consecutive k
+// (k0 = 8*(lane>>4)) of row/col (lane&15).  f16/bf16: one v_mfma_f32_16x16x32.  f32: eight
+// v_mfma_f32_16x16x4_f32, instruction j consuming k = 8*(lane>>4)+j of every lane group (A and B
+// use the same k permutation, so the product is unchanged); exact f32 (fmaf chain).
+template <class T> struct Mma;
+template <> struct Mma<float> {
+    typedef vec<float, 8> frag;
+    static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+        return c;
+    }
+};
+template <> struct Mma<f16> {
+    typedef vec<f16, 8> frag;
+    static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    typedef vec<bf16, 8> frag;
+    static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+// LDS transposing read (gfx950 ds_read_b64_tr_b16): within each 16-lane group the lanes' 8-byte
+// reads form a [4][16] block of 16-bit values; lane t receives column t (4 consecutive rows).
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <class T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+template <class T> __device__ __forceinline__ T from_f(float v) { return (T)v; }
+
+template <class T> __device__ __forceinline__ vec<T, 8> zero8() {
+    vec<T, 8> z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (T)0.0f;
+    return z;
+}
+template <class T> __device__ __forceinline__ vec<T, 8> load8(const T* p) { return *(const vec<T, 8>*)p; }
+template <class T> __device__ __forceinline__ void store8(T* p, const vec<T, 8>& v) { *(vec<T, 8>*)p = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// labels arrive as u8 / i32 / i64 / f32 class ids (the reference's datasets hand out int64)
+enum LabelType { LT_U8 = 0, LT_I32 = 1, LT_I64 = 2, LT_F32 = 3 };
+__device__ __forceinline__ int load_label(const void* p, int lt, long long i) {
+    switch (lt) {
+        case LT_U8: return (int)((const uint8_t*)p)[i];
+        case LT_I32: return ((const int*)p)[i];
+        case LT_I64: return (int)((const long long*)p)[i];
+        default: return (int)((const float*)p)[i];
+    }
+}
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+}  // namespace seg

@@ -1,0 +1,409 @@
+// Implicit-GEMM convolution family for gfx950 (MFMA 16x16, LDS double buffering, NDHWC).
+//   conv_igemm_kernel<T,NT,SCATTER> : conv 3^d/2^d s2/1^d (+virtual concat), their data-gradients and
+//                                      ConvTranspose 2^d s2 (scatter epilogue); fused bias + GroupNorm
+//                                      sum / sum-of-squares partials.
+//   conv_stem_kernel<T>             : direct conv for the 1..4-channel image (K=27 is not MFMA shaped)
+//   head_fwd/bwd                    : 1^d conv to `numclass` + sigmoid/softmax, and its backward.
+// Semantics pinned by torch.nn.Conv3d/ConvTranspose3d call sites: networks/VNet3d.py:8,28,29,49,65,70,88,
+// networks/Unet3d.py:26-34,66-80 (reference file:line).
+#include "kernels.h"
+
+namespace seg {
+
+namespace {
+
+constexpr int BM = 128;   // GEMM rows (voxels) per workgroup
+constexpr int BK = 32;    // reduction elements per step
+constexpr int LDT = BK + 8;
+
+struct RowCoord { int n, d, h, w; };
+__device__ __forceinline__ RowCoord decode_row(long long m, int D, int H, int W) {
+    RowCoord r;
+    r.w = (int)(m % W); m /= W;
+    r.h = (int)(m % H); m /= H;
+    r.d = (int)(m % D);
+    r.n = (int)(m / D);
+    return r;
+}
+
+// Per-column sum / sum-of-squares of an LDS tile [rows][BN] into stats[n][Cout][2] (double atomics).
+// rows of the tile may straddle samples when the per-sample volume is not a multiple of BM.
+template <class T, int BN>
+__device__ __forceinline__ void tile_stats(const T* Os, int ldo, int rows_valid, long long m0, long long Vrow,
+                                           double* stats, int Cout, int co_base, float* red) {
+    constexpr int G = 256 / BN;
+    const int col = threadIdx.x % BN, g = threadIdx.x / BN;
+    const int n_first = (int)(m0 / Vrow), n_last = (int)((m0 + rows_valid - 1) / Vrow);
+    if (n_first == n_last) {
+        float s = 0.f, ss = 0.f;
+        for (int r = g; r < rows_valid; r += G) {
+            const float v = to_f(Os[r * ldo + col]);
+            s += v; ss += v * v;
+        }
+        red[(g * BN + col) * 2 + 0] = s;
+        red[(g * BN + col) * 2 + 1] = ss;
+        __syncthreads();
+        if (threadIdx.x < BN) {
+            double ts = 0.0, tss = 0.0;
+            for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
+            double* dst = stats + ((long long)n_first * Cout + co_base + col) * 2;
+            atomicAdd(dst, ts);
+            atomicAdd(dst + 1, tss);
+        }
+    } else {
+        // rare (tiny volumes / sample boundary): run-length flush per thread
+        double s = 0.0, ss = 0.0;
+        int ncur = -1;
+        for (int r = g; r < rows_valid; r += G) {
+            const int n = (int)((m0 + r) / Vrow);
+            if (n != ncur) {
+                if (ncur >= 0) {
+                    double* dst = stats + ((long long)ncur * Cout + co_base + col) * 2;
+                    atomicAdd(dst, s); atomicAdd(dst + 1, ss);
+                }
+                ncur = n; s = 0.0; ss = 0.0;
+            }
+            const float v = to_f(Os[r * ldo + col]);
+            s += v; ss += (double)v * v;
+        }
+        if (ncur >= 0) {
+            double* dst = stats + ((long long)ncur * Cout + co_base + col) * 2;
+            atomicAdd(dst, s); atomicAdd(dst + 1, ss);
+        }
+    }
+}
+
+template <class T, int NT, bool SCATTER>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int BN = 16 * NT;
+    __shared__ T As[2 * BM * LDT];
+    __shared__ T Bs[2 * BN * LDT];
+    __shared__ float red[512];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const long long Vrow = (long long)a.OD * a.OH * a.OW;
+    const long long M = (long long)a.N * Vrow;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int cog0 = blockIdx.y * BN;           // first GEMM column of this block
+    const int Cin = a.C0 + a.C1;
+    const int lg = 31 - __builtin_clz(Cin);     // Cin is a power of two
+    const T* in0 = (const T*)a.in0;
+    const T* in1 = (const T*)a.in1;
+    const T* wp = (const T*)a.w;
+
+    // ---- A-gather bookkeeping: this thread stages chunk `ac` (8 k) of rows ar0 and ar0+64
+    const int ac = tid & 3, ar0 = tid >> 2;
+    RowCoord rc[2];
+    bool rvalid[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long m = m0 + ar0 + 64 * i;
+        rvalid[i] = m < M;
+        rc[i] = decode_row(rvalid[i] ? m : 0, a.OD, a.OH, a.OW);
+        if (!SCATTER) { rc[i].d *= a.sd; rc[i].h *= a.sh; rc[i].w *= a.sw; }
+    }
+    const bool bload = tid < BN * 4;
+    const int brow = tid >> 2;
+
+    vec<T, 8> areg[2], breg;
+    auto gload = [&](int ks) {
+        const int k0 = ks * BK + ac * 8;
+        const int tap = SCATTER ? 0 : (k0 >> lg);
+        const int ci = SCATTER ? k0 : (k0 & (Cin - 1));
+        const bool kin = k0 < a.K;
+        int td = 0, th = 0, tw = 0;
+        if (!SCATTER && kin) { td = a.taps.d[tap]; th = a.taps.h[tap]; tw = a.taps.w[tap]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = rc[i].d + td, ih = rc[i].h + th, iw = rc[i].w + tw;
+            const bool ok = kin && rvalid[i] && (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH &&
+                            (unsigned)iw < (unsigned)a.IW;
+            if (ok) {
+                const long long vox = (((long long)rc[i].n * a.ID + id) * a.IH + ih) * a.IW + iw;
+                areg[i] = (ci < a.C0) ? load8(in0 + vox * a.C0 + ci) : load8(in1 + vox * a.C1 + (ci - a.C0));
+            } else {
+                areg[i] = zero8<T>();
+            }
+        }
+        if (bload) breg = load8(wp + (long long)(cog0 + brow) * a.Kpad + ks * BK + ac * 8);
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) store8(&As[(buf * BM + ar0 + 64 * i) * LDT + ac * 8], areg[i]);
+        if (bload) store8(&Bs[(buf * BN + brow) * LDT + ac * 8], breg);
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.Kpad / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) gload(ks + 1);
+        typename Mma<T>::frag af[2], bf[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = load8(&As[(buf * BM + wv * 32 + i * 16 + l15) * LDT + q * 8]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = load8(&Bs[(buf * BN + j * 16 + l15) * LDT + q * 8]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = Mma<T>::run(af[i], bf[j], acc[i][j]);
+        if (ks + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, stage the tile in LDS (aliases As), coalesced stores, GN partial sums
+    constexpr int LDO = BN + 8;
+    T* Os = As;
+    const int co_real0 = SCATTER ? (cog0 % a.Cout) : cog0;   // first real output channel of the block
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = j * 16 + l15;
+        const float b = a.bias ? a.bias[co_real0 + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Os[(wv * 32 + i * 16 + q * 4 + r) * LDO + col] = from_f<T>(acc[i][j][r] + b);
+    }
+    __syncthreads();
+    const int rows_valid = (int)((M - m0) < BM ? (M - m0) : BM);
+    T* out = (T*)a.out;
+    int od_ = 0, oh_ = 0, ow_ = 0;
+    if (SCATTER) { const int tap = cog0 / a.Cout; od_ = a.taps.d[tap]; oh_ = a.taps.h[tap]; ow_ = a.taps.w[tap]; }
+    constexpr int CPR = BN / 8;
+    for (int ch = tid; ch < BM * CPR; ch += 256) {
+        const int row = ch / CPR, cc = ch % CPR;
+        if (row >= rows_valid) continue;
+        const vec<T, 8> v = load8(&Os[row * LDO + cc * 8]);
+        long long orow;
+        if (SCATTER) {
+            const RowCoord r = decode_row(m0 + row, a.OD, a.OH, a.OW);
+            orow = (((long long)r.n * a.FD + r.d * a.sd + od_) * a.FH + r.h * a.sh + oh_) * a.FW + r.w * a.sw + ow_;
+        } else {
+            orow = m0 + row;
+        }
+        store8(out + orow * a.Cout + co_real0 + cc * 8, v);
+    }
+    if (a.stats) tile_stats<T, BN>(Os, LDO, rows_valid, m0, Vrow, a.stats, a.Cout, co_real0, red);
+}
+
+template <class T>
+void conv_dispatch(const ConvArgs& a, hipStream_t s) {
+    const long long M = (long long)a.N * a.OD * a.OH * a.OW;
+    const int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
+    dim3 grid(cdiv(M, BM), a.Ngemm / (16 * nt));
+#define SEG_LAUNCH_CONV(NT)                                                                          \
+    if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true>), grid, dim3(256), 0, s, a);  \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false>), grid, dim3(256), 0, s, a);
+    if (nt == 4) { SEG_LAUNCH_CONV(4) } else if (nt == 2) { SEG_LAUNCH_CONV(2) } else { SEG_LAUNCH_CONV(1) }
+#undef SEG_LAUNCH_CONV
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: direct conv, Cimg in 1..4, Cout multiple of 8 (<= 64).  256 voxels per workgroup.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs a) {
+    constexpr int MAXW = 27 * 4 * 32;   // taps x Cimg(<=4) x Cout(<=32)
+    __shared__ float ws[MAXW];          // [tap][ci][co]
+    __shared__ T Os[256 * (32 + 8)];
+    __shared__ float red[512];
+    const int tid = threadIdx.x;
+    const int nt = a.taps.n, Cimg = a.Cimg, Cout = a.Cout;
+    for (int i = tid; i < nt * Cimg * Cout; i += 256) {
+        const int co = i % Cout, ci = (i / Cout) % Cimg, t = i / (Cout * Cimg);
+        ws[i] = a.w[((long long)co * Cimg + ci) * nt + t];
+    }
+    __syncthreads();
+    const long long V = (long long)a.D * a.H * a.W, M = (long long)a.N * V;
+    const long long m0 = (long long)blockIdx.x * 256;
+    const long long m = m0 + tid;
+    const int LDO = Cout + 8;
+    const T* in = (const T*)a.in;
+    if (m < M) {
+        const RowCoord r = decode_row(m, a.D, a.H, a.W);
+        for (int c0 = 0; c0 < Cout; c0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = a.bias ? a.bias[c0 + j] : 0.f;
+            for (int t = 0; t < nt; ++t) {
+                const int id = r.d + a.taps.d[t], ih = r.h + a.taps.h[t], iw = r.w + a.taps.w[t];
+                if ((unsigned)id >= (unsigned)a.D || (unsigned)ih >= (unsigned)a.H || (unsigned)iw >= (unsigned)a.W) continue;
+                const long long vox = (((long long)r.n * a.D + id) * a.H + ih) * a.W + iw;
+                for (int ci = 0; ci < Cimg; ++ci) {
+                    const float xv = to_f(in[vox * Cimg + ci]);
+                    const float* wr = &ws[(t * Cimg + ci) * Cout + c0];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Os[tid * LDO + c0 + j] = from_f<T>(acc[j]);
+        }
+    }
+    __syncthreads();
+    const int rows_valid = (int)((M - m0) < 256 ? (M - m0) : 256);
+    T* out = (T*)a.out;
+    const int CPR = Cout / 8;
+    for (int ch = tid; ch < 256 * CPR; ch += 256) {
+        const int row = ch / CPR, cc = ch % CPR;
+        if (row < rows_valid) store8(out + (m0 + row) * Cout + cc * 8, load8(&Os[row * LDO + cc * 8]));
+    }
+    if (a.stats) {
+        // column sums, 16 columns at a time with the shared helper
+        for (int c0 = 0; c0 < Cout; c0 += 16) {
+            tile_stats<T, 16>(Os + c0, LDO, rows_valid, m0, V, a.stats, Cout, c0, red);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: per-voxel dot products to numclass logits, planar fp32 outputs (the reference API returns
+// NC[D]HW float32 logits and probabilities).  One thread per voxel.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXCLS = 8;
+
+template <class T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+    __shared__ float ws[MAXCLS * 64 + MAXCLS];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.C * a.Cin; i += 256) ws[i] = a.w[i];
+    if (tid < a.C) ws[MAXCLS * 64 + tid] = a.bias ? a.bias[tid] : 0.f;
+    __syncthreads();
+    const long long M = (long long)a.N * a.V;
+    const T* in = (const T*)a.in;
+    for (long long m = (long long)blockIdx.x * 256 + tid; m < M; m += (long long)gridDim.x * 256) {
+        float z[MAXCLS];
+        for (int c = 0; c < a.C; ++c) z[c] = ws[MAXCLS * 64 + c];
+        for (int k0 = 0; k0 < a.Cin; k0 += 8) {
+            const vec<T, 8> x = load8(in + m * a.Cin + k0);
+            for (int c = 0; c < a.C; ++c) {
+                float s = z[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = fmaf(to_f(x[j]), ws[c * a.Cin + k0 + j], s);
+                z[c] = s;
+            }
+        }
+        const long long n = m / a.V, v = m % a.V;
+        if (a.C == 1) {
+            a.logits[m] = z[0];
+            a.probs[m] = 1.f / (1.f + expf(-z[0]));
+        } else {
+            float mx = z[0];
+            for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, z[c]);
+            float e[MAXCLS], se = 0.f;
+            for (int c = 0; c < a.C; ++c) { e[c] = expf(z[c] - mx); se += e[c]; }
+            const float inv = 1.f / se;
+            for (int c = 0; c < a.C; ++c) {
+                const long long o = (n * a.C + c) * a.V + v;
+                a.logits[o] = z[c];
+                a.probs[o] = e[c] * inv;
+            }
+        }
+    }
+}
+
+// backward: din[m][ci] = sum_c dlogit[n][c][v] w[c][ci]; dw[c][ci] += sum_m dlogit*in; db[c] += sum dlogit.
+// Thread = (voxel, 8-channel chunk); dw partials are reduced over the block in LDS.
+template <class T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
+    __shared__ float ws[MAXCLS * 64];
+    __shared__ float red[256 * 9];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.C * a.Cin; i += 256) ws[i] = a.w[i];
+    __syncthreads();
+    const int CPR = a.Cin / 8;                 // chunks per voxel (power of two, <= 8)
+    const int cc = tid % CPR, vslot = tid / CPR, VPB = 256 / CPR;
+    const long long M = (long long)a.N * a.V;
+    const T* in = (const T*)a.in;
+    T* din = (T*)a.din;
+    float dw[MAXCLS][8], db[MAXCLS];
+    for (int c = 0; c < MAXCLS; ++c) { db[c] = 0.f; for (int j = 0; j < 8; ++j) dw[c][j] = 0.f; }
+    for (long long m = (long long)blockIdx.x * VPB + vslot; m < M; m += (long long)gridDim.x * VPB) {
+        const long long n = m / a.V, v = m % a.V;
+        const vec<T, 8> x = load8(in + m * a.Cin + cc * 8);
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = 0.f;
+        for (int c = 0; c < a.C; ++c) {
+            const float dl = a.dlogits[(n * a.C + c) * a.V + v];
+            db[c] += dl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                g[j] = fmaf(dl, ws[c * a.Cin + cc * 8 + j], g[j]);
+                dw[c][j] = fmaf(dl, to_f(x[j]), dw[c][j]);
+            }
+        }
+        vec<T, 8> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = from_f<T>(g[j]);
+        store8(din + m * a.Cin + cc * 8, o);
+    }
+    // block reduction: for each class, 8 dw columns (+ db) per thread -> sum over threads with equal cc
+    for (int c = 0; c < a.C; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 9 + j] = dw[c][j];
+        red[tid * 9 + 8] = db[c];
+        __syncthreads();
+        if (tid < CPR * 8) {
+            const int ccx = tid / 8, j = tid % 8;
+            float s = 0.f;
+            for (int t = ccx; t < 256; t += CPR) s += red[t * 9 + j];
+            atomicAdd(&a.dw[c * a.Cin + ccx * 8 + j], s);
+        }
+        if (tid == 255) {
+            float s = 0.f;
+            for (int t = 0; t < 256; t += CPR) s += red[t * 9 + 8];   // db counted once per voxel (cc == 0 lanes)
+            atomicAdd(&a.db[c], s);
+        }
+    }
+}
+
+}  // namespace
+
+void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s) {
+    if (dtype == DT_F32) conv_dispatch<float>(a, s);
+    else if (dtype == DT_F16) conv_dispatch<f16>(a, s);
+    else conv_dispatch<bf16>(a, s);
+}
+
+void launch_conv_stem(const StemArgs& a, int dtype, hipStream_t s) {
+    const long long M = (long long)a.N * a.D * a.H * a.W;
+    dim3 grid(cdiv(M, 256));
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stem_kernel<float>), grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stem_kernel<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stem_kernel<bf16>), grid, dim3(256), 0, s, a);
+}
+
+void launch_head_fwd(const HeadArgs& a, int dtype, hipStream_t s) {
+    const long long M = (long long)a.N * a.V;
+    int blocks = cdiv(M, 256);
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid(blocks);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_fwd_kernel<float>), grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_fwd_kernel<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(head_fwd_kernel<bf16>), grid, dim3(256), 0, s, a);
+}
+
+void launch_head_bwd(const HeadBwdArgs& a, int dtype, hipStream_t s) {
+    const long long M = (long long)a.N * a.V;
+    const int VPB = 256 / (a.Cin / 8);
+    int blocks = cdiv(M, VPB);
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid(blocks);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<float>), grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<bf16>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace seg

@@ -1,0 +1,866 @@
+// Segmentation engine: network graph (VNet / UNet, 2-D and 3-D), workspace planner, forward and
+// backward schedules, C-ABI (include/segengine.h).  Host code only; kernels live in conv.hip,
+// wgrad.hip, norm.hip, misc.hip.
+//
+// The graph is a list of steps over channels-last tensors:
+//   UNIT  raw = conv(in0 [, in1 as virtual concat]) ; optional GroupNorm(8)+dropout+ReLU parameters
+//   ACT   out = relu-gn(unit_a) [+ relu-gn(unit_b)] [+ residual tensor]
+//   POOL  out = maxpool 2^d (UNet)          HEAD  logits/probs
+// Backward is derived from the same list in reverse: every tensor collects up to three gradient
+// contributions (residual fan-in, skip connections) that the GroupNorm-backward kernels sum on the
+// fly, so no explicit `add` or `cat` tensor is ever materialised.
+// Reference structure: networks/VNet3d.py:25-158, networks/Unet3d.py:6-86 (+ the 2-D twins).
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace seg;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return -1; }
+
+enum ConvKind { CK_K3, CK_K1, CK_K2S2, CK_KT, CK_STEM3, CK_STEM1 };
+enum StepType { ST_UNIT, ST_ACT, ST_POOL, ST_HEAD };
+
+struct Param { std::string name; std::vector<int> shape; long long off; long long numel; };
+
+struct Ten {
+    int C, lvl;
+    size_t off = 0;          // workspace byte offset
+    bool image = false;
+    std::vector<int> grads;  // gradient contribution tensors (ids)
+};
+
+struct Step {
+    int type;
+    // UNIT
+    int ck = 0, in0 = -1, in1 = -1, raw = -1, Cin = 0, Cout = 0;
+    int w = -1, b = -1, gn_w = -1, gn_b = -1;   // param indices (-1: absent)
+    int mask_slot = -1;
+    size_t stats = 0, scale = 0, shift = 0, mean = 0, rstd = 0, Q = 0, coef = 0;
+    size_t wp_fwd = 0, wp_dg0 = 0, wp_dg1 = 0;
+    int draw = -1;           // gradient wrt raw
+    // ACT
+    int ua = -1, ub = -1, res = -1, out = -1;
+    // POOL / HEAD
+    int in = -1;
+};
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct seg_engine {
+    int kind, ndim, in_ch, ncls, feat, dtype;
+    std::vector<Param> params;
+    long long nparam = 0;
+    std::vector<Ten> tens;
+    std::vector<Step> steps;
+    std::vector<int> drop_ch;    // channels per dropout call
+    int image_ten = -1;
+    // plan
+    int N = 0, D = 0, H = 0, W = 0;
+    size_t ws_bytes = 0;
+    size_t off_masks = 0, off_stats = 0, stats_bytes = 0, off_Q = 0, Q_bytes = 0, off_packdesc = 0, off_step = 0;
+    std::vector<PackDesc> packdescs;   // dst/src stored as OFFSETS until bind
+    long long pack_max = 0;
+    bool planned = false;
+    // bind
+    float* p = nullptr; float* g = nullptr; char* ws = nullptr;
+    float loss_scale = 1.f;
+    int mask_mode = 0;
+    std::vector<std::function<void(hipStream_t)>> fwd_ops, bwd_ops;
+    const float* cur_x = nullptr; float* cur_logits = nullptr; float* cur_probs = nullptr;
+    const float* cur_dlogits = nullptr;
+    size_t esz() const { return dtype == DT_F32 ? 4 : 2; }
+    int ld_mask() const { return 16 * feat; }
+    int dim_d(int l) const { return ndim == 3 ? (D >> l) : 1; }
+    int dim_h(int l) const { return H >> l; }
+    int dim_w(int l) const { return W >> l; }
+    long long vol(int l) const { return (long long)dim_d(l) * dim_h(l) * dim_w(l); }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// graph construction
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+    seg_engine& e;
+    int nd;
+    explicit Builder(seg_engine& e_) : e(e_), nd(e_.ndim) {}
+
+    int param(const std::string& name, std::vector<int> shape) {
+        Param p; p.name = name; p.shape = shape; p.off = e.nparam; p.numel = 1;
+        for (int s : shape) p.numel *= s;
+        // keep every tensor 64-float aligned inside the flat buffer (vector loads, 256-B alignment)
+        e.nparam += (p.numel + 63) / 64 * 64;
+        e.params.push_back(p);
+        return (int)e.params.size() - 1;
+    }
+    std::vector<int> kshape(int a, int b, int k) {
+        std::vector<int> s{a, b};
+        for (int i = 0; i < nd; ++i) s.push_back(k);
+        return s;
+    }
+    int tensor(int C, int lvl, bool image = false) {
+        Ten t; t.C = C; t.lvl = lvl; t.image = image;
+        e.tens.push_back(t);
+        return (int)e.tens.size() - 1;
+    }
+    // conv (+ optional GroupNorm params gw/gb: -2 => create "<gn>.weight/.bias")
+    int unit(int ck, const std::string& cname, bool bias, int in0, int in1, int Cout, int lvl_out,
+             const std::string& gname, int gw = -2, int gb = -2, bool has_gn = true) {
+        Step s; s.type = ST_UNIT; s.ck = ck; s.in0 = in0; s.in1 = in1;
+        s.Cin = e.tens[in0].C + (in1 >= 0 ? e.tens[in1].C : 0);
+        s.Cout = Cout;
+        const int k = (ck == CK_K3 || ck == CK_STEM3) ? 3 : (ck == CK_K2S2 || ck == CK_KT) ? 2 : 1;
+        s.w = param(cname + ".weight", ck == CK_KT ? kshape(s.Cin, Cout, k) : kshape(Cout, s.Cin, k));
+        if (bias) s.b = param(cname + ".bias", {Cout});
+        if (has_gn) {
+            if (gw == -2) { gw = param(gname + ".weight", {Cout}); gb = param(gname + ".bias", {Cout}); }
+            s.gn_w = gw; s.gn_b = gb;
+            s.mask_slot = (int)e.drop_ch.size();
+            e.drop_ch.push_back(Cout);
+        }
+        s.raw = tensor(Cout, lvl_out);
+        e.steps.push_back(s);
+        return (int)e.steps.size() - 1;
+    }
+    int act(int ua, int ub, int res) {
+        Step s; s.type = ST_ACT; s.ua = ua; s.ub = ub; s.res = res;
+        const Ten& r = e.tens[e.steps[ua].raw];
+        s.out = tensor(r.C, r.lvl);
+        e.steps.push_back(s);
+        return s.out;
+    }
+    int pool(int in) {
+        Step s; s.type = ST_POOL; s.in = in;
+        s.out = tensor(e.tens[in].C, e.tens[in].lvl + 1);
+        e.steps.push_back(s);
+        return s.out;
+    }
+    void head(int in, const std::string& cname) {
+        Step s; s.type = ST_HEAD; s.in = in; s.Cin = e.tens[in].C; s.Cout = e.ncls;
+        s.w = param(cname + ".weight", kshape(e.ncls, s.Cin, 1));
+        s.b = param(cname + ".bias", {e.ncls});
+        e.steps.push_back(s);
+    }
+
+    void build_vnet() {   // networks/VNet3d.py:102-158
+        const int F = e.feat;
+        const int x = tensor(e.in_ch, 0, true);
+        e.image_ten = x;
+        // InputTransition (VNet3d.py:25-43): parameter order conv1, conv2, bn1; ONE GroupNorm for both branches
+        const int ua = unit(CK_STEM3, "in_tr.conv1", true, x, -1, F, 0, "", -1, -1, false);
+        const int ub = unit(CK_STEM1, "in_tr.conv2", true, x, -1, F, 0, "", -1, -1, false);
+        const int gw = param("in_tr.bn1.weight", {F}), gb = param("in_tr.bn1.bias", {F});
+        for (int u : {ua, ub}) {
+            e.steps[u].gn_w = gw; e.steps[u].gn_b = gb;
+            e.steps[u].mask_slot = (int)e.drop_ch.size();
+            e.drop_ch.push_back(F);
+        }
+        int prev = act(ua, ub, -1);
+        std::vector<int> skips{prev};
+        const int nconv_down[4] = {2, 3, 3, 3};
+        for (int l = 1; l <= 4; ++l) {   // DownTransition (VNet3d.py:46-59)
+            const int C = F << l;
+            const std::string pre = "down_tr" + std::to_string(32 << (l - 1));
+            const int ud = unit(CK_K2S2, pre + ".down_conv", true, prev, -1, C, l, pre + ".bn1");
+            const int down = act(ud, -1, -1);
+            int t = down;
+            for (int i = 0; i < nconv_down[l - 1]; ++i) {
+                const std::string op = pre + ".ops." + std::to_string(i);
+                const int u = unit(CK_K3, op + ".conv1", true, t, -1, C, l, op + ".bn1");
+                t = act(u, -1, i == nconv_down[l - 1] - 1 ? down : -1);
+            }
+            prev = t;
+            skips.push_back(prev);
+        }
+        skips.pop_back();
+        const int nconv_up[4] = {3, 3, 2, 1};
+        for (int k = 0; k < 4; ++k) {    // UpTransition (VNet3d.py:62-80): parameter order up_conv, bn, ops, conv
+            const int l = 3 - k, C = F << l;
+            const std::string pre = "up_tr" + std::to_string(256 >> k);
+            const int skip = skips.back(); skips.pop_back();
+            const int uu = unit(CK_KT, pre + ".up_conv", true, prev, -1, C, l, pre + ".bn");
+            const int gwu = e.steps[uu].gn_w, gbu = e.steps[uu].gn_b;
+            const int up = act(uu, -1, -1);
+            // the LUConv parameters are registered BEFORE `conv` in the reference module; keep state_dict order
+            // by creating the ops' parameters first and the 1^d conv's afterwards.
+            std::vector<int> opw, opb, opgw, opgb;
+            for (int i = 0; i < nconv_up[k]; ++i) {
+                const std::string op = pre + ".ops." + std::to_string(i);
+                opw.push_back(param(op + ".conv1.weight", kshape(C, C, 3)));
+                opb.push_back(param(op + ".conv1.bias", {C}));
+                opgw.push_back(param(op + ".bn1.weight", {C}));
+                opgb.push_back(param(op + ".bn1.bias", {C}));
+            }
+            const int cw = param(pre + ".conv.weight", kshape(C, 2 * C, 1));
+            const int cb = param(pre + ".conv.bias", {C});
+            const int uc = unit_preparam(CK_K1, cw, cb, up, skip, C, l, gwu, gbu);
+            const int xcat = act(uc, -1, -1);
+            int t = xcat;
+            for (int i = 0; i < nconv_up[k]; ++i) {
+                const int u = unit_preparam(CK_K3, opw[i], opb[i], t, -1, C, l, opgw[i], opgb[i]);
+                t = act(u, -1, i == nconv_up[k] - 1 ? xcat : -1);
+            }
+            prev = t;
+        }
+        head(prev, "out_tr.conv");
+    }
+    int unit_preparam(int ck, int w, int b, int in0, int in1, int Cout, int lvl, int gw, int gb) {
+        Step s; s.type = ST_UNIT; s.ck = ck; s.in0 = in0; s.in1 = in1;
+        s.Cin = e.tens[in0].C + (in1 >= 0 ? e.tens[in1].C : 0);
+        s.Cout = Cout; s.w = w; s.b = b; s.gn_w = gw; s.gn_b = gb;
+        s.mask_slot = (int)e.drop_ch.size();
+        e.drop_ch.push_back(Cout);
+        s.raw = tensor(Cout, lvl);
+        e.steps.push_back(s);
+        return (int)e.steps.size() - 1;
+    }
+
+    int unet_block(const std::string& mod, const std::string& name, int in0, int in1, int C, int lvl, bool first) {
+        // Unet3d.py:64-86: conv3(no bias) GN drop relu, twice
+        const int u1 = unit(first ? CK_STEM3 : CK_K3, mod + "." + name + "conv1", false, in0, in1, C, lvl, mod + "." + name + "norm1");
+        const int a1 = act(u1, -1, -1);
+        const int u2 = unit(CK_K3, mod + "." + name + "conv2", false, a1, -1, C, lvl, mod + "." + name + "norm2");
+        return act(u2, -1, -1);
+    }
+    void build_unet() {   // networks/Unet3d.py:6-62
+        const int F = e.feat;
+        const int x = tensor(e.in_ch, 0, true);
+        e.image_ten = x;
+        int t = x;
+        std::vector<int> enc;
+        for (int l = 0; l < 4; ++l) {
+            const std::string nm = "enc" + std::to_string(l + 1);
+            const int en = unet_block("encoder" + std::to_string(l + 1), nm, t, -1, F << l, l, l == 0);
+            enc.push_back(en);
+            t = pool(en);
+        }
+        t = unet_block("bottleneck", "bottleneck", t, -1, F << 4, 4, false);
+        for (int l = 3; l >= 0; --l) {
+            const std::string up = "upconv" + std::to_string(l + 1);
+            const int uu = unit(CK_KT, up, true, t, -1, F << l, l, "", -1, -1, false);
+            // plain ConvTranspose: its raw output IS the activation fed to the concat
+            t = unet_block("decoder" + std::to_string(l + 1), "dec" + std::to_string(l + 1), e.steps[uu].raw, enc[l], F << l, l, false);
+        }
+        head(t, "conv");
+    }
+};
+
+Taps make_taps(int ndim, int k, int pad) {
+    Taps t; t.n = 0;
+    const int kd = ndim == 3 ? k : 1;
+    for (int a = 0; a < kd; ++a)
+        for (int b = 0; b < k; ++b)
+            for (int c = 0; c < k; ++c) {
+                t.d[t.n] = (int8_t)(ndim == 3 ? a - pad : 0);
+                t.h[t.n] = (int8_t)(b - pad);
+                t.w[t.n] = (int8_t)(c - pad);
+                ++t.n;
+            }
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// planning: workspace layout + forward / backward schedules
+// ------------------------------------------------------------------------------------------------
+struct Planner {
+    seg_engine& e;
+    size_t cur = 0;
+    explicit Planner(seg_engine& e_) : e(e_) {}
+    size_t alloc(size_t bytes) { size_t o = cur; cur = align_up(cur + bytes); return o; }
+    size_t ten_bytes(const Ten& t) const { return (size_t)e.N * e.vol(t.lvl) * t.C * e.esz(); }
+    int new_grad(int like) {
+        Ten t; t.C = e.tens[like].C; t.lvl = e.tens[like].lvl;
+        t.off = alloc(ten_bytes(t));
+        e.tens.push_back(t);
+        return (int)e.tens.size() - 1;
+    }
+    template <class T = void> T* P(size_t off) const { return (T*)(e.ws + off); }
+
+    int ntaps(int ck) const {
+        const int k = (ck == CK_K3 || ck == CK_STEM3) ? 3 : (ck == CK_K2S2 || ck == CK_KT) ? 2 : 1;
+        return e.ndim == 3 ? k * k * k : k * k;
+    }
+    void add_pack(size_t dst, long long src_off, int R1, int R2, int T, int Cc, long long s1, long long s2, long long sT, long long sC, int flip) {
+        PackDesc d;
+        d.src = (const float*)(uintptr_t)src_off;   // offsets; resolved in seg_bind
+        d.dst = (void*)(uintptr_t)dst;
+        d.R1 = R1; d.R2 = R2; d.T = T; d.Cc = Cc;
+        d.Kpad = (T * Cc + 31) / 32 * 32;
+        d.s1 = s1; d.s2 = s2; d.sT = sT; d.sC = sC; d.flipT = flip;
+        e.packdescs.push_back(d);
+        const long long tot = (long long)R1 * R2 * d.Kpad;
+        if (tot > e.pack_max) e.pack_max = tot;
+    }
+    size_t alloc_pack(int rows, int K) { return alloc((size_t)rows * ((K + 31) / 32 * 32) * e.esz()); }
+
+    void plan() {
+        seg_engine& E = e;
+        const int N = E.N, dt = E.dtype;
+        E.fwd_ops.clear(); E.bwd_ops.clear(); E.packdescs.clear(); E.pack_max = 0;
+        // drop gradient tensors of a previous plan
+        size_t nfw = 0;
+        for (auto& s : E.steps) { nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1); s.draw = -1; }
+        E.tens.resize(std::max<size_t>(nfw, (size_t)E.image_ten + 1));
+        for (auto& t : E.tens) t.grads.clear();
+
+        // ---- small persistent regions
+        E.off_step = alloc(256);
+        E.off_masks = alloc((size_t)E.drop_ch.size() * N * E.ld_mask() * 4);
+        // forward tensors
+        for (auto& t : E.tens) t.off = alloc(ten_bytes(t));
+        // statistics (fp64) contiguous so one memset clears them; same for Q
+        const size_t s0 = cur;
+        for (auto& s : E.steps)
+            if (s.type == ST_UNIT && s.gn_w >= 0) s.stats = alloc((size_t)N * s.Cout * 2 * 8);
+        E.off_stats = s0; E.stats_bytes = cur - s0;
+        const size_t q0 = cur;
+        for (auto& s : E.steps)
+            if (s.type == ST_UNIT && s.gn_w >= 0) s.Q = alloc((size_t)N * s.Cout * 2 * 8);
+        E.off_Q = q0; E.Q_bytes = cur - q0;
+        for (auto& s : E.steps)
+            if (s.type == ST_UNIT && s.gn_w >= 0) {
+                s.scale = alloc((size_t)N * s.Cout * 4);
+                s.shift = alloc((size_t)N * s.Cout * 4);
+                s.mean = alloc((size_t)N * GN_GROUPS * 4);
+                s.rstd = alloc((size_t)N * GN_GROUPS * 4);
+                s.coef = alloc((size_t)N * s.Cout * 3 * 4);
+            }
+        // ---- packed weights
+        for (auto& s : E.steps) {
+            if (s.type != ST_UNIT) continue;
+            const int T = ntaps(s.ck), Ci = s.Cin, Co = s.Cout;
+            const long long woff = E.params[s.w].off;
+            const int C0 = E.tens[s.in0].C, C1 = s.in1 >= 0 ? E.tens[s.in1].C : 0;
+            switch (s.ck) {
+                case CK_K3: case CK_K1: case CK_K2S2:
+                    s.wp_fwd = alloc_pack(Co, T * Ci);
+                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0);
+                    if (s.ck == CK_K2S2) {       // data-gradient = scatter GEMM, rows (a, ci), K = Cout
+                        s.wp_dg0 = alloc_pack(T * Ci, Co);
+                        add_pack(s.wp_dg0, woff, T, Ci, 1, Co, 1, T, 0, (long long)Ci * T, 0);
+                    } else {                     // data-gradient = gather conv with flipped taps, rows ci, k = (tap, co)
+                        if (!E.tens[s.in0].image) {
+                            s.wp_dg0 = alloc_pack(C0, T * Co);
+                            add_pack(s.wp_dg0, woff, C0, 1, T, Co, T, 0, 1, (long long)Ci * T, 1);
+                        }
+                        if (C1) {
+                            s.wp_dg1 = alloc_pack(C1, T * Co);
+                            add_pack(s.wp_dg1, woff + (long long)C0 * T, C1, 1, T, Co, T, 0, 1, (long long)Ci * T, 1);
+                        }
+                    }
+                    break;
+                case CK_KT:                      // forward = scatter GEMM rows (a, co), K = Cin
+                    s.wp_fwd = alloc_pack(T * Co, Ci);
+                    add_pack(s.wp_fwd, woff, T, Co, 1, Ci, 1, T, 0, (long long)Co * T, 0);
+                    s.wp_dg0 = alloc_pack(Ci, T * Co);   // data-gradient = gather stride 2, rows ci, k = (a, co)
+                    add_pack(s.wp_dg0, woff, Ci, 1, T, Co, (long long)Co * T, 0, 1, T, 0);
+                    break;
+                default: break;                  // stem convs read the fp32 master weights directly
+            }
+        }
+        E.off_packdesc = alloc(E.packdescs.size() * sizeof(PackDesc));
+
+        // ------------------------------------------------------------------ forward schedule
+        E.fwd_ops.push_back([this_ = &E](hipStream_t st) {
+            seg_engine& E = *this_;
+            (void)hipMemsetAsync(E.ws + E.off_stats, 0, E.stats_bytes, st);
+            const Ten& x = E.tens[E.image_ten];
+            launch_ingest(E.cur_x, E.ws + x.off, E.N, x.C, E.vol(0), E.dtype, st);
+        });
+        for (size_t si = 0; si < E.steps.size(); ++si) {
+            Step& s = E.steps[si];
+            if (s.type == ST_UNIT) {
+                E.fwd_ops.push_back([this_ = &E, si](hipStream_t st) {
+                    seg_engine& E = *this_;
+                    const Step& s = E.steps[si];
+                    const Ten& i0 = E.tens[s.in0];
+                    const Ten& ro = E.tens[s.raw];
+                    double* stats = s.gn_w >= 0 ? (double*)(E.ws + s.stats) : nullptr;
+                    const float* bias = s.b >= 0 ? E.p + E.params[s.b].off : nullptr;
+                    if (s.ck == CK_STEM3 || s.ck == CK_STEM1) {
+                        StemArgs a;
+                        a.in = E.ws + i0.off; a.w = E.p + E.params[s.w].off; a.bias = bias;
+                        a.out = E.ws + ro.off; a.stats = stats;
+                        a.N = E.N; a.D = E.dim_d(0); a.H = E.dim_h(0); a.W = E.dim_w(0); a.Cimg = i0.C; a.Cout = s.Cout;
+                        a.taps = make_taps(E.ndim, s.ck == CK_STEM3 ? 3 : 1, s.ck == CK_STEM3 ? 1 : 0);
+                        launch_conv_stem(a, E.dtype, st);
+                    } else {
+                        ConvArgs a{};
+                        a.in0 = E.ws + i0.off; a.C0 = i0.C;
+                        a.in1 = s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr;
+                        a.C1 = s.in1 >= 0 ? E.tens[s.in1].C : 0;
+                        a.w = E.ws + s.wp_fwd; a.bias = bias; a.out = E.ws + ro.off; a.stats = stats;
+                        a.N = E.N; a.Cout = s.Cout;
+                        const int li = i0.lvl, lo = ro.lvl;
+                        a.ID = E.dim_d(li); a.IH = E.dim_h(li); a.IW = E.dim_w(li);
+                        if (s.ck == CK_KT) {
+                            a.scatter = 1;
+                            a.OD = a.ID; a.OH = a.IH; a.OW = a.IW;
+                            a.FD = E.dim_d(lo); a.FH = E.dim_h(lo); a.FW = E.dim_w(lo);
+                            a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
+                            a.taps = make_taps(E.ndim, 2, 0);
+                            a.K = s.Cin; a.Ngemm = a.taps.n * s.Cout;
+                        } else {
+                            a.scatter = 0;
+                            a.OD = E.dim_d(lo); a.OH = E.dim_h(lo); a.OW = E.dim_w(lo);
+                            const int k = s.ck == CK_K3 ? 3 : s.ck == CK_K2S2 ? 2 : 1;
+                            a.taps = make_taps(E.ndim, k, s.ck == CK_K3 ? 1 : 0);
+                            const int str = s.ck == CK_K2S2 ? 2 : 1;
+                            a.sd = E.ndim == 3 ? str : 1; a.sh = str; a.sw = str;
+                            a.K = a.taps.n * s.Cin; a.Ngemm = s.Cout;
+                        }
+                        a.Kpad = (a.K + 31) / 32 * 32;
+                        launch_conv_igemm(a, E.dtype, st);
+                    }
+                    if (s.gn_w >= 0) {
+                        GnFinArgs f;
+                        f.stats = stats; f.gamma = E.p + E.params[s.gn_w].off; f.beta = E.p + E.params[s.gn_b].off;
+                        f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
+                                 : (const float*)(E.ws + E.off_masks) + (size_t)s.mask_slot * E.N * E.ld_mask();
+                        f.mask_ld = E.ld_mask();
+                        f.scale = (float*)(E.ws + s.scale); f.shift = (float*)(E.ws + s.shift);
+                        f.mean = (float*)(E.ws + s.mean); f.rstd = (float*)(E.ws + s.rstd);
+                        f.N = E.N; f.C = s.Cout; f.V = E.vol(ro.lvl); f.eps = 1e-5f;
+                        launch_gn_finalize(f, st);
+                    }
+                });
+            } else if (s.type == ST_ACT) {
+                E.fwd_ops.push_back([this_ = &E, si](hipStream_t st) {
+                    seg_engine& E = *this_;
+                    const Step& s = E.steps[si];
+                    const Step& ua = E.steps[s.ua];
+                    ActArgs a{};
+                    a.r1 = E.ws + E.tens[ua.raw].off; a.scale1 = (float*)(E.ws + ua.scale); a.shift1 = (float*)(E.ws + ua.shift);
+                    if (s.ub >= 0) {
+                        const Step& ub = E.steps[s.ub];
+                        a.r2 = E.ws + E.tens[ub.raw].off; a.scale2 = (float*)(E.ws + ub.scale); a.shift2 = (float*)(E.ws + ub.shift);
+                    }
+                    a.res = s.res >= 0 ? E.ws + E.tens[s.res].off : nullptr;
+                    a.out = E.ws + E.tens[s.out].off;
+                    a.N = E.N; a.C = E.tens[s.out].C; a.V = E.vol(E.tens[s.out].lvl);
+                    launch_gn_act(a, E.dtype, st);
+                });
+            } else if (s.type == ST_POOL) {
+                E.fwd_ops.push_back([this_ = &E, si](hipStream_t st) {
+                    seg_engine& E = *this_;
+                    const Step& s = E.steps[si];
+                    const Ten& ti = E.tens[s.in];
+                    PoolArgs a{};
+                    a.in = E.ws + ti.off; a.out = E.ws + E.tens[s.out].off;
+                    a.N = E.N; a.D = E.dim_d(ti.lvl); a.H = E.dim_h(ti.lvl); a.W = E.dim_w(ti.lvl); a.C = ti.C;
+                    a.pd = E.ndim == 3 ? 2 : 1; a.ph = 2; a.pw = 2;
+                    launch_maxpool_fwd(a, E.dtype, st);
+                });
+            } else {   // HEAD
+                E.fwd_ops.push_back([this_ = &E, si](hipStream_t st) {
+                    seg_engine& E = *this_;
+                    const Step& s = E.steps[si];
+                    HeadArgs a;
+                    a.in = E.ws + E.tens[s.in].off; a.w = E.p + E.params[s.w].off; a.bias = E.p + E.params[s.b].off;
+                    a.logits = E.cur_logits; a.probs = E.cur_probs;
+                    a.N = E.N; a.V = (int)E.vol(0); a.Cin = s.Cin; a.C = s.Cout;
+                    launch_head_fwd(a, E.dtype, st);
+                });
+            }
+        }
+
+        // ------------------------------------------------------------------ backward schedule
+        E.bwd_ops.push_back([this_ = &E](hipStream_t st) {
+            seg_engine& E = *this_;
+            (void)hipMemsetAsync(E.ws + E.off_Q, 0, E.Q_bytes, st);
+        });
+        for (int si = (int)E.steps.size() - 1; si >= 0; --si) {
+            Step& s = E.steps[si];
+            if (s.type == ST_HEAD) {
+                const int gin = new_grad(s.in);
+                E.tens[s.in].grads.push_back(gin);
+                E.bwd_ops.push_back([this_ = &E, si, gin](hipStream_t st) {
+                    seg_engine& E = *this_;
+                    const Step& s = E.steps[si];
+                    HeadBwdArgs a;
+                    a.in = E.ws + E.tens[s.in].off; a.w = E.p + E.params[s.w].off; a.dlogits = E.cur_dlogits;
+                    a.din = E.ws + E.tens[gin].off;
+                    a.dw = E.g + E.params[s.w].off; a.db = E.g + E.params[s.b].off;
+                    a.N = E.N; a.V = (int)E.vol(0); a.Cin = s.Cin; a.C = s.Cout;
+                    launch_head_bwd(a, E.dtype, st);
+                });
+            } else if (s.type == ST_POOL) {
+                std::vector<int> gl = E.tens[s.out].grads;
+                if (gl.size() != 1) { g_err = "internal: pool output needs exactly one gradient"; return; }
+                const int gin = new_grad(s.in);
+                E.tens[s.in].grads.push_back(gin);
+                const int gout = gl[0];
+                E.bwd_ops.push_back([this_ = &E, si, gin, gout](hipStream_t st) {
+                    seg_engine& E = *this_;
+                    const Step& s = E.steps[si];
+                    const Ten& ti = E.tens[s.in];
+                    PoolArgs a{};
+                    a.in = E.ws + ti.off; a.dout = E.ws + E.tens[gout].off; a.din = E.ws + E.tens[gin].off;
+                    a.N = E.N; a.D = E.dim_d(ti.lvl); a.H = E.dim_h(ti.lvl); a.W = E.dim_w(ti.lvl); a.C = ti.C;
+                    a.pd = E.ndim == 3 ? 2 : 1; a.ph = 2; a.pw = 2;
+                    launch_maxpool_bwd(a, E.dtype, st);
+                });
+            } else if (s.type == ST_ACT) {
+                std::vector<int> gl = E.tens[s.out].grads;
+                if (gl.empty() || gl.size() > 3) { g_err = "internal: unsupported gradient fan-in"; return; }
+                if (s.res >= 0) for (int gi : gl) E.tens[s.res].grads.push_back(gi);
+                for (int ui : {s.ua, s.ub}) {
+                    if (ui < 0) continue;
+                    Step& u = E.steps[ui];
+                    u.draw = new_grad(u.raw);
+                    E.bwd_ops.push_back([this_ = &E, ui, gl](hipStream_t st) {
+                        seg_engine& E = *this_;
+                        const Step& u = E.steps[ui];
+                        const Ten& r = E.tens[u.raw];
+                        GnBwdArgs a{};
+                        a.ndy = (int)gl.size();
+                        for (int i = 0; i < a.ndy; ++i) a.dy[i] = E.ws + E.tens[gl[i]].off;
+                        a.r = E.ws + r.off;
+                        a.scale = (float*)(E.ws + u.scale); a.shift = (float*)(E.ws + u.shift);
+                        a.Q = (double*)(E.ws + u.Q); a.coef = (float*)(E.ws + u.coef);
+                        a.dr = E.ws + E.tens[u.draw].off;
+                        a.N = E.N; a.C = r.C; a.V = E.vol(r.lvl);
+                        launch_gn_bwd_reduce(a, E.dtype, st);
+                        GnBwdFinArgs f{};
+                        f.Q = a.Q; f.stats = (double*)(E.ws + u.stats);
+                        f.gamma = E.p + E.params[u.gn_w].off;
+                        f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
+                                 : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                        f.mask_ld = E.ld_mask();
+                        f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
+                        f.dgamma = E.g + E.params[u.gn_w].off; f.dbeta = E.g + E.params[u.gn_b].off;
+                        f.dbias = u.b >= 0 ? E.g + E.params[u.b].off : nullptr;
+                        f.coef = (float*)(E.ws + u.coef);
+                        f.N = E.N; f.C = r.C; f.V = a.V;
+                        launch_gn_bwd_finalize(f, st);
+                        launch_gn_bwd_apply(a, E.dtype, st);
+                    });
+                }
+            } else {   // UNIT: weight gradient + data gradient given d(raw)
+                int draw = s.draw;
+                if (s.gn_w < 0) {
+                    // plain ConvTranspose (UNet up-conv): d(raw) is the (single) gradient of its output tensor
+                    std::vector<int> gl = E.tens[s.raw].grads;
+                    if (gl.size() != 1) { g_err = "internal: plain conv output needs exactly one gradient"; return; }
+                    draw = gl[0];
+                }
+                if (draw < 0) { g_err = "internal: unit without output gradient"; return; }
+                const bool need_dg0 = !E.tens[s.in0].image;
+                int g0 = -1, g1 = -1;
+                if (need_dg0) { g0 = new_grad(s.in0); E.tens[s.in0].grads.push_back(g0); }
+                if (s.in1 >= 0) { g1 = new_grad(s.in1); E.tens[s.in1].grads.push_back(g1); }
+                E.bwd_ops.push_back([this_ = &E, si, draw, g0, g1](hipStream_t st) {
+                    seg_engine& E = *this_;
+                    const Step& s = E.steps[si];
+                    const Ten& i0 = E.tens[s.in0];
+                    const Ten& ro = E.tens[s.raw];
+                    const int li = i0.lvl, lo = ro.lvl;
+                    const int T = (s.ck == CK_K3 || s.ck == CK_STEM3) ? (E.ndim == 3 ? 27 : 9)
+                                  : (s.ck == CK_K2S2 || s.ck == CK_KT) ? (E.ndim == 3 ? 8 : 4) : 1;
+                    // ---- bias gradient of convs without GroupNorm
+                    if (s.gn_w < 0 && s.b >= 0)
+                        launch_colsum(E.ws + E.tens[draw].off, E.g + E.params[s.b].off, (long long)E.N * E.vol(lo), s.Cout, E.dtype, st);
+                    // ---- weight gradient
+                    WgradArgs w{};
+                    w.dw = E.g + E.params[s.w].off; w.N = E.N; w.sT = 1; w.sQ = T;
+                    if (s.ck == CK_KT) {
+                        // dW[ci][co][a] = sum_coarse X[m][ci] * dY[2m+a][co]
+                        w.dr = E.ws + i0.off; w.P = s.Cin;
+                        w.x0 = E.ws + E.tens[draw].off; w.C0 = s.Cout; w.x1 = nullptr; w.C1 = 0; w.Q = s.Cout;
+                        w.ID = E.dim_d(lo); w.IH = E.dim_h(lo); w.IW = E.dim_w(lo);
+                        w.OD = E.dim_d(li); w.OH = E.dim_h(li); w.OW = E.dim_w(li);
+                        w.sd = E.ndim == 3 ? 2 : 1; w.sh = 2; w.sw = 2;
+                        w.taps = make_taps(E.ndim, 2, 0);
+                        w.sP = (long long)s.Cout * T;
+                    } else {
+                        w.dr = E.ws + E.tens[draw].off; w.P = s.Cout;
+                        w.x0 = E.ws + i0.off; w.C0 = i0.C;
+                        w.x1 = s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr;
+                        w.C1 = s.in1 >= 0 ? E.tens[s.in1].C : 0;
+                        w.Q = s.Cin;
+                        w.ID = E.dim_d(li); w.IH = E.dim_h(li); w.IW = E.dim_w(li);
+                        w.OD = E.dim_d(lo); w.OH = E.dim_h(lo); w.OW = E.dim_w(lo);
+                        const int k = (s.ck == CK_K3 || s.ck == CK_STEM3) ? 3 : s.ck == CK_K2S2 ? 2 : 1;
+                        const int str = s.ck == CK_K2S2 ? 2 : 1;
+                        w.sd = E.ndim == 3 ? str : 1; w.sh = str; w.sw = str;
+                        w.taps = make_taps(E.ndim, k, k == 3 ? 1 : 0);
+                        w.sP = (long long)s.Cin * T;
+                        if (s.ck == CK_STEM3 || s.ck == CK_STEM1) { w.stem = 1; w.Q = T * s.Cin; }
+                    }
+                    launch_wgrad(w, E.dtype, st);
+                    // ---- data gradient(s)
+                    if (g0 < 0 && g1 < 0) return;
+                    ConvArgs a{};
+                    a.in0 = E.ws + E.tens[draw].off; a.C0 = s.Cout; a.in1 = nullptr; a.C1 = 0;
+                    a.bias = nullptr; a.stats = nullptr; a.N = E.N;
+                    if (s.ck == CK_K2S2) {
+                        // d_in[2o+a][ci] = sum_co draw[o][co] W[co][ci][a] : scatter GEMM over coarse rows
+                        a.scatter = 1; a.w = E.ws + s.wp_dg0; a.out = E.ws + E.tens[g0].off;
+                        a.ID = a.OD = E.dim_d(lo); a.IH = a.OH = E.dim_h(lo); a.IW = a.OW = E.dim_w(lo);
+                        a.FD = E.dim_d(li); a.FH = E.dim_h(li); a.FW = E.dim_w(li);
+                        a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
+                        a.taps = make_taps(E.ndim, 2, 0);
+                        a.Cout = s.Cin; a.K = s.Cout; a.Ngemm = a.taps.n * s.Cin; a.Kpad = (a.K + 31) / 32 * 32;
+                        launch_conv_igemm(a, E.dtype, st);
+                    } else if (s.ck == CK_KT) {
+                        // d_X[i][ci] = sum_{a,co} dY[2i+a][co] Wt[ci][co][a] : gather, stride 2 over the fine gradient
+                        a.scatter = 0; a.w = E.ws + s.wp_dg0; a.out = E.ws + E.tens[g0].off;
+                        a.ID = E.dim_d(lo); a.IH = E.dim_h(lo); a.IW = E.dim_w(lo);
+                        a.OD = E.dim_d(li); a.OH = E.dim_h(li); a.OW = E.dim_w(li);
+                        a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
+                        a.taps = make_taps(E.ndim, 2, 0);
+                        a.Cout = s.Cin; a.Ngemm = s.Cin; a.K = a.taps.n * s.Cout; a.Kpad = (a.K + 31) / 32 * 32;
+                        launch_conv_igemm(a, E.dtype, st);
+                    } else {
+                        // conv 3^d / 1^d: gather conv of d(raw) with flipped taps, once per concat source
+                        a.scatter = 0;
+                        a.ID = a.OD = E.dim_d(lo); a.IH = a.OH = E.dim_h(lo); a.IW = a.OW = E.dim_w(lo);
+                        a.sd = a.sh = a.sw = 1;
+                        const int k = s.ck == CK_K3 ? 3 : 1;
+                        a.taps = make_taps(E.ndim, k, k == 3 ? 1 : 0);
+                        a.K = a.taps.n * s.Cout; a.Kpad = (a.K + 31) / 32 * 32;
+                        if (g0 >= 0) {
+                            a.w = E.ws + s.wp_dg0; a.out = E.ws + E.tens[g0].off; a.Cout = a.Ngemm = E.tens[s.in0].C;
+                            launch_conv_igemm(a, E.dtype, st);
+                        }
+                        if (g1 >= 0) {
+                            a.w = E.ws + s.wp_dg1; a.out = E.ws + E.tens[g1].off; a.Cout = a.Ngemm = E.tens[s.in1].C;
+                            launch_conv_igemm(a, E.dtype, st);
+                        }
+                    }
+                });
+            }
+        }
+        E.ws_bytes = align_up(cur, 4096);
+        E.planned = true;
+        (void)dt;
+    }
+};
+
+int check_handle(seg_handle h) { return h ? 0 : fail("null handle"); }
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_features, int dtype, seg_handle* out) {
+    if (!out) return fail("seg_create: out is null");
+    if (net_kind != SEG_NET_VNET && net_kind != SEG_NET_UNET) return fail("seg_create: unknown net kind");
+    if (ndim != 2 && ndim != 3) return fail("seg_create: ndim must be 2 or 3");
+    if (dtype < 0 || dtype > 2) return fail("seg_create: dtype must be SEG_F32/F16/BF16");
+    if (init_features != 16) return fail("seg_create: init_features must be 16 (GroupNorm(8) tiles; the reference never overrides the default)");
+    if (num_class < 1 || num_class > 8) return fail("seg_create: num_class must be in 1..8");
+    if (in_channels < 1 || in_channels > 4 || (ndim == 3 && in_channels > 1)) return fail("seg_create: in_channels must be 1 (3-D) or 1..3 (2-D)");
+    seg_engine* e = new seg_engine();
+    e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
+    e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
+    Builder b(*e);
+    if (net_kind == SEG_NET_VNET) b.build_vnet(); else b.build_unet();
+    *out = e;
+    return 0;
+}
+
+void seg_destroy(seg_handle h) { delete h; }
+
+int seg_param_count(seg_handle h) { return h ? (int)h->params.size() : -1; }
+long long seg_param_numel(seg_handle h) { return h ? h->nparam : -1; }
+int seg_param_info(seg_handle h, int index, char* name, int name_cap, int* shape8, int* ndim, long long* offset) {
+    if (check_handle(h)) return -1;
+    if (index < 0 || index >= (int)h->params.size()) return fail("seg_param_info: index out of range");
+    const Param& p = h->params[index];
+    if (name && name_cap > 0) { snprintf(name, name_cap, "%s", p.name.c_str()); }
+    if (shape8) for (size_t i = 0; i < 8; ++i) shape8[i] = i < p.shape.size() ? p.shape[i] : 0;
+    if (ndim) *ndim = (int)p.shape.size();
+    if (offset) *offset = p.off;
+    return 0;
+}
+int seg_dropout_calls(seg_handle h) { return h ? (int)h->drop_ch.size() : -1; }
+int seg_dropout_ld(seg_handle h) { return h ? h->ld_mask() : -1; }
+int seg_dropout_channels(seg_handle h, int call) {
+    if (!h || call < 0 || call >= (int)h->drop_ch.size()) return -1;
+    return h->drop_ch[call];
+}
+
+int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
+    if (check_handle(h)) return -1;
+    if (n < 1) return fail("seg_plan: batch must be >= 1");
+    if (h->ndim == 2) d = 1;
+    if ((h->ndim == 3 && (d % 16 || d < 16)) || hgt % 16 || wid % 16 || hgt < 16 || wid < 16)
+        return fail("seg_plan: spatial dims must be multiples of 16 (four 2x down-samplings)");
+    h->N = n; h->D = d; h->H = hgt; h->W = wid;
+    g_err.clear();
+    Planner pl(*h);
+    pl.plan();
+    if (!g_err.empty()) return -1;
+    h->p = nullptr; h->g = nullptr; h->ws = nullptr;
+    return 0;
+}
+long long seg_workspace_bytes(seg_handle h) { return (h && h->planned) ? (long long)h->ws_bytes : -1; }
+
+int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
+    if (check_handle(h)) return -1;
+    if (!h->planned) return fail("seg_bind: call seg_plan first");
+    if (!params || !workspace) return fail("seg_bind: params/workspace must not be null");
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)workspace) & 255) return fail("seg_bind: buffers must be 256-byte aligned");
+    h->p = params; h->g = grads; h->ws = (char*)workspace;
+    // resolve and upload the weight re-layout descriptors; reset the device-side step counter
+    std::vector<PackDesc> d = h->packdescs;
+    for (auto& x : d) {
+        x.src = h->p + (long long)(uintptr_t)x.src;
+        x.dst = h->ws + (size_t)(uintptr_t)x.dst;
+    }
+    if (hipMemcpy(h->ws + h->off_packdesc, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice) != hipSuccess)
+        return fail("seg_bind: descriptor upload failed");
+    if (hipMemset(h->ws + h->off_step, 0, 256) != hipSuccess) return fail("seg_bind: memset failed");
+    return 0;
+}
+
+int seg_pack_weights(seg_handle h, void* stream) {
+    if (check_handle(h)) return -1;
+    if (!h->ws) return fail("seg_pack_weights: not bound");
+    hipStream_t st = (hipStream_t)stream;
+    launch_pack((const PackDesc*)(h->ws + h->off_packdesc), (int)h->packdescs.size(), (int)h->pack_max, h->dtype, st);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_pack_weights: launch failed");
+}
+
+int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks, unsigned long long seed, float* logits,
+                float* probs, void* stream) {
+    if (check_handle(h)) return -1;
+    if (!h->ws) return fail("seg_forward: not bound");
+    if (!x || !logits || !probs) return fail("seg_forward: null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    h->mask_mode = mask_mode;
+    const size_t mbytes = (size_t)h->drop_ch.size() * h->N * h->ld_mask() * 4;
+    if (mask_mode == SEG_MASKS_GIVEN) {
+        if (!masks) return fail("seg_forward: SEG_MASKS_GIVEN needs a mask table");
+        (void)hipMemcpyAsync(h->ws + h->off_masks, masks, mbytes, hipMemcpyDeviceToDevice, st);
+    } else if (mask_mode == SEG_MASKS_RANDOM) {
+        launch_dropout_masks((float*)(h->ws + h->off_masks), (int)h->drop_ch.size(), h->N, h->ld_mask(), 0.2f, seed,
+                             (const int*)(h->ws + h->off_step), st);
+    }
+    h->cur_x = x; h->cur_logits = logits; h->cur_probs = probs;
+    for (auto& op : h->fwd_ops) op(st);
+    return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_forward: ") + hipGetErrorString(hipGetLastError()));
+}
+
+int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* stream) {
+    if (check_handle(h)) return -1;
+    if (!h->ws || !h->g) return fail("seg_backward: gradients not bound");
+    if (!dlogits) return fail("seg_backward: null dlogits");
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_grads) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
+    h->cur_dlogits = dlogits;
+    for (auto& op : h->bwd_ops) op(st);
+    return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));
+}
+
+int seg_set_loss_scale(seg_handle h, float scale) {
+    if (check_handle(h)) return -1;
+    if (!(scale > 0.f)) return fail("seg_set_loss_scale: scale must be positive");
+    h->loss_scale = scale;
+    return 0;
+}
+float seg_get_loss_scale(seg_handle h) { return h ? h->loss_scale : 0.f; }
+
+long long seg_loss_ws_bytes(int n, int c) { return (long long)align_up(loss_sums_count(n, c) * sizeof(double)); }
+
+static int fill_loss(LossArgs& a, const float* logits, const void* target, int label_type, int n, int c, long long v,
+                     int loss_kind, float focal_alpha, float focal_gamma, void* ws) {
+    if (!logits || !target || !ws) return fail("loss: null pointer");
+    if (c < 1 || c > 8) return fail("loss: classes must be 1..8");
+    if (loss_kind < 0 || loss_kind > 6) return fail("loss: unknown loss kind");
+    if ((c == 1) != (loss_kind <= SEG_LOSS_BINARY_CE_DICE)) return fail("loss: binary losses need C == 1, multi-class losses C > 1");
+    a.logits = logits; a.target = target; a.label_type = label_type; a.N = n; a.C = c; a.V = v; a.kind = loss_kind;
+    a.focal_alpha = focal_alpha; a.focal_gamma = focal_gamma; a.class_alpha = nullptr; a.sums = (double*)ws;
+    a.out = nullptr; a.dlogits = nullptr; a.grad_scale = 1.f;
+    return 0;
+}
+
+int seg_loss_forward(const float* logits, const void* target, int label_type, int n, int c, long long v, int loss_kind,
+                     float focal_alpha, float focal_gamma, const float* class_alpha, void* ws, float* out3, void* stream) {
+    LossArgs a;
+    if (fill_loss(a, logits, target, label_type, n, c, v, loss_kind, focal_alpha, focal_gamma, ws)) return -1;
+    if (!out3) return fail("seg_loss_forward: out3 is null");
+    a.class_alpha = class_alpha; a.out = out3;
+    launch_loss_forward(a, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_loss_forward: launch failed");
+}
+
+int seg_loss_backward(const float* logits, const void* target, int label_type, int n, int c, long long v, int loss_kind,
+                      float focal_alpha, float focal_gamma, void* ws, float grad_scale, float* dlogits, void* stream) {
+    LossArgs a;
+    if (fill_loss(a, logits, target, label_type, n, c, v, loss_kind, focal_alpha, focal_gamma, ws)) return -1;
+    if (!dlogits) return fail("seg_loss_backward: dlogits is null");
+    a.dlogits = dlogits; a.grad_scale = grad_scale;
+    launch_loss_backward(a, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_loss_backward: launch failed");
+}
+
+int seg_metric(const float* probs, const void* target, int label_type, int n, int c, long long v, void* ws, float* out2, void* stream) {
+    if (!probs || !target || !ws || !out2) return fail("seg_metric: null pointer");
+    if (c < 1 || c > 8) return fail("seg_metric: classes must be 1..8");
+    launch_metric(probs, target, label_type, n, c, v, (double*)ws, out2, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_metric: launch failed");
+}
+
+int seg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long numel, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int decoupled, float inv_scale, int check_finite, int* state, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !state) return fail("seg_adam_step: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    AdamArgs a;
+    a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = numel;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.decoupled = decoupled;
+    a.inv_scale = inv_scale; a.step = state; a.found_inf = state + 1;
+    (void)hipMemsetAsync(state + 1, 0, sizeof(int), st);
+    if (check_finite) launch_grad_check(grads, numel, state + 1, st);
+    launch_adam(a, st);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_adam_step: launch failed");
+}
+
+int seg_op_conv(const seg_conv_args* a, int dtype, void* stream) {
+    if (!a || !a->in0 || !a->w || !a->out) return fail("seg_op_conv: null pointer");
+    const int cin = a->C0 + a->C1;
+    if (cin < 8 || (cin & (cin - 1)) || a->C0 % 8) return fail("seg_op_conv: channel counts must be powers of two >= 8");
+    if (a->Cout % 16 || a->Ngemm % 16 || a->Kpad % 32 || a->Kpad < a->K) return fail("seg_op_conv: bad GEMM extents");
+    launch_conv_igemm(*a, dtype, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_conv: launch failed");
+}
+int seg_op_wgrad(const seg_wgrad_args* a, int dtype, void* stream) {
+    if (!a || !a->dr || !a->x0 || !a->dw) return fail("seg_op_wgrad: null pointer");
+    if (a->P % 16) return fail("seg_op_wgrad: P must be a multiple of 16");
+    if (a->stem ? (a->Q > 32) : (a->Q % 16 != 0)) return fail("seg_op_wgrad: bad Q");
+    launch_wgrad(*a, dtype, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_wgrad: launch failed");
+}
+int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int dtype, void* stream) {
+    if (!descs || ndesc < 1) return fail("seg_op_pack: no descriptors");
+    launch_pack(descs, ndesc, (int)max_elems, dtype, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_pack: launch failed");
+}
+int seg_abi_sizeof(int which) {
+    return which == 0 ? (int)sizeof(seg_conv_args) : which == 1 ? (int)sizeof(seg_wgrad_args) : (int)sizeof(seg_pack_desc);
+}
+
+const char* seg_last_error(void) { return g_err.c_str(); }
+
+const char* seg_build_info(void) {
+#ifdef SEG_EMU
+    return "segengine host-checker build (tests only)";
+#else
+    return "segengine gfx950";
+#endif
+}
+
+}  // extern "C"

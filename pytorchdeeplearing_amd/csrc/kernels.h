@@ -1,0 +1,164 @@
+// Launch interfaces of the gfx950 kernels (host side).  All tensors are channels-last
+// [N][D][H][W][C] in the run dtype T (f32 / f16 / bf16); statistics and gradients of parameters
+// are fp32/fp64.  Every launch is asynchronous on the given stream.
+#pragma once
+#include "../../include/segengine.h"
+#include "common.h"
+
+namespace seg {
+
+typedef seg_taps Taps;
+// Implicit-GEMM convolution arguments: see seg_conv_args in include/segengine.h
+typedef seg_conv_args ConvArgs;
+void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s);
+
+// Direct convolution for a tiny input-channel count (stem: image_channel -> features)
+struct StemArgs {
+    const void* in;     // [N][V][Cimg] T
+    const float* w;     // fp32 master weights, PyTorch layout [Cout][Cimg][taps]
+    const float* bias;  // or null
+    void* out;          // [N][V][Cout] T
+    double* stats;
+    int N, D, H, W, Cimg, Cout;
+    Taps taps;
+};
+void launch_conv_stem(const StemArgs& a, int dtype, hipStream_t s);
+
+// 1^d head: logits[n][c][v] (planar fp32) = act[n][v][:] . w[c][:] + b[c]; probs = sigmoid/softmax
+struct HeadArgs {
+    const void* in;     // [M][Cin] T
+    const float* w;     // fp32 [C][Cin]
+    const float* bias;  // [C]
+    float* logits;      // [N][C][V]
+    float* probs;       // [N][C][V]
+    int N, V, Cin, C;
+};
+void launch_head_fwd(const HeadArgs& a, int dtype, hipStream_t s);
+
+struct HeadBwdArgs {
+    const void* in;        // activated input [M][Cin] T
+    const float* w;        // [C][Cin]
+    const float* dlogits;  // [N][C][V] fp32 (already multiplied by the loss scale)
+    void* din;             // [M][Cin] T
+    float* dw;             // [C][Cin] +=
+    float* db;             // [C] +=
+    int N, V, Cin, C;
+};
+void launch_head_bwd(const HeadBwdArgs& a, int dtype, hipStream_t s);
+
+// GroupNorm(8) finalize: stats -> per-(n,c) scale/shift (dropout multiplier folded in) + mean/rstd
+struct GnFinArgs {
+    const double* stats;  // [N][C][2]
+    const float* gamma;
+    const float* beta;
+    const float* mask;    // [N][mask_ld] dropout multipliers or null (eval)
+    int mask_ld;
+    float* scale;         // [N][C]
+    float* shift;         // [N][C]
+    float* mean;          // [N][8]
+    float* rstd;          // [N][8]
+    int N, C;
+    long long V;
+    float eps;
+};
+void launch_gn_finalize(const GnFinArgs& a, hipStream_t s);
+
+// y = relu(scale1*r1+shift1) [+ relu(scale2*r2+shift2)] [+ res]
+struct ActArgs {
+    const void* r1; const float* scale1; const float* shift1;
+    const void* r2; const float* scale2; const float* shift2;
+    const void* res;
+    void* out;
+    int N, C;
+    long long V;
+};
+void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s);
+
+// GroupNorm+dropout+ReLU backward, pass 1: Q[n][c] = {sum dzr, sum dzr*r}, dzr = (sum_i dy_i)*[scale*r+shift>0]
+struct GnBwdArgs {
+    const void* dy[3]; int ndy;
+    const void* r;
+    const float* scale; const float* shift;    // forward scale/shift [N][C]
+    double* Q;                                  // [N][C][2]
+    const float* coef;                          // pass 2: [N][C][3] (A,B,Cc)
+    void* dr;                                   // pass 2 output T
+    int N, C;
+    long long V;
+};
+void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
+void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s);
+
+struct GnBwdFinArgs {
+    const double* Q;       // [N][C][2]
+    const double* stats;   // forward [N][C][2]
+    const float* gamma;
+    const float* mask; int mask_ld;
+    const float* mean; const float* rstd;   // [N][8]
+    float* dgamma; float* dbeta;            // += (fp32 master-grad layout)
+    float* dbias;                           // conv bias grad += or null
+    float* coef;                            // [N][C][3]
+    int N, C;
+    long long V;
+};
+void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s);
+
+// Weight gradient: see seg_wgrad_args in include/segengine.h
+typedef seg_wgrad_args WgradArgs;
+void launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s);
+
+struct PoolArgs {
+    const void* in; void* out;       // fwd: in fine, out coarse
+    const void* dout; void* din;     // bwd
+    int N, D, H, W, C;               // fine dims
+    int pd, ph, pw;                  // window/stride (1 or 2)
+};
+void launch_maxpool_fwd(const PoolArgs& a, int dtype, hipStream_t s);
+void launch_maxpool_bwd(const PoolArgs& a, int dtype, hipStream_t s);
+
+// fp32 NC[D]HW image -> channels-last T
+void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s);
+
+// Generic weight re-layout: see seg_pack_desc in include/segengine.h
+typedef seg_pack_desc PackDesc;
+void launch_pack(const PackDesc* descs_dev, int ndesc, int max_rows, int dtype, hipStream_t s);
+
+// Losses on planar fp32 logits [N][C][V]
+enum LossKind { L_BIN_DICE = 0, L_BIN_CE = 1, L_BIN_FOCAL = 2, L_BIN_CE_DICE = 3, L_MC_CE = 4, L_MC_FOCAL = 5, L_MC_DICE = 6 };
+struct LossArgs {
+    const float* logits;
+    const void* target; int label_type;
+    int N, C; long long V;
+    int kind;
+    float focal_alpha, focal_gamma;
+    const float* class_alpha;   // [C] (MutilDiceLoss) or null -> ones
+    double* sums;               // workspace, zeroed by the launcher
+    float* out;                 // [0]=loss [1]=dice metric [2]=iou metric
+    float* dlogits;             // [N][C][V] or null
+    float grad_scale;           // loss scale folded into dlogits
+};
+size_t loss_sums_count(int N, int C);
+void launch_loss_forward(const LossArgs& a, hipStream_t s);    // reduce + finalize (writes out[], coefficient block in sums)
+void launch_loss_backward(const LossArgs& a, hipStream_t s);   // dlogits from the finalized coefficients
+
+// dice / iou on probabilities (model/metric.py): out2 = {dice, iou}; sums = 3*N*C doubles (zeroed by the launcher)
+void launch_metric(const float* probs, const void* target, int label_type, int N, int C, long long V, double* sums, float* out2, hipStream_t s);
+// out[c] += sum_m x[m][c]   (bias gradient of a conv without GroupNorm)
+void launch_colsum(const void* x, float* out, long long M, int C, int dtype, hipStream_t s);
+
+// Fused AdamW / Adam over the flat fp32 buffers; also clears nothing (grads are re-zeroed by the engine)
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    long long n;
+    float lr, beta1, beta2, eps, weight_decay;
+    int decoupled;          // 1 AdamW, 0 Adam (L2 folded in the gradient)
+    float inv_scale;        // 1/loss_scale
+    int* step;              // device step counter (incremented by the kernel launch)
+    int* found_inf;         // device flag: when nonzero the update is skipped
+};
+void launch_grad_check(const float* g, long long n, int* found_inf, hipStream_t s);
+void launch_adam(const AdamArgs& a, hipStream_t s);
+
+// channel-dropout multipliers: masks[l][n][ld] in {0, 1/(1-p)}
+void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s);
+
+}  // namespace seg

@@ -1,0 +1,501 @@
+// Memory-bound helpers of the segmentation engine: layout ingest, weight packing, MaxPool 2^d,
+// the seven losses + Dice/IoU metrics (model/losses.py, model/metric.py of the reference), fused
+// Adam/AdamW (torch.optim semantics, model/modelVNet.py:548, model/modelUnet.py:849) and the
+// channel-dropout multiplier generator.
+#include "kernels.h"
+
+namespace seg {
+namespace {
+
+inline int ew_blocks(long long total_threads, int cap = 16384) {
+    long long b = (total_threads + 255) / 256;
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+// ---------------------------------------------------------------- ingest: fp32 NC[D]HW -> T N[D]HWC
+template <class T>
+__global__ __launch_bounds__(256) void ingest_kernel(const float* x, T* out, int N, int C, long long V) {
+    const long long total = (long long)N * V * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long nv = i / C;
+        const long long n = nv / V, v = nv % V;
+        out[i] = from_f<T>(x[(n * C + c) * V + v]);
+    }
+}
+
+// ---------------------------------------------------------------- weight packing
+template <class T>
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs) {
+    const PackDesc d = descs[blockIdx.y];
+    const long long rows = (long long)d.R1 * d.R2, total = rows * d.Kpad;
+    const int K = d.T * d.Cc;
+    T* dst = (T*)d.dst;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int k = (int)(i % d.Kpad);
+        const long long row = i / d.Kpad;
+        float v = 0.f;
+        if (k < K) {
+            const int t = k / d.Cc, c = k % d.Cc;
+            const int tt = d.flipT ? (d.T - 1 - t) : t;
+            const long long r1 = row / d.R2, r2 = row % d.R2;
+            v = d.src[r1 * d.s1 + r2 * d.s2 + tt * d.sT + c * d.sC];
+        }
+        dst[i] = from_f<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------- MaxPool (kernel = stride = p)
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolArgs a) {
+    const int OD = a.D / a.pd, OH = a.H / a.ph, OW = a.W / a.pw, CPR = a.C / 8;
+    const long long total = (long long)a.N * OD * OH * OW * CPR;
+    const T* in = (const T*)a.in;
+    T* out = (T*)a.out;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cc = (int)(i % CPR);
+        long long o = i / CPR;
+        const int ow = (int)(o % OW); o /= OW;
+        const int oh = (int)(o % OH); o /= OH;
+        const int od = (int)(o % OD);
+        const long long n = o / OD;
+        float best[8];
+        bool first = true;
+        for (int dz = 0; dz < a.pd; ++dz)
+            for (int dy = 0; dy < a.ph; ++dy)
+                for (int dx = 0; dx < a.pw; ++dx) {
+                    const long long vox = ((n * a.D + od * a.pd + dz) * a.H + oh * a.ph + dy) * a.W + ow * a.pw + dx;
+                    const vec<T, 8> x = load8(in + vox * a.C + cc * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xv = to_f(x[j]);
+                        if (first || xv > best[j]) best[j] = xv;
+                    }
+                    first = false;
+                }
+        vec<T, 8> r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = from_f<T>(best[j]);
+        store8(out + i * 8, r);
+    }
+}
+
+// gradient goes to the FIRST maximum of each window in (d,h,w) scan order (ATen max_pool backward)
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolArgs a) {
+    const int OD = a.D / a.pd, OH = a.H / a.ph, OW = a.W / a.pw, CPR = a.C / 8;
+    const long long total = (long long)a.N * OD * OH * OW * CPR;
+    const T* in = (const T*)a.in;
+    const T* dout = (const T*)a.dout;
+    T* din = (T*)a.din;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cc = (int)(i % CPR);
+        long long o = i / CPR;
+        const int ow = (int)(o % OW); o /= OW;
+        const int oh = (int)(o % OH); o /= OH;
+        const int od = (int)(o % OD);
+        const long long n = o / OD;
+        float best[8];
+        int arg[8];
+        int pos = 0;
+        for (int dz = 0; dz < a.pd; ++dz)
+            for (int dy = 0; dy < a.ph; ++dy)
+                for (int dx = 0; dx < a.pw; ++dx, ++pos) {
+                    const long long vox = ((n * a.D + od * a.pd + dz) * a.H + oh * a.ph + dy) * a.W + ow * a.pw + dx;
+                    const vec<T, 8> x = load8(in + vox * a.C + cc * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xv = to_f(x[j]);
+                        if (pos == 0 || xv > best[j]) { best[j] = xv; arg[j] = pos; }
+                    }
+                }
+        const vec<T, 8> g = load8(dout + i * 8);
+        pos = 0;
+        for (int dz = 0; dz < a.pd; ++dz)
+            for (int dy = 0; dy < a.ph; ++dy)
+                for (int dx = 0; dx < a.pw; ++dx, ++pos) {
+                    const long long vox = ((n * a.D + od * a.pd + dz) * a.H + oh * a.ph + dy) * a.W + ow * a.pw + dx;
+                    vec<T, 8> r;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] = (arg[j] == pos) ? g[j] : from_f<T>(0.f);
+                    store8(din + vox * a.C + cc * 8, r);
+                }
+    }
+}
+
+// ---------------------------------------------------------------- losses + metrics
+constexpr int MAXCLS = 8;
+constexpr int S_GLOBAL = 0;                 // [0]=sum p*y [1]=sum p [2]=sum y [3]=sum bce|nll [4]=sum focal
+constexpr int S_CLASS = 8;                  // + 3*c : I_c, P_c, Y_c
+constexpr int S_METRIC = S_CLASS + 3 * MAXCLS;   // + ((n*C + c)*3) : inter, msum, ysum of thresholded masks
+inline __host__ __device__ int s_coef(int N, int C) { return S_METRIC + 3 * N * C; }   // + 4 + 2*MAXCLS coefficients
+
+__device__ __forceinline__ float bce_with_logits(float z, float y) {
+    return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
+}
+
+// grid = (slabs, N); one block reduces LOSS_VPB voxels of one sample
+constexpr int LOSS_VPB = 256 * 16;
+__global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
+    const int n = blockIdx.y, tid = threadIdx.x, C = a.C;
+    const long long v0 = (long long)blockIdx.x * LOSS_VPB;
+    const long long v1 = (v0 + LOSS_VPB < a.V) ? v0 + LOSS_VPB : a.V;
+    float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float cls[MAXCLS][3], met[MAXCLS][3];
+    for (int c = 0; c < MAXCLS; ++c)
+        for (int j = 0; j < 3; ++j) { cls[c][j] = 0.f; met[c][j] = 0.f; }
+    if (C == 1) {
+        for (long long v = v0 + tid; v < v1; v += 256) {
+            const long long i = (long long)n * a.V + v;
+            const float z = a.logits[i];
+            const float y = (float)load_label(a.target, a.label_type, i);
+            const float p = 1.f / (1.f + expf(-z));
+            g[0] += p * y; g[1] += p; g[2] += y;
+            const float b = bce_with_logits(z, y);
+            g[3] += b;
+            const float pt = expf(-b);
+            g[4] += a.focal_alpha * powf(1.f - pt, a.focal_gamma) * b;
+            const float mk = p > 0.5f ? 1.f : 0.f;
+            met[0][0] += mk * y; met[0][1] += mk; met[0][2] += y;
+        }
+    } else {
+        for (long long v = v0 + tid; v < v1; v += 256) {
+            const int t = load_label(a.target, a.label_type, (long long)n * a.V + v);
+            float z[MAXCLS], mx = -3.0e38f;
+            for (int c = 0; c < C; ++c) { z[c] = a.logits[((long long)n * C + c) * a.V + v]; mx = fmaxf(mx, z[c]); }
+            float se = 0.f, e[MAXCLS];
+            for (int c = 0; c < C; ++c) { e[c] = expf(z[c] - mx); se += e[c]; }
+            const float inv = 1.f / se;
+            const float lse = mx + logf(se);
+            float zt = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float p = e[c] * inv;
+                const float y = (c == t) ? 1.f : 0.f;
+                if (c == t) zt = z[c];
+                cls[c][0] += y * p; cls[c][1] += p; cls[c][2] += y;
+                const float mk = p > 0.5f ? 1.f : 0.f;
+                met[c][0] += mk * y; met[c][1] += mk; met[c][2] += y;
+            }
+            const float nll = lse - zt;
+            g[3] += nll;
+            const float pt = expf(-nll);
+            g[4] += powf(1.f - pt, a.focal_gamma) * nll;
+        }
+    }
+    const int lane = tid & 63;
+    for (int j = 0; j < 5; ++j) {
+        const float s = wave_sum(g[j]);
+        if (lane == 0 && s != 0.f) atomicAdd(a.sums + S_GLOBAL + j, (double)s);
+    }
+    for (int c = 0; c < C; ++c)
+        for (int j = 0; j < 3; ++j) {
+            if (C > 1) {
+                const float s = wave_sum(cls[c][j]);
+                if (lane == 0 && s != 0.f) atomicAdd(a.sums + S_CLASS + 3 * c + j, (double)s);
+            }
+            const float m = wave_sum(met[c][j]);
+            if (lane == 0 && m != 0.f) atomicAdd(a.sums + S_METRIC + ((long long)n * C + c) * 3 + j, (double)m);
+        }
+}
+
+// single block: scalar loss, metrics and the coefficients consumed by the backward pass
+__global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
+    if (threadIdx.x != 0) return;
+    const int C = a.C, N = a.N;
+    double* S = a.sums;
+    double* K = S + s_coef(N, C);
+    const double smooth = 1e-5, eps = 1e-7;
+    const double Ntot = (double)N * (double)a.V;
+    double loss = 0.0;
+    for (int i = 0; i < 4 + 2 * MAXCLS; ++i) K[i] = 0.0;
+    if (C == 1) {
+        const double I = S[0], P = S[1], Y = S[2];
+        double D = P + Y + smooth, c0 = 0.0;
+        if (D < eps) D = eps; else c0 = (2.0 * I + smooth) / (D * D);
+        const double dice = 1.0 - (2.0 * I + smooth) / D;
+        const double bce = S[3] / Ntot, focal = S[4] / Ntot;
+        if (a.kind == L_BIN_DICE) loss = dice;
+        else if (a.kind == L_BIN_CE) loss = bce;
+        else if (a.kind == L_BIN_FOCAL) loss = focal;
+        else loss = bce + dice;
+        K[0] = -2.0 / D;      // d dice / d p_i = K0*y_i + K1
+        K[1] = c0;
+        K[2] = 1.0 / Ntot;
+    } else {
+        int cnt = 0;
+        for (int c = 0; c < C; ++c) cnt += S[S_CLASS + 3 * c + 2] > 0.0;
+        double dl = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const double I = S[S_CLASS + 3 * c], P = S[S_CLASS + 3 * c + 1], Y = S[S_CLASS + 3 * c + 2];
+            const double al = a.class_alpha ? (double)a.class_alpha[c] : 1.0;
+            const double D = Y + P + smooth;
+            double dice = (2.0 * I + smooth) / D;
+            const bool present = Y > 0.0;
+            double ac = 0.0, bc = 0.0;
+            if (present && dice >= eps) {
+                ac = -al / cnt * 2.0 / D;
+                bc = al / cnt * (2.0 * I + smooth) / (D * D);
+            }
+            if (dice < eps) dice = eps;
+            if (present) dl += -dice * al / cnt;
+            K[4 + c] = ac;                 // d L / d p_c(v) = ac*y_c(v) + bc
+            K[4 + MAXCLS + c] = bc;
+        }
+        if (a.kind == L_MC_DICE) loss = dl;
+        else if (a.kind == L_MC_CE) loss = S[3] / Ntot;
+        else loss = S[4] / Ntot;
+        K[2] = 1.0 / Ntot;
+    }
+    // metrics: model/metric.py:146-181 (binary: class 0; multi-class: classes 1..C-1)
+    double dsum = 0.0, isum = 0.0;
+    const int c_lo = (C == 1) ? 0 : 1;
+    for (int c = c_lo; c < C; ++c) {
+        double dc = 0.0, ic = 0.0;
+        for (int n = 0; n < N; ++n) {
+            const double* m = S + S_METRIC + ((long long)n * C + c) * 3;
+            dc += (2.0 * m[0] + 1e-5) / (m[1] + m[2] + 1e-5);
+            ic += (m[0] + 1e-5) / (m[1] + m[2] - m[0] + 1e-5);
+        }
+        dsum += dc / N; isum += ic / N;
+    }
+    const int nc = (C == 1) ? 1 : (C - 1);
+    a.out[0] = (float)loss;
+    a.out[1] = (float)(dsum / nc);
+    a.out[2] = (float)(isum / nc);
+}
+
+__global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
+    const int C = a.C;
+    const double* K = a.sums + s_coef(a.N, C);
+    const long long total = (long long)a.N * a.V;
+    const float gs = a.grad_scale;
+    if (C == 1) {
+        const float k0 = (float)K[0], k1 = (float)K[1], kn = (float)K[2];
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const float z = a.logits[i];
+            const float y = (float)load_label(a.target, a.label_type, i);
+            const float p = 1.f / (1.f + expf(-z));
+            float dz = 0.f;
+            if (a.kind == L_BIN_DICE || a.kind == L_BIN_CE_DICE) dz += (k0 * y + k1) * p * (1.f - p);
+            if (a.kind == L_BIN_CE || a.kind == L_BIN_CE_DICE) dz += (p - y) * kn;
+            if (a.kind == L_BIN_FOCAL) {
+                const float b = bce_with_logits(z, y);
+                const float pt = expf(-b), om = 1.f - pt;
+                const float w = powf(om, a.focal_gamma) + a.focal_gamma * powf(om, a.focal_gamma - 1.f) * pt * b;
+                dz += a.focal_alpha * w * (p - y) * kn;
+            }
+            a.dlogits[i] = dz * gs;
+        }
+    } else {
+        const float kn = (float)K[2];
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const long long n = i / a.V, v = i % a.V;
+            const int t = load_label(a.target, a.label_type, i);
+            float z[MAXCLS], p[MAXCLS], mx = -3.0e38f, se = 0.f;
+            for (int c = 0; c < C; ++c) { z[c] = a.logits[(n * C + c) * a.V + v]; mx = fmaxf(mx, z[c]); }
+            for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - mx); se += p[c]; }
+            const float inv = 1.f / se;
+            for (int c = 0; c < C; ++c) p[c] *= inv;
+            if (a.kind == L_MC_DICE) {
+                float gsum = 0.f, gc[MAXCLS];
+                for (int c = 0; c < C; ++c) {
+                    gc[c] = (float)K[4 + c] * ((c == t) ? 1.f : 0.f) + (float)K[4 + MAXCLS + c];
+                    gsum += p[c] * gc[c];
+                }
+                for (int c = 0; c < C; ++c) a.dlogits[(n * C + c) * a.V + v] = p[c] * (gc[c] - gsum) * gs;
+            } else {
+                float w = kn;
+                if (a.kind == L_MC_FOCAL) {
+                    const float nll = (mx + logf(se)) - z[t];
+                    const float pt = expf(-nll), om = 1.f - pt;
+                    w *= powf(om, a.focal_gamma) + a.focal_gamma * powf(om, a.focal_gamma - 1.f) * pt * nll;
+                }
+                for (int c = 0; c < C; ++c)
+                    a.dlogits[(n * C + c) * a.V + v] = w * (p[c] - ((c == t) ? 1.f : 0.f)) * gs;
+            }
+        }
+    }
+}
+
+// metric on probabilities: thresholded masks per (sample, class)
+__global__ __launch_bounds__(256) void metric_reduce_kernel(const float* probs, const void* target, int lt, int N, int C, long long V, double* sums) {
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const long long v0 = (long long)blockIdx.x * LOSS_VPB;
+    const long long v1 = (v0 + LOSS_VPB < V) ? v0 + LOSS_VPB : V;
+    const int c_lo = (C == 1) ? 0 : 1;
+    for (int c = c_lo; c < C; ++c) {
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        for (long long v = v0 + tid; v < v1; v += 256) {
+            const int t = load_label(target, lt, (long long)n * V + v);
+            const float y = (C == 1) ? (float)t : ((t == c) ? 1.f : 0.f);
+            const float mk = probs[((long long)n * C + c) * V + v] > 0.5f ? 1.f : 0.f;
+            m0 += mk * y; m1 += mk; m2 += y;
+        }
+        m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2);
+        if ((tid & 63) == 0) {
+            double* d = sums + ((long long)n * C + c) * 3;
+            atomicAdd(d, (double)m0); atomicAdd(d + 1, (double)m1); atomicAdd(d + 2, (double)m2);
+        }
+    }
+}
+__global__ __launch_bounds__(64) void metric_finalize_kernel(int N, int C, const double* sums, float* out2) {
+    if (threadIdx.x != 0) return;
+    double dsum = 0.0, isum = 0.0;
+    const int c_lo = (C == 1) ? 0 : 1;
+    for (int c = c_lo; c < C; ++c) {
+        double dc = 0.0, ic = 0.0;
+        for (int n = 0; n < N; ++n) {
+            const double* m = sums + ((long long)n * C + c) * 3;
+            dc += (2.0 * m[0] + 1e-5) / (m[1] + m[2] + 1e-5);
+            ic += (m[0] + 1e-5) / (m[1] + m[2] - m[0] + 1e-5);
+        }
+        dsum += dc / N; isum += ic / N;
+    }
+    const int nc = (C == 1) ? 1 : (C - 1);
+    out2[0] = (float)(dsum / nc);
+    out2[1] = (float)(isum / nc);
+}
+
+// column sums of a [M][C] tensor (bias gradient of convs that are not followed by GroupNorm)
+template <class T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, long long M, int C) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x, CPR = C / 8, G = 256 / CPR;
+    const int cc = tid % CPR, g = tid / CPR;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    const long long rows_per_block = 4096;
+    const long long m0 = (long long)blockIdx.x * rows_per_block;
+    const long long m1 = (m0 + rows_per_block < M) ? m0 + rows_per_block : M;
+    if (tid < G * CPR)
+        for (long long m = m0 + g; m < m1; m += G) {
+            const vec<T, 8> v = load8(x + m * C + cc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += to_f(v[j]);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = s[j];
+    __syncthreads();
+    for (int col = tid; col < C; col += 256) {
+        float t = 0.f;
+        for (int k = 0; k < G; ++k) t += red[(k * CPR + col / 8) * 8 + (col & 7)];
+        atomicAdd(out + col, t);
+    }
+}
+
+// ---------------------------------------------------------------- optimiser
+__global__ __launch_bounds__(256) void grad_check_kernel(const float* g, long long n, int* found_inf) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = g[i];
+        bad |= !(fabsf(v) <= 3.0e38f);
+    }
+    if (bad) atomicOr(found_inf, 1);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    if (a.found_inf && *a.found_inf) return;
+    const int t = *a.step + 1;
+    const float bc1 = 1.f - powf(a.beta1, (float)t), bc2 = 1.f - powf(a.beta2, (float)t);
+    const float step_size = a.lr / bc1, rs_bc2 = 1.f / sqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+        float p = a.p[i], g = a.g[i] * a.inv_scale;
+        if (a.decoupled) p *= (1.f - a.lr * a.weight_decay);
+        else if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        a.m[i] = m; a.v[i] = v;
+        a.p[i] = p - step_size * m / (sqrtf(v) * rs_bc2 + a.eps);
+    }
+}
+__global__ __launch_bounds__(64) void adam_bump_kernel(int* step, const int* found_inf) {
+    if (threadIdx.x == 0 && !(found_inf && *found_inf)) *step += 1;
+}
+
+// ---------------------------------------------------------------- channel dropout multipliers
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* masks, long long total, float p, unsigned long long seed, const int* step) {
+    const unsigned long long st = step ? (unsigned long long)*step : 0ull;
+    const float keep = 1.f - p, inv = 1.f / keep;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const unsigned long long h = splitmix64(splitmix64(seed ^ (st * 0xD1B54A32D192ED03ull)) + (unsigned long long)i);
+        const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+        masks[i] = (u < keep) ? inv : 0.f;
+    }
+}
+
+}  // namespace
+
+void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s) {
+    dim3 grid(ew_blocks((long long)N * V * C));
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<float>), grid, dim3(256), 0, s, x, (float*)out, N, C, V);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<f16>), grid, dim3(256), 0, s, x, (f16*)out, N, C, V);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<bf16>), grid, dim3(256), 0, s, x, (bf16*)out, N, C, V);
+}
+
+void launch_pack(const PackDesc* descs_dev, int ndesc, int max_elems, int dtype, hipStream_t s) {
+    dim3 grid(ew_blocks(max_elems, 512), ndesc);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<float>), grid, dim3(256), 0, s, descs_dev);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<f16>), grid, dim3(256), 0, s, descs_dev);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<bf16>), grid, dim3(256), 0, s, descs_dev);
+}
+
+void launch_maxpool_fwd(const PoolArgs& a, int dtype, hipStream_t s) {
+    dim3 grid(ew_blocks((long long)a.N * (a.D / a.pd) * (a.H / a.ph) * (a.W / a.pw) * (a.C / 8)));
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(maxpool_fwd_kernel<float>), grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(maxpool_fwd_kernel<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(maxpool_fwd_kernel<bf16>), grid, dim3(256), 0, s, a);
+}
+void launch_maxpool_bwd(const PoolArgs& a, int dtype, hipStream_t s) {
+    dim3 grid(ew_blocks((long long)a.N * (a.D / a.pd) * (a.H / a.ph) * (a.W / a.pw) * (a.C / 8)));
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(maxpool_bwd_kernel<float>), grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(maxpool_bwd_kernel<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(maxpool_bwd_kernel<bf16>), grid, dim3(256), 0, s, a);
+}
+
+size_t loss_sums_count(int N, int C) { return (size_t)s_coef(N, C) + 4 + 2 * MAXCLS; }
+
+void launch_loss_forward(const LossArgs& a, hipStream_t s) {
+    (void)hipMemsetAsync(a.sums, 0, loss_sums_count(a.N, a.C) * sizeof(double), s);
+    dim3 grid(cdiv(a.V, LOSS_VPB), a.N);
+    hipLaunchKernelGGL(loss_reduce_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, a);
+}
+void launch_loss_backward(const LossArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(loss_backward_kernel, dim3(ew_blocks((long long)a.N * a.V)), dim3(256), 0, s, a);
+}
+
+void launch_metric(const float* probs, const void* target, int lt, int N, int C, long long V, double* sums, float* out2, hipStream_t s) {
+    (void)hipMemsetAsync(sums, 0, sizeof(double) * 3 * N * C, s);
+    hipLaunchKernelGGL(metric_reduce_kernel, dim3(cdiv(V, LOSS_VPB), N), dim3(256), 0, s, probs, target, lt, N, C, V, sums);
+    hipLaunchKernelGGL(metric_finalize_kernel, dim3(1), dim3(64), 0, s, N, C, (const double*)sums, out2);
+}
+
+void launch_colsum(const void* x, float* out, long long M, int C, int dtype, hipStream_t s) {
+    dim3 grid(cdiv(M, 4096));
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, out, M, C);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(colsum_kernel<f16>), grid, dim3(256), 0, s, (const f16*)x, out, M, C);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(colsum_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)x, out, M, C);
+}
+
+void launch_grad_check(const float* g, long long n, int* found_inf, hipStream_t s) {
+    hipLaunchKernelGGL(grad_check_kernel, dim3(ew_blocks(n, 2048)), dim3(256), 0, s, g, n, found_inf);
+}
+void launch_adam(const AdamArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(a.n, 4096)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, a.step, (const int*)a.found_inf);
+}
+
+void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s) {
+    const long long total = (long long)L * N * ld;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(total, 1024)), dim3(256), 0, s, masks, total, p, seed, step);
+    if (step) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, (int*)step, (const int*)nullptr);
+}
+
+}  // namespace seg

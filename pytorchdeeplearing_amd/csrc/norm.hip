@@ -1,0 +1,245 @@
+// GroupNorm(8) + channel dropout + ReLU (+ residual add), forward and backward, channels-last.
+// Reference semantics: relu(dropout3d(group_norm(conv(x)))) — networks/VNet3d.py:13-15,34-43,55-59,72-80;
+// networks/Unet3d.py:64-86.  Statistics are per (sample, group) over (C/8)*V elements, biased
+// variance, eps 1e-5 (torch.nn.GroupNorm).  The conv epilogues deliver per-(n,c) sum / sum-of-squares
+// in fp64, so the whole GN forward is: finalize (tiny) + one elementwise pass; the backward is one
+// reduction pass + finalize (tiny) + one elementwise pass.
+#include "kernels.h"
+
+namespace seg {
+namespace {
+
+// grid = N, block = 256 (C <= 256 handled per thread; larger C loops)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnFinArgs a) {
+    __shared__ double gsum[GN_GROUPS][2];
+    __shared__ float gm[GN_GROUPS], gr[GN_GROUPS];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = a.C / GN_GROUPS;
+    if (tid < GN_GROUPS) {
+        double s = 0.0, ss = 0.0;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            s += a.stats[((long long)n * a.C + c) * 2];
+            ss += a.stats[((long long)n * a.C + c) * 2 + 1];
+        }
+        const double cnt = (double)cpg * (double)a.V;
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        gm[tid] = (float)mean;
+        gr[tid] = rstd;
+        a.mean[n * GN_GROUPS + tid] = (float)mean;
+        a.rstd[n * GN_GROUPS + tid] = rstd;
+    }
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+        const int g = c / cpg;
+        const float mk = a.mask ? a.mask[(long long)n * a.mask_ld + c] : 1.f;
+        const float ga = a.gamma[c], be = a.beta[c];
+        a.scale[(long long)n * a.C + c] = mk * ga * gr[g];
+        a.shift[(long long)n * a.C + c] = mk * (be - ga * gm[g] * gr[g]);
+    }
+}
+
+// elementwise; one thread = one 8-channel chunk
+template <class T>
+__global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
+    const int CPR = a.C / 8;
+    const long long per_n = a.V * CPR, total = (long long)a.N * per_n;
+    const T* r1 = (const T*)a.r1;
+    const T* r2 = (const T*)a.r2;
+    const T* res = (const T*)a.res;
+    T* out = (T*)a.out;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / per_n);
+        const int c0 = (int)(i % CPR) * 8;
+        const vec<T, 8> x = load8(r1 + i * 8);
+        const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale1 + (long long)n * a.C + c0);
+        const vec<float, 8> sh = *(const vec<float, 8>*)(a.shift1 + (long long)n * a.C + c0);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = fmaxf(fmaf(sc[j], to_f(x[j]), sh[j]), 0.f);
+        if (r2) {
+            const vec<T, 8> x2 = load8(r2 + i * 8);
+            const vec<float, 8> sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + c0);
+            const vec<float, 8> sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] += fmaxf(fmaf(sc2[j], to_f(x2[j]), sh2[j]), 0.f);
+        }
+        if (res) {
+            const vec<T, 8> rr = load8(res + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] += to_f(rr[j]);
+        }
+        vec<T, 8> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = from_f<T>(y[j]);
+        store8(out + i * 8, o);
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void load_dy_sum(const GnBwdArgs& a, long long i, float* g) {
+    const vec<T, 8> d0 = load8((const T*)a.dy[0] + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = to_f(d0[j]);
+    if (a.ndy > 1) {
+        const vec<T, 8> d1 = load8((const T*)a.dy[1] + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += to_f(d1[j]);
+    }
+    if (a.ndy > 2) {
+        const vec<T, 8> d2 = load8((const T*)a.dy[2] + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += to_f(d2[j]);
+    }
+}
+
+// pass 1.  grid = (slabs, N); a block reduces `rows_per_block` voxels of one sample over all channels.
+// thread = (chunk column cc, row group g); LDS tree over row groups; fp64 atomics per (n,c).
+constexpr int GNB_ROWS = 2048;
+template <class T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a) {
+    __shared__ float red[256 * 16];
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int CPR = a.C / 8;                  // 2..32 (power of two)
+    const int G = 256 / CPR;
+    const int cc = tid % CPR, g = tid / CPR;
+    const long long v0 = (long long)blockIdx.x * GNB_ROWS;
+    const long long v1 = (v0 + GNB_ROWS < a.V) ? v0 + GNB_ROWS : a.V;
+    const T* r = (const T*)a.r;
+    const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale + (long long)n * a.C + cc * 8);
+    const vec<float, 8> sh = *(const vec<float, 8>*)(a.shift + (long long)n * a.C + cc * 8);
+    float q1[8], q2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
+    for (long long v = v0 + g; v < v1; v += G) {
+        const long long i = ((long long)n * a.V + v) * CPR + cc;
+        float dy[8];
+        load_dy_sum<T>(a, i, dy);
+        const vec<T, 8> x = load8(r + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = to_f(x[j]);
+            const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
+            q1[j] += d;
+            q2[j] = fmaf(d, xv, q2[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = q1[j]; red[tid * 16 + 8 + j] = q2[j]; }
+    __syncthreads();
+    // column (cc, j, which) summed over the G row groups by one thread each: CPR*16 <= 512 columns
+    for (int col = tid; col < CPR * 16; col += 256) {
+        const int ccx = col / 16, jj = col % 16;
+        double s = 0.0;
+        for (int k = 0; k < G; ++k) s += red[(k * CPR + ccx) * 16 + jj];
+        const int c = ccx * 8 + (jj & 7), which = jj >> 3;
+        atomicAdd(a.Q + ((long long)n * a.C + c) * 2 + which, s);
+    }
+}
+
+// finalize: grid = N, block = 256
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
+    __shared__ double S1[GN_GROUPS], S2[GN_GROUPS];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = a.C / GN_GROUPS;
+    if (tid < GN_GROUPS) { S1[tid] = 0.0; S2[tid] = 0.0; }
+    __syncthreads();
+    for (int c = tid; c < a.C; c += 256) {
+        const int g = c / cpg;
+        const double mk = a.mask ? (double)a.mask[(long long)n * a.mask_ld + c] : 1.0;
+        const double mu = a.mean[n * GN_GROUPS + g], rs = a.rstd[n * GN_GROUPS + g];
+        const double q1 = mk * a.Q[((long long)n * a.C + c) * 2];          // sum dz
+        const double q2 = mk * a.Q[((long long)n * a.C + c) * 2 + 1];      // sum dz * r
+        const double qx = (q2 - mu * q1) * rs;                              // sum dz * xhat
+        atomicAdd(&a.dbeta[c], (float)q1);
+        atomicAdd(&a.dgamma[c], (float)qx);
+        const double ga = a.gamma[c];
+        atomicAdd(&S1[g], ga * q1);
+        atomicAdd(&S2[g], ga * qx);
+    }
+    __syncthreads();
+    const double Mg = (double)cpg * (double)a.V;
+    for (int c = tid; c < a.C; c += 256) {
+        const int g = c / cpg;
+        const double mk = a.mask ? (double)a.mask[(long long)n * a.mask_ld + c] : 1.0;
+        const double mu = a.mean[n * GN_GROUPS + g], rs = a.rstd[n * GN_GROUPS + g];
+        const double ga = a.gamma[c];
+        const double A = rs * ga * mk;
+        const double B = -rs * rs * S2[g] / Mg;
+        const double Cc = -rs * S1[g] / Mg + rs * rs * S2[g] * mu / Mg;
+        float* co = a.coef + ((long long)n * a.C + c) * 3;
+        co[0] = (float)A; co[1] = (float)B; co[2] = (float)Cc;
+        if (a.dbias) {
+            // sum_v dr = A*sum(dzr) + B*sum(r) + Cc*V   (sum(r) from the forward statistics)
+            const double R1 = a.stats[((long long)n * a.C + c) * 2];
+            const double Q1 = a.Q[((long long)n * a.C + c) * 2];
+            atomicAdd(&a.dbias[c], (float)(A * Q1 + B * R1 + Cc * (double)a.V));
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
+    const int CPR = a.C / 8;
+    const long long per_n = a.V * CPR, total = (long long)a.N * per_n;
+    const T* r = (const T*)a.r;
+    T* dr = (T*)a.dr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / per_n);
+        const int c0 = (int)(i % CPR) * 8;
+        float dy[8];
+        load_dy_sum<T>(a, i, dy);
+        const vec<T, 8> x = load8(r + i * 8);
+        const float* sc = a.scale + (long long)n * a.C + c0;
+        const float* sh = a.shift + (long long)n * a.C + c0;
+        const float* co = a.coef + ((long long)n * a.C + c0) * 3;
+        vec<T, 8> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = to_f(x[j]);
+            const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
+            o[j] = from_f<T>(fmaf(co[j * 3], d, fmaf(co[j * 3 + 1], xv, co[j * 3 + 2])));
+        }
+        store8(dr + i * 8, o);
+    }
+}
+
+inline int ew_blocks(long long total_threads) {
+    long long b = (total_threads + 255) / 256;
+    return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+void launch_gn_finalize(const GnFinArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.N), dim3(256), 0, s, a);
+}
+
+void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
+    dim3 grid(ew_blocks((long long)a.N * a.V * (a.C / 8)));
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<float>), grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<bf16>), grid, dim3(256), 0, s, a);
+}
+
+void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
+    dim3 grid(cdiv(a.V, GNB_ROWS), a.N);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<float>), grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<bf16>), grid, dim3(256), 0, s, a);
+}
+
+void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a.N), dim3(256), 0, s, a);
+}
+
+void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s) {
+    dim3 grid(ew_blocks((long long)a.N * a.V * (a.C / 8)));
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<float>), grid, dim3(256), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<f16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<bf16>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace seg

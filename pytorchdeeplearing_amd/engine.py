@@ -1,0 +1,229 @@
+"""Host-side owner of one libsegengine handle: flat fp32 parameters / gradients / Adam state, the
+workspace, and the train-step sequence of the reference loop (model/modelVNet.py:570-596):
+
+    fwd -> loss (+ Dice metric) -> zero_grad -> backward -> [RCCL all-reduce] -> Adam(W) step
+
+PyTorch is used for device memory, streams and torch.distributed only; all arithmetic runs in the
+HIP library through the C-ABI (include/segengine.h)."""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _capi
+
+
+def aligned_empty(nbytes, device, align=256):
+    """uint8 tensor whose data pointer is `align`-byte aligned (the CPU allocator only gives 64)."""
+    raw = torch.empty(int(nbytes) + align, dtype=torch.uint8, device=device)
+    off = (-raw.data_ptr()) % align
+    return raw[off:off + int(nbytes)]
+
+
+def aligned_zeros_f32(numel, device):
+    t = aligned_empty(int(numel) * 4, device).view(torch.float32)
+    t.zero_()
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+class SegEngine:
+    def __init__(self, kind, ndim, in_channels, numclass, init_features=16, dtype="f16", device="cuda", lib=None):
+        self.device = torch.device(device)
+        self.lib = lib if lib is not None else _capi.lib_for(self.device)
+        self.kind, self.ndim, self.in_channels, self.numclass = kind, ndim, in_channels, numclass
+        self.dtype = dtype
+        h = C.c_void_p()
+        self.lib.check(self.lib.seg_create(_capi.NET_KIND[kind], ndim, in_channels, numclass, init_features,
+                                           _capi.DTYPE[dtype], C.byref(h)), "seg_create")
+        self.h = h
+        self.numel = self.lib.seg_param_numel(h)
+        self.table = OrderedDict()
+        name = C.create_string_buffer(256)
+        shape = (C.c_int * 8)()
+        nd = C.c_int()
+        off = C.c_longlong()
+        for i in range(self.lib.seg_param_count(h)):
+            self.lib.check(self.lib.seg_param_info(h, i, name, 256, shape, C.byref(nd), C.byref(off)), "seg_param_info")
+            self.table[name.value.decode()] = (tuple(shape[:nd.value]), off.value)
+        self.n_drop = self.lib.seg_dropout_calls(h)
+        self.drop_ld = self.lib.seg_dropout_ld(h)
+        self.drop_channels = [self.lib.seg_dropout_channels(h, i) for i in range(self.n_drop)]
+        self.params = aligned_zeros_f32(self.numel, self.device)
+        self.grads = aligned_zeros_f32(self.numel, self.device)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.opt_state = None
+        self.shape = None
+        self.ws = None
+        self._loss_ws = None
+        self._out3 = None
+        self._dlogits = None
+        self.seed = 0x5EEDC0DE
+        self.packed = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.seg_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameters -----------------------------------------------------------------------------
+    def param_view(self, name, grad=False):
+        shape, off = self.table[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return (self.grads if grad else self.params)[off:off + n].view(shape)
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            for k in self.table:
+                self.param_view(k).copy_(sd[k].to(device=self.device, dtype=torch.float32))
+        self.packed = False
+
+    def state_dict(self):
+        return OrderedDict((k, self.param_view(k).clone()) for k in self.table)
+
+    def grad_dict(self, unscale=True):
+        inv = 1.0 / self.loss_scale if unscale else 1.0
+        return OrderedDict((k, self.param_view(k, grad=True) * inv) for k in self.table)
+
+    @property
+    def loss_scale(self):
+        return float(self.lib.seg_get_loss_scale(self.h))
+
+    @loss_scale.setter
+    def loss_scale(self, v):
+        self.lib.check(self.lib.seg_set_loss_scale(self.h, float(v)), "seg_set_loss_scale")
+
+    # ---- planning -------------------------------------------------------------------------------
+    def plan(self, n, spatial):
+        spatial = tuple(int(s) for s in spatial)
+        key = (int(n),) + spatial
+        if self.shape == key and self.ws is not None:
+            return
+        d, hgt, wid = (spatial if self.ndim == 3 else (1,) + spatial)
+        self.lib.check(self.lib.seg_plan(self.h, int(n), d, hgt, wid), "seg_plan")
+        nbytes = self.lib.seg_workspace_bytes(self.h)
+        self.ws = None
+        self.ws = aligned_empty(nbytes, self.device)
+        self.lib.check(self.lib.seg_bind(self.h, _ptr(self.params), _ptr(self.grads), _ptr(self.ws)), "seg_bind")
+        self.shape = key
+        self.packed = False
+        v = 1
+        for s in spatial:
+            v *= s
+        self.V = v
+        self._loss_ws = aligned_empty(self.lib.seg_loss_ws_bytes(int(n), self.numclass), self.device)
+        self._out3 = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._dlogits = torch.empty((int(n), self.numclass) + spatial, dtype=torch.float32, device=self.device)
+
+    def rebind(self):
+        """Re-bind after the caller replaced self.params / self.grads (they must be 256-B aligned)."""
+        self.lib.check(self.lib.seg_bind(self.h, _ptr(self.params), _ptr(self.grads), _ptr(self.ws)), "seg_bind")
+        self.packed = False
+
+    def stream(self):
+        return _capi.stream_for(self.device)
+
+    def pack_weights(self):
+        self.lib.check(self.lib.seg_pack_weights(self.h, self.stream()), "seg_pack_weights")
+        self.packed = True
+
+    # ---- forward / backward ---------------------------------------------------------------------
+    def forward(self, x, mask_mode=_capi.MASKS_EVAL, masks=None, logits=None, probs=None):
+        """x: fp32 NC[D]HW.  Returns (logits, probs) fp32 NC[D]HW."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.device.type == self.device.type
+        self.plan(x.shape[0], x.shape[2:])
+        if not self.packed:
+            self.pack_weights()
+        oshape = (x.shape[0], self.numclass) + tuple(x.shape[2:])
+        if logits is None:
+            logits = torch.empty(oshape, dtype=torch.float32, device=self.device)
+        if probs is None:
+            probs = torch.empty(oshape, dtype=torch.float32, device=self.device)
+        mt = None
+        if mask_mode == _capi.MASKS_GIVEN:
+            mt = self.mask_table(masks)
+        self.lib.check(self.lib.seg_forward(self.h, _ptr(x), mask_mode, _ptr(mt), C.c_ulonglong(self.seed),
+                                            _ptr(logits), _ptr(probs), self.stream()), "seg_forward")
+        self._keep = (x, mt)
+        return logits, probs
+
+    def mask_table(self, masks):
+        """list of (N, C_i) multipliers in dropout-call order -> dense [calls][N][ld] fp32 table."""
+        if torch.is_tensor(masks):
+            return masks.to(device=self.device, dtype=torch.float32).contiguous()
+        n = masks[0].shape[0]
+        t = torch.zeros((self.n_drop, n, self.drop_ld), dtype=torch.float32, device=self.device)
+        assert len(masks) == self.n_drop
+        for i, m in enumerate(masks):
+            assert m.shape[1] == self.drop_channels[i]
+            t[i, :, :m.shape[1]] = m.to(self.device)
+        return t
+
+    def backward(self, dlogits, zero_grads=True):
+        """dlogits: fp32 NC[D]HW, already multiplied by self.loss_scale.  Accumulates into self.grads."""
+        assert dlogits.dtype == torch.float32 and dlogits.is_contiguous()
+        self.lib.check(self.lib.seg_backward(self.h, _ptr(dlogits), 1 if zero_grads else 0, self.stream()), "seg_backward")
+
+    # ---- losses ---------------------------------------------------------------------------------
+    def loss_forward(self, logits, target, loss_name, focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, out3=None):
+        n, c = logits.shape[0], logits.shape[1]
+        out3 = self._out3 if out3 is None else out3
+        target = target.contiguous()
+        self.lib.check(self.lib.seg_loss_forward(
+            _ptr(logits), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, c, self.V, _capi.LOSS_KIND[loss_name],
+            float(focal_alpha), float(focal_gamma), _ptr(class_alpha), _ptr(self._loss_ws), _ptr(out3), self.stream()),
+            "seg_loss_forward")
+        self._keep_loss = (target, class_alpha)
+        return out3
+
+    def loss_backward(self, logits, target, loss_name, focal_alpha=0.25, focal_gamma=2.0, dlogits=None, grad_scale=None):
+        n, c = logits.shape[0], logits.shape[1]
+        dlogits = self._dlogits if dlogits is None else dlogits
+        target = target.contiguous()
+        gs = self.loss_scale if grad_scale is None else grad_scale
+        self.lib.check(self.lib.seg_loss_backward(
+            _ptr(logits), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, c, self.V, _capi.LOSS_KIND[loss_name],
+            float(focal_alpha), float(focal_gamma), _ptr(self._loss_ws), float(gs), _ptr(dlogits), self.stream()),
+            "seg_loss_backward")
+        return dlogits
+
+    # ---- optimiser ------------------------------------------------------------------------------
+    def init_optimizer(self):
+        self.exp_avg = aligned_zeros_f32(self.numel, self.device)
+        self.exp_avg_sq = aligned_zeros_f32(self.numel, self.device)
+        self.opt_state = torch.zeros(64, dtype=torch.int32, device=self.device)
+
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decoupled=True, check_finite=None):
+        if self.exp_avg is None:
+            self.init_optimizer()
+        if check_finite is None:
+            check_finite = self.dtype in ("f16", "fp16", "float16")
+        self.lib.check(self.lib.seg_adam_step(
+            _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), self.numel,
+            float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 1 if decoupled else 0,
+            1.0 / self.loss_scale, 1 if check_finite else 0, _ptr(self.opt_state), self.stream()), "seg_adam_step")
+        self.packed = False
+
+    # ---- one optimisation step of the reference loop --------------------------------------------
+    def train_step(self, x, target, loss_name="BinaryDiceLoss", lr=1e-3, weight_decay=0.01, decoupled=True,
+                   focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, mask_mode=_capi.MASKS_RANDOM, masks=None,
+                   allreduce=None, logits=None, probs=None):
+        """Returns out3 = device tensor [loss, dice metric, iou metric] (no host sync)."""
+        logits, probs = self.forward(x, mask_mode, masks, logits, probs)
+        out3 = self.loss_forward(logits, target, loss_name, focal_alpha, focal_gamma, class_alpha)
+        dl = self.loss_backward(logits, target, loss_name, focal_alpha, focal_gamma)
+        self.backward(dl, zero_grads=True)
+        if allreduce is not None:
+            allreduce(self.grads)
+        self.adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled)
+        self.pack_weights()
+        return out3

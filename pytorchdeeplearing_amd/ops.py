@@ -1,0 +1,186 @@
+"""Operator-level host bindings (seg_op_conv / seg_op_wgrad / seg_op_pack of include/segengine.h).
+
+Tensors are channels-last [N][D][H][W][C] in the run dtype (2-D: D = 1).  These are the same kernel
+launches the network engine issues; they exist so every kernel can be checked in isolation against
+torch.nn.functional (the reference's operator layer: networks/VNet3d.py:8,28,29,49,65,70,88)."""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from .engine import aligned_empty
+
+TORCH_DTYPE = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+class Taps(C.Structure):
+    _fields_ = [("n", C.c_int), ("d", C.c_byte * 27), ("h", C.c_byte * 27), ("w", C.c_byte * 27)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("in0", C.c_void_p), ("in1", C.c_void_p), ("C0", C.c_int), ("C1", C.c_int), ("w", C.c_void_p),
+                ("bias", C.c_void_p), ("out", C.c_void_p), ("stats", C.c_void_p),
+                ("N", C.c_int), ("ID", C.c_int), ("IH", C.c_int), ("IW", C.c_int),
+                ("OD", C.c_int), ("OH", C.c_int), ("OW", C.c_int),
+                ("FD", C.c_int), ("FH", C.c_int), ("FW", C.c_int),
+                ("Cout", C.c_int), ("Ngemm", C.c_int), ("K", C.c_int), ("Kpad", C.c_int),
+                ("sd", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("scatter", C.c_int), ("taps", Taps)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("dr", C.c_void_p), ("x0", C.c_void_p), ("x1", C.c_void_p), ("C0", C.c_int), ("C1", C.c_int),
+                ("dw", C.c_void_p), ("P", C.c_int), ("Q", C.c_int),
+                ("N", C.c_int), ("ID", C.c_int), ("IH", C.c_int), ("IW", C.c_int),
+                ("OD", C.c_int), ("OH", C.c_int), ("OW", C.c_int),
+                ("sd", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("taps", Taps),
+                ("sP", C.c_longlong), ("sQ", C.c_longlong), ("sT", C.c_longlong), ("stem", C.c_int)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R1", C.c_int), ("R2", C.c_int), ("T", C.c_int),
+                ("Cc", C.c_int), ("Kpad", C.c_int), ("s1", C.c_longlong), ("s2", C.c_longlong),
+                ("sT", C.c_longlong), ("sC", C.c_longlong), ("flipT", C.c_int)]
+
+
+def check_abi(lib):
+    assert lib.dll.seg_abi_sizeof(0) == C.sizeof(ConvArgs), (lib.dll.seg_abi_sizeof(0), C.sizeof(ConvArgs))
+    assert lib.dll.seg_abi_sizeof(1) == C.sizeof(WgradArgs)
+    assert lib.dll.seg_abi_sizeof(2) == C.sizeof(PackDesc)
+
+
+def make_taps(ndim, k, pad):
+    t = Taps()
+    n = 0
+    for a in range(k if ndim == 3 else 1):
+        for b in range(k):
+            for c in range(k):
+                t.d[n] = (a - pad) if ndim == 3 else 0
+                t.h[n] = b - pad
+                t.w[n] = c - pad
+                n += 1
+    t.n = n
+    return t
+
+
+def _kpad(k):
+    return (k + 31) // 32 * 32
+
+
+def _alloc(shape, dtype, device, zero=False):
+    n = 1
+    for s in shape:
+        n *= s
+    t = aligned_empty(n * torch.empty((), dtype=dtype).element_size(), device).view(dtype).view(shape)
+    if zero:
+        t.zero_()
+    return t
+
+
+def aligned_like(t, dtype=None):
+    o = _alloc(tuple(t.shape), dtype or t.dtype, t.device)
+    o.copy_(t)
+    return o
+
+
+def pack(w, layout, dtype):
+    """Re-layout an fp32 PyTorch-layout conv / conv-transpose weight for the GEMM kernels.
+    layouts: conv_fwd [co][(t,ci)] | conv_dgrad [ci][(flip t,co)] | k2s2_dgrad [(a,ci)][co] |
+             convT_fwd [(a,co)][ci] | convT_dgrad [ci][(a,co)]"""
+    lib = _capi.lib_for(w.device)
+    w = aligned_like(w.float().contiguous())
+    A, B = w.shape[0], w.shape[1]
+    T = 1
+    for s in w.shape[2:]:
+        T *= s
+    d = PackDesc()
+    d.src = w.data_ptr()
+    if layout == "conv_fwd":            # w (Cout, Cin, k..)
+        rows, d.R1, d.R2, d.T, d.Cc = A, A, 1, T, B
+        d.s1, d.s2, d.sT, d.sC, d.flipT = B * T, 0, 1, T, 0
+    elif layout == "conv_dgrad":
+        rows, d.R1, d.R2, d.T, d.Cc = B, B, 1, T, A
+        d.s1, d.s2, d.sT, d.sC, d.flipT = T, 0, 1, B * T, 1
+    elif layout == "k2s2_dgrad":
+        rows, d.R1, d.R2, d.T, d.Cc = T * B, T, B, 1, A
+        d.s1, d.s2, d.sT, d.sC, d.flipT = 1, T, 0, B * T, 0
+    elif layout == "convT_fwd":         # w (Cin, Cout, k..)
+        rows, d.R1, d.R2, d.T, d.Cc = T * B, T, B, 1, A
+        d.s1, d.s2, d.sT, d.sC, d.flipT = 1, T, 0, B * T, 0
+    elif layout == "convT_dgrad":
+        rows, d.R1, d.R2, d.T, d.Cc = A, A, 1, T, B
+        d.s1, d.s2, d.sT, d.sC, d.flipT = B * T, 0, 1, T, 0
+    else:
+        raise ValueError(layout)
+    d.Kpad = _kpad(d.T * d.Cc)
+    out = _alloc((rows, d.Kpad), TORCH_DTYPE[dtype], w.device)
+    d.dst = out.data_ptr()
+    raw = bytes(d)
+    dev = aligned_empty(len(raw), w.device)
+    dev.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+    lib.check(lib.dll.seg_op_pack(C.c_void_p(dev.data_ptr()), 1, C.c_longlong(rows * d.Kpad), _capi.DTYPE[dtype],
+                                  _capi.stream_for(w.device)), "seg_op_pack")
+    return out
+
+
+def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=None, scatter=False, want_stats=False):
+    """x0 (and optional concat source x1): [N,D,H,W,C] in dtype.  Gather conv (k, stride, pad) or, with
+    scatter=True, the k2-s2 transposed conv.  Returns out [N,OD,OH,OW,cout] (+ stats [N,cout,2] fp64)."""
+    lib = _capi.lib_for(x0.device)
+    N, D, H, W, C0 = x0.shape
+    a = ConvArgs()
+    a.in0, a.C0 = x0.data_ptr(), C0
+    a.in1, a.C1 = (x1.data_ptr(), x1.shape[-1]) if x1 is not None else (None, 0)
+    cin = a.C0 + a.C1
+    a.w = wpacked.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.N, a.ID, a.IH, a.IW = N, D, H, W
+    a.Cout = cout
+    up = lambda v, dim3: v * 2 if (dim3 or ndim == 3) else v
+    if scatter:
+        a.scatter = 1
+        a.OD, a.OH, a.OW = D, H, W
+        a.FD, a.FH, a.FW = (D * 2 if ndim == 3 else 1), H * 2, W * 2
+        a.sd, a.sh, a.sw = (2 if ndim == 3 else 1), 2, 2
+        a.taps = make_taps(ndim, 2, 0)
+        a.K, a.Ngemm = cin, a.taps.n * cout
+        oshape = (N, a.FD, a.FH, a.FW, cout)
+    else:
+        a.scatter = 0
+        od = (D + 2 * pad - k) // stride + 1 if ndim == 3 else 1
+        a.OD, a.OH, a.OW = od, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        a.sd, a.sh, a.sw = (stride if ndim == 3 else 1), stride, stride
+        a.taps = make_taps(ndim, k, pad)
+        a.K, a.Ngemm = a.taps.n * cin, cout
+        oshape = (N, a.OD, a.OH, a.OW, cout)
+    a.Kpad = _kpad(a.K)
+    assert tuple(wpacked.shape) == (a.Ngemm, a.Kpad), (tuple(wpacked.shape), a.Ngemm, a.Kpad)
+    out = _alloc(oshape, TORCH_DTYPE[dtype], x0.device, zero=True)
+    a.out = out.data_ptr()
+    stats = None
+    if want_stats:
+        stats = _alloc((N, cout, 2), torch.float64, x0.device, zero=True)
+        a.stats = stats.data_ptr()
+    lib.check(lib.dll.seg_op_conv(C.byref(a), _capi.DTYPE[dtype], _capi.stream_for(x0.device)), "seg_op_conv")
+    return (out, stats) if want_stats else out
+
+
+def wgrad(dr, x0, dtype, ndim, k, stride=1, pad=0, x1=None, stem=False):
+    """dW[p][q][tap] (PyTorch conv-weight layout (P, Q, k..)) = sum_m dr[m][p] * x[vox(m,tap)][q]."""
+    lib = _capi.lib_for(dr.device)
+    N, OD, OH, OW, P = dr.shape
+    _, D, H, W, C0 = x0.shape
+    a = WgradArgs()
+    a.dr, a.x0, a.C0 = dr.data_ptr(), x0.data_ptr(), C0
+    a.x1, a.C1 = (x1.data_ptr(), x1.shape[-1]) if x1 is not None else (None, 0)
+    a.taps = make_taps(ndim, k, pad)
+    T = a.taps.n
+    qc = C0 + a.C1
+    a.P, a.Q = P, (T * qc if stem else qc)
+    a.N, a.ID, a.IH, a.IW, a.OD, a.OH, a.OW = N, D, H, W, OD, OH, OW
+    a.sd, a.sh, a.sw = (stride if ndim == 3 else 1), stride, stride
+    a.sP, a.sQ, a.sT = qc * T, T, 1
+    a.stem = 1 if stem else 0
+    dw = _alloc((P, qc) + (k,) * ndim, torch.float32, dr.device, zero=True)
+    a.dw = dw.data_ptr()
+    lib.check(lib.dll.seg_op_wgrad(C.byref(a), _capi.DTYPE[dtype], _capi.stream_for(dr.device)), "seg_op_wgrad")
+    return dw

@@ -8,14 +8,43 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 
 
-GOLDEN = os.path.join(ROOT, "tests", "golden")
-
-
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+_emu_lib = None
+
+
+def emu_library():
+    """Host-side wave64 checker build of the UNMODIFIED HIP sources (tests/emu) — CPU tests only."""
+    global _emu_lib
+    if _emu_lib is None:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import build_emu
+        from pytorchdeeplearing_amd import _capi
+        _emu_lib = _capi.SegLib(build_emu.build())
+        _capi.inject_library(_emu_lib)
+    return _emu_lib
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)])
+def dev(request):
+    """'emu': kernel sources run on the host-side execution-model checker (logic / indexing check);
+    'gpu': the real gfx950 library on cuda:0 (the parity tests proper)."""
+    import torch
+    if request.param == "emu":
+        emu_library()
+        return torch.device("cpu")
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from pytorchdeeplearing_amd import _capi
+    _capi.product_library()      # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")

@@ -1,0 +1,40 @@
+"""TEST INFRASTRUCTURE ONLY: compile the unmodified HIP sources of the engine with the host clang
+against tests/emu/hip/hip_runtime.h (wave64 execution-model checker) -> tests/emu/_build/libsegengine_emu.so.
+The product package never loads this library; tests inject it explicitly."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "pytorchdeeplearing_amd", "csrc")
+OUT = os.path.join(HERE, "_build", "libsegengine_emu.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+SRCS = ["conv.hip", "wgrad.hip", "norm.hip", "misc.hip", "engine.hip"]
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, s) for s in SRCS]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"),
+                   os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "segengine.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(HERE, "_build", os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I", HERE, "-I", CSRC, "-Wno-unused-value",
+               "-Wno-vla-cxx-extension", "-c", s, "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out = p.communicate()[0].decode()
+        if p.returncode:
+            raise RuntimeError("emu build failed for %s:\n%s" % (s, out))
+    subprocess.check_call([CLANG, "-shared", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="-f" in sys.argv))

@@ -1,0 +1,198 @@
+"""Network-level parity: the HIP engine (forward, loss, backward, optimiser step) against the CPU
+oracle (oracle/seg_oracle.py, pinned to the real reference by tests/test_oracle.py) on identical
+seeded inputs.  Tolerances: fp32 run dtype -> logits within 1e-3 (BASELINE.json north_star; measured
+~1e-5), thresholded masks / Dice identical, gradients within 1e-3 relative; f16 / bf16 run dtypes are
+gated on Dice difference and gradient direction instead (SURVEY.md §7 'Parity target')."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import seg_oracle as seg
+from pytorchdeeplearing_amd import SegEngine, _capi
+
+CASES = {
+    # tag: kind, ndim, shape, numclass, loss
+    "vnet3d": ("vnet", 3, (2, 1, 16, 16, 16), 1, "BinaryDiceLoss"),
+    "unet3d": ("unet", 3, (1, 1, 16, 16, 16), 4, "MutilDiceLoss"),
+    "vnet2d": ("vnet", 2, (2, 1, 32, 32), 2, "MutilCrossEntropyLoss"),
+    "unet2d": ("unet", 2, (2, 1, 32, 32), 1, "BinaryCrossEntropyDiceLoss"),
+    "vnet2d_s": ("vnet", 2, (2, 1, 16, 16), 1, "BinaryFocalLoss"),
+    "unet2d_s": ("unet", 2, (1, 3, 16, 32), 3, "MutilFocalLoss"),
+    "vnet3d_48": ("vnet", 3, (2, 1, 48, 48, 48), 1, "BinaryDiceLoss"),
+    "unet3d_32": ("unet", 3, (2, 1, 32, 32, 32), 4, "MutilDiceLoss"),
+    "vnet2d_128": ("vnet", 2, (3, 1, 128, 128), 2, "MutilCrossEntropyLoss"),
+}
+
+
+def build(tag, dtype, dev, train):
+    kind, ndim, shape, ncls, loss = CASES[tag]
+    e = SegEngine(kind, ndim, shape[1], ncls, dtype=dtype, device=dev)
+    params = seg.perturb_params(seg.init_params(kind, ndim, shape[1], ncls, seed=0), seed=7)
+    assert list(params.keys()) == list(e.table.keys())
+    e.load_state_dict(params)
+    x, y = seg.synthetic_batch(shape[0], shape[2:], shape[1], ncls, seed=1)
+    masks = None
+    if train:
+        g = torch.Generator().manual_seed(5)
+        masks = seg.draw_masks(kind, shape[0], generator=g)
+    return e, params, x, y, masks, torch.ones(ncls), loss
+
+
+def run_engine(e, x, y, masks, alpha, loss, dev):
+    xd, yd = x.to(dev), y.to(dev)
+    logits, probs = e.forward(xd, _capi.MASKS_GIVEN if masks is not None else _capi.MASKS_EVAL, masks)
+    out3 = e.loss_forward(logits, yd, loss, class_alpha=alpha.to(dev)).clone()
+    dl = e.loss_backward(logits, yd, loss)
+    e.backward(dl)
+    return logits.cpu(), probs.cpu(), out3.cpu(), {k: v.cpu() for k, v in e.grad_dict().items()}
+
+
+def oracle_metric(probs, y, ncls):
+    return seg.dice_coeff(probs, y) if ncls == 1 else seg.multiclass_dice_coeff(probs, y)
+
+
+def check_f32(tag, dev, train):
+    e, params, x, y, masks, alpha, loss = build(tag, "f32", dev, train)
+    ncls = CASES[tag][3]
+    logits, probs, out3, grads = run_engine(e, x, y, masks, alpha, loss, dev)
+    r = seg.forward_backward(CASES[tag][0], params, x, y, loss, masks=masks, alpha=alpha)
+    assert float((logits - r["logits"]).abs().max()) < 1e-3          # north_star tolerance
+    assert float((logits - r["logits"]).abs().max()) < 2e-4          # what fp32 MFMA actually delivers
+    assert float((probs - r["probs"]).abs().max()) < 1e-4
+    # Dice metric bit-identical at integer-mask level
+    assert torch.equal(probs > 0.5, r["probs"] > 0.5)
+    assert abs(float(out3[1]) - float(oracle_metric(r["probs"], y, ncls))) < 1e-6
+    assert abs(float(out3[0]) - float(r["loss"])) < 2e-5
+    for k, g in grads.items():
+        ref = r["grads"][k]
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((g - ref).abs().max()) / scale < 1e-3, k
+
+
+@pytest.mark.parametrize("tag,train", [("vnet2d_s", False), ("unet2d_s", True), ("unet3d", True), ("vnet3d", False)])
+def test_parity_f32_small(dev, tag, train):
+    check_f32(tag, dev, train)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,train", [("vnet3d", True), ("unet3d", False), ("vnet2d", True), ("unet2d", True),
+                                       ("vnet3d_48", True), ("unet3d_32", True), ("vnet2d_128", False)])
+def test_parity_f32_gpu(tag, train):
+    check_f32(tag, torch.device("cuda:0"), train)
+
+
+def check_lowp(tag, dtype, dev, train, logit_tol, flip_frac):
+    e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, train)
+    ncls = CASES[tag][3]
+    logits, probs, out3, grads = run_engine(e, x, y, masks, alpha, loss, dev)
+    r = seg.forward_backward(CASES[tag][0], params, x, y, loss, masks=masks, alpha=alpha)
+    assert float((logits - r["logits"]).abs().max()) < logit_tol
+    flips = int(((probs > 0.5) != (r["probs"] > 0.5)).sum())
+    assert flips <= flip_frac * probs.numel(), flips
+    assert abs(float(out3[1]) - float(oracle_metric(r["probs"], y, ncls))) < 2e-2
+    assert abs(float(out3[0]) - float(r["loss"])) < 5e-3
+    cos = []
+    for k, g in grads.items():
+        ref = r["grads"][k].double().flatten()
+        if float(ref.norm()) < 1e-12:
+            continue
+        cos.append(float(torch.nn.functional.cosine_similarity(g.double().flatten(), ref, dim=0)))
+    assert min(cos) > (0.95 if dtype == "f16" else 0.85), min(cos)
+
+
+@pytest.mark.parametrize("dtype,tol,ff", [("f16", 3e-2, 2e-3), ("bf16", 3e-1, 2e-2)])
+def test_parity_lowp_small(dev, dtype, tol, ff):
+    check_lowp("vnet2d_s", dtype, dev, True, tol, ff)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["vnet3d", "unet3d", "vnet3d_48"])
+@pytest.mark.parametrize("dtype,tol,ff", [("f16", 3e-2, 2e-3), ("bf16", 3e-1, 2e-2)])
+def test_parity_lowp_gpu(tag, dtype, tol, ff):
+    check_lowp(tag, dtype, torch.device("cuda:0"), True, tol, ff)
+
+
+@pytest.mark.parametrize("decoupled", [True, False])
+def test_train_steps_vs_oracle(dev, decoupled):
+    """three full optimisation steps (fwd, loss, backward, Adam/AdamW) with injected dropout masks."""
+    tag = "unet2d_s" if dev.type == "cpu" else "vnet3d"
+    e, params, x, y, _, alpha, loss = build(tag, "f32", dev, True)
+    kind = CASES[tag][0]
+    xd, yd = x.to(dev), y.to(dev)
+    cur, st = params, {}
+    wd = 0.01 if decoupled else 0.0
+    for it in range(3):
+        g = torch.Generator().manual_seed(100 + it)
+        masks = seg.draw_masks(kind, x.shape[0], generator=g)
+        out3 = e.train_step(xd, yd, loss, lr=1e-3, weight_decay=wd, decoupled=decoupled, class_alpha=alpha.to(dev),
+                            mask_mode=_capi.MASKS_GIVEN, masks=masks).clone()
+        r = seg.forward_backward(kind, cur, x, y, loss, masks=masks, alpha=alpha)
+        cur = seg.adamw_step(cur, r["grads"], st, lr=1e-3, weight_decay=wd, decoupled=decoupled)
+        assert abs(float(out3[0]) - float(r["loss"])) < 5e-4, it
+    # Adam normalises every update to ~lr regardless of |g|, so elements whose gradient is at the
+    # fp32 noise floor may legitimately move differently (bounded by 2*lr per step); everything else
+    # must agree closely.  The optimiser kernel itself is checked exactly in test_adam_kernel_exact.
+    sd = e.state_dict()
+    tot = bad = 0
+    for k in cur:
+        d = (sd[k].cpu() - cur[k]).abs()
+        assert float(d.max()) < 3 * 2e-3, k
+        tot += d.numel()
+        bad += int((d > 1e-4).sum())
+    assert bad <= 0.01 * tot, (bad, tot)
+
+
+@pytest.mark.parametrize("decoupled", [True, False])
+def test_adam_kernel_exact(dev, decoupled):
+    """seg_adam_step vs torch.optim.AdamW / Adam on the same gradients (model/modelVNet.py:548, modelUnet.py:849)."""
+    e = SegEngine("unet", 2, 1, 1, dtype="f32", device=dev)
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(e.numel, generator=g)
+    e.params.copy_(p0.to(dev))
+    ref = p0.clone().requires_grad_(True)
+    wd = 0.01 if decoupled else 0.0
+    opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref], lr=1e-3, weight_decay=wd)
+    for it in range(4):
+        gr = torch.randn(e.numel, generator=g) * (10.0 ** (it - 2))
+        e.grads.copy_(gr.to(dev))
+        ref.grad = gr.clone()
+        opt.step()
+        e.adam_step(lr=1e-3, weight_decay=wd, decoupled=decoupled, check_finite=True)
+    assert int(e.opt_state[0]) == 4
+    assert float((e.params.cpu() - ref.detach()).abs().max()) < 2e-6
+
+
+def test_random_masks_and_loss_scale_skip(dev):
+    """engine-drawn dropout multipliers are {0, 1.25}; a non-finite gradient skips the update."""
+    e, params, x, y, _, alpha, loss = build("vnet2d_s", "f16", dev, False)
+    xd, yd = x.to(dev), y.to(dev)
+    before = e.params.clone()
+    e.train_step(xd, yd, loss, lr=1e-3)
+    assert not torch.equal(before, e.params)
+    assert int(e.opt_state[0]) == 1 and int(e.opt_state[1]) == 0
+    e.plan(x.shape[0], x.shape[2:])
+    # poison the gradient: the optimiser must refuse the step and raise the flag
+    e.grads[5] = float("inf")
+    mid = e.params.clone()
+    e.adam_step(lr=1e-3)
+    assert torch.equal(mid, e.params)
+    assert int(e.opt_state[0]) == 1 and int(e.opt_state[1]) == 1
+
+
+def test_errors_are_reported(dev):
+    e = SegEngine("vnet", 3, 1, 1, dtype="f32", device=dev)
+    with pytest.raises(RuntimeError, match="multiples of 16"):
+        e.plan(1, (20, 16, 16))
+    with pytest.raises(RuntimeError):
+        SegEngine("vnet", 3, 1, 99, dtype="f32", device=dev)
+
+
+def test_cpu_tensors_fail_loudly_without_the_gpu_library():
+    """No CPU fallback in the product path: with nothing injected, CPU devices are refused."""
+    saved = _capi._injected
+    _capi._injected = None
+    try:
+        with pytest.raises(RuntimeError, match="MI355X"):
+            SegEngine("vnet", 3, 1, 1, device="cpu")
+    finally:
+        _capi._injected = saved

@@ -1,0 +1,174 @@
+"""Operator-level parity: each HIP kernel (implicit-GEMM conv in gather / scatter mode, data-gradient
+forms, weight gradients) against torch.nn.functional on integer-valued data, where f32, f16 and bf16
+arithmetic is exact -> bit-exact comparison for all three run dtypes."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pytorchdeeplearing_amd import _capi, ops
+
+DT = ["f32", "f16", "bf16"]
+
+
+def cl(x):      # NC[D]HW -> N D H W C (2-D: D = 1)
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(x, ndim):
+    x = x.permute(0, 4, 1, 2, 3).contiguous()
+    return x.squeeze(2) if ndim == 2 else x
+
+
+def ints(shape, lo, hi, g, density=1.0):
+    t = torch.randint(lo, hi + 1, shape, generator=g).float()
+    if density < 1.0:
+        t = t * (torch.rand(shape, generator=g) < density).float()
+    return t
+
+
+def to_dev(t, dtype, dev):
+    return ops.aligned_like(t.to(dev).to(ops.TORCH_DTYPE[dtype]))
+
+
+def test_abi_struct_sizes(dev):
+    ops.check_abi(_capi.lib_for(dev))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [
+    # ndim, N, spatial, Cin(list = concat), Cout, k, stride, pad
+    (3, 2, (6, 5, 7), [16], 16, 3, 1, 1),
+    (3, 1, (4, 6, 8), [32], 64, 3, 1, 1),
+    (3, 3, (4, 4, 4), [16], 32, 2, 2, 0),
+    (3, 2, (5, 4, 6), [16, 16], 16, 1, 1, 0),
+    (2, 2, (9, 11), [16], 16, 3, 1, 1),
+    (2, 1, (8, 12), [64, 64], 64, 1, 1, 0),
+    (3, 1, (3, 4, 5), [64], 128, 3, 1, 1),
+])
+def test_conv_gather_exact(dev, dtype, case):
+    ndim, N, sp, cins, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(sp) * 7 + cout)
+    cin = sum(cins)
+    x = ints((N, cin) + sp, -2, 2, g)
+    w = ints((cout, cin) + (k,) * ndim, -1, 1, g, density=0.2)
+    b = ints((cout,), -3, 3, g)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    ref = conv(x, w, b, stride=stride, padding=pad)
+    assert float(ref.abs().max()) <= 256
+    xs = torch.split(x, cins, dim=1)
+    x0 = to_dev(cl(xs[0]), dtype, dev)
+    x1 = to_dev(cl(xs[1]), dtype, dev) if len(xs) > 1 else None
+    wp = ops.pack(w.to(dev), "conv_fwd", dtype)
+    out, stats = ops.conv(x0, wp, dtype, ndim, k, stride, pad, x1=x1, bias=ops.aligned_like(b.to(dev)), cout=cout, want_stats=True)
+    got = ncdhw(out.float().cpu(), ndim)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    rs = torch.stack([ref.double().flatten(2).sum(2), (ref.double() ** 2).flatten(2).sum(2)], dim=2)
+    assert torch.equal(stats.cpu(), rs)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(3, 2, (3, 4, 5), 32, 16), (2, 2, (6, 7), 16, 16), (3, 1, (2, 2, 3), 128, 64)])
+def test_conv_transpose_scatter_exact(dev, dtype, case):
+    ndim, N, sp, cin, cout = case
+    g = torch.Generator().manual_seed(7)
+    x = ints((N, cin) + sp, -2, 2, g)
+    w = ints((cin, cout) + (2,) * ndim, -1, 1, g, density=0.3)
+    b = ints((cout,), -3, 3, g)
+    convT = F.conv_transpose3d if ndim == 3 else F.conv_transpose2d
+    ref = convT(x, w, b, stride=2)
+    assert float(ref.abs().max()) <= 256
+    wp = ops.pack(w.to(dev), "convT_fwd", dtype)
+    out, stats = ops.conv(to_dev(cl(x), dtype, dev), wp, dtype, ndim, 2, scatter=True, bias=ops.aligned_like(b.to(dev)),
+                          cout=cout, want_stats=True)
+    assert torch.equal(ncdhw(out.float().cpu(), ndim), ref)
+    rs = torch.stack([ref.double().flatten(2).sum(2), (ref.double() ** 2).flatten(2).sum(2)], dim=2)
+    assert torch.equal(stats.cpu(), rs)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_data_gradients_exact(dev, dtype):
+    """dgrad of conv k3 (flipped gather), of conv k2s2 (scatter) and of convT k2s2 (strided gather)."""
+    g = torch.Generator().manual_seed(11)
+    # conv 3^3, 16 -> 32
+    x = ints((2, 16, 4, 5, 6), -2, 2, g).requires_grad_(True)
+    w = ints((32, 16, 3, 3, 3), -1, 1, g, density=0.15)
+    dy = ints((2, 32, 4, 5, 6), -1, 1, g, density=0.5)
+    F.conv3d(x, w, padding=1).backward(dy)
+    assert float(x.grad.abs().max()) <= 256
+    wp = ops.pack(w.to(dev), "conv_dgrad", dtype)
+    got = ops.conv(to_dev(cl(dy), dtype, dev), wp, dtype, 3, 3, 1, 1, cout=16)
+    assert torch.equal(ncdhw(got.float().cpu(), 3), x.grad)
+    # conv 2^3 stride 2, 16 -> 32 : gradient is a scatter GEMM
+    x = ints((2, 16, 4, 6, 4), -2, 2, g).requires_grad_(True)
+    w = ints((32, 16, 2, 2, 2), -1, 1, g, density=0.3)
+    dy = ints((2, 32, 2, 3, 2), -1, 1, g)
+    F.conv3d(x, w, stride=2).backward(dy)
+    wp = ops.pack(w.to(dev), "k2s2_dgrad", dtype)
+    got = ops.conv(to_dev(cl(dy), dtype, dev), wp, dtype, 3, 2, scatter=True, cout=16)
+    assert torch.equal(ncdhw(got.float().cpu(), 3), x.grad)
+    # conv-transpose 2^3 stride 2, 32 -> 16 : gradient is a stride-2 gather
+    x = ints((1, 32, 2, 3, 4), -2, 2, g).requires_grad_(True)
+    w = ints((32, 16, 2, 2, 2), -1, 1, g, density=0.3)
+    dy = ints((1, 16, 4, 6, 8), -1, 1, g)
+    F.conv_transpose3d(x, w, stride=2).backward(dy)
+    wp = ops.pack(w.to(dev), "convT_dgrad", dtype)
+    got = ops.conv(to_dev(cl(dy), dtype, dev), wp, dtype, 3, 2, 2, 0, cout=32)
+    assert torch.equal(ncdhw(got.float().cpu(), 3), x.grad)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [
+    # ndim, N, spatial(in), Cin list, Cout, k, stride, pad
+    (3, 2, (5, 4, 6), [16], 16, 3, 1, 1),
+    (3, 1, (4, 4, 6), [32], 64, 3, 1, 1),
+    (3, 2, (4, 6, 4), [16], 32, 2, 2, 0),
+    (3, 2, (3, 5, 4), [16, 16], 16, 1, 1, 0),
+    (2, 3, (7, 9), [16], 32, 3, 1, 1),
+    (3, 1, (2, 3, 4), [128], 128, 3, 1, 1),
+])
+def test_wgrad_exact(dev, dtype, case):
+    ndim, N, sp, cins, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(5)
+    cin = sum(cins)
+    x = ints((N, cin) + sp, -2, 2, g)
+    w = torch.zeros((cout, cin) + (k,) * ndim, requires_grad=True)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    y = conv(x, w, stride=stride, padding=pad)
+    dy = ints(tuple(y.shape), -2, 2, g)
+    y.backward(dy)
+    xs = torch.split(x, cins, dim=1)
+    x1 = to_dev(cl(xs[1]), dtype, dev) if len(xs) > 1 else None
+    got = ops.wgrad(to_dev(cl(dy), dtype, dev), to_dev(cl(xs[0]), dtype, dev), dtype, ndim, k, stride, pad, x1=x1)
+    assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_wgrad_conv_transpose_and_stem_exact(dev, dtype):
+    g = torch.Generator().manual_seed(3)
+    # ConvTranspose k2 s2 (32 -> 16): dW[ci][co][a] = sum_coarse x[m][ci] * dy[2m+a][co]
+    x = ints((2, 32, 2, 3, 2), -2, 2, g)
+    w = torch.zeros((32, 16, 2, 2, 2), requires_grad=True)
+    y = F.conv_transpose3d(x, w, stride=2)
+    dy = ints(tuple(y.shape), -2, 2, g)
+    y.backward(dy)
+    got = ops.wgrad(to_dev(cl(x), dtype, dev), to_dev(cl(dy), dtype, dev), dtype, 3, 2, 2, 0)
+    assert torch.equal(got.cpu(), w.grad)
+    # stem: 1 -> 16, 3^3 pad 1 (direct K = 27), and the 1^3 twin
+    for k, pad in ((3, 1), (1, 0)):
+        x = ints((2, 1, 5, 6, 4), -3, 3, g)
+        w = torch.zeros((16, 1, k, k, k), requires_grad=True)
+        y = F.conv3d(x, w, padding=pad)
+        dy = ints(tuple(y.shape), -2, 2, g)
+        y.backward(dy)
+        got = ops.wgrad(to_dev(cl(dy), dtype, dev), to_dev(cl(x), dtype, dev), dtype, 3, k, 1, pad, stem=True)
+        assert torch.equal(got.cpu(), w.grad)
+    # 2-D RGB stem: 3 -> 16, 3x3
+    x = ints((2, 3, 6, 7), -3, 3, g)
+    w = torch.zeros((16, 3, 3, 3), requires_grad=True)
+    y = F.conv2d(x, w, padding=1)
+    dy = ints(tuple(y.shape), -2, 2, g)
+    y.backward(dy)
+    got = ops.wgrad(to_dev(cl(dy), dtype, dev), to_dev(cl(x), dtype, dev), dtype, 2, 3, 1, 1, stem=True)
+    assert torch.equal(got.cpu(), w.grad)
