@@ -1,0 +1,140 @@
+"""Headline benchmark: volumes/s of a full VNet3d train step (fwd + BinaryDiceLoss + backward +
+[RCCL grad all-reduce] + AdamW + weight re-pack) at 4 x 1 x 96^3 fp16 per GPU (BASELINE.json configs[2]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU; batch shards on the batch axis (weak scaling: 4 volumes per GPU); gradients are
+all-reduced (sum, then averaged) over RCCL before the optimiser step.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per 96^3 volume and train step
+GFLOP_PER_VOLUME = 216.5
+GB_PER_VOLUME = 2.85
+PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-ops", action="store_true", help="extra instrumented pass: per-kernel-class time")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, seconds_budget=25.0):
+    """The oracle (= the reference's torch-CPU path, oracle/seg_oracle.py) timed on this box's host
+    cores on a bounded sample of the same workload: 1 x 1 x size^3 train steps (fp32, all cores)."""
+    from oracle import seg_oracle as seg
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    params = seg.init_params("vnet", 3, 1, 1, seed=0)
+    x, y = seg.synthetic_batch(1, (size,) * 3, 1, 1, seed=1234)
+    g = torch.Generator().manual_seed(0)
+    st = {}
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        masks = seg.draw_masks("vnet", 1, generator=g)
+        t0 = time.time()
+        r = seg.forward_backward("vnet", params, x, y, "BinaryDiceLoss", masks=masks)
+        params = seg.adamw_step(params, r["grads"], st)
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
+            "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (torch CPU, %d threads), best step %.3f s" % (len(times), size, ncores, best)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from oracle import seg_oracle as seg   # only used for synthetic inputs + the cpu_baseline leg
+    from pytorchdeeplearing_amd import SegEngine
+
+    S = a.size
+    e = SegEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev)
+    e.load_state_dict(seg.init_params("vnet", 3, 1, 1, seed=0))
+    x, y = seg.synthetic_batch(a.batch, (S, S, S), 1, 1, seed=1234 + rank)
+    x, y = x.to(dev), y.to(dev)
+    logits = torch.empty((a.batch, 1, S, S, S), dtype=torch.float32, device=dev)
+    probs = torch.empty_like(logits)
+
+    allreduce = None
+    if world > 1:
+        inv = 1.0 / world
+
+        def allreduce(g):
+            dist.all_reduce(g)
+            g.mul_(inv)
+
+    def step():
+        return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs)
+
+    for _ in range(a.warmup):
+        out3 = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out3 = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms = dt / a.steps * 1e3
+    vols = world * a.batch * a.steps / dt
+    loss = float(out3[0])
+    if rank == 0:
+        line = {
+            "metric": "volumes/sec VNet3d 96^3 fp16 train step", "value": round(vols, 2), "unit": "volumes/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "VNet3d(1,1) binary seg, %dx1x%d^3 per GPU, BinaryDiceLoss, AdamW, dropout on" % (a.batch, S),
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world},
+            "final_loss": round(loss, 5),
+            "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME * vols / world / PEAK_HBM_GBS, 4),
+                           "mfma_frac": round(GFLOP_PER_VOLUME * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,10 +63,18 @@ def check_f32(tag, dev, train):
     assert torch.equal(probs > 0.5, r["probs"] > 0.5)
     assert abs(float(out3[1]) - float(oracle_metric(r["probs"], y, ncls))) < 1e-6
     assert abs(float(out3[0]) - float(r["loss"])) < 2e-5
+    # Gradients: a handful of tensors are ill-conditioned in fp32 (ReLU gates sitting at ~0 flip with
+    # 1e-6 forward noise: torch-CPU fp32 itself is up to ~2e-2 away from its own fp64 run), so the
+    # yardstick is the fp64 oracle and the allowance is tied to the fp32 oracle's own deviation.
+    p64 = {k: v.double() for k, v in params.items()}
+    m64 = None if masks is None else [m.double() for m in masks]
+    r64 = seg.forward_backward(CASES[tag][0], p64, x.double(), y, loss, masks=m64, alpha=alpha.double())
     for k, g in grads.items():
-        ref = r["grads"][k]
-        scale = float(ref.abs().max()) + 1e-12
-        assert float((g - ref).abs().max()) / scale < 1e-3, k
+        ref = r64["grads"][k]
+        scale = float(ref.abs().max()) + 1e-30
+        own = float((r["grads"][k].double() - ref).abs().max()) / scale
+        err = float((g.double() - ref).abs().max()) / scale
+        assert err < max(1e-3, 4 * own), (k, err, own)
 
 
 @pytest.mark.parametrize("tag,train", [("vnet2d_s", False), ("unet2d_s", True), ("unet3d", True), ("vnet3d", False)])
