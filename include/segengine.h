@@ -160,6 +160,16 @@ typedef struct seg_pack_desc {
     int flipT;
 } seg_pack_desc;
 int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int dtype, void* stream);
+/* LDS halo-tile kernels for the 3^d (ndim 3) / 3^2 (ndim 2, D = 1) stride-1 pad-1 convolutions.
+ * seg_op_conv3: out[N][D][H][W][Cout] = conv(in[N][D][H][W][Cin], w packed [Cout][Kpad], k = (tap, ci)) + bias,
+ * optional GroupNorm partial sums; with the "conv_dgrad" weight layout it is the data-gradient.
+ * seg_op_wgrad3: dw[p][q][tap] += sum_m dr[m][p] * x[m + tap][q]; `partial` needs
+ * seg_op_wgrad3_partial_bytes(...) bytes of scratch (deterministic two-stage reduction). */
+int seg_op_conv3(const void* in, const void* w, const float* bias, void* out, double* stats, int n, int d, int h,
+                 int wid, int cin, int cout, int ndim, int dtype, void* stream);
+long long seg_op_wgrad3_partial_bytes(int ndim, int n, int d, int h, int wid, int p, int q);
+int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int n, int d, int h, int wid, int p,
+                  int q, int ndim, int dtype, void* stream);
 /* sizeof of the structs above as compiled into the library: 0 conv, 1 wgrad, 2 pack */
 int seg_abi_sizeof(int which);
 

@@ -1,0 +1,430 @@
+// LDS halo-tile kernels for the 3^d (or 3^2) stride-1 pad-1 convolutions — the LUConv / _block layers
+// that carry >90 % of the FLOPs (networks/VNet3d.py:8, networks/Unet3d.py:66-80).
+//
+//   conv3_kernel  : forward and data-gradient (same kernel, flipped packed weights).  A workgroup
+//                   owns a TD x TH x TW box of output voxels; the (TD+2)(TH+2)(TW+2) input halo of one
+//                   32- (or 16-) channel chunk is staged ONCE in LDS and reused by all 27 taps, so
+//                   HBM/L2 traffic is ~1x the tensor instead of 27x.  MFMA 16x16x32 (f16/bf16) or
+//                   8 x 16x16x4 (f32), weights streamed from L2 with one-tap-ahead prefetch, fused
+//                   bias + GroupNorm partial sums + coalesced channels-last stores.
+//   wgrad3_kernel : weight gradient.  Both operands need the voxel axis as the MFMA K dimension, so
+//                   dR and the X halo are staged row-major and read with ds_read_b64_tr_b16.  Each
+//                   workgroup walks a strided list of boxes accumulating a [CP x taps x CQ] tile in
+//                   registers and writes ONE partial tile; wgrad3_reduce_kernel sums the partials
+//                   (deterministic; no fp32 atomics).
+#include "kernels.h"
+
+namespace seg {
+namespace {
+
+template <int TD, int TH, int TW, int KD> struct Box {
+    static constexpr int V = TD * TH * TW;            // output voxels per box
+    static constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2;
+    static constexpr int HV = HD * HH * HW;           // halo voxels
+    static constexpr int PD = (KD - 1) / 2;           // pad along depth (0 for 2-D)
+    static constexpr int NTAP = KD * 9;
+    static __device__ __forceinline__ int halo_base(int v) {      // box voxel -> halo index of tap (0,0,0)
+        const int vx = v % TW, vy = (v / TW) % TH, vz = v / (TW * TH);
+        return (vz * HH + vy) * HW + vx;
+    }
+    static __device__ __forceinline__ int tap_off(int t) {        // tap -> halo index offset
+        const int kw = t % 3, kh = (t / 3) % 3, kd = t / 9;
+        return (kd * HH + kh) * HW + kw;
+    }
+};
+
+struct BoxPos { int n, z0, y0, x0; };
+template <class B, int TD, int TH, int TW>
+__device__ __forceinline__ BoxPos box_pos(long long b, int D, int H, int W) {
+    const int nbx = (W + TW - 1) / TW, nby = (H + TH - 1) / TH, nbz = (D + TD - 1) / TD;
+    BoxPos p;
+    p.x0 = (int)(b % nbx) * TW; b /= nbx;
+    p.y0 = (int)(b % nby) * TH; b /= nby;
+    p.z0 = (int)(b % nbz) * TD;
+    p.n = (int)(b / nbz);
+    return p;
+}
+
+// stage the halo of channels [c0, c0+CH) of tensor `in` ([N][D][H][W][C]) into LDS rows of LD elements
+template <class T, class B, int CH, int LD>
+__device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, const BoxPos& p, int D, int H, int W) {
+    constexpr int CPV = CH / 8;
+    for (int i = threadIdx.x; i < B::HV * CPV; i += 256) {
+        const int hv = i / CPV, c8 = i % CPV;
+        const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
+        const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
+        vec<T, 8> v = zero8<T>();
+        if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+            v = load8(in + ((((long long)p.n * D + z) * H + y) * W + x) * C + c0 + c8 * 8);
+        store8(&Xs[hv * LD + c8 * 8], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient
+// ------------------------------------------------------------------------------------------------
+struct Conv3Args {
+    const void* in; const void* w; const float* bias; void* out; double* stats;
+    int N, D, H, W, Cin, Cout, Kpad;
+};
+
+template <class T, int TD, int TH, int TW, int KD, int CH, int NT>
+__global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
+    typedef Box<TD, TH, TW, KD> B;
+    constexpr int XLD = CH + 8;                         // 80 B (CH=32) / 48 B (CH=16) rows: conflict-light b128 reads
+    constexpr int MT = B::V / 64;                       // 16-voxel M tiles per wave
+    constexpr int BN = NT * 16, OLD = BN + 8;
+    constexpr int XS_ELEMS = B::HV * XLD, OS_ELEMS = B::V * OLD;
+    __shared__ T Xs[XS_ELEMS > OS_ELEMS ? XS_ELEMS : OS_ELEMS];
+    __shared__ float red[512];
+    static_assert(B::V % 64 == 0, "box must hold a multiple of 64 voxels");
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const BoxPos bp = box_pos<B, TD, TH, TW>(blockIdx.x, a.D, a.H, a.W);
+    const int co0 = blockIdx.y * BN;
+    const T* in = (const T*)a.in;
+    const T* wp = (const T*)a.w;
+
+    int hb[MT];                                          // halo base index of this lane's voxel per M tile
+#pragma unroll
+    for (int m = 0; m < MT; ++m) hb[m] = B::halo_base((wv * MT + m) * 16 + l15);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* wrow[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wrow[j] = wp + (long long)(co0 + j * 16 + l15) * a.Kpad + q * 8;
+
+    // K order of the packed weights is (tap, ci).  CH == 32: step s = (tap s) x (32 channels of chunk cc).
+    // CH == 16 (Cin == 16): step s covers taps 2s, 2s+1; lanes q = 0,1 -> tap 2s, q = 2,3 -> tap 2s+1.
+    constexpr int NSTEP = CH == 32 ? B::NTAP : (B::NTAP + 1) / 2;
+    const int nchunk = a.Cin / CH;
+    for (int cc = 0; cc < nchunk; ++cc) {
+        if (cc) __syncthreads();
+        stage_halo<T, B, CH, XLD>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W);
+        __syncthreads();
+        typename Mma<T>::frag bcur[NT], bnext[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bcur[j] = load8(wrow[j] + (CH == 32 ? cc * 32 : 0));
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bnext[j] = load8(wrow[j] + (CH == 32 ? (s + 1) * a.Cin + cc * 32 : (s + 1) * 32));
+            }
+            int toff, col;
+            bool tvalid = true;
+            if (CH == 32) { toff = B::tap_off(s); col = q * 8; }
+            else {
+                const int t = 2 * s + (q >> 1);
+                tvalid = t < B::NTAP;
+                toff = B::tap_off(tvalid ? t : 0);
+                col = (q & 1) * 8;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                typename Mma<T>::frag af = load8(&Xs[(hb[m] + toff) * XLD + col]);
+                if (CH == 16 && !tvalid) af = zero8<T>();
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[m][j] = Mma<T>::run(af, bcur[j], acc[m][j]);
+            }
+            if (s + 1 < NSTEP) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bcur[j] = bnext[j];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: bias -> LDS tile [voxel][co] -> coalesced stores + per-channel sums
+    T* Os = Xs;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = j * 16 + l15;
+        const float bsv = a.bias ? a.bias[co0 + col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Os[((wv * MT + m) * 16 + q * 4 + r) * OLD + col] = from_f<T>(acc[m][j][r] + bsv);
+    }
+    __syncthreads();
+    T* out = (T*)a.out;
+    constexpr int CPR = BN / 8;
+    for (int i = tid; i < B::V * CPR; i += 256) {
+        const int v = i / CPR, c8 = i % CPR;
+        const int x = bp.x0 + v % TW, y = bp.y0 + (v / TW) % TH, z = bp.z0 + v / (TW * TH);
+        if (x < a.W && y < a.H && z < a.D)
+            store8(out + ((((long long)bp.n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8, load8(&Os[v * OLD + c8 * 8]));
+    }
+    if (a.stats) {
+        constexpr int G = 256 / BN;
+        const int col = tid % BN, g = tid / BN;
+        float s = 0.f, ss = 0.f;
+        for (int v = g; v < B::V; v += G) {
+            const int x = bp.x0 + v % TW, y = bp.y0 + (v / TW) % TH, z = bp.z0 + v / (TW * TH);
+            if (x < a.W && y < a.H && z < a.D) {
+                const float f = to_f(Os[v * OLD + col]);
+                s += f; ss += f * f;
+            }
+        }
+        red[(g * BN + col) * 2] = s;
+        red[(g * BN + col) * 2 + 1] = ss;
+        __syncthreads();
+        if (tid < BN) {
+            double ts = 0.0, tss = 0.0;
+            for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
+            double* dst = a.stats + ((long long)bp.n * a.Cout + co0 + col) * 2;
+            atomicAdd(dst, ts);
+            atomicAdd(dst + 1, tss);
+        }
+    }
+}
+
+template <int TD, int TH, int TW>
+inline long long num_boxes(int N, int D, int H, int W) {
+    return (long long)N * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+}
+
+template <class T, int TD, int TH, int TW, int KD>
+void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
+    int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
+    if (a.Cin == 16 && nt == 4) nt = 2;
+    dim3 grid((unsigned)num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W), a.Cout / (16 * nt));
+#define SEG_C3(CH, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_kernel<T, TD, TH, TW, KD, CH, NT>), grid, dim3(256), 0, s, a)
+    if (a.Cin == 16) { if (nt == 1) SEG_C3(16, 1); else SEG_C3(16, 2); }
+    else { if (nt == 1) SEG_C3(32, 1); else if (nt == 2) SEG_C3(32, 2); else SEG_C3(32, 4); }
+#undef SEG_C3
+}
+
+// box shape per level: x extent 16 when the row length suits it, else 8x8 tiles (24^3, 6^3 levels)
+inline bool wide_box(int W) { return W % 16 == 0 || W == 12; }
+
+template <class T>
+void conv3_dispatch(const Conv3Args& a, int ndim, hipStream_t s) {
+    if (ndim == 3) {
+        if (wide_box(a.W)) conv3_launch_shape<T, 3, 4, 16, 3>(a, s);
+        else conv3_launch_shape<T, 3, 8, 8, 3>(a, s);
+    } else {
+        if (wide_box(a.W)) conv3_launch_shape<T, 1, 8, 16, 1>(a, s);
+        else conv3_launch_shape<T, 1, 8, 8, 1>(a, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct Wgrad3Args {
+    const void* dr; const void* x; float* partial;
+    int N, D, H, W, P, Q;       // channel counts of dr / x
+    int nb;                     // workgroups per (p-tile, q-tile) combo
+};
+
+template <class T, int C> struct WLd { static constexpr int v = C == 32 ? 48 : 16; };   // 96 B / 32 B rows: conflict-free tr reads
+template <int C> struct WLd<float, C> { static constexpr int v = C + 4; };
+
+template <class T, int LD> struct TrFrag {
+    // rows (k slots) r0..r0+3 per 16-lane group via two transposing reads; row addresses are arbitrary
+    static __device__ __forceinline__ typename Mma<T>::frag load(const T* base, const int* rowoff, int col0, int lane) {
+        const int t = lane & 15;
+        const s16x4 lo = lds_read_tr16(base + rowoff[0] + col0 + (t & 3) * 4);
+        const s16x4 hi = lds_read_tr16(base + rowoff[1] + col0 + (t & 3) * 4);
+        vec<short, 8> v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+        return __builtin_bit_cast(typename Mma<T>::frag, v);
+    }
+};
+template <int LD> struct TrFrag<float, LD> {
+    static __device__ __forceinline__ Mma<float>::frag load(const float* base, const int* rowoff, int col0, int lane) {
+        Mma<float>::frag f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = base[rowoff[j] + col0 + (lane & 15)];
+        return f;
+    }
+};
+
+template <class T, int TD, int TH, int TW, int KD, int CP, int CQ>
+__global__ __launch_bounds__(256, 2) void wgrad3_kernel(Wgrad3Args a) {
+    typedef Box<TD, TH, TW, KD> B;
+    constexpr int DLD = WLd<T, CP>::v, XLD = WLd<T, CQ>::v;
+    constexpr int PT = CP / 16, QT = CQ / 16;
+    constexpr int NTW = (B::NTAP + 3) / 4;               // taps per wave
+    constexpr int NR = sizeof(T) == 4 ? 8 : 2;           // row slots a lane addresses per K step
+    __shared__ T Ds[B::V * DLD];
+    __shared__ T Xs[B::HV * XLD];
+    static_assert(B::V % 32 == 0, "box must hold a multiple of 32 voxels");
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int nqt = a.Q / CQ;
+    const int combo = blockIdx.y, p0 = (combo / nqt) * CP, q0 = (combo % nqt) * CQ;
+    const T* dr = (const T*)a.dr;
+    const T* x = (const T*)a.x;
+    const long long nbox = (long long)a.N * ((a.D + TD - 1) / TD) * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
+
+    f32x4 acc[NTW][PT][QT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (long long b = blockIdx.x; b < nbox; b += gridDim.x) {
+        const BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
+        __syncthreads();                                  // previous box fully consumed
+        // dR tile [voxel][CP] (zero rows outside the volume)
+        constexpr int CPV = CP / 8;
+        for (int i = tid; i < B::V * CPV; i += 256) {
+            const int v = i / CPV, c8 = i % CPV;
+            const int xx = bp.x0 + v % TW, yy = bp.y0 + (v / TW) % TH, zz = bp.z0 + v / (TW * TH);
+            vec<T, 8> val = zero8<T>();
+            if (xx < a.W && yy < a.H && zz < a.D)
+                val = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.P + p0 + c8 * 8);
+            store8(&Ds[v * DLD + c8 * 8], val);
+        }
+        stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W);
+        __syncthreads();
+#pragma unroll 1
+        for (int ks = 0; ks < B::V / 32; ++ks) {
+            int drow[NR], xrow[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                // 16-bit: slot j covers rows 16j + 4q + (l15>>2); f32: MFMA j consumes row 4j + q
+                const int r = sizeof(T) == 4 ? (4 * j + q) : (16 * j + 4 * q + (l15 >> 2));
+                const int v = ks * 32 + r;
+                drow[j] = v * DLD;
+                xrow[j] = B::halo_base(v) * XLD;
+            }
+            typename Mma<T>::frag af[PT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i) af[i] = TrFrag<T, DLD>::load(Ds, drow, i * 16, lane);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int tap = wv + 4 * t;
+                if (tap < B::NTAP) {
+                    const int toff = B::tap_off(tap) * XLD;
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) {
+                        const typename Mma<T>::frag bf = TrFrag<T, XLD>::load(Xs + toff, xrow, j * 16, lane);
+#pragma unroll
+                        for (int i = 0; i < PT; ++i) acc[t][i][j] = Mma<T>::run(af[i], bf, acc[t][i][j]);
+                    }
+                }
+            }
+        }
+    }
+    // partial tile [p][tap][q] of this workgroup
+    float* dst = a.partial + ((long long)combo * a.nb + blockIdx.x) * (CP * B::NTAP * CQ);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tap = wv + 4 * t;
+        if (tap < B::NTAP) {
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int j = 0; j < QT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[((i * 16 + 4 * q + r) * B::NTAP + tap) * CQ + j * 16 + l15] = acc[t][i][j][r];
+        }
+    }
+}
+
+// dw[p*sP + q*sQ + tap] += sum_b partial[combo][b][p'][tap][q']
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial, float* dw, int P, int Q, int CP, int CQ, int ntap, int nb,
+                                                            long long sP, long long sQ) {
+    const long long total = (long long)P * Q * ntap;
+    const int tile = CP * ntap * CQ, nqt = Q / CQ;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int combo = (int)(i / tile), e = (int)(i % tile);
+        const int qq = e % CQ, tap = (e / CQ) % ntap, pp = e / (CQ * ntap);
+        const float* src = partial + (long long)combo * nb * tile + e;
+        float s = 0.f;
+        for (int b = 0; b < nb; ++b) s += src[(long long)b * tile];
+        const int p = (combo / nqt) * CP + pp, qc = (combo % nqt) * CQ + qq;
+        dw[p * sP + qc * sQ + tap] += s;
+    }
+}
+
+template <class T, int TD, int TH, int TW, int KD>
+void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s) {
+    Wgrad3Args a = a0;
+    const int CP = a.P >= 32 ? 32 : 16, CQ = a.Q >= 32 ? 32 : 16;
+    const int combos = (a.P / CP) * (a.Q / CQ);
+    dim3 grid(a.nb, combos);
+#define SEG_W3(CPv, CQv) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3_kernel<T, TD, TH, TW, KD, CPv, CQv>), grid, dim3(256), 0, s, a)
+    if (CP == 32 && CQ == 32) SEG_W3(32, 32);
+    else if (CP == 32) SEG_W3(32, 16);
+    else if (CQ == 32) SEG_W3(16, 32);
+    else SEG_W3(16, 16);
+#undef SEG_W3
+    const int ntap = KD * 9;
+    const long long total = (long long)a.P * a.Q * ntap;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, a.nb, sP, sQ);
+}
+
+template <class T>
+void wgrad3_dispatch(const Wgrad3Args& a, int ndim, float* dw, long long sP, long long sQ, hipStream_t s) {
+    if (ndim == 3) {
+        if (wide_box(a.W)) wgrad3_launch_shape<T, 3, 4, 16, 3>(a, dw, sP, sQ, s);
+        else wgrad3_launch_shape<T, 3, 8, 8, 3>(a, dw, sP, sQ, s);
+    } else {
+        if (wide_box(a.W)) wgrad3_launch_shape<T, 1, 8, 16, 1>(a, dw, sP, sQ, s);
+        else wgrad3_launch_shape<T, 1, 8, 8, 1>(a, dw, sP, sQ, s);
+    }
+}
+
+inline long long boxes_for(int ndim, int N, int D, int H, int W) {
+    if (ndim == 3) return wide_box(W) ? num_boxes<3, 4, 16>(N, D, H, W) : num_boxes<3, 8, 8>(N, D, H, W);
+    return wide_box(W) ? num_boxes<1, 8, 16>(N, 1, H, W) : num_boxes<1, 8, 8>(N, 1, H, W);
+}
+
+}  // namespace
+
+// ---- host entry points (declared in kernels.h) -----------------------------------------------------
+void launch_conv3(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cin,
+                  int Cout, int ndim, int dtype, hipStream_t s) {
+    Conv3Args a;
+    a.in = in; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.Kpad = ((ndim == 3 ? 27 : 9) * Cin + 31) / 32 * 32;
+    if (dtype == DT_F32) conv3_dispatch<float>(a, ndim, s);
+    else if (dtype == DT_F16) conv3_dispatch<f16>(a, ndim, s);
+    else conv3_dispatch<bf16>(a, ndim, s);
+}
+
+int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) {
+    const int CP = P >= 32 ? 32 : 16, CQ = Q >= 32 ? 32 : 16;
+    const int combos = (P / CP) * (Q / CQ);
+    long long nb = 512 / combos;
+    if (nb < 1) nb = 1;
+    const long long nbox = boxes_for(ndim, N, D, H, W);
+    if (nb > nbox) nb = nbox;
+    return (int)nb;
+}
+
+size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) {
+    const int CP = P >= 32 ? 32 : 16, CQ = Q >= 32 ? 32 : 16;
+    const int combos = (P / CP) * (Q / CQ);
+    return (size_t)combos * wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q) * CP * (ndim == 3 ? 27 : 9) * CQ * sizeof(float);
+}
+
+void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
+                   int dtype, hipStream_t s) {
+    Wgrad3Args a;
+    a.dr = dr; a.x = x; a.partial = partial;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.P = P; a.Q = Q;
+    a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q);
+    const int T = ndim == 3 ? 27 : 9;
+    if (dtype == DT_F32) wgrad3_dispatch<float>(a, ndim, dw, (long long)Q * T, T, s);
+    else if (dtype == DT_F16) wgrad3_dispatch<f16>(a, ndim, dw, (long long)Q * T, T, s);
+    else wgrad3_dispatch<bf16>(a, ndim, dw, (long long)Q * T, T, s);
+}
+
+}  // namespace seg

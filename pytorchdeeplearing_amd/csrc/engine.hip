@@ -65,6 +65,7 @@ struct seg_engine {
     // plan
     int N = 0, D = 0, H = 0, W = 0;
     size_t ws_bytes = 0;
+    size_t off_partial = 0;
     size_t off_masks = 0, off_stats = 0, stats_bytes = 0, off_Q = 0, Q_bytes = 0, off_packdesc = 0, off_step = 0;
     std::vector<PackDesc> packdescs;   // dst/src stored as OFFSETS until bind
     long long pack_max = 0;
@@ -368,6 +369,14 @@ struct Planner {
             }
         }
         E.off_packdesc = alloc(E.packdescs.size() * sizeof(PackDesc));
+        // partial-tile buffer of the halo weight-gradient kernel (largest K3 layer)
+        size_t pmax = 0;
+        for (auto& s : E.steps)
+            if (s.type == ST_UNIT && s.ck == CK_K3 && s.in1 < 0) {
+                const int l = E.tens[s.raw].lvl;
+                pmax = std::max(pmax, wgrad3_partial_bytes(E.ndim, N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cout, s.Cin));
+            }
+        E.off_partial = alloc(pmax);
 
         // ------------------------------------------------------------------ forward schedule
         E.fwd_ops.push_back([this_ = &E](hipStream_t st) {
@@ -393,6 +402,10 @@ struct Planner {
                         a.N = E.N; a.D = E.dim_d(0); a.H = E.dim_h(0); a.W = E.dim_w(0); a.Cimg = i0.C; a.Cout = s.Cout;
                         a.taps = make_taps(E.ndim, s.ck == CK_STEM3 ? 3 : 1, s.ck == CK_STEM3 ? 1 : 0);
                         launch_conv_stem(a, E.dtype, st);
+                    } else if (s.ck == CK_K3 && s.in1 < 0) {
+                        const int l = ro.lvl;
+                        launch_conv3(E.ws + i0.off, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l),
+                                     s.Cin, s.Cout, E.ndim, E.dtype, st);
                     } else {
                         ConvArgs a{};
                         a.in0 = E.ws + i0.off; a.C0 = i0.C;
@@ -569,6 +582,15 @@ struct Planner {
                     // ---- bias gradient of convs without GroupNorm
                     if (s.gn_w < 0 && s.b >= 0)
                         launch_colsum(E.ws + E.tens[draw].off, E.g + E.params[s.b].off, (long long)E.N * E.vol(lo), s.Cout, E.dtype, st);
+                    if (s.ck == CK_K3 && s.in1 < 0) {
+                        // halo-tile kernels: weight gradient (deterministic two-stage reduction) + data gradient
+                        launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.off_partial), E.g + E.params[s.w].off,
+                                      E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
+                        if (g0 >= 0)
+                            launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
+                                         E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
+                        return;
+                    }
                     // ---- weight gradient
                     WgradArgs w{};
                     w.dw = E.g + E.params[s.w].off; w.N = E.N; w.sT = 1; w.sQ = T;
@@ -848,6 +870,23 @@ int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int 
     if (!descs || ndesc < 1) return fail("seg_op_pack: no descriptors");
     launch_pack(descs, ndesc, (int)max_elems, dtype, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_pack: launch failed");
+}
+int seg_op_conv3(const void* in, const void* w, const float* bias, void* out, double* stats, int n, int d, int h, int wid, int cin,
+                 int cout, int ndim, int dtype, void* stream) {
+    if (!in || !w || !out) return fail("seg_op_conv3: null pointer");
+    if (cin < 16 || (cin & (cin - 1)) || cout % 16) return fail("seg_op_conv3: Cin must be a power of two >= 16, Cout a multiple of 16");
+    launch_conv3(in, w, bias, out, stats, n, ndim == 3 ? d : 1, h, wid, cin, cout, ndim, dtype, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_conv3: launch failed");
+}
+long long seg_op_wgrad3_partial_bytes(int ndim, int n, int d, int h, int wid, int p, int q) {
+    return (long long)wgrad3_partial_bytes(ndim, n, ndim == 3 ? d : 1, h, wid, p, q);
+}
+int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int n, int d, int h, int wid, int p, int q, int ndim,
+                  int dtype, void* stream) {
+    if (!dr || !x || !partial || !dw) return fail("seg_op_wgrad3: null pointer");
+    if (p % 16 || q % 16 || (p > 16 && p % 32) || (q > 16 && q % 32)) return fail("seg_op_wgrad3: channel counts must be 16 or multiples of 32");
+    launch_wgrad3(dr, x, partial, dw, n, ndim == 3 ? d : 1, h, wid, p, q, ndim, dtype, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_wgrad3: launch failed");
 }
 int seg_abi_sizeof(int which) {
     return which == 0 ? (int)sizeof(seg_conv_args) : which == 1 ? (int)sizeof(seg_wgrad_args) : (int)sizeof(seg_pack_desc);

@@ -12,6 +12,14 @@ typedef seg_taps Taps;
 typedef seg_conv_args ConvArgs;
 void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s);
 
+// LDS halo-tile kernels for 3^d stride-1 pad-1 convs (conv3.hip): forward / data-gradient and weight gradient
+void launch_conv3(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cin,
+                  int Cout, int ndim, int dtype, hipStream_t s);
+int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q);
+size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
+void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
+                   int dtype, hipStream_t s);
+
 // Direct convolution for a tiny input-channel count (stem: image_channel -> features)
 struct StemArgs {
     const void* in;     // [N][V][Cimg] T

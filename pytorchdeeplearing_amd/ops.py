@@ -184,3 +184,28 @@ def wgrad(dr, x0, dtype, ndim, k, stride=1, pad=0, x1=None, stem=False):
     a.dw = dw.data_ptr()
     lib.check(lib.dll.seg_op_wgrad(C.byref(a), _capi.DTYPE[dtype], _capi.stream_for(dr.device)), "seg_op_wgrad")
     return dw
+
+
+def conv3(x, wpacked, dtype, ndim, cout, bias=None, want_stats=False):
+    """LDS halo-tile 3^d / 3^2 stride-1 pad-1 conv (forward, or data-gradient with the conv_dgrad layout)."""
+    lib = _capi.lib_for(x.device)
+    N, D, H, W, cin = x.shape
+    out = _alloc((N, D, H, W, cout), TORCH_DTYPE[dtype], x.device, zero=True)
+    stats = _alloc((N, cout, 2), torch.float64, x.device, zero=True) if want_stats else None
+    lib.check(lib.seg_op_conv3(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                               stats.data_ptr() if stats is not None else None, N, D, H, W, cin, cout, ndim, _capi.DTYPE[dtype],
+                               _capi.stream_for(x.device)), "seg_op_conv3")
+    return (out, stats) if want_stats else out
+
+
+def wgrad3(dr, x, dtype, ndim):
+    """weight gradient of the 3^d / 3^2 stride-1 pad-1 conv in PyTorch layout (P, Q, k..)."""
+    lib = _capi.lib_for(dr.device)
+    N, D, H, W, P = dr.shape
+    Q = x.shape[-1]
+    nbytes = lib.seg_op_wgrad3_partial_bytes(ndim, N, D, H, W, P, Q)
+    partial = aligned_empty(nbytes, dr.device).view(torch.float32)
+    dw = _alloc((P, Q) + (3,) * ndim, torch.float32, dr.device, zero=True)
+    lib.check(lib.seg_op_wgrad3(dr.data_ptr(), x.data_ptr(), partial.data_ptr(), dw.data_ptr(), N, D, H, W, P, Q, ndim,
+                                _capi.DTYPE[dtype], _capi.stream_for(dr.device)), "seg_op_wgrad3")
+    return dw

@@ -172,3 +172,56 @@ def test_wgrad_conv_transpose_and_stem_exact(dev, dtype):
     y.backward(dy)
     got = ops.wgrad(to_dev(cl(dy), dtype, dev), to_dev(cl(x), dtype, dev), dtype, 2, 3, 1, 1, stem=True)
     assert torch.equal(got.cpu(), w.grad)
+
+
+HALO_CASES = [
+    # ndim, N, spatial, Cin, Cout   (box shapes: W%16==0 or 12 -> 3x4x16 / 1x8x16, else 3x8x8 / 1x8x8; partial boxes masked)
+    (3, 2, (6, 8, 16), 16, 16),
+    (3, 1, (3, 5, 12), 32, 32),
+    (3, 2, (4, 6, 6), 64, 64),
+    (3, 1, (6, 8, 24), 16, 32),
+    (3, 1, (3, 4, 16), 32, 16),
+    (2, 2, (16, 32), 16, 16),
+    (2, 1, (12, 24), 64, 128),
+    (3, 1, (2, 3, 5), 128, 64),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3_halo_exact(dev, dtype, case):
+    ndim, N, sp, cin, cout = case
+    g = torch.Generator().manual_seed(sum(sp) + cin)
+    x = ints((N, cin) + sp, -2, 2, g)
+    w = ints((cout, cin) + (3,) * ndim, -1, 1, g, density=0.15)
+    b = ints((cout,), -3, 3, g)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    xr = x.clone().requires_grad_(True)
+    ref = conv(xr, w, b, padding=1)
+    assert float(ref.abs().max()) <= 256
+    out, stats = ops.conv3(to_dev(cl(x), dtype, dev), ops.pack(w.to(dev), "conv_fwd", dtype), dtype, ndim, cout,
+                           bias=ops.aligned_like(b.to(dev)), want_stats=True)
+    assert torch.equal(ncdhw(out.float().cpu(), ndim), ref.detach())
+    rs = torch.stack([ref.detach().double().flatten(2).sum(2), (ref.detach().double() ** 2).flatten(2).sum(2)], dim=2)
+    assert torch.equal(stats.cpu(), rs)
+    # data-gradient through the same kernel with the flipped layout
+    dy = ints(tuple(ref.shape), -1, 1, g, density=0.4)
+    ref.backward(dy)
+    assert float(xr.grad.abs().max()) <= 256
+    got = ops.conv3(to_dev(cl(dy), dtype, dev), ops.pack(w.to(dev), "conv_dgrad", dtype), dtype, ndim, cin)
+    assert torch.equal(ncdhw(got.float().cpu(), ndim), xr.grad)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_wgrad3_halo_exact(dev, dtype, case):
+    ndim, N, sp, cin, cout = case
+    g = torch.Generator().manual_seed(sum(sp) + cout)
+    x = ints((N, cin) + sp, -2, 2, g)
+    w = torch.zeros((cout, cin) + (3,) * ndim, requires_grad=True)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    y = conv(x, w, padding=1)
+    dy = ints(tuple(y.shape), -2, 2, g)
+    y.backward(dy)
+    got = ops.wgrad3(to_dev(cl(dy), dtype, dev), to_dev(cl(x), dtype, dev), dtype, ndim)
+    assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
