@@ -107,15 +107,20 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
         if (cc) __syncthreads();
         stage_halo<T, B, CH, XLD>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W);
         __syncthreads();
-        typename Mma<T>::frag bcur[NT], bnext[NT];
+        // weights come straight from L2 (every workgroup reads the same few KB); a PF-deep register ring
+        // keeps PF taps in flight so the ~0.5 us L2 round trip hides behind MT*NT MFMAs per tap
+        constexpr int PF = 3;
+        typename Mma<T>::frag bq[PF + 1][NT];
+        auto wofs = [&](int s) { return CH == 32 ? s * a.Cin + cc * 32 : s * 32; };
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bcur[j] = load8(wrow[j] + (CH == 32 ? cc * 32 : 0));
+        for (int s = 0; s < PF && s < NSTEP; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bq[s][j] = load8(wrow[j] + wofs(s));
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) {
+            if (s + PF < NSTEP) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bnext[j] = load8(wrow[j] + (CH == 32 ? (s + 1) * a.Cin + cc * 32 : (s + 1) * 32));
+                for (int j = 0; j < NT; ++j) bq[(s + PF) % (PF + 1)][j] = load8(wrow[j] + wofs(s + PF));
             }
             int toff, col;
             bool tvalid = true;
@@ -131,11 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
                 typename Mma<T>::frag af = load8(&Xs[(hb[m] + toff) * XLD + col]);
                 if (CH == 16 && !tvalid) af = zero8<T>();
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[m][j] = Mma<T>::run(af, bcur[j], acc[m][j]);
-            }
-            if (s + 1 < NSTEP) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bcur[j] = bnext[j];
+                for (int j = 0; j < NT; ++j) acc[m][j] = Mma<T>::run(af, bq[s % (PF + 1)][j], acc[m][j]);
             }
         }
     }
@@ -193,7 +194,9 @@ template <class T, int TD, int TH, int TW, int KD>
 void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
     int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     if (a.Cin == 16 && nt == 4) nt = 2;
-    dim3 grid((unsigned)num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W), a.Cout / (16 * nt));
+    const long long nbox = num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W);
+    while (nt > 1 && nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;      // small levels: favour more workgroups
+    dim3 grid((unsigned)nbox, a.Cout / (16 * nt));
 #define SEG_C3(CH, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_kernel<T, TD, TH, TW, KD, CH, NT>), grid, dim3(256), 0, s, a)
     if (a.Cin == 16) { if (nt == 1) SEG_C3(16, 1); else SEG_C3(16, 2); }
     else { if (nt == 1) SEG_C3(32, 1); else if (nt == 2) SEG_C3(32, 2); else SEG_C3(32, 4); }
@@ -334,19 +337,24 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(Wgrad3Args a) {
     }
 }
 
-// dw[p*sP + q*sQ + tap] += sum_b partial[combo][b][p'][tap][q']
+// dw[p][q][tap] += sum_b partial[combo][b][p'][tap][q']   (one thread per dw element: coalesced read-modify-write of
+// the master gradient, partial tiles gathered through L1/L2)
 __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial, float* dw, int P, int Q, int CP, int CQ, int ntap, int nb,
                                                             long long sP, long long sQ) {
     const long long total = (long long)P * Q * ntap;
     const int tile = CP * ntap * CQ, nqt = Q / CQ;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int combo = (int)(i / tile), e = (int)(i % tile);
-        const int qq = e % CQ, tap = (e / CQ) % ntap, pp = e / (CQ * ntap);
-        const float* src = partial + (long long)combo * nb * tile + e;
-        float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += src[(long long)b * tile];
-        const int p = (combo / nqt) * CP + pp, qc = (combo % nqt) * CQ + qq;
-        dw[p * sP + qc * sQ + tap] += s;
+        const int tap = (int)(i % ntap), qc = (int)((i / ntap) % Q), p = (int)(i / ((long long)ntap * Q));
+        const int combo = (p / CP) * nqt + qc / CQ;
+        const float* src = partial + (long long)combo * nb * tile + ((p % CP) * ntap + tap) * CQ + qc % CQ;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 4 <= nb; b += 4) {
+            s0 += src[(long long)b * tile]; s1 += src[(long long)(b + 1) * tile];
+            s2 += src[(long long)(b + 2) * tile]; s3 += src[(long long)(b + 3) * tile];
+        }
+        for (; b < nb; ++b) s0 += src[(long long)b * tile];
+        dw[p * sP + qc * sQ + tap] += (s0 + s1) + (s2 + s3);
     }
 }
 

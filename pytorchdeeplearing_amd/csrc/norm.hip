@@ -97,7 +97,7 @@ __device__ __forceinline__ void load_dy_sum(const GnBwdArgs& a, long long i, flo
 
 // pass 1.  grid = (slabs, N); a block reduces `rows_per_block` voxels of one sample over all channels.
 // thread = (chunk column cc, row group g); LDS tree over row groups; fp64 atomics per (n,c).
-constexpr int GNB_ROWS = 2048;
+constexpr int GNB_ROWS = 512;
 template <class T>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a) {
     __shared__ float red[256 * 16];
@@ -113,7 +113,24 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a) {
     float q1[8], q2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
-    for (long long v = v0 + g; v < v1; v += G) {
+    // two rows in flight per thread: the loop is pure streaming (2-4 x 16 B loads per row)
+    long long v = v0 + g;
+    for (; v + G < v1; v += 2 * G) {
+        const long long i0 = ((long long)n * a.V + v) * CPR + cc, i1 = i0 + (long long)G * CPR;
+        float dy0[8], dy1[8];
+        load_dy_sum<T>(a, i0, dy0);
+        load_dy_sum<T>(a, i1, dy1);
+        const vec<T, 8> x0 = load8(r + i0 * 8), x1 = load8(r + i1 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xa = to_f(x0[j]), xb = to_f(x1[j]);
+            const float da = (fmaf(sc[j], xa, sh[j]) > 0.f) ? dy0[j] : 0.f;
+            const float db = (fmaf(sc[j], xb, sh[j]) > 0.f) ? dy1[j] : 0.f;
+            q1[j] += da + db;
+            q2[j] = fmaf(da, xa, fmaf(db, xb, q2[j]));
+        }
+    }
+    for (; v < v1; v += G) {
         const long long i = ((long long)n * a.V + v) * CPR + cc;
         float dy[8];
         load_dy_sum<T>(a, i, dy);
