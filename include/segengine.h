@@ -121,7 +121,7 @@ typedef struct seg_conv_args {
     const void* w;      /* packed [Ngemm][Kpad] in dtype, zero padded */
     const float* bias;  /* [Cout] or null */
     void* out;
-    double* stats;      /* [N][Cout][2] sum / sum of squares (+=) or null */
+    double* stats;      /* [32][N][Cout][2] sum / sum of squares (+=), 32 replicas to be summed, or null */
     int N, ID, IH, IW;  /* gather source dims */
     int OD, OH, OW;     /* row-space dims */
     int FD, FH, FW;     /* scatter: fine output dims */
@@ -133,7 +133,8 @@ typedef struct seg_conv_args {
 int seg_op_conv(const seg_conv_args* a, int dtype, void* stream);
 
 /* weight gradient dW[p][tap][q] += sum_m dR[m][p] * X[vox(m,tap)][q], written to
- * dw[p*sP + q*sQ + tap*sT] (fp32).  stem=1: X is [N][V][C0] with tiny C0 and q enumerates (tap,ci). */
+ * dw[p*sP + q*sQ + tap*sT] (fp32) through per-slice partial tiles in `partial_scratch`
+ * (seg_op_wgrad_partial_bytes bytes; deterministic reduction).  stem=1: X is [N][V][C0] with tiny C0 and q enumerates (tap,ci). */
 typedef struct seg_wgrad_args {
     const void* dr;
     const void* x0;
@@ -147,7 +148,8 @@ typedef struct seg_wgrad_args {
     long long sP, sQ, sT;
     int stem;
 } seg_wgrad_args;
-int seg_op_wgrad(const seg_wgrad_args* a, int dtype, void* stream);
+long long seg_op_wgrad_partial_bytes(const seg_wgrad_args* a);
+int seg_op_wgrad(const seg_wgrad_args* a, float* partial_scratch, int dtype, void* stream);
 
 /* weight re-layout: dst[r1][r2][t][c] (dtype, row length Kpad, zero padded) = src[r1*s1+r2*s2+t'*sT+c*sC],
  * t' = flipT ? T-1-t : t.  `descs` is a DEVICE array. */
@@ -161,6 +163,7 @@ typedef struct seg_pack_desc {
 } seg_pack_desc;
 int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int dtype, void* stream);
 /* LDS halo-tile kernels for the 3^d (ndim 3) / 3^2 (ndim 2, D = 1) stride-1 pad-1 convolutions.
+ * (stats, when given, is [32][N][Cout][2] like seg_conv_args.stats.)
  * seg_op_conv3: out[N][D][H][W][Cout] = conv(in[N][D][H][W][Cin], w packed [Cout][Kpad], k = (tap, ci)) + bias,
  * optional GroupNorm partial sums; with the "conv_dgrad" weight layout it is the data-gradient.
  * seg_op_wgrad3: dw[p][q][tap] += sum_m dr[m][p] * x[m + tap][q]; `partial` needs

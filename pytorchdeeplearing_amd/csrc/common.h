@@ -20,6 +20,9 @@ template <> struct dtype_of<bf16> { static constexpr int v = DT_BF16; };
 
 constexpr int kWave = 64;
 constexpr int GN_GROUPS = 8;
+// Reduction targets that many workgroups hit (GroupNorm sums, loss sums) are replicated STAT_REP times and
+// summed by the tiny finalize kernels: same-address atomics serialize at ~60 ns each on gfx950.
+constexpr int STAT_REP = 32;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }

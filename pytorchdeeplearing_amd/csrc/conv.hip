@@ -30,8 +30,9 @@ __device__ __forceinline__ RowCoord decode_row(long long m, int D, int H, int W)
 // rows of the tile may straddle samples when the per-sample volume is not a multiple of BM.
 template <class T, int BN>
 __device__ __forceinline__ void tile_stats(const T* Os, int ldo, int rows_valid, long long m0, long long Vrow,
-                                           double* stats, int Cout, int co_base, float* red) {
+                                           double* stats, int Cout, int co_base, float* red, int N) {
     constexpr int G = 256 / BN;
+    stats += (long long)(blockIdx.x % STAT_REP) * N * Cout * 2;       // replica of this workgroup
     const int col = threadIdx.x % BN, g = threadIdx.x / BN;
     const int n_first = (int)(m0 / Vrow), n_last = (int)((m0 + rows_valid - 1) / Vrow);
     if (n_first == n_last) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
         store8(out + orow * a.Cout + co_real0 + cc * 8, v);
     }
-    if (a.stats) tile_stats<T, BN>(Os, LDO, rows_valid, m0, Vrow, a.stats, a.Cout, co_real0, red);
+    if (a.stats) tile_stats<T, BN>(Os, LDO, rows_valid, m0, Vrow, a.stats, a.Cout, co_real0, red, a.N);
 }
 
 template <class T>
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs a) {
     if (a.stats) {
         // column sums, 16 columns at a time with the shared helper
         for (int c0 = 0; c0 < Cout; c0 += 16) {
-            tile_stats<T, 16>(Os + c0, LDO, rows_valid, m0, V, a.stats, Cout, c0, red);
+            tile_stats<T, 16>(Os + c0, LDO, rows_valid, m0, V, a.stats, Cout, c0, red, a.N);
             __syncthreads();
         }
     }
@@ -399,7 +400,7 @@ void launch_head_bwd(const HeadBwdArgs& a, int dtype, hipStream_t s) {
     const long long M = (long long)a.N * a.V;
     const int VPB = 256 / (a.Cin / 8);
     int blocks = cdiv(M, VPB);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     dim3 grid(blocks);
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<float>), grid, dim3(256), 0, s, a);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<f16>), grid, dim3(256), 0, s, a);

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
         if (tid < BN) {
             double ts = 0.0, tss = 0.0;
             for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
-            double* dst = a.stats + ((long long)bp.n * a.Cout + co0 + col) * 2;
+            double* dst = a.stats + ((long long)(blockIdx.x % STAT_REP) * a.N * a.Cout + (long long)bp.n * a.Cout + co0 + col) * 2;
             atomicAdd(dst, ts);
             atomicAdd(dst + 1, tss);
         }
@@ -341,20 +341,24 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(Wgrad3Args a) {
 // the master gradient, partial tiles gathered through L1/L2)
 __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial, float* dw, int P, int Q, int CP, int CQ, int ntap, int nb,
                                                             long long sP, long long sQ) {
+    // grid.y slices the partial list (32 partial tiles per slice); slices meet in dw through one atomic each
     const long long total = (long long)P * Q * ntap;
     const int tile = CP * ntap * CQ, nqt = Q / CQ;
+    const int b0 = blockIdx.y * 32, b1 = (b0 + 32 < nb) ? b0 + 32 : nb;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int tap = (int)(i % ntap), qc = (int)((i / ntap) % Q), p = (int)(i / ((long long)ntap * Q));
         const int combo = (p / CP) * nqt + qc / CQ;
         const float* src = partial + (long long)combo * nb * tile + ((p % CP) * ntap + tap) * CQ + qc % CQ;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int b = 0;
-        for (; b + 4 <= nb; b += 4) {
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
             s0 += src[(long long)b * tile]; s1 += src[(long long)(b + 1) * tile];
             s2 += src[(long long)(b + 2) * tile]; s3 += src[(long long)(b + 3) * tile];
         }
-        for (; b < nb; ++b) s0 += src[(long long)b * tile];
-        dw[p * sP + qc * sQ + tap] += (s0 + s1) + (s2 + s3);
+        for (; b < b1; ++b) s0 += src[(long long)b * tile];
+        const float tot = (s0 + s1) + (s2 + s3);
+        if (gridDim.y == 1) dw[p * sP + qc * sQ + tap] += tot;
+        else atomicAdd(&dw[p * sP + qc * sQ + tap], tot);
     }
 }
 
@@ -374,7 +378,7 @@ void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long lon
     const long long total = (long long)a.P * a.Q * ntap;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, a.nb, sP, sQ);
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, a.nb, sP, sQ);
 }
 
 template <class T>

@@ -269,6 +269,44 @@ Taps make_taps(int ndim, int k, int pad) {
     return t;
 }
 
+// weight-gradient launch arguments of a UNIT (pointers are null until the engine is bound)
+WgradArgs make_wgrad_args(const seg_engine& E, const Step& s, int draw) {
+    const Ten& i0 = E.tens[s.in0];
+    const Ten& ro = E.tens[s.raw];
+    const int li = i0.lvl, lo = ro.lvl;
+    const int T = (s.ck == CK_K3 || s.ck == CK_STEM3) ? (E.ndim == 3 ? 27 : 9)
+                  : (s.ck == CK_K2S2 || s.ck == CK_KT) ? (E.ndim == 3 ? 8 : 4) : 1;
+    char* ws = E.ws;
+    auto P = [&](size_t off) -> const void* { return ws ? ws + off : nullptr; };
+    WgradArgs w{};
+    w.dw = E.g ? E.g + E.params[s.w].off : nullptr; w.N = E.N; w.sT = 1; w.sQ = T;
+    if (s.ck == CK_KT) {
+        // dW[ci][co][a] = sum_coarse X[m][ci] * dY[2m+a][co]
+        w.dr = P(i0.off); w.P = s.Cin;
+        w.x0 = draw >= 0 ? P(E.tens[draw].off) : nullptr; w.C0 = s.Cout; w.x1 = nullptr; w.C1 = 0; w.Q = s.Cout;
+        w.ID = E.dim_d(lo); w.IH = E.dim_h(lo); w.IW = E.dim_w(lo);
+        w.OD = E.dim_d(li); w.OH = E.dim_h(li); w.OW = E.dim_w(li);
+        w.sd = E.ndim == 3 ? 2 : 1; w.sh = 2; w.sw = 2;
+        w.taps = make_taps(E.ndim, 2, 0);
+        w.sP = (long long)s.Cout * T;
+    } else {
+        w.dr = draw >= 0 ? P(E.tens[draw].off) : nullptr; w.P = s.Cout;
+        w.x0 = P(i0.off); w.C0 = i0.C;
+        w.x1 = s.in1 >= 0 ? P(E.tens[s.in1].off) : nullptr;
+        w.C1 = s.in1 >= 0 ? E.tens[s.in1].C : 0;
+        w.Q = s.Cin;
+        w.ID = E.dim_d(li); w.IH = E.dim_h(li); w.IW = E.dim_w(li);
+        w.OD = E.dim_d(lo); w.OH = E.dim_h(lo); w.OW = E.dim_w(lo);
+        const int k = (s.ck == CK_K3 || s.ck == CK_STEM3) ? 3 : s.ck == CK_K2S2 ? 2 : 1;
+        const int str = s.ck == CK_K2S2 ? 2 : 1;
+        w.sd = E.ndim == 3 ? str : 1; w.sh = str; w.sw = str;
+        w.taps = make_taps(E.ndim, k, k == 3 ? 1 : 0);
+        w.sP = (long long)s.Cin * T;
+        if (s.ck == CK_STEM3 || s.ck == CK_STEM1) { w.stem = 1; w.Q = T * s.Cin; }
+    }
+    return w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // planning: workspace layout + forward / backward schedules
 // ------------------------------------------------------------------------------------------------
@@ -321,11 +359,11 @@ struct Planner {
         // statistics (fp64) contiguous so one memset clears them; same for Q
         const size_t s0 = cur;
         for (auto& s : E.steps)
-            if (s.type == ST_UNIT && s.gn_w >= 0) s.stats = alloc((size_t)N * s.Cout * 2 * 8);
+            if (s.type == ST_UNIT && s.gn_w >= 0) s.stats = alloc((size_t)STAT_REP * N * s.Cout * 2 * 8);
         E.off_stats = s0; E.stats_bytes = cur - s0;
         const size_t q0 = cur;
         for (auto& s : E.steps)
-            if (s.type == ST_UNIT && s.gn_w >= 0) s.Q = alloc((size_t)N * s.Cout * 2 * 8);
+            if (s.type == ST_UNIT && s.gn_w >= 0) s.Q = alloc((size_t)STAT_REP * N * s.Cout * 2 * 8);
         E.off_Q = q0; E.Q_bytes = cur - q0;
         for (auto& s : E.steps)
             if (s.type == ST_UNIT && s.gn_w >= 0) {
@@ -372,9 +410,15 @@ struct Planner {
         // partial-tile buffer of the halo weight-gradient kernel (largest K3 layer)
         size_t pmax = 0;
         for (auto& s : E.steps)
-            if (s.type == ST_UNIT && s.ck == CK_K3 && s.in1 < 0) {
-                const int l = E.tens[s.raw].lvl;
-                pmax = std::max(pmax, wgrad3_partial_bytes(E.ndim, N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cout, s.Cin));
+            if (s.type == ST_UNIT) {
+                if (s.ck == CK_K3 && s.in1 < 0) {
+                    const int l = E.tens[s.raw].lvl;
+                    pmax = std::max(pmax, wgrad3_partial_bytes(E.ndim, N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cout, s.Cin));
+                } else {
+                    char* keep = E.ws; E.ws = nullptr;
+                    pmax = std::max(pmax, wgrad_partial_bytes(make_wgrad_args(E, s, -1)));
+                    E.ws = keep;
+                }
             }
         E.off_partial = alloc(pmax);
 
@@ -592,33 +636,8 @@ struct Planner {
                         return;
                     }
                     // ---- weight gradient
-                    WgradArgs w{};
-                    w.dw = E.g + E.params[s.w].off; w.N = E.N; w.sT = 1; w.sQ = T;
-                    if (s.ck == CK_KT) {
-                        // dW[ci][co][a] = sum_coarse X[m][ci] * dY[2m+a][co]
-                        w.dr = E.ws + i0.off; w.P = s.Cin;
-                        w.x0 = E.ws + E.tens[draw].off; w.C0 = s.Cout; w.x1 = nullptr; w.C1 = 0; w.Q = s.Cout;
-                        w.ID = E.dim_d(lo); w.IH = E.dim_h(lo); w.IW = E.dim_w(lo);
-                        w.OD = E.dim_d(li); w.OH = E.dim_h(li); w.OW = E.dim_w(li);
-                        w.sd = E.ndim == 3 ? 2 : 1; w.sh = 2; w.sw = 2;
-                        w.taps = make_taps(E.ndim, 2, 0);
-                        w.sP = (long long)s.Cout * T;
-                    } else {
-                        w.dr = E.ws + E.tens[draw].off; w.P = s.Cout;
-                        w.x0 = E.ws + i0.off; w.C0 = i0.C;
-                        w.x1 = s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr;
-                        w.C1 = s.in1 >= 0 ? E.tens[s.in1].C : 0;
-                        w.Q = s.Cin;
-                        w.ID = E.dim_d(li); w.IH = E.dim_h(li); w.IW = E.dim_w(li);
-                        w.OD = E.dim_d(lo); w.OH = E.dim_h(lo); w.OW = E.dim_w(lo);
-                        const int k = (s.ck == CK_K3 || s.ck == CK_STEM3) ? 3 : s.ck == CK_K2S2 ? 2 : 1;
-                        const int str = s.ck == CK_K2S2 ? 2 : 1;
-                        w.sd = E.ndim == 3 ? str : 1; w.sh = str; w.sw = str;
-                        w.taps = make_taps(E.ndim, k, k == 3 ? 1 : 0);
-                        w.sP = (long long)s.Cin * T;
-                        if (s.ck == CK_STEM3 || s.ck == CK_STEM1) { w.stem = 1; w.Q = T * s.Cin; }
-                    }
-                    launch_wgrad(w, E.dtype, st);
+                    WgradArgs w = make_wgrad_args(E, s, draw);
+                    launch_wgrad(w, (float*)(E.ws + E.off_partial), E.dtype, st);
                     // ---- data gradient(s)
                     if (g0 < 0 && g1 < 0) return;
                     ConvArgs a{};
@@ -796,7 +815,7 @@ int seg_set_loss_scale(seg_handle h, float scale) {
 }
 float seg_get_loss_scale(seg_handle h) { return h ? h->loss_scale : 0.f; }
 
-long long seg_loss_ws_bytes(int n, int c) { return (long long)align_up(loss_sums_count(n, c) * sizeof(double)); }
+long long seg_loss_ws_bytes(int n, int c) { return (long long)align_up(loss_sums_count(n, c) * sizeof(double) * STAT_REP); }
 
 static int fill_loss(LossArgs& a, const float* logits, const void* target, int label_type, int n, int c, long long v,
                      int loss_kind, float focal_alpha, float focal_gamma, void* ws) {
@@ -859,11 +878,12 @@ int seg_op_conv(const seg_conv_args* a, int dtype, void* stream) {
     launch_conv_igemm(*a, dtype, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_conv: launch failed");
 }
-int seg_op_wgrad(const seg_wgrad_args* a, int dtype, void* stream) {
-    if (!a || !a->dr || !a->x0 || !a->dw) return fail("seg_op_wgrad: null pointer");
+long long seg_op_wgrad_partial_bytes(const seg_wgrad_args* a) { return a ? (long long)wgrad_partial_bytes(*a) : -1; }
+int seg_op_wgrad(const seg_wgrad_args* a, float* partial_scratch, int dtype, void* stream) {
+    if (!a || !a->dr || !a->x0 || !a->dw || !partial_scratch) return fail("seg_op_wgrad: null pointer");
     if (a->P % 16) return fail("seg_op_wgrad: P must be a multiple of 16");
     if (a->stem ? (a->Q > 32) : (a->Q % 16 != 0)) return fail("seg_op_wgrad: bad Q");
-    launch_wgrad(*a, dtype, (hipStream_t)stream);
+    launch_wgrad(*a, partial_scratch, dtype, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_wgrad: launch failed");
 }
 int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int dtype, void* stream) {

@@ -112,7 +112,8 @@ void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s);
 
 // Weight gradient: see seg_wgrad_args in include/segengine.h
 typedef seg_wgrad_args WgradArgs;
-void launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s);
+size_t wgrad_partial_bytes(const WgradArgs& a);   // scratch for the per-slice partial tiles
+void launch_wgrad(const WgradArgs& a, float* partial, int dtype, hipStream_t s);
 
 struct PoolArgs {
     const void* in; void* out;       // fwd: in fine, out coarse
@@ -144,7 +145,7 @@ struct LossArgs {
     float* dlogits;             // [N][C][V] or null
     float grad_scale;           // loss scale folded into dlogits
 };
-size_t loss_sums_count(int N, int C);
+__host__ __device__ size_t loss_sums_count(int N, int C);   // doubles per replica (STAT_REP replicas)
 void launch_loss_forward(const LossArgs& a, hipStream_t s);    // reduce + finalize (writes out[], coefficient block in sums)
 void launch_loss_backward(const LossArgs& a, hipStream_t s);   // dlogits from the finalized coefficients
 

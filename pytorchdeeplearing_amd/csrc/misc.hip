@@ -129,6 +129,9 @@ constexpr int S_GLOBAL = 0;                 // [0]=sum p*y [1]=sum p [2]=sum y [
 constexpr int S_CLASS = 8;                  // + 3*c : I_c, P_c, Y_c
 constexpr int S_METRIC = S_CLASS + 3 * MAXCLS;   // + ((n*C + c)*3) : inter, msum, ysum of thresholded masks
 inline __host__ __device__ int s_coef(int N, int C) { return S_METRIC + 3 * N * C; }   // + 4 + 2*MAXCLS coefficients
+}  // namespace
+__host__ __device__ size_t loss_sums_count(int N, int C) { return (size_t)s_coef(N, C) + 4 + 2 * MAXCLS; }
+namespace {
 
 __device__ __forceinline__ float bce_with_logits(float z, float y) {
     return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
@@ -183,26 +186,34 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
         }
     }
     const int lane = tid & 63;
+    double* sums = a.sums + (long long)((blockIdx.x * 4 + (tid >> 6)) % STAT_REP) * loss_sums_count(a.N, C);
     for (int j = 0; j < 5; ++j) {
         const float s = wave_sum(g[j]);
-        if (lane == 0 && s != 0.f) atomicAdd(a.sums + S_GLOBAL + j, (double)s);
+        if (lane == 0 && s != 0.f) atomicAdd(sums + S_GLOBAL + j, (double)s);
     }
     for (int c = 0; c < C; ++c)
         for (int j = 0; j < 3; ++j) {
             if (C > 1) {
                 const float s = wave_sum(cls[c][j]);
-                if (lane == 0 && s != 0.f) atomicAdd(a.sums + S_CLASS + 3 * c + j, (double)s);
+                if (lane == 0 && s != 0.f) atomicAdd(sums + S_CLASS + 3 * c + j, (double)s);
             }
             const float m = wave_sum(met[c][j]);
-            if (lane == 0 && m != 0.f) atomicAdd(a.sums + S_METRIC + ((long long)n * C + c) * 3 + j, (double)m);
+            if (lane == 0 && m != 0.f) atomicAdd(sums + S_METRIC + ((long long)n * C + c) * 3 + j, (double)m);
         }
 }
 
 // single block: scalar loss, metrics and the coefficients consumed by the backward pass
 __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
-    if (threadIdx.x != 0) return;
     const int C = a.C, N = a.N;
     double* S = a.sums;
+    const int cnt_all = s_coef(N, C);
+    for (int i = threadIdx.x; i < cnt_all; i += 64) {          // fold the replicas into copy 0
+        double t = S[i];
+        for (int rep = 1; rep < STAT_REP; ++rep) t += S[(long long)rep * loss_sums_count(N, C) + i];
+        S[i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double* K = S + s_coef(N, C);
     const double smooth = 1e-5, eps = 1e-7;
     const double Ntot = (double)N * (double)a.V;
@@ -459,10 +470,10 @@ void launch_maxpool_bwd(const PoolArgs& a, int dtype, hipStream_t s) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(maxpool_bwd_kernel<bf16>), grid, dim3(256), 0, s, a);
 }
 
-size_t loss_sums_count(int N, int C) { return (size_t)s_coef(N, C) + 4 + 2 * MAXCLS; }
+
 
 void launch_loss_forward(const LossArgs& a, hipStream_t s) {
-    (void)hipMemsetAsync(a.sums, 0, loss_sums_count(a.N, a.C) * sizeof(double), s);
+    (void)hipMemsetAsync(a.sums, 0, loss_sums_count(a.N, a.C) * sizeof(double) * STAT_REP, s);
     dim3 grid(cdiv(a.V, LOSS_VPB), a.N);
     hipLaunchKernelGGL(loss_reduce_kernel, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, a);

@@ -15,12 +15,20 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnFinArgs a) {
     __shared__ float gm[GN_GROUPS], gr[GN_GROUPS];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int cpg = a.C / GN_GROUPS;
+    __shared__ double csum[256][2];
+    for (int c = tid; c < a.C; c += 256) {       // every channel folds its STAT_REP replicas in parallel
+        double s = 0.0, ss = 0.0;
+        for (int rep = 0; rep < STAT_REP; ++rep) {
+            const double* st = a.stats + (((long long)rep * a.N + n) * a.C + c) * 2;
+            s += st[0];
+            ss += st[1];
+        }
+        csum[c][0] = s; csum[c][1] = ss;
+    }
+    __syncthreads();
     if (tid < GN_GROUPS) {
         double s = 0.0, ss = 0.0;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-            s += a.stats[((long long)n * a.C + c) * 2];
-            ss += a.stats[((long long)n * a.C + c) * 2 + 1];
-        }
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += csum[c][0]; ss += csum[c][1]; }
         const double cnt = (double)cpg * (double)a.V;
         const double mean = s / cnt;
         double var = ss / cnt - mean * mean;
@@ -152,13 +160,14 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a) {
         double s = 0.0;
         for (int k = 0; k < G; ++k) s += red[(k * CPR + ccx) * 16 + jj];
         const int c = ccx * 8 + (jj & 7), which = jj >> 3;
-        atomicAdd(a.Q + ((long long)n * a.C + c) * 2 + which, s);
+        atomicAdd(a.Q + (((long long)(blockIdx.x % STAT_REP) * a.N + n) * a.C + c) * 2 + which, s);
     }
 }
 
 // finalize: grid = N, block = 256
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
     __shared__ double S1[GN_GROUPS], S2[GN_GROUPS];
+    __shared__ double sQ1[256], sR1[256];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int cpg = a.C / GN_GROUPS;
     if (tid < GN_GROUPS) { S1[tid] = 0.0; S2[tid] = 0.0; }
@@ -167,8 +176,14 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
         const int g = c / cpg;
         const double mk = a.mask ? (double)a.mask[(long long)n * a.mask_ld + c] : 1.0;
         const double mu = a.mean[n * GN_GROUPS + g], rs = a.rstd[n * GN_GROUPS + g];
-        const double q1 = mk * a.Q[((long long)n * a.C + c) * 2];          // sum dz
-        const double q2 = mk * a.Q[((long long)n * a.C + c) * 2 + 1];      // sum dz * r
+        double Q1 = 0.0, Q2 = 0.0, R1 = 0.0;
+        for (int rep = 0; rep < STAT_REP; ++rep) {
+            const long long o = (((long long)rep * a.N + n) * a.C + c) * 2;
+            Q1 += a.Q[o]; Q2 += a.Q[o + 1]; R1 += a.stats[o];
+        }
+        sQ1[c] = Q1; sR1[c] = R1;
+        const double q1 = mk * Q1;          // sum dz
+        const double q2 = mk * Q2;          // sum dz * r
         const double qx = (q2 - mu * q1) * rs;                              // sum dz * xhat
         atomicAdd(&a.dbeta[c], (float)q1);
         atomicAdd(&a.dgamma[c], (float)qx);
@@ -190,9 +205,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
         co[0] = (float)A; co[1] = (float)B; co[2] = (float)Cc;
         if (a.dbias) {
             // sum_v dr = A*sum(dzr) + B*sum(r) + Cc*V   (sum(r) from the forward statistics)
-            const double R1 = a.stats[((long long)n * a.C + c) * 2];
-            const double Q1 = a.Q[((long long)n * a.C + c) * 2];
-            atomicAdd(&a.dbias[c], (float)(A * Q1 + B * R1 + Cc * (double)a.V));
+            atomicAdd(&a.dbias[c], (float)(A * sQ1[c] + B * sR1[c] + Cc * (double)a.V));
         }
     }
 }

@@ -1,10 +1,14 @@
-// Weight-gradient GEMM for gfx950:  dW[p][tap][q] += sum_m dR[m][p] * X[vox(m,tap)][q]
-// Both operands are reduced along the voxel axis m, which is the SLOW axis of the channels-last
-// tensors, so both MFMA fragments need a transpose: tiles are staged row-major [m][c] in LDS and
-// read with ds_read_b64_tr_b16 (f16/bf16) or element-wise (f32, v_mfma_f32_16x16x4_f32 wants one
-// k per lane).  Partial tiles are accumulated into the fp32 master-gradient with atomics; the voxel
-// axis is split over gridDim.y.  Pinned by autograd of the conv call sites in networks/VNet3d.py /
-// Unet3d.py (reference), i.e. torch `convolution_backward` weight gradients.
+// Generic weight-gradient GEMM for gfx950:  dW[p][tap][q] = sum_m dR[m][p] * X[vox(m,tap)][q]
+// (conv 2^d s2, conv 1^d on a virtual concat, ConvTranspose 2^d s2, the image stem, and 3^d convs
+// whose input is a concat; the plain 3^d convs use the halo kernel in conv3.hip).
+// Both operands are reduced along the voxel axis m, the SLOW axis of the channels-last tensors, so
+// both MFMA fragments need a transpose: tiles are staged row-major [m][c] in LDS and read with
+// ds_read_b64_tr_b16 (f16/bf16) or element-wise (f32).  A workgroup owns a (p-tile, q-tile) pair for
+// up to 8 taps (all taps of the 2^d kernels: their windows do not overlap, so every voxel is read
+// once) and a slice of the voxel axis; global loads of step s+1 are in flight while step s runs on
+// the matrix cores.  Each workgroup writes ONE partial tile; wgrad_reduce_kernel sums the slices
+// (deterministic, no same-address atomics).
+// Pinned by autograd of the conv call sites in networks/VNet3d.py / Unet3d.py (reference).
 #include "kernels.h"
 
 namespace seg {
@@ -13,6 +17,7 @@ namespace {
 constexpr int WM = 32;        // voxel rows per step (one MFMA K-step)
 constexpr int WT = 64;        // max tile extent along p and q
 constexpr int LDW = WT + 8;
+constexpr int MAXTB = 8;      // taps handled inside one workgroup
 
 struct RowCoord { int n, d, h, w; };
 __device__ __forceinline__ RowCoord decode_row(long long m, int D, int H, int W) {
@@ -25,7 +30,6 @@ __device__ __forceinline__ RowCoord decode_row(long long m, int D, int H, int W)
 }
 
 template <class T> struct TFrag {
-    // 16-bit types: two transposing reads -> 8 k-values (rows 4q..4q+3 and 16+4q..16+4q+3) of column col0+l15
     static __device__ __forceinline__ typename Mma<T>::frag load(const T* tile, int col0, int lane) {
         const int t = lane & 15, q = lane >> 4;
         const T* p0 = tile + (4 * q + (t >> 2)) * LDW + col0 + (t & 3) * 4;
@@ -47,49 +51,55 @@ template <> struct TFrag<float> {
     }
 };
 
-template <class T, bool STEM>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, int TP, int TQ, int ntq, int ntile, long long Mc) {
+struct WgPlan { int TP, TQ, ntq, ntile, TB, ntg; long long Mc; int parts; };
+
+// partial layout per voxel slice: [P][T][Qc]  (Qc = Q, or the (tap,ci) column count of the stem)
+template <class T, bool STEM, int NTB>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, float* partial) {
     __shared__ T Ds[WM * LDW];
-    __shared__ T Xs[WM * LDW];
+    __shared__ T Xs[NTB * WM * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tap = STEM ? 0 : (int)(blockIdx.x / ntile);
-    const int tile = (int)(blockIdx.x % ntile);
-    const int p0 = (tile / ntq) * TP, q0 = (tile % ntq) * TQ;
+    const int tg = (int)(blockIdx.x / pl.ntile), tile = (int)(blockIdx.x % pl.ntile);
+    const int tap0 = tg * NTB;
+    const int TP = pl.TP, TQ = pl.TQ;
+    const int p0 = (tile / pl.ntq) * TP, q0 = (tile % pl.ntq) * TQ;
     const long long M = (long long)a.N * a.OD * a.OH * a.OW;
-    const long long mbeg = (long long)blockIdx.y * Mc;
-    const long long mend = (mbeg + Mc < M) ? mbeg + Mc : M;
-    const int Qc = a.C0 + a.C1;
+    const long long mbeg = (long long)blockIdx.y * pl.Mc;
+    const long long mend = (mbeg + pl.Mc < M) ? mbeg + pl.Mc : M;
     const T* dr = (const T*)a.dr;
     const T* x0 = (const T*)a.x0;
     const T* x1 = (const T*)a.x1;
-    int td = 0, th = 0, tw = 0;
-    if (!STEM) { td = a.taps.d[tap]; th = a.taps.h[tap]; tw = a.taps.w[tap]; }
+    const int ntaps = STEM ? 1 : a.taps.n;
+    const int ntb = (ntaps - tap0 < NTB) ? ntaps - tap0 : NTB;      // taps of this workgroup
 
-    const int nt_p = TP / 16, nt_q = (TQ + 15) / 16, n16 = nt_p * nt_q;
-    f32x4 acc[4];
+    const int nt_p = TP / 16, nt_q = (TQ + 15) / 16, n16 = nt_p * nt_q;   // 16x16 tiles per tap
+    const int nwork = ntb * n16;                                          // (tap, tile) work items, split over the 4 waves
+    constexpr int MAXW = NTB == 1 ? 4 : 8;
+    f32x4 acc[MAXW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MAXW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int cpr_p = TP / 8;
-    const int cpr_q = STEM ? 8 : TQ / 8;
-    for (long long ms = mbeg; ms < mend; ms += WM) {
-        // ---- stage dR rows
-        if (tid < WM * cpr_p) {
-            const int row = tid / cpr_p, cc = tid % cpr_p;
-            const long long m = ms + row;
-            vec<T, 8> v = zero8<T>();
-            if (m < mend) v = load8(dr + m * a.P + p0 + cc * 8);
-            store8(&Ds[row * LDW + cc * 8], v);
+    // ---- staging assignment: thread -> (row, 8-channel chunk) of dR, and of X for each tap slot
+    const int cpr_p = TP / 8, cpr_q = STEM ? 8 : TQ / 8;
+    const bool dload = tid < WM * cpr_p;
+    const int drow_ = tid / cpr_p, dcc = tid % cpr_p;
+    const bool xload = STEM || tid < WM * cpr_q;
+    const int xrow_ = STEM ? (tid >> 3) : tid / cpr_q, xcc = STEM ? (tid & 7) : tid % cpr_q;
+
+    vec<T, 8> dreg, xreg[NTB];
+    float sreg[4];
+    auto gload = [&](long long ms) {
+        if (dload) {
+            const long long m = ms + drow_;
+            dreg = (m < mend) ? load8(dr + m * a.P + p0 + dcc * 8) : zero8<T>();
         }
-        // ---- stage gathered X rows
         if (STEM) {
-            const int row = tid >> 3, c4 = (tid & 7) * 4;
-            const long long m = ms + row;
+            const long long m = ms + xrow_;
             const bool mv = m < mend;
             const RowCoord r = decode_row(mv ? m : 0, a.OD, a.OH, a.OW);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int col = c4 + j;
+                const int col = xcc * 4 + j;
                 float xv = 0.f;
                 if (mv && col < a.Q) {
                     const int tp = col / a.C0, ci = col % a.C0;
@@ -97,88 +107,146 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, int TP, int TQ,
                     if ((unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
                         xv = to_f(x0[((((long long)r.n * a.ID + id) * a.IH + ih) * a.IW + iw) * a.C0 + ci]);
                 }
-                Xs[row * LDW + col] = from_f<T>(xv);
+                sreg[j] = xv;
             }
-        } else if (tid < WM * cpr_q) {
-            const int row = tid / cpr_q, cc = tid % cpr_q;
-            const long long m = ms + row;
-            vec<T, 8> v = zero8<T>();
-            if (m < mend) {
-                const RowCoord r = decode_row(m, a.OD, a.OH, a.OW);
-                const int id = r.d * a.sd + td, ih = r.h * a.sh + th, iw = r.w * a.sw + tw;
-                if ((unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) {
-                    const long long vox = (((long long)r.n * a.ID + id) * a.IH + ih) * a.IW + iw;
-                    const int qc = q0 + cc * 8;
-                    v = (qc < a.C0) ? load8(x0 + vox * a.C0 + qc) : load8(x1 + vox * a.C1 + (qc - a.C0));
-                }
-            }
-            store8(&Xs[row * LDW + cc * 8], v);
-        }
-        __syncthreads();
+        } else if (xload) {
+            const long long m = ms + xrow_;
+            const bool mv = m < mend;
+            const RowCoord r = decode_row(mv ? m : 0, a.OD, a.OH, a.OW);
+            const int qc = q0 + xcc * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int tt = wv + 4 * i;
-            if (tt < n16) {
+            for (int t = 0; t < NTB; ++t) {
+                vec<T, 8> v = zero8<T>();
+                if (mv && t < ntb) {
+                    const int tp = tap0 + t;
+                    const int id = r.d * a.sd + a.taps.d[tp], ih = r.h * a.sh + a.taps.h[tp], iw = r.w * a.sw + a.taps.w[tp];
+                    if ((unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) {
+                        const long long vox = (((long long)r.n * a.ID + id) * a.IH + ih) * a.IW + iw;
+                        v = (qc < a.C0) ? load8(x0 + vox * a.C0 + qc) : load8(x1 + vox * a.C1 + (qc - a.C0));
+                    }
+                }
+                xreg[t] = v;
+            }
+        }
+    };
+    auto sstore = [&]() {
+        if (dload) store8(&Ds[drow_ * LDW + dcc * 8], dreg);
+        if (STEM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Xs[xrow_ * LDW + xcc * 4 + j] = from_f<T>(sreg[j]);
+        } else if (xload) {
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) store8(&Xs[(t * WM + xrow_) * LDW + xcc * 8], xreg[t]);
+        }
+    };
+
+    if (mbeg < mend) gload(mbeg);
+    for (long long ms = mbeg; ms < mend; ms += WM) {
+        sstore();
+        __syncthreads();
+        if (ms + WM < mend) gload(ms + WM);              // next step's loads fly while the MFMAs run
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i) {
+            const int wi = wv + 4 * i;
+            if (wi < nwork) {
+                const int t = wi / n16, tt = wi % n16;
                 const int pi = tt / nt_q, qi = tt % nt_q;
                 const typename Mma<T>::frag af = TFrag<T>::load(Ds, pi * 16, lane);
-                const typename Mma<T>::frag bf = TFrag<T>::load(Xs, qi * 16, lane);
+                const typename Mma<T>::frag bf = TFrag<T>::load(Xs + t * WM * LDW, qi * 16, lane);
                 acc[i] = Mma<T>::run(af, bf, acc[i]);
             }
         }
         __syncthreads();
     }
-    (void)Qc;
-    // ---- scatter-add the partial tile into the fp32 master gradient
+    // ---- partial tile of this voxel slice
     const int l15 = lane & 15, q = lane >> 4;
+    const int Tn = STEM ? 1 : a.taps.n, Qc = a.Q;
+    float* dst = partial + (long long)blockIdx.y * a.P * Tn * Qc;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tt = wv + 4 * i;
-        if (tt < n16) {
+    for (int i = 0; i < MAXW; ++i) {
+        const int wi = wv + 4 * i;
+        if (wi < nwork) {
+            const int t = wi / n16, tt = wi % n16;
             const int pi = tt / nt_q, qi = tt % nt_q;
             const int qq = q0 + qi * 16 + l15;
+            if (qq < Qc) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = p0 + pi * 16 + 4 * q + r;
-                if (STEM) {
-                    if (qq < a.Q) {
-                        const int tp = qq / a.C0, ci = qq % a.C0;
-                        atomicAdd(a.dw + p * a.sP + ci * a.sQ + tp * a.sT, acc[i][r]);
-                    }
-                } else {
-                    atomicAdd(a.dw + p * a.sP + qq * a.sQ + tap * a.sT, acc[i][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int p = p0 + pi * 16 + 4 * q + r;
+                    dst[((long long)p * Tn + tap0 + t) * Qc + qq] = acc[i][r];
                 }
             }
         }
     }
 }
 
-template <class T>
-void wgrad_dispatch(const WgradArgs& a, hipStream_t s) {
+// dw[p*sP + q*sQ + tap*sT] += sum_slices partial[slice][p][tap][q]    (stem: column q = (tap, ci))
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, int P, int Tn, int Qc, int parts, long long sP,
+                                                           long long sQ, long long sT, int stem_cimg) {
+    const long long total = (long long)P * Tn * Qc;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float s0 = 0.f, s1 = 0.f;
+        int b = 0;
+        for (; b + 2 <= parts; b += 2) { s0 += partial[(long long)b * total + i]; s1 += partial[(long long)(b + 1) * total + i]; }
+        if (b < parts) s0 += partial[(long long)b * total + i];
+        const int qq = (int)(i % Qc), tap = (int)((i / Qc) % Tn), p = (int)(i / ((long long)Qc * Tn));
+        long long o;
+        if (stem_cimg) o = p * sP + (qq % stem_cimg) * sQ + (qq / stem_cimg) * sT;
+        else o = p * sP + qq * sQ + tap * sT;
+        dw[o] += s0 + s1;
+    }
+}
+
+WgPlan make_plan(const WgradArgs& a) {
+    WgPlan pl;
     const long long M = (long long)a.N * a.OD * a.OH * a.OW;
-    const int TP = a.P < WT ? a.P : WT;
-    int TQ, ntq, bx;
-    if (a.stem) { TQ = 32; ntq = 1; }
-    else { TQ = a.Q < WT ? a.Q : WT; ntq = a.Q / TQ; }
-    const int ntile = (a.P / TP) * ntq;
-    bx = a.stem ? ntile : a.taps.n * ntile;
-    long long gy = 4096 / bx;
-    if (gy < 1) gy = 1;
-    const long long maxgy = (M + WM - 1) / WM;
-    if (gy > maxgy) gy = maxgy;
-    long long Mc = (M + gy - 1) / gy;
+    const int T = a.stem ? 1 : a.taps.n;
+    pl.TB = (T <= MAXTB) ? T : 1;                      // taps per workgroup
+    int cap = (pl.TB > 1) ? 32 : WT;                   // keep the accumulator count per wave <= 8
+    pl.TP = a.P < cap ? a.P : cap;
+    if (a.stem) { pl.TQ = 32; pl.ntq = 1; }
+    else { pl.TQ = a.Q < cap ? a.Q : cap; pl.ntq = a.Q / pl.TQ; }
+    pl.ntile = (a.P / pl.TP) * pl.ntq;
+    pl.ntg = (T + pl.TB - 1) / pl.TB;
+    const int bx = pl.ntg * pl.ntile;
+    long long parts = 1024 / bx;
+    if (parts < 1) parts = 1;
+    if (parts > 64) parts = 64;
+    const long long maxp = (M + WM - 1) / WM;
+    if (parts > maxp) parts = maxp;
+    long long Mc = (M + parts - 1) / parts;
     Mc = (Mc + WM - 1) / WM * WM;
-    gy = (M + Mc - 1) / Mc;
-    dim3 grid(bx, (unsigned)gy);
-    if (a.stem) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, true>), grid, dim3(256), 0, s, a, TP, TQ, ntq, ntile, Mc);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, false>), grid, dim3(256), 0, s, a, TP, TQ, ntq, ntile, Mc);
+    pl.Mc = Mc;
+    pl.parts = (int)((M + Mc - 1) / Mc);
+    return pl;
+}
+
+template <class T>
+void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s) {
+    const WgPlan pl = make_plan(a);
+    dim3 grid(pl.ntg * pl.ntile, pl.parts);
+    if (a.stem) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, true, 1>), grid, dim3(256), 0, s, a, pl, partial);
+    else if (pl.TB == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, false, 1>), grid, dim3(256), 0, s, a, pl, partial);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, false, MAXTB>), grid, dim3(256), 0, s, a, pl, partial);
+    const int Tn = a.stem ? 1 : a.taps.n;
+    const long long total = (long long)a.P * Tn * a.Q;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)partial, a.dw, a.P, Tn, a.Q, pl.parts, a.sP, a.sQ,
+                       a.sT, a.stem ? a.C0 : 0);
 }
 
 }  // namespace
 
-void launch_wgrad(const WgradArgs& a, int dtype, hipStream_t s) {
-    if (dtype == DT_F32) wgrad_dispatch<float>(a, s);
-    else if (dtype == DT_F16) wgrad_dispatch<f16>(a, s);
-    else wgrad_dispatch<bf16>(a, s);
+size_t wgrad_partial_bytes(const WgradArgs& a) {
+    const WgPlan pl = make_plan(a);
+    return (size_t)pl.parts * a.P * (a.stem ? 1 : a.taps.n) * a.Q * sizeof(float);
+}
+
+void launch_wgrad(const WgradArgs& a, float* partial, int dtype, hipStream_t s) {
+    if (dtype == DT_F32) wgrad_dispatch<float>(a, partial, s);
+    else if (dtype == DT_F16) wgrad_dispatch<f16>(a, partial, s);
+    else wgrad_dispatch<bf16>(a, partial, s);
 }
 
 }  // namespace seg

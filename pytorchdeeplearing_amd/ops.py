@@ -158,10 +158,10 @@ def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=
     a.out = out.data_ptr()
     stats = None
     if want_stats:
-        stats = _alloc((N, cout, 2), torch.float64, x0.device, zero=True)
+        stats = _alloc((32, N, cout, 2), torch.float64, x0.device, zero=True)
         a.stats = stats.data_ptr()
     lib.check(lib.dll.seg_op_conv(C.byref(a), _capi.DTYPE[dtype], _capi.stream_for(x0.device)), "seg_op_conv")
-    return (out, stats) if want_stats else out
+    return (out, stats.sum(0)) if want_stats else out
 
 
 def wgrad(dr, x0, dtype, ndim, k, stride=1, pad=0, x1=None, stem=False):
@@ -182,7 +182,8 @@ def wgrad(dr, x0, dtype, ndim, k, stride=1, pad=0, x1=None, stem=False):
     a.stem = 1 if stem else 0
     dw = _alloc((P, qc) + (k,) * ndim, torch.float32, dr.device, zero=True)
     a.dw = dw.data_ptr()
-    lib.check(lib.dll.seg_op_wgrad(C.byref(a), _capi.DTYPE[dtype], _capi.stream_for(dr.device)), "seg_op_wgrad")
+    scratch = aligned_empty(lib.seg_op_wgrad_partial_bytes(C.byref(a)), dr.device)
+    lib.check(lib.seg_op_wgrad(C.byref(a), scratch.data_ptr(), _capi.DTYPE[dtype], _capi.stream_for(dr.device)), "seg_op_wgrad")
     return dw
 
 
@@ -191,11 +192,11 @@ def conv3(x, wpacked, dtype, ndim, cout, bias=None, want_stats=False):
     lib = _capi.lib_for(x.device)
     N, D, H, W, cin = x.shape
     out = _alloc((N, D, H, W, cout), TORCH_DTYPE[dtype], x.device, zero=True)
-    stats = _alloc((N, cout, 2), torch.float64, x.device, zero=True) if want_stats else None
+    stats = _alloc((32, N, cout, 2), torch.float64, x.device, zero=True) if want_stats else None
     lib.check(lib.seg_op_conv3(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                stats.data_ptr() if stats is not None else None, N, D, H, W, cin, cout, ndim, _capi.DTYPE[dtype],
                                _capi.stream_for(x.device)), "seg_op_conv3")
-    return (out, stats) if want_stats else out
+    return (out, stats.sum(0)) if want_stats else out
 
 
 def wgrad3(dr, x, dtype, ndim):
