@@ -183,17 +183,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, floa
 // dw[p*sP + q*sQ + tap*sT] += sum_slices partial[slice][p][tap][q]    (stem: column q = (tap, ci))
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, int P, int Tn, int Qc, int parts, long long sP,
                                                            long long sQ, long long sT, int stem_cimg) {
+    // grid.y slices the partial list (32 per slice); slices meet in dw through one atomic each
     const long long total = (long long)P * Tn * Qc;
+    const int b0 = blockIdx.y * 32, b1 = (b0 + 32 < parts) ? b0 + 32 : parts;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        float s0 = 0.f, s1 = 0.f;
-        int b = 0;
-        for (; b + 2 <= parts; b += 2) { s0 += partial[(long long)b * total + i]; s1 += partial[(long long)(b + 1) * total + i]; }
-        if (b < parts) s0 += partial[(long long)b * total + i];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            s0 += partial[(long long)b * total + i]; s1 += partial[(long long)(b + 1) * total + i];
+            s2 += partial[(long long)(b + 2) * total + i]; s3 += partial[(long long)(b + 3) * total + i];
+        }
+        for (; b < b1; ++b) s0 += partial[(long long)b * total + i];
         const int qq = (int)(i % Qc), tap = (int)((i / Qc) % Tn), p = (int)(i / ((long long)Qc * Tn));
         long long o;
         if (stem_cimg) o = p * sP + (qq % stem_cimg) * sQ + (qq / stem_cimg) * sT;
         else o = p * sP + qq * sQ + tap * sT;
-        dw[o] += s0 + s1;
+        const float tot = (s0 + s1) + (s2 + s3);
+        if (gridDim.y == 1) dw[o] += tot;
+        else atomicAdd(&dw[o], tot);
     }
 }
 
@@ -209,9 +216,13 @@ WgPlan make_plan(const WgradArgs& a) {
     pl.ntile = (a.P / pl.TP) * pl.ntq;
     pl.ntg = (T + pl.TB - 1) / pl.TB;
     const int bx = pl.ntg * pl.ntile;
-    long long parts = 1024 / bx;
+    // voxel-axis split: ~2048 workgroups in total, at most 1024 slices and 16 MB of partial tiles
+    long long parts = 2048 / bx;
     if (parts < 1) parts = 1;
-    if (parts > 64) parts = 64;
+    if (parts > 1024) parts = 1024;
+    const long long elems = (long long)a.P * T * a.Q;
+    if (parts * elems > (4ll << 20)) parts = (4ll << 20) / elems;
+    if (parts < 1) parts = 1;
     const long long maxp = (M + WM - 1) / WM;
     if (parts > maxp) parts = maxp;
     long long Mc = (M + parts - 1) / parts;
@@ -232,7 +243,7 @@ void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s) {
     const long long total = (long long)a.P * Tn * a.Q;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)partial, a.dw, a.P, Tn, a.Q, pl.parts, a.sP, a.sQ,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, (pl.parts + 31) / 32), dim3(256), 0, s, (const float*)partial, a.dw, a.P, Tn, a.Q, pl.parts, a.sP, a.sQ,
                        a.sT, a.stem ? a.C0 : 0);
 }
 
