@@ -1,12 +1,16 @@
 """Headline benchmark: volumes/s of a full VNet3d train step (fwd + BinaryDiceLoss + backward +
-[RCCL grad all-reduce] + AdamW + weight re-pack) at 4 x 1 x 96^3 fp16 per GPU (BASELINE.json configs[2]).
+[RCCL grad all-reduce] + AdamW + weight re-pack) at 4 x 1 x 96^3 fp16 per GPU — BASELINE.json
+configs[2], the configuration the metric is quoted on.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One process per GPU; batch shards on the batch axis (weak scaling: 4 volumes per GPU); gradients are
-all-reduced (sum, then averaged) over RCCL before the optimiser step.  Prints ONE JSON line on rank 0.
+One process per GPU; the batch shards on the batch axis (weak scaling: 4 volumes per GPU); the flat
+fp32 gradient buffer is all-reduced over RCCL (sum, then 1/N) before the fused optimiser step.  Inputs
+are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with the extra objects
+  "roofline"     – the dominant kernel class, timed live with HIP events inside the timed region
+  "cpu_baseline" – the oracle (torch-CPU port of the reference path) on this box's host cores.
 """
 import argparse
 import json
@@ -20,10 +24,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic work per 96^3 volume and train step
-GFLOP_PER_VOLUME = 216.5
-GB_PER_VOLUME = 2.85
-PEAK_HBM_GBS = 8000.0
-PEAK_MFMA_TFLOPS = 2500.0
+GFLOP_PER_VOLUME_96 = 216.5
+GB_PER_VOLUME_96 = 2.85
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
+PEAK_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA
+# kernel classes whose launches are ONE kernel symbol each (so rocprofv3's per-kernel average is comparable)
+ROOFLINE_CANDIDATES = ["gn_bwd_reduce", "gn_bwd_apply", "gn_act"]
+KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel", "gn_bwd_apply": "gn_bwd_apply_kernel", "gn_act": "gn_act_kernel"}
 
 
 def parse():
@@ -35,13 +42,14 @@ def parse():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-ops", action="store_true", help="extra instrumented pass: per-kernel-class time")
+    ap.add_argument("--roofline-kernel", default="gn_bwd_reduce", help="kernel class bracketed with HIP events in the timed region")
+    ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
     return ap.parse_args()
 
 
 def cpu_baseline(size, seconds_budget=25.0):
-    """The oracle (= the reference's torch-CPU path, oracle/seg_oracle.py) timed on this box's host
-    cores on a bounded sample of the same workload: 1 x 1 x size^3 train steps (fp32, all cores)."""
+    """The oracle (torch-CPU port of the reference path, oracle/seg_oracle.py) on this box's host cores,
+    bounded sample of the same workload: VNet3d 1 x 1 x size^3 train steps (fp32, all cores, dropout on)."""
     from oracle import seg_oracle as seg
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
@@ -51,7 +59,7 @@ def cpu_baseline(size, seconds_budget=25.0):
     st = {}
     times = []
     t_start = time.time()
-    for it in range(4):
+    for it in range(6):
         masks = seg.draw_masks("vnet", 1, generator=g)
         t0 = time.time()
         r = seg.forward_backward("vnet", params, x, y, "BinaryDiceLoss", masks=masks)
@@ -61,7 +69,8 @@ def cpu_baseline(size, seconds_budget=25.0):
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
     return {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
-            "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (torch CPU, %d threads), best step %.3f s" % (len(times), size, ncores, best)}
+            "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (torch %s CPU, %d threads), best step %.3f s"
+                      % (len(times), size, torch.__version__, ncores, best)}
 
 
 def main():
@@ -75,8 +84,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    from oracle import seg_oracle as seg   # only used for synthetic inputs + the cpu_baseline leg
+    from oracle import seg_oracle as seg   # synthetic inputs + the cpu_baseline leg only
     from pytorchdeeplearing_amd import SegEngine
+    from pytorchdeeplearing_amd.parallel import GradAllReduce
 
     S = a.size
     e = SegEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev)
@@ -85,21 +95,16 @@ def main():
     x, y = x.to(dev), y.to(dev)
     logits = torch.empty((a.batch, 1, S, S, S), dtype=torch.float32, device=dev)
     probs = torch.empty_like(logits)
-
-    allreduce = None
-    if world > 1:
-        inv = 1.0 / world
-
-        def allreduce(g):
-            dist.all_reduce(g)
-            g.mul_(inv)
+    allreduce = GradAllReduce(world) if world > 1 else None
 
     def step():
         return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs)
 
+    e.profile_enable([a.roofline_kernel])
     for _ in range(a.warmup):
         out3 = step()
     torch.cuda.synchronize()
+    e.profile_read()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -111,6 +116,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    prof = e.profile_read()
+    e.profile_enable([])
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -118,17 +125,49 @@ def main():
     ms = dt / a.steps * 1e3
     vols = world * a.batch * a.steps / dt
     loss = float(out3[0])
+
+    table = None
+    if a.all_classes and rank == 0:
+        from pytorchdeeplearing_amd import _capi
+        e.profile_enable(_capi.KERNEL_CLASSES)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        table = {k: {"calls_per_step": v["calls"] // 3, "ms_per_step": round(v["ms"] / 3, 3),
+                     "GBs": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None,
+                     "TFLOPs": round(v["flops"] / v["ms"] / 1e9, 1) if v["flops"] else None}
+                 for k, v in e.profile_read().items()}
+        e.profile_enable([])
+
     if rank == 0:
+        scale = (S / 96.0) ** 3
         line = {
             "metric": "volumes/sec VNet3d 96^3 fp16 train step", "value": round(vols, 2), "unit": "volumes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "VNet3d(1,1) binary seg, %dx1x%d^3 per GPU, BinaryDiceLoss, AdamW, dropout on" % (a.batch, S),
+            "config": {"workload": "VNet3d(1,1) binary seg, %dx1x%d^3 per GPU, BinaryDiceLoss + Dice metric, AdamW, dropout p=0.2 on, "
+                                   "random-init weights (BASELINE.json configs[2])" % (a.batch, S),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world},
             "final_loss": round(loss, 5),
-            "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME * vols / world / PEAK_HBM_GBS, 4),
-                           "mfma_frac": round(GFLOP_PER_VOLUME * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},
+            "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME_96 * scale * vols / world / PEAK_HBM_GBS, 4),
+                           "mfma_frac": round(GFLOP_PER_VOLUME_96 * scale * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},
         }
+        k = a.roofline_kernel
+        if k in prof and prof[k]["ms"] > 0:
+            p = prof[k]
+            per_launch_bytes = p["bytes"] / p["calls"]
+            avg_us = p["ms"] / p["calls"] * 1e3
+            ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+            line["roofline"] = {
+                "kernel": KERNEL_SYMBOL.get(k, k), "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                "launches_per_step": p["calls"] // a.steps, "avg_launch_us": round(avg_us, 2),
+                "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                "ms_per_step": round(p["ms"] / a.steps, 3),
+                "note": "HIP events on the launch stream around every launch of this kernel inside the timed region; "
+                        "bytes = (grad sources + 1) x tensor bytes per launch (DESIGN.md §5)"}
+        if table:
+            line["kernel_classes"] = table
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(line))

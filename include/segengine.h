@@ -176,6 +176,26 @@ int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int 
 /* sizeof of the structs above as compiled into the library: 0 conv, 1 wgrad, 2 pack */
 int seg_abi_sizeof(int which);
 
+/* ---- measurement: HIP-event timing of kernel classes inside a running forward/backward.
+ * seg_profile_enable(h, mask): from now on every launch whose class bit is set in `mask` is
+ * bracketed by hipEventRecord on the launch stream (0 disables).  seg_profile_read(h, ...)
+ * synchronises the recorded events, returns per class {launch count, total ms, algorithmic bytes,
+ * algorithmic flops} accumulated since the last read, and clears the records. */
+enum {
+    SEG_K_CONV3 = 0,          /* halo-tile 3^d conv, forward + data-gradient */
+    SEG_K_WGRAD3 = 1,         /* halo-tile weight gradient (main kernel + partial reduce) */
+    SEG_K_CONV_GENERIC = 2,   /* gather / scatter implicit GEMM */
+    SEG_K_WGRAD_GENERIC = 3,
+    SEG_K_STEM = 4,
+    SEG_K_GN_ACT = 5,
+    SEG_K_GN_BWD_REDUCE = 6,
+    SEG_K_GN_BWD_APPLY = 7,
+    SEG_K_HEAD = 8,
+    SEG_K_COUNT = 9
+};
+int seg_profile_enable(seg_handle h, unsigned mask);
+int seg_profile_read(seg_handle h, int* calls, float* ms, double* bytes, double* flops);
+
 const char* seg_last_error(void);
 const char* seg_build_info(void);
 

@@ -18,6 +18,7 @@ LOSS_KIND = {
     "MutilCrossEntropyLoss": 4, "MutilFocalLoss": 5, "MutilDiceLoss": 6,
 }
 MASKS_EVAL, MASKS_GIVEN, MASKS_RANDOM = 0, 1, 2
+KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head"]
 
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
@@ -51,6 +52,8 @@ SIGNATURES = {
     "seg_op_wgrad3_partial_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
     "seg_op_wgrad3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "seg_abi_sizeof": (_i, [_i]),
+    "seg_profile_enable": (_i, [_vp, C.c_uint]),
+    "seg_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "seg_last_error": (C.c_char_p, []),
     "seg_build_info": (C.c_char_p, []),
 }

@@ -77,6 +77,25 @@ struct seg_engine {
     std::vector<std::function<void(hipStream_t)>> fwd_ops, bwd_ops;
     const float* cur_x = nullptr; float* cur_logits = nullptr; float* cur_probs = nullptr;
     const float* cur_dlogits = nullptr;
+    // measurement (seg_profile_*)
+    struct ProfRec { hipEvent_t a, b; int cls; double bytes, flops; };
+    unsigned prof_mask = 0;
+    std::vector<ProfRec> prof_pool;
+    size_t prof_used = 0;
+    int prof_begin(hipStream_t st, int cls, double bytes, double flops) {
+        if (!(prof_mask >> cls & 1u)) return -1;
+        if (prof_used == prof_pool.size()) {
+            ProfRec r{};
+            (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+            prof_pool.push_back(r);
+        }
+        ProfRec& r = prof_pool[prof_used];
+        r.cls = cls; r.bytes = bytes; r.flops = flops;
+        (void)hipEventRecord(r.a, st);
+        return (int)prof_used++;
+    }
+    void prof_end(hipStream_t st, int idx) { if (idx >= 0) (void)hipEventRecord(prof_pool[idx].b, st); }
+    double tbytes(int ten) const { return (double)N * vol(tens[ten].lvl) * tens[ten].C * esz(); }
     size_t esz() const { return dtype == DT_F32 ? 4 : 2; }
     int ld_mask() const { return 16 * feat; }
     int dim_d(int l) const { return ndim == 3 ? (D >> l) : 1; }
@@ -445,11 +464,17 @@ struct Planner {
                         a.out = E.ws + ro.off; a.stats = stats;
                         a.N = E.N; a.D = E.dim_d(0); a.H = E.dim_h(0); a.W = E.dim_w(0); a.Cimg = i0.C; a.Cout = s.Cout;
                         a.taps = make_taps(E.ndim, s.ck == CK_STEM3 ? 3 : 1, s.ck == CK_STEM3 ? 1 : 0);
+                        const int pi = E.prof_begin(st, SEG_K_STEM, E.tbytes(s.in0) + E.tbytes(s.raw),
+                                                    2.0 * E.N * E.vol(0) * a.taps.n * i0.C * s.Cout);
                         launch_conv_stem(a, E.dtype, st);
+                        E.prof_end(st, pi);
                     } else if (s.ck == CK_K3 && s.in1 < 0) {
                         const int l = ro.lvl;
+                        const int pi = E.prof_begin(st, SEG_K_CONV3, E.tbytes(s.in0) + E.tbytes(s.raw),
+                                                    2.0 * E.N * E.vol(l) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout);
                         launch_conv3(E.ws + i0.off, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l),
                                      s.Cin, s.Cout, E.ndim, E.dtype, st);
+                        E.prof_end(st, pi);
                     } else {
                         ConvArgs a{};
                         a.in0 = E.ws + i0.off; a.C0 = i0.C;
@@ -476,7 +501,11 @@ struct Planner {
                             a.K = a.taps.n * s.Cin; a.Ngemm = s.Cout;
                         }
                         a.Kpad = (a.K + 31) / 32 * 32;
+                        const int pi = E.prof_begin(st, SEG_K_CONV_GENERIC,
+                                                    E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0) + E.tbytes(s.raw),
+                                                    2.0 * E.N * E.vol(s.ck == CK_KT ? li : lo) * (double)a.K * a.Ngemm);
                         launch_conv_igemm(a, E.dtype, st);
+                        E.prof_end(st, pi);
                     }
                     if (s.gn_w >= 0) {
                         GnFinArgs f;
@@ -504,7 +533,9 @@ struct Planner {
                     a.res = s.res >= 0 ? E.ws + E.tens[s.res].off : nullptr;
                     a.out = E.ws + E.tens[s.out].off;
                     a.N = E.N; a.C = E.tens[s.out].C; a.V = E.vol(E.tens[s.out].lvl);
+                    const int pi = E.prof_begin(st, SEG_K_GN_ACT, E.tbytes(s.out) * (2 + (s.ub >= 0) + (s.res >= 0)), 0.0);
                     launch_gn_act(a, E.dtype, st);
+                    E.prof_end(st, pi);
                 });
             } else if (s.type == ST_POOL) {
                 E.fwd_ops.push_back([this_ = &E, si](hipStream_t st) {
@@ -586,7 +617,9 @@ struct Planner {
                         a.Q = (double*)(E.ws + u.Q); a.coef = (float*)(E.ws + u.coef);
                         a.dr = E.ws + E.tens[u.draw].off;
                         a.N = E.N; a.C = r.C; a.V = E.vol(r.lvl);
+                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
                         launch_gn_bwd_reduce(a, E.dtype, st);
+                        E.prof_end(st, pi);
                         GnBwdFinArgs f{};
                         f.Q = a.Q; f.stats = (double*)(E.ws + u.stats);
                         f.gamma = E.p + E.params[u.gn_w].off;
@@ -599,7 +632,9 @@ struct Planner {
                         f.coef = (float*)(E.ws + u.coef);
                         f.N = E.N; f.C = r.C; f.V = a.V;
                         launch_gn_bwd_finalize(f, st);
+                        pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
                         launch_gn_bwd_apply(a, E.dtype, st);
+                        E.prof_end(st, pi);
                     });
                 }
             } else {   // UNIT: weight gradient + data gradient given d(raw)
@@ -628,16 +663,27 @@ struct Planner {
                         launch_colsum(E.ws + E.tens[draw].off, E.g + E.params[s.b].off, (long long)E.N * E.vol(lo), s.Cout, E.dtype, st);
                     if (s.ck == CK_K3 && s.in1 < 0) {
                         // halo-tile kernels: weight gradient (deterministic two-stage reduction) + data gradient
+                        const double fl = 2.0 * E.N * E.vol(lo) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout;
+                        int pi = E.prof_begin(st, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0), fl);
                         launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.off_partial), E.g + E.params[s.w].off,
                                       E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
-                        if (g0 >= 0)
+                        E.prof_end(st, pi);
+                        if (g0 >= 0) {
+                            pi = E.prof_begin(st, SEG_K_CONV3, E.tbytes(draw) + E.tbytes(g0), fl);
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
+                            E.prof_end(st, pi);
+                        }
                         return;
                     }
                     // ---- weight gradient
                     WgradArgs w = make_wgrad_args(E, s, draw);
-                    launch_wgrad(w, (float*)(E.ws + E.off_partial), E.dtype, st);
+                    {
+                        const int pi = E.prof_begin(st, (s.ck == CK_STEM3 || s.ck == CK_STEM1) ? SEG_K_STEM : SEG_K_WGRAD_GENERIC,
+                                                    E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
+                        launch_wgrad(w, (float*)(E.ws + E.off_partial), E.dtype, st);
+                        E.prof_end(st, pi);
+                    }
                     // ---- data gradient(s)
                     if (g0 < 0 && g1 < 0) return;
                     ConvArgs a{};
@@ -910,6 +956,33 @@ int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int 
 }
 int seg_abi_sizeof(int which) {
     return which == 0 ? (int)sizeof(seg_conv_args) : which == 1 ? (int)sizeof(seg_wgrad_args) : (int)sizeof(seg_pack_desc);
+}
+
+int seg_profile_enable(seg_handle h, unsigned mask) {
+    if (check_handle(h)) return -1;
+    h->prof_mask = mask;
+    return 0;
+}
+int seg_profile_read(seg_handle h, int* calls, float* ms, double* bytes, double* flops) {
+    if (check_handle(h)) return -1;
+    for (int c = 0; c < SEG_K_COUNT; ++c) {
+        if (calls) calls[c] = 0;
+        if (ms) ms[c] = 0.f;
+        if (bytes) bytes[c] = 0.0;
+        if (flops) flops[c] = 0.0;
+    }
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        auto& r = h->prof_pool[i];
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        if (calls) calls[r.cls] += 1;
+        if (ms) ms[r.cls] += t;
+        if (bytes) bytes[r.cls] += r.bytes;
+        if (flops) flops[r.cls] += r.flops;
+    }
+    h->prof_used = 0;
+    return 0;
 }
 
 const char* seg_last_error(void) { return g_err.c_str(); }

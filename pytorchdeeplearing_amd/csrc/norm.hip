@@ -16,16 +16,26 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnFinArgs a) {
     const int n = blockIdx.x, tid = threadIdx.x;
     const int cpg = a.C / GN_GROUPS;
     __shared__ double csum[256][2];
-    for (int c = tid; c < a.C; c += 256) {       // every channel folds its STAT_REP replicas in parallel
-        double s = 0.0, ss = 0.0;
-        for (int rep = 0; rep < STAT_REP; ++rep) {
-            const double* st = a.stats + (((long long)rep * a.N + n) * a.C + c) * 2;
-            s += st[0];
-            ss += st[1];
+    __shared__ double fold[256][2];
+    {   // fold the STAT_REP replicas with all 256 threads: thread -> (channel, replica group)
+        const int Cc = a.C < 256 ? a.C : 256, RG = 256 / Cc;
+        for (int cb = 0; cb < a.C; cb += 256) {
+            const int c = cb + tid % Cc, rg = tid / Cc;
+            double s = 0.0, ss = 0.0;
+            for (int rep = rg; rep < STAT_REP; rep += RG) {
+                const double* st = a.stats + (((long long)rep * a.N + n) * a.C + c) * 2;
+                s += st[0];
+                ss += st[1];
+            }
+            fold[tid][0] = s; fold[tid][1] = ss;
+            __syncthreads();
+            if (tid < Cc) {
+                for (int k = 1; k < RG; ++k) { s += fold[tid + k * Cc][0]; ss += fold[tid + k * Cc][1]; }
+                csum[cb + tid][0] = s; csum[cb + tid][1] = ss;
+            }
+            __syncthreads();
         }
-        csum[c][0] = s; csum[c][1] = ss;
     }
-    __syncthreads();
     if (tid < GN_GROUPS) {
         double s = 0.0, ss = 0.0;
         for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += csum[c][0]; ss += csum[c][1]; }
@@ -172,16 +182,29 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
     const int cpg = a.C / GN_GROUPS;
     if (tid < GN_GROUPS) { S1[tid] = 0.0; S2[tid] = 0.0; }
     __syncthreads();
+    __shared__ double sQ2[256];
+    __shared__ double fold3[256][3];
+    {
+        const int Cc = a.C < 256 ? a.C : 256, RG = 256 / Cc;
+        const int c = tid % Cc, rg = tid / Cc;
+        double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+        for (int rep = rg; rep < STAT_REP; rep += RG) {
+            const long long o = (((long long)rep * a.N + n) * a.C + c) * 2;
+            f1 += a.Q[o]; f2 += a.Q[o + 1]; f3 += a.stats[o];
+        }
+        fold3[tid][0] = f1; fold3[tid][1] = f2; fold3[tid][2] = f3;
+        __syncthreads();
+        if (tid < Cc) {
+            for (int k = 1; k < RG; ++k) { f1 += fold3[tid + k * Cc][0]; f2 += fold3[tid + k * Cc][1]; f3 += fold3[tid + k * Cc][2]; }
+            sQ1[tid] = f1; sQ2[tid] = f2; sR1[tid] = f3;
+        }
+        __syncthreads();
+    }
     for (int c = tid; c < a.C; c += 256) {
         const int g = c / cpg;
         const double mk = a.mask ? (double)a.mask[(long long)n * a.mask_ld + c] : 1.0;
         const double mu = a.mean[n * GN_GROUPS + g], rs = a.rstd[n * GN_GROUPS + g];
-        double Q1 = 0.0, Q2 = 0.0, R1 = 0.0;
-        for (int rep = 0; rep < STAT_REP; ++rep) {
-            const long long o = (((long long)rep * a.N + n) * a.C + c) * 2;
-            Q1 += a.Q[o]; Q2 += a.Q[o + 1]; R1 += a.stats[o];
-        }
-        sQ1[c] = Q1; sR1[c] = R1;
+        const double Q1 = sQ1[c], Q2 = sQ2[c];
         const double q1 = mk * Q1;          // sum dz
         const double q2 = mk * Q2;          // sum dz * r
         const double qx = (q2 - mu * q1) * rs;                              // sum dz * xhat

@@ -213,6 +213,22 @@ class SegEngine:
             1.0 / self.loss_scale, 1 if check_finite else 0, _ptr(self.opt_state), self.stream()), "seg_adam_step")
         self.packed = False
 
+    # ---- measurement ------------------------------------------------------------------------------
+    def profile_enable(self, classes):
+        """bracket every launch of the named kernel classes with HIP events (empty list: off)."""
+        mask = 0
+        for c in classes:
+            mask |= 1 << _capi.KERNEL_CLASSES.index(c)
+        self.lib.check(self.lib.seg_profile_enable(self.h, mask), "seg_profile_enable")
+
+    def profile_read(self):
+        n = len(_capi.KERNEL_CLASSES)
+        calls, ms = (C.c_int * n)(), (C.c_float * n)()
+        nbytes, flops = (C.c_double * n)(), (C.c_double * n)()
+        self.lib.check(self.lib.seg_profile_read(self.h, calls, ms, nbytes, flops), "seg_profile_read")
+        return {k: dict(calls=calls[i], ms=ms[i], bytes=nbytes[i], flops=flops[i])
+                for i, k in enumerate(_capi.KERNEL_CLASSES) if calls[i]}
+
     # ---- one optimisation step of the reference loop --------------------------------------------
     def train_step(self, x, target, loss_name="BinaryDiceLoss", lr=1e-3, weight_decay=0.01, decoupled=True,
                    focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, mask_mode=_capi.MASKS_RANDOM, masks=None,

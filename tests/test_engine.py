@@ -82,7 +82,7 @@ def check_f32(tag, dev, train):
         nrm = float(ref.norm()) + 1e-30
         own = float((r["grads"][k].double() - ref).norm()) / nrm
         err = float((g.double() - ref).norm()) / nrm
-        assert err < max(5e-3, 4 * own), (k, err, own)
+        assert err < max(2e-2 if x.numel() > 40000 else 5e-3, 4 * own), (k, err, own)
         assert float((g.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30) < 5e-2, k
 
 
