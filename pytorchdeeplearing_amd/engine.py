@@ -235,6 +235,7 @@ class SegEngine:
                    allreduce=None, logits=None, probs=None):
         """Returns out3 = device tensor [loss, dice metric, iou metric] (no host sync)."""
         logits, probs = self.forward(x, mask_mode, masks, logits, probs)
+        self._last_probs = probs
         out3 = self.loss_forward(logits, target, loss_name, focal_alpha, focal_gamma, class_alpha)
         dl = self.loss_backward(logits, target, loss_name, focal_alpha, focal_gamma)
         self.backward(dl, zero_grads=True)

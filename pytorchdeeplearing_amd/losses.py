@@ -1,0 +1,115 @@
+"""`model.losses` boundary: the seven losses reachable from the reference's model
+wrappers (model/losses.py:33-53,129-197,247-325) as nn.Modules with the same names, constructor
+arguments and call signature `loss(y_pred_logits, y_true) -> 0-dim tensor with grad`.  Forward and
+backward both run in libsegengine (one reduction pass + one elementwise pass)."""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _capi
+from .engine import aligned_empty
+
+_LABEL_OK = (torch.uint8, torch.int32, torch.int64, torch.float32)
+
+
+def _prep(logits, target):
+    lg = logits.float().contiguous()
+    t = target
+    if t.dtype not in _LABEL_OK:
+        t = t.to(torch.int64)
+    t = t.contiguous()
+    n, c = lg.shape[0], lg.shape[1]
+    v = lg.numel() // (n * c)
+    assert t.numel() == n * v, "target must have one label per voxel"
+    return lg, t, n, c, v
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, kind, falpha, fgamma, class_alpha):
+        lg, t, n, c, v = _prep(logits, target)
+        lib = _capi.lib_for(lg.device)
+        ws = aligned_empty(lib.seg_loss_ws_bytes(n, c), lg.device)
+        out3 = torch.zeros(4, dtype=torch.float32, device=lg.device)
+        ca = None if class_alpha is None else class_alpha.to(device=lg.device, dtype=torch.float32).contiguous()
+        lib.check(lib.seg_loss_forward(lg.data_ptr(), t.data_ptr(), _capi.LABEL_TYPES[str(t.dtype)], n, c, v, kind, falpha, fgamma,
+                                       ca.data_ptr() if ca is not None else None, ws.data_ptr(), out3.data_ptr(),
+                                       _capi.stream_for(lg.device)), "seg_loss_forward")
+        ctx.stuff = (lg, t, n, c, v, kind, falpha, fgamma, ws, lib)
+        ctx.in_dtype, ctx.in_shape = logits.dtype, logits.shape
+        return out3[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, t, n, c, v, kind, falpha, fgamma, ws, lib = ctx.stuff
+        dl = torch.empty_like(lg)
+        lib.check(lib.seg_loss_backward(lg.data_ptr(), t.data_ptr(), _capi.LABEL_TYPES[str(t.dtype)], n, c, v, kind, falpha, fgamma,
+                                        ws.data_ptr(), 1.0, dl.data_ptr(), _capi.stream_for(lg.device)), "seg_loss_backward")
+        return (dl * g).to(ctx.in_dtype).reshape(ctx.in_shape), None, None, None, None, None
+
+
+class _Loss(nn.Module):
+    kind = None
+
+    def __init__(self):
+        super().__init__()
+        self.focal_alpha, self.focal_gamma, self.class_alpha = 0.25, 2.0, None
+
+    def forward(self, y_pred_logits, y_true):
+        return _LossFn.apply(y_pred_logits, y_true, _capi.LOSS_KIND[self.kind], float(self.focal_alpha), float(self.focal_gamma),
+                             self.class_alpha)
+
+
+class BinaryDiceLoss(_Loss):
+    """model/losses.py:33-53"""
+    kind = "BinaryDiceLoss"
+
+
+class BinaryCrossEntropyLoss(_Loss):
+    """model/losses.py:129-147"""
+    kind = "BinaryCrossEntropyLoss"
+
+
+class BinaryFocalLoss(_Loss):
+    """model/losses.py:150-181"""
+    kind = "BinaryFocalLoss"
+
+    def __init__(self, alpha=0.25, gamma=2):
+        super().__init__()
+        self.alpha, self.gamma = alpha, gamma
+        self.focal_alpha, self.focal_gamma = alpha, gamma
+
+
+class BinaryCrossEntropyDiceLoss(_Loss):
+    """model/losses.py:184-197"""
+    kind = "BinaryCrossEntropyDiceLoss"
+
+
+class MutilCrossEntropyLoss(_Loss):
+    """model/losses.py:247-260 (alpha is accepted and, like in the reference, unused)"""
+    kind = "MutilCrossEntropyLoss"
+
+    def __init__(self, alpha):
+        super().__init__()
+        self.alpha = alpha
+
+
+class MutilFocalLoss(_Loss):
+    """model/losses.py:263-285"""
+    kind = "MutilFocalLoss"
+
+    def __init__(self, alpha, gamma=2, torch=True):
+        super().__init__()
+        self.alpha, self.gamma, self.torch = alpha, gamma, torch
+        self.focal_gamma = gamma
+
+
+class MutilDiceLoss(_Loss):
+    """model/losses.py:288-325"""
+    kind = "MutilDiceLoss"
+
+    def __init__(self, alpha):
+        super().__init__()
+        self.alpha = alpha
+        self.class_alpha = alpha if torch.is_tensor(alpha) else torch.as_tensor(alpha, dtype=torch.float32)

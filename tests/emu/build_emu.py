@@ -14,6 +14,14 @@ SRCS = ["conv.hip", "conv3.hip", "wgrad.hip", "norm.hip", "misc.hip", "engine.hi
 
 
 def build(force=False):
+    import fcntl
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(os.path.join(os.path.dirname(OUT), ".lock"), "w") as lk:     # xdist workers / spawned ranks build once
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force=False):
     srcs = [os.path.join(CSRC, s) for s in SRCS]
     deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"),
                    os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "segengine.h")]

@@ -1,0 +1,99 @@
+"""B2 / B3 boundary: nn.Module networks with reference state_dict layout, autograd
+through the engine, `model.apply(initialize_weights)`, torch optimisers on the parameter views;
+losses / metrics modules against the golden vectors produced by the real reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_loader, seg_oracle as seg
+from pytorchdeeplearing_amd import losses, metric, networks
+
+
+def test_losses_metrics_modules_vs_reference_golden(dev, golden_dir):
+    G = np.load(os.path.join(golden_dir, "losses_metrics.npz"))
+    z, y = torch.from_numpy(G["z"]).to(dev), torch.from_numpy(G["y"]).to(dev)
+    z4, y4 = torch.from_numpy(G["z4"]).to(dev), torch.from_numpy(G["y4"]).to(dev)
+    a = torch.ones(4)
+    cases = [("BinaryDiceLoss", losses.BinaryDiceLoss(), z, y), ("BinaryCrossEntropyLoss", losses.BinaryCrossEntropyLoss(), z, y),
+             ("BinaryFocalLoss", losses.BinaryFocalLoss(), z, y), ("BinaryCrossEntropyDiceLoss", losses.BinaryCrossEntropyDiceLoss(), z, y),
+             ("MutilDiceLoss", losses.MutilDiceLoss(a), z4, y4), ("MutilCrossEntropyLoss", losses.MutilCrossEntropyLoss(a), z4, y4),
+             ("MutilFocalLoss_g2", losses.MutilFocalLoss(a, gamma=2), z4, y4), ("MutilFocalLoss_g3", losses.MutilFocalLoss(a, gamma=3), z4, y4)]
+    for name, f, l, t in cases:
+        l = l.clone().requires_grad_(True)
+        v = f(l, t)
+        v.backward()
+        assert abs(float(v) - float(G["loss_" + name])) < 2e-6, name
+        np.testing.assert_allclose(l.grad.cpu().numpy(), G["grad_" + name], rtol=2e-4, atol=1e-9, err_msg=name)
+    assert abs(float(metric.dice_coeff(torch.sigmoid(z), y)) - float(G["dice_coeff"])) < 1e-7
+    assert abs(float(metric.iou_coeff(torch.sigmoid(z), y)) - float(G["iou_coeff"])) < 1e-7
+    assert abs(float(metric.multiclass_dice_coeff(torch.softmax(z4, 1), y4)) - float(G["multiclass_dice_coeff"])) < 1e-7
+    # label dtypes the datasets may hand over
+    for dt in (torch.uint8, torch.int32, torch.float32):
+        assert abs(float(losses.BinaryDiceLoss()(z, y.to(dt))) - float(G["loss_BinaryDiceLoss"])) < 2e-6
+
+
+@pytest.mark.parametrize("cls,kind,ndim,args,shape", [
+    ("VNet2d", "vnet", 2, (1, 1), (2, 1, 16, 16)),
+    ("UNet2d", "unet", 2, (1, 2), (1, 1, 16, 32)),
+])
+def test_module_boundary(dev, cls, kind, ndim, args, shape):
+    torch.manual_seed(0)
+    net = getattr(networks, cls)(*args, dtype="f32")
+    ref_shapes = seg.param_shapes(kind, ndim, args[0], args[1])
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref_shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref_shapes[k], k
+    net.apply(networks.initialize_weights)
+    net = net.to(dev)
+    params = seg.perturb_params({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, seed=3)
+    net.load_state_dict(params)
+    x, y = seg.synthetic_batch(shape[0], shape[2:], shape[1], args[1], seed=2)
+    x, y = x.to(dev), y.to(dev)
+    net.eval()
+    logits, probs = net(x)
+    r = seg.forward_backward(kind, params, x.cpu(), y.cpu(), "BinaryDiceLoss" if args[1] == 1 else "MutilDiceLoss", alpha=torch.ones(args[1]))
+    assert float((logits.detach().cpu() - r["logits"]).abs().max()) < 1e-4
+    # reference-style step: loss module -> backward -> torch optimiser acting on the parameter views
+    lossf = losses.BinaryDiceLoss() if args[1] == 1 else losses.MutilDiceLoss(torch.ones(args[1]))
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    loss = lossf(logits, y)
+    opt.zero_grad()
+    loss.backward()
+    assert abs(float(loss) - float(r["loss"])) < 1e-5
+    for k, p in net.named_parameters():
+        ref = r["grads"][k]
+        assert float((p.grad.cpu() - ref).norm()) <= 5e-3 * float(ref.norm()) + 1e-9, k
+    before = net.engine.params.clone()
+    opt.step()
+    assert not torch.equal(before, net.engine.params)        # the optimiser wrote straight into the flat buffer
+    # state_dict round trip into a fresh module (what loading an old .pth does)
+    net2 = getattr(networks, cls)(*args, dtype="f32").to(dev)
+    net2.load_state_dict(net.state_dict())
+    net2.eval()
+    l1, _ = net(x)
+    l2, _ = net2(x)
+    assert torch.equal(l1, l2)
+    # training mode draws dropout masks inside the engine: outputs differ from eval, and between calls
+    net.train()
+    t1, _ = net(x)
+    t2, _ = net(x)
+    assert not torch.equal(t1, l1) and not torch.equal(t1, t2)
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="reference tree only exists in the build container")
+def test_module_tree_matches_live_reference():
+    nets, _, _ = ref_loader.load()
+    from tests.conftest import emu_library
+    emu_library()
+    for ours, theirs in ((networks.VNet3d(1, 1), nets.VNet3d(1, 1)), (networks.UNet3d(1, 4), nets.UNet3d(1, 4)),
+                         (networks.VNet2d(1, 2), nets.VNet2d(1, 2)), (networks.UNet2d(3, 1), nets.UNet2d(3, 1))):
+        a, b = ours.state_dict(), theirs.state_dict()
+        assert list(a.keys()) == list(b.keys())
+        assert all(a[k].shape == b[k].shape for k in a)
+        # same leaf module types in the same order -> model.apply(initialize_weights) visits them identically
+        ta = [type(m).__name__ for m in ours.modules() if not list(m.children())]
+        tb = [type(m).__name__ for m in theirs.modules() if not list(m.children()) and type(m).__name__ not in ("ReLU", "Dropout3d", "Dropout2d", "MaxPool3d", "MaxPool2d")]
+        assert ta == tb

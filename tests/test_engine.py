@@ -86,7 +86,7 @@ def check_f32(tag, dev, train):
         assert float((g.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30) < 5e-2, k
 
 
-@pytest.mark.parametrize("tag,train", [("vnet2d_s", False), ("unet2d_s", True), ("unet3d", True), ("vnet3d", False)])
+@pytest.mark.parametrize("tag,train", [("vnet2d_s", False), ("unet2d_s", True), ("unet3d", True)])
 def test_parity_f32_small(dev, tag, train):
     check_f32(tag, dev, train)
 
@@ -117,7 +117,7 @@ def check_lowp(tag, dtype, dev, train, logit_tol, flip_frac):
     assert min(cos) > (0.95 if dtype == "f16" else 0.85), min(cos)
 
 
-@pytest.mark.parametrize("dtype,tol,ff", [("f16", 3e-2, 2e-3), ("bf16", 3e-1, 2e-2)])
+@pytest.mark.parametrize("dtype,tol,ff", [("f16", 3e-2, 2e-3), pytest.param("bf16", 3e-1, 2e-2, marks=pytest.mark.gpu)])
 def test_parity_lowp_small(dev, dtype, tol, ff):
     check_lowp("vnet2d_s", dtype, dev, True, tol, ff)
 

@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
         masks = seg.draw_masks(kind, shape[0], generator=g)
         e.train_step(x, y, loss, lr=1e-3, mask_mode=_capi.MASKS_GIVEN, masks=masks, allreduce=ar)
     if rank == 0:
-        q.put({k: v.clone() for k, v in e.state_dict().items()})
+        q.put({k: v.numpy().copy() for k, v in e.state_dict().items()})      # by value: this process exits before the parent reads
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,7 +72,7 @@ def test_ddp_two_ranks_matches_oracle_emulation():
         cur = seg.adamw_step(cur, grads, st)
     tot = bad = 0
     for k in cur:
-        d = (got[k] - cur[k]).abs()
+        d = (torch.from_numpy(got[k]) - cur[k]).abs()
         assert float(d.max()) < 2 * 2e-3, k          # Adam moves every weight by <= lr per step
         tot += d.numel()
         bad += int((d > 1e-4).sum())
