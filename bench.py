@@ -51,7 +51,9 @@ def cpu_baseline(size, seconds_budget=25.0):
     """The oracle (torch-CPU port of the reference path, oracle/seg_oracle.py) on this box's host cores,
     bounded sample of the same workload: VNet3d 1 x 1 x size^3 train steps (fp32, all cores, dropout on)."""
     from oracle import seg_oracle as seg
-    ncores = os.cpu_count() or 1
+    # torch-CPU convolutions stop scaling (and then collapse) beyond a few dozen threads on a many-core host:
+    # 32 threads is the fastest setting for this workload on the 256-core GPU box (all 256: 134 s/step)
+    ncores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(ncores)
     params = seg.init_params("vnet", 3, 1, 1, seed=0)
     x, y = seg.synthetic_batch(1, (size,) * 3, 1, 1, seed=1234)
@@ -59,7 +61,7 @@ def cpu_baseline(size, seconds_budget=25.0):
     st = {}
     times = []
     t_start = time.time()
-    for it in range(6):
+    for it in range(4):
         masks = seg.draw_masks("vnet", 1, generator=g)
         t0 = time.time()
         r = seg.forward_backward("vnet", params, x, y, "BinaryDiceLoss", masks=masks)

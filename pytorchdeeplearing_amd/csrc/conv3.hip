@@ -195,7 +195,8 @@ void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
     int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     if (a.Cin == 16 && nt == 4) nt = 2;
     const long long nbox = num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W);
-    while (nt > 1 && nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;      // small levels: favour more workgroups
+    // every workgroup streams its weights from L2 once per tap: NT = 4 amortises that latency over 4x the MFMAs,
+    // which beats spawning more (equally latency-bound) workgroups even on the small levels
     dim3 grid((unsigned)nbox, a.Cout / (16 * nt));
 #define SEG_C3(CH, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_kernel<T, TD, TH, TW, KD, CH, NT>), grid, dim3(256), 0, s, a)
     if (a.Cin == 16) { if (nt == 1) SEG_C3(16, 1); else SEG_C3(16, 2); }
