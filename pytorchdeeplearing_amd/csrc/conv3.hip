@@ -60,6 +60,54 @@ __device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, co
     }
 }
 
+// shared epilogue of the box kernels: bias -> LDS tile [voxel][co] (aliases the halo buffer) -> coalesced
+// channels-last stores + per-channel sum / sum-of-squares into this workgroup's statistics replica
+template <class T, class B, int TW, int TH, int MT, int NT>
+__device__ __forceinline__ void box_epilogue(f32x4 (&acc)[MT][NT], T* Os, float* red, const float* bias, T* out, double* stats,
+                                             const BoxPos& bp, int co0, int N, int D, int H, int W, int Cout) {
+    constexpr int BN = NT * 16, OLD = BN + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = j * 16 + l15;
+        const float bsv = bias ? bias[co0 + col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Os[((wv * MT + m) * 16 + q * 4 + r) * OLD + col] = from_f<T>(acc[m][j][r] + bsv);
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    for (int i = tid; i < B::V * CPR; i += 256) {
+        const int v = i / CPR, c8 = i % CPR;
+        const int x = bp.x0 + v % TW, y = bp.y0 + (v / TW) % TH, z = bp.z0 + v / (TW * TH);
+        if (x < W && y < H && z < D)
+            store8(out + ((((long long)bp.n * D + z) * H + y) * W + x) * Cout + co0 + c8 * 8, load8(&Os[v * OLD + c8 * 8]));
+    }
+    if (stats) {
+        constexpr int G = 256 / BN;
+        const int col = tid % BN, g = tid / BN;
+        float s = 0.f, ss = 0.f;
+        for (int v = g; v < B::V; v += G) {
+            const int x = bp.x0 + v % TW, y = bp.y0 + (v / TW) % TH, z = bp.z0 + v / (TW * TH);
+            if (x < W && y < H && z < D) {
+                const float f = to_f(Os[v * OLD + col]);
+                s += f; ss += f * f;
+            }
+        }
+        red[(g * BN + col) * 2] = s;
+        red[(g * BN + col) * 2 + 1] = ss;
+        __syncthreads();
+        if (tid < BN) {
+            double ts = 0.0, tss = 0.0;
+            for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
+            double* dst = stats + ((long long)(blockIdx.x % STAT_REP) * N * Cout + (long long)bp.n * Cout + co0 + col) * 2;
+            atomicAdd(dst, ts);
+            atomicAdd(dst + 1, tss);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient
 // ------------------------------------------------------------------------------------------------
@@ -141,48 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
         }
     }
     __syncthreads();
-    // ---- epilogue: bias -> LDS tile [voxel][co] -> coalesced stores + per-channel sums
-    T* Os = Xs;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int col = j * 16 + l15;
-        const float bsv = a.bias ? a.bias[co0 + col] : 0.f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Os[((wv * MT + m) * 16 + q * 4 + r) * OLD + col] = from_f<T>(acc[m][j][r] + bsv);
-    }
-    __syncthreads();
-    T* out = (T*)a.out;
-    constexpr int CPR = BN / 8;
-    for (int i = tid; i < B::V * CPR; i += 256) {
-        const int v = i / CPR, c8 = i % CPR;
-        const int x = bp.x0 + v % TW, y = bp.y0 + (v / TW) % TH, z = bp.z0 + v / (TW * TH);
-        if (x < a.W && y < a.H && z < a.D)
-            store8(out + ((((long long)bp.n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8, load8(&Os[v * OLD + c8 * 8]));
-    }
-    if (a.stats) {
-        constexpr int G = 256 / BN;
-        const int col = tid % BN, g = tid / BN;
-        float s = 0.f, ss = 0.f;
-        for (int v = g; v < B::V; v += G) {
-            const int x = bp.x0 + v % TW, y = bp.y0 + (v / TW) % TH, z = bp.z0 + v / (TW * TH);
-            if (x < a.W && y < a.H && z < a.D) {
-                const float f = to_f(Os[v * OLD + col]);
-                s += f; ss += f * f;
-            }
-        }
-        red[(g * BN + col) * 2] = s;
-        red[(g * BN + col) * 2 + 1] = ss;
-        __syncthreads();
-        if (tid < BN) {
-            double ts = 0.0, tss = 0.0;
-            for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
-            double* dst = a.stats + ((long long)(blockIdx.x % STAT_REP) * a.N * a.Cout + (long long)bp.n * a.Cout + co0 + col) * 2;
-            atomicAdd(dst, ts);
-            atomicAdd(dst + 1, tss);
-        }
-    }
+    box_epilogue<T, B, TW, TH, MT, NT>(acc, Xs, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
 }
 
 template <int TD, int TH, int TW>
@@ -393,6 +400,174 @@ void wgrad3_dispatch(const Wgrad3Args& a, int ndim, float* dw, long long sP, lon
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// image stem: Cimg in 1..3, K = taps*Cimg <= 32 -> ONE MFMA K-step per 16 voxels.  The im2col fragment
+// is gathered from the scalar halo in LDS; `center` = 1 evaluates a 1^d conv (K = Cimg) on the same tiles.
+// ------------------------------------------------------------------------------------------------
+struct StemMArgs {
+    const void* in; const void* w; const float* bias; void* out; double* stats;
+    const void* dr; float* partial;
+    int N, D, H, W, Cimg, Cout, center, nb;
+};
+
+template <class B>
+__device__ __forceinline__ int stem_k_to_halo(int k, int Cimg, int center, int& ci) {   // reduction index -> halo offset
+    const int tap = center ? (B::NTAP / 2) : k / Cimg;
+    ci = center ? k : k % Cimg;
+    return B::tap_off(tap);
+}
+
+template <class T, int TD, int TH, int TW, int KD>
+__global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemMArgs a) {
+    typedef Box<TD, TH, TW, KD> B;
+    constexpr int MT = B::V / 64, OLD = 16 + 8;
+    constexpr int XS = B::HV * 3, OS = B::V * OLD;
+    __shared__ T Xs[XS > OS ? XS : OS];
+    __shared__ float red[512];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const BoxPos bp = box_pos<B, TD, TH, TW>(blockIdx.x, a.D, a.H, a.W);
+    const int co0 = blockIdx.y * 16, Cimg = a.Cimg;
+    const T* in = (const T*)a.in;
+    const int K = a.center ? Cimg : B::NTAP * Cimg;
+    for (int i = tid; i < B::HV * Cimg; i += 256) {
+        const int hv = i / Cimg, ci = i % Cimg;
+        const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
+        const int z = bp.z0 + hz - B::PD, y = bp.y0 + hy - 1, x = bp.x0 + hx - 1;
+        T v = from_f<T>(0.f);
+        if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+            v = in[((((long long)bp.n * a.D + z) * a.H + y) * a.W + x) * Cimg + ci];
+        Xs[i] = v;
+    }
+    const typename Mma<T>::frag bf = load8((const T*)a.w + (long long)(co0 + l15) * 32 + q * 8);
+    __syncthreads();
+    f32x4 acc[MT][1];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int hb = B::halo_base((wv * MT + m) * 16 + l15);
+        typename Mma<T>::frag af;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = q * 8 + j;
+            int ci;
+            const int toff = stem_k_to_halo<B>(k < K ? k : 0, Cimg, a.center, ci);
+            af[j] = k < K ? Xs[(hb + toff) * Cimg + ci] : from_f<T>(0.f);
+        }
+        acc[m][0] = Mma<T>::run(af, bf, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    __syncthreads();
+    box_epilogue<T, B, TW, TH, MT, 1>(acc, Xs, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
+}
+
+// dW[co][k] = sum_v dR[v][co] * xcol[v][k]; partial tile [16][32] per workgroup (Cout == 16 per grid.y slice)
+template <class T, int TD, int TH, int TW, int KD>
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemMArgs a) {
+    typedef Box<TD, TH, TW, KD> B;
+    constexpr int DLD = WLd<T, 16>::v, CLD = WLd<T, 32>::v;
+    constexpr int NR = sizeof(T) == 4 ? 8 : 2, KS = B::V / 32;
+    __shared__ T Ds[B::V * DLD];
+    __shared__ T Xc[B::V * CLD];
+    __shared__ T Xs[B::HV * 3];
+    __shared__ float wred[4 * 2 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int co0 = blockIdx.y * 16, Cimg = a.Cimg;
+    const int K = a.center ? Cimg : B::NTAP * Cimg;
+    const T* dr = (const T*)a.dr;
+    const T* in = (const T*)a.in;
+    const long long nbox = (long long)a.N * ((a.D + TD - 1) / TD) * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    for (long long b = blockIdx.x; b < nbox; b += gridDim.x) {
+        const BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
+        __syncthreads();
+        for (int i = tid; i < B::V * 2; i += 256) {                  // dR tile [voxel][16]
+            const int v = i >> 1, c8 = i & 1;
+            const int xx = bp.x0 + v % TW, yy = bp.y0 + (v / TW) % TH, zz = bp.z0 + v / (TW * TH);
+            vec<T, 8> val = zero8<T>();
+            if (xx < a.W && yy < a.H && zz < a.D)
+                val = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.Cout + co0 + c8 * 8);
+            store8(&Ds[v * DLD + c8 * 8], val);
+        }
+        for (int i = tid; i < B::HV * Cimg; i += 256) {              // scalar halo
+            const int hv = i / Cimg, ci = i % Cimg;
+            const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
+            const int z = bp.z0 + hz - B::PD, y = bp.y0 + hy - 1, x = bp.x0 + hx - 1;
+            T v = from_f<T>(0.f);
+            if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                v = in[((((long long)bp.n * a.D + z) * a.H + y) * a.W + x) * Cimg + ci];
+            Xs[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < B::V * 32; i += 256) {                 // im2col tile [voxel][32]
+            const int v = i >> 5, k = i & 31;
+            int ci;
+            const int toff = stem_k_to_halo<B>(k < K ? k : 0, Cimg, a.center, ci);
+            Xc[v * CLD + k] = k < K ? Xs[(B::halo_base(v) + toff) * Cimg + ci] : from_f<T>(0.f);
+        }
+        __syncthreads();
+        for (int ks = wv; ks < KS; ks += 4) {                        // K steps split over the 4 waves
+            int drow[NR], xrow[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = sizeof(T) == 4 ? (4 * j + q) : (16 * j + 4 * q + (l15 >> 2));
+                drow[j] = (ks * 32 + r) * DLD;
+                xrow[j] = (ks * 32 + r) * CLD;
+            }
+            const typename Mma<T>::frag af = TrFrag<T, DLD>::load(Ds, drow, 0, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = Mma<T>::run(af, TrFrag<T, CLD>::load(Xc, xrow, j * 16, lane), acc[j]);
+        }
+    }
+    // cross-wave sum of the [16][32] tile, then ONE partial tile per workgroup
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wred[(wv * 2 + j) * 256 + (4 * q + r) * 16 + l15] = acc[j][r];
+    __syncthreads();
+    for (int i = tid; i < 512; i += 256) {
+        const int j = i >> 8, e = i & 255;
+        const float s = wred[(0 * 2 + j) * 256 + e] + wred[(1 * 2 + j) * 256 + e] + wred[(2 * 2 + j) * 256 + e] + wred[(3 * 2 + j) * 256 + e];
+        const int p = e >> 4, kk = j * 16 + (e & 15);
+        if (kk < K) a.partial[((long long)blockIdx.x * a.Cout + co0 + p) * K + kk] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* partial, float* dw, int P, int K, int Cimg, int ntap, int center,
+                                                                int nb) {
+    // dw layout [co][ci][tap]; partial [nb][co][k], k = tap*Cimg + ci (center: k = ci, tap 0 of a 1^d kernel)
+    const int total = P * K;
+    const int b0 = blockIdx.y * 32, b1 = (b0 + 32 < nb) ? b0 + 32 : nb;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        float s = 0.f;
+        for (int b = b0; b < b1; ++b) s += partial[(long long)b * total + i];
+        const int p = i / K, k = i % K;
+        const int tap = center ? 0 : k / Cimg, ci = center ? k : k % Cimg;
+        atomicAdd(&dw[((long long)p * Cimg + ci) * (center ? 1 : ntap) + tap], s);
+    }
+}
+
+template <class T, int TD, int TH, int TW, int KD>
+void stem_launch_shape(const StemMArgs& a, bool wgrad, float* dw, hipStream_t s) {
+    const long long nbox = num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W);
+    if (!wgrad) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_fwd_kernel<T, TD, TH, TW, KD>), dim3((unsigned)nbox, a.Cout / 16), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_wgrad_kernel<T, TD, TH, TW, KD>), dim3(a.nb, a.Cout / 16), dim3(256), 0, s, a);
+        const int K = a.center ? a.Cimg : KD * 9 * a.Cimg;
+        hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((a.Cout * K + 255) / 256, (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw,
+                           a.Cout, K, a.Cimg, KD * 9, a.center, a.nb);
+    }
+}
+
+template <class T>
+void stem_dispatch(const StemMArgs& a, int ndim, bool wgrad, float* dw, hipStream_t s) {
+    if (ndim == 3) {
+        if (wide_box(a.W)) stem_launch_shape<T, 3, 4, 16, 3>(a, wgrad, dw, s);
+        else stem_launch_shape<T, 3, 8, 8, 3>(a, wgrad, dw, s);
+    } else {
+        if (wide_box(a.W)) stem_launch_shape<T, 1, 8, 16, 1>(a, wgrad, dw, s);
+        else stem_launch_shape<T, 1, 8, 8, 1>(a, wgrad, dw, s);
+    }
+}
+
 inline long long boxes_for(int ndim, int N, int D, int H, int W) {
     if (ndim == 3) return wide_box(W) ? num_boxes<3, 4, 16>(N, D, H, W) : num_boxes<3, 8, 8>(N, D, H, W);
     return wide_box(W) ? num_boxes<1, 8, 16>(N, 1, H, W) : num_boxes<1, 8, 8>(N, 1, H, W);
@@ -440,4 +615,34 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
     else wgrad3_dispatch<bf16>(a, ndim, dw, (long long)Q * T, T, s);
 }
 
+}  // namespace seg
+
+namespace seg {
+int stem_wgrad_blocks(int ndim, int N, int D, int H, int W) {
+    long long nb = boxes_for(ndim, N, D, H, W);
+    return (int)(nb < 1024 ? nb : 1024);
+}
+size_t stem_wgrad_partial_bytes(int ndim, int N, int D, int H, int W, int Cout) {
+    return (size_t)stem_wgrad_blocks(ndim, N, D, H, W) * Cout * 32 * sizeof(float);
+}
+// forward: out = conv(in, w) (+bias, statistics); `center` = 1: 1^d conv.  w = packed [Cout][32] in dtype.
+void launch_stem_fwd(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cimg,
+                     int Cout, int center, int ndim, int dtype, hipStream_t s) {
+    StemMArgs a{};
+    a.in = in; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cimg = Cimg; a.Cout = Cout; a.center = center;
+    if (dtype == DT_F32) stem_dispatch<float>(a, ndim, false, nullptr, s);
+    else if (dtype == DT_F16) stem_dispatch<f16>(a, ndim, false, nullptr, s);
+    else stem_dispatch<bf16>(a, ndim, false, nullptr, s);
+}
+void launch_stem_wgrad(const void* dr, const void* in, float* partial, float* dw, int N, int D, int H, int W, int Cimg, int Cout,
+                       int center, int ndim, int dtype, hipStream_t s) {
+    StemMArgs a{};
+    a.dr = dr; a.in = in; a.partial = partial;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cimg = Cimg; a.Cout = Cout; a.center = center;
+    a.nb = stem_wgrad_blocks(ndim, N, D, H, W);
+    if (dtype == DT_F32) stem_dispatch<float>(a, ndim, true, dw, s);
+    else if (dtype == DT_F16) stem_dispatch<f16>(a, ndim, true, dw, s);
+    else stem_dispatch<bf16>(a, ndim, true, dw, s);
+}
 }  // namespace seg

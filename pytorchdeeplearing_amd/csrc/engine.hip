@@ -422,7 +422,10 @@ struct Planner {
                     s.wp_dg0 = alloc_pack(Ci, T * Co);   // data-gradient = gather stride 2, rows ci, k = (a, co)
                     add_pack(s.wp_dg0, woff, Ci, 1, T, Co, (long long)Co * T, 0, 1, T, 0);
                     break;
-                default: break;                  // stem convs read the fp32 master weights directly
+                default:                         // image stems: [Cout][32] with k = tap*Cimg + ci (1^d stem: k = ci)
+                    s.wp_fwd = alloc_pack(Co, T * Ci);
+                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0);
+                    break;
             }
         }
         E.off_packdesc = alloc(E.packdescs.size() * sizeof(PackDesc));
@@ -433,6 +436,8 @@ struct Planner {
                 if (s.ck == CK_K3 && s.in1 < 0) {
                     const int l = E.tens[s.raw].lvl;
                     pmax = std::max(pmax, wgrad3_partial_bytes(E.ndim, N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cout, s.Cin));
+                } else if (s.ck == CK_STEM3 || s.ck == CK_STEM1) {
+                    pmax = std::max(pmax, stem_wgrad_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), s.Cout));
                 } else {
                     char* keep = E.ws; E.ws = nullptr;
                     pmax = std::max(pmax, wgrad_partial_bytes(make_wgrad_args(E, s, -1)));
@@ -459,14 +464,10 @@ struct Planner {
                     double* stats = s.gn_w >= 0 ? (double*)(E.ws + s.stats) : nullptr;
                     const float* bias = s.b >= 0 ? E.p + E.params[s.b].off : nullptr;
                     if (s.ck == CK_STEM3 || s.ck == CK_STEM1) {
-                        StemArgs a;
-                        a.in = E.ws + i0.off; a.w = E.p + E.params[s.w].off; a.bias = bias;
-                        a.out = E.ws + ro.off; a.stats = stats;
-                        a.N = E.N; a.D = E.dim_d(0); a.H = E.dim_h(0); a.W = E.dim_w(0); a.Cimg = i0.C; a.Cout = s.Cout;
-                        a.taps = make_taps(E.ndim, s.ck == CK_STEM3 ? 3 : 1, s.ck == CK_STEM3 ? 1 : 0);
-                        const int pi = E.prof_begin(st, SEG_K_STEM, E.tbytes(s.in0) + E.tbytes(s.raw),
-                                                    2.0 * E.N * E.vol(0) * a.taps.n * i0.C * s.Cout);
-                        launch_conv_stem(a, E.dtype, st);
+                        const int T = s.ck == CK_STEM3 ? (E.ndim == 3 ? 27 : 9) : 1;
+                        const int pi = E.prof_begin(st, SEG_K_STEM, E.tbytes(s.in0) + E.tbytes(s.raw), 2.0 * E.N * E.vol(0) * T * i0.C * s.Cout);
+                        launch_stem_fwd(E.ws + i0.off, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N, E.dim_d(0), E.dim_h(0), E.dim_w(0),
+                                        i0.C, s.Cout, s.ck == CK_STEM1, E.ndim, E.dtype, st);
                         E.prof_end(st, pi);
                     } else if (s.ck == CK_K3 && s.in1 < 0) {
                         const int l = ro.lvl;
@@ -674,6 +675,13 @@ struct Planner {
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);
                         }
+                        return;
+                    }
+                    if (s.ck == CK_STEM3 || s.ck == CK_STEM1) {
+                        const int pi = E.prof_begin(st, SEG_K_STEM, E.tbytes(draw) + E.tbytes(s.in0), 0.0);
+                        launch_stem_wgrad(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.off_partial), E.g + E.params[s.w].off,
+                                          E.N, E.dim_d(0), E.dim_h(0), E.dim_w(0), i0.C, s.Cout, s.ck == CK_STEM1, E.ndim, E.dtype, st);
+                        E.prof_end(st, pi);
                         return;
                     }
                     // ---- weight gradient

@@ -20,6 +20,13 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
                    int dtype, hipStream_t s);
 
+// MFMA image stem (K = taps*Cimg <= 32): forward and weight gradient on box tiles (conv3.hip)
+void launch_stem_fwd(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cimg,
+                     int Cout, int center, int ndim, int dtype, hipStream_t s);
+size_t stem_wgrad_partial_bytes(int ndim, int N, int D, int H, int W, int Cout);
+void launch_stem_wgrad(const void* dr, const void* in, float* partial, float* dw, int N, int D, int H, int W, int Cimg, int Cout,
+                       int center, int ndim, int dtype, hipStream_t s);
+
 // Direct convolution for a tiny input-channel count (stem: image_channel -> features)
 struct StemArgs {
     const void* in;     // [N][V][Cimg] T
