@@ -202,8 +202,9 @@ void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
     int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     if (a.Cin == 16 && nt == 4) nt = 2;
     const long long nbox = num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W);
-    // every workgroup streams its weights from L2 once per tap: NT = 4 amortises that latency over 4x the MFMAs,
-    // which beats spawning more (equally latency-bound) workgroups even on the small levels
+    // measured on MI355X: on the small levels more, narrower workgroups (several resident per CU) beat NT = 4
+    // tiles (conv3 class 2.3 ms vs 3.4 ms per step) - the per-workgroup tap loop is latency-bound, so occupancy wins
+    while (nt > 1 && nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;
     dim3 grid((unsigned)nbox, a.Cout / (16 * nt));
 #define SEG_C3(CH, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_kernel<T, TD, TH, TW, KD, CH, NT>), grid, dim3(256), 0, s, a)
     if (a.Cin == 16) { if (nt == 1) SEG_C3(16, 1); else SEG_C3(16, 2); }
@@ -440,18 +441,21 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemMArgs a) {
     }
     const typename Mma<T>::frag bf = load8((const T*)a.w + (long long)(co0 + l15) * 32 + q * 8);
     __syncthreads();
+    int koff[8];                                     // element offset of this lane's 8 reduction slots (-1: padding)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = q * 8 + j;
+        int ci;
+        const int toff = stem_k_to_halo<B>(k < K ? k : 0, Cimg, a.center, ci);
+        koff[j] = k < K ? toff * Cimg + ci : -1;
+    }
     f32x4 acc[MT][1];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int hb = B::halo_base((wv * MT + m) * 16 + l15);
+        const int hb = B::halo_base((wv * MT + m) * 16 + l15) * Cimg;
         typename Mma<T>::frag af;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = q * 8 + j;
-            int ci;
-            const int toff = stem_k_to_halo<B>(k < K ? k : 0, Cimg, a.center, ci);
-            af[j] = k < K ? Xs[(hb + toff) * Cimg + ci] : from_f<T>(0.f);
-        }
+        for (int j = 0; j < 8; ++j) af[j] = koff[j] >= 0 ? Xs[hb + koff[j]] : from_f<T>(0.f);
         acc[m][0] = Mma<T>::run(af, bf, f32x4{0.f, 0.f, 0.f, 0.f});
     }
     __syncthreads();
@@ -468,9 +472,15 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemMArgs a) {
     __shared__ T Xc[B::V * CLD];
     __shared__ T Xs[B::HV * 3];
     __shared__ float wred[4 * 2 * 256];
+    __shared__ int ktab[32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int co0 = blockIdx.y * 16, Cimg = a.Cimg;
     const int K = a.center ? Cimg : B::NTAP * Cimg;
+    if (tid < 32) {
+        int ci;
+        const int toff = stem_k_to_halo<B>(tid < K ? tid : 0, Cimg, a.center, ci);
+        ktab[tid] = tid < K ? toff * Cimg + ci : -1;
+    }
     const T* dr = (const T*)a.dr;
     const T* in = (const T*)a.in;
     const long long nbox = (long long)a.N * ((a.D + TD - 1) / TD) * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
@@ -498,9 +508,8 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemMArgs a) {
         __syncthreads();
         for (int i = tid; i < B::V * 32; i += 256) {                 // im2col tile [voxel][32]
             const int v = i >> 5, k = i & 31;
-            int ci;
-            const int toff = stem_k_to_halo<B>(k < K ? k : 0, Cimg, a.center, ci);
-            Xc[v * CLD + k] = k < K ? Xs[(B::halo_base(v) + toff) * Cimg + ci] : from_f<T>(0.f);
+            const int ko = ktab[k];
+            Xc[v * CLD + k] = ko >= 0 ? Xs[B::halo_base(v) * Cimg + ko] : from_f<T>(0.f);
         }
         __syncthreads();
         for (int ks = wv; ks < KS; ks += 4) {                        // K steps split over the 4 waves
