@@ -48,15 +48,28 @@ __device__ __forceinline__ BoxPos box_pos(long long b, int D, int H, int W) {
 // stage the halo of channels [c0, c0+CH) of tensor `in` ([N][D][H][W][C]) into LDS rows of LD elements
 template <class T, class B, int CH, int LD>
 __device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, const BoxPos& p, int D, int H, int W) {
-    constexpr int CPV = CH / 8;
-    for (int i = threadIdx.x; i < B::HV * CPV; i += 256) {
-        const int hv = i / CPV, c8 = i % CPV;
-        const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
-        const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
-        vec<T, 8> v = zero8<T>();
-        if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-            v = load8(in + ((((long long)p.n * D + z) * H + y) * W + x) * C + c0 + c8 * 8);
-        store8(&Xs[hv * LD + c8 * 8], v);
+    // All global loads of a batch are issued before the first LDS store: a load->wait->store loop would
+    // serialise ~9 HBM round trips per box (measured: the dominant cost of the first version).
+    constexpr int CPV = CH / 8, TOTAL = B::HV * CPV, NIT = (TOTAL + 255) / 256;
+    constexpr int UN = sizeof(T) == 2 ? NIT : (NIT + 1) / 2;        // f32 fragments are twice as wide: two batches
+#pragma unroll
+    for (int b0 = 0; b0 < NIT; b0 += UN) {
+        vec<T, 8> v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = (b0 + u) * 256 + threadIdx.x;
+            const int hv = i / CPV, c8 = i % CPV;
+            const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
+            const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
+            v[u] = zero8<T>();
+            if (b0 + u < NIT && i < TOTAL && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                v[u] = load8(in + ((((long long)p.n * D + z) * H + y) * W + x) * C + c0 + c8 * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = (b0 + u) * 256 + threadIdx.x;
+            if (b0 + u < NIT && i < TOTAL) store8(&Xs[(i / CPV) * LD + (i % CPV) * 8], v[u]);
+        }
     }
 }
 
@@ -289,14 +302,21 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(Wgrad3Args a) {
         const BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
         __syncthreads();                                  // previous box fully consumed
         // dR tile [voxel][CP] (zero rows outside the volume)
-        constexpr int CPV = CP / 8;
-        for (int i = tid; i < B::V * CPV; i += 256) {
+        constexpr int CPV = CP / 8, DN = (B::V * CPV + 255) / 256;
+        vec<T, 8> dv[DN];
+#pragma unroll
+        for (int u = 0; u < DN; ++u) {
+            const int i = u * 256 + tid;
             const int v = i / CPV, c8 = i % CPV;
             const int xx = bp.x0 + v % TW, yy = bp.y0 + (v / TW) % TH, zz = bp.z0 + v / (TW * TH);
-            vec<T, 8> val = zero8<T>();
-            if (xx < a.W && yy < a.H && zz < a.D)
-                val = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.P + p0 + c8 * 8);
-            store8(&Ds[v * DLD + c8 * 8], val);
+            dv[u] = zero8<T>();
+            if (i < B::V * CPV && xx < a.W && yy < a.H && zz < a.D)
+                dv[u] = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.P + p0 + c8 * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < DN; ++u) {
+            const int i = u * 256 + tid;
+            if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], dv[u]);
         }
         stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W);
         __syncthreads();
@@ -411,6 +431,29 @@ struct StemMArgs {
     int N, D, H, W, Cimg, Cout, center, nb;
 };
 
+// scalar (1..3-channel) image halo -> LDS, loads issued in one batch
+template <class T, class B>
+__device__ __forceinline__ void stage_scalar_halo(T* Xs, const T* in, int Cimg, const BoxPos& bp, int D, int H, int W) {
+    constexpr int NIT = (B::HV * 3 + 255) / 256;
+    const int total = B::HV * Cimg;
+    T v[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = u * 256 + threadIdx.x;
+        const int hv = i / Cimg, ci = i % Cimg;
+        const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
+        const int z = bp.z0 + hz - B::PD, y = bp.y0 + hy - 1, x = bp.x0 + hx - 1;
+        v[u] = from_f<T>(0.f);
+        if (i < total && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+            v[u] = in[((((long long)bp.n * D + z) * H + y) * W + x) * Cimg + ci];
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = u * 256 + threadIdx.x;
+        if (i < total) Xs[i] = v[u];
+    }
+}
+
 template <class B>
 __device__ __forceinline__ int stem_k_to_halo(int k, int Cimg, int center, int& ci) {   // reduction index -> halo offset
     const int tap = center ? (B::NTAP / 2) : k / Cimg;
@@ -430,15 +473,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemMArgs a) {
     const int co0 = blockIdx.y * 16, Cimg = a.Cimg;
     const T* in = (const T*)a.in;
     const int K = a.center ? Cimg : B::NTAP * Cimg;
-    for (int i = tid; i < B::HV * Cimg; i += 256) {
-        const int hv = i / Cimg, ci = i % Cimg;
-        const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
-        const int z = bp.z0 + hz - B::PD, y = bp.y0 + hy - 1, x = bp.x0 + hx - 1;
-        T v = from_f<T>(0.f);
-        if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-            v = in[((((long long)bp.n * a.D + z) * a.H + y) * a.W + x) * Cimg + ci];
-        Xs[i] = v;
-    }
+    stage_scalar_halo<T, B>(Xs, in, Cimg, bp, a.D, a.H, a.W);
     const typename Mma<T>::frag bf = load8((const T*)a.w + (long long)(co0 + l15) * 32 + q * 8);
     __syncthreads();
     int koff[8];                                     // element offset of this lane's 8 reduction slots (-1: padding)
@@ -496,15 +531,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemMArgs a) {
                 val = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.Cout + co0 + c8 * 8);
             store8(&Ds[v * DLD + c8 * 8], val);
         }
-        for (int i = tid; i < B::HV * Cimg; i += 256) {              // scalar halo
-            const int hv = i / Cimg, ci = i % Cimg;
-            const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
-            const int z = bp.z0 + hz - B::PD, y = bp.y0 + hy - 1, x = bp.x0 + hx - 1;
-            T v = from_f<T>(0.f);
-            if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-                v = in[((((long long)bp.n * a.D + z) * a.H + y) * a.W + x) * Cimg + ci];
-            Xs[i] = v;
-        }
+        stage_scalar_halo<T, B>(Xs, in, Cimg, bp, a.D, a.H, a.W);
         __syncthreads();
         for (int i = tid; i < B::V * 32; i += 256) {                 // im2col tile [voxel][32]
             const int v = i >> 5, k = i & 31;
