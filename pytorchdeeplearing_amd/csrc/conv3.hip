@@ -12,6 +12,8 @@
 //                   workgroup walks a strided list of boxes accumulating a [CP x taps x CQ] tile in
 //                   registers and writes ONE partial tile; wgrad3_reduce_kernel sums the partials
 //                   (deterministic; no fp32 atomics).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace seg {
@@ -127,6 +129,7 @@ __device__ __forceinline__ void box_epilogue(f32x4 (&acc)[MT][NT], T* Os, float*
 struct Conv3Args {
     const void* in; const void* w; const float* bias; void* out; double* stats;
     int N, D, H, W, Cin, Cout, Kpad;
+    int dbg;   // ablation mask (SEG_CONV3_DBG): 1 no halo loads, 2 no weight loads, 4 no MFMA loop, 8 no epilogue
 };
 
 template <class T, int TD, int TH, int TW, int KD, int CH, int NT>
@@ -166,20 +169,21 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
     const int nchunk = a.Cin / CH;
     for (int cc = 0; cc < nchunk; ++cc) {
         if (cc) __syncthreads();
-        stage_halo<T, B, CH, XLD>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W);
+        if (!(a.dbg & 1)) stage_halo<T, B, CH, XLD>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W);
         __syncthreads();
+        if (a.dbg & 4) continue;
         // weights come straight from L2 (every workgroup reads the same few KB); a PF-deep register ring
         // keeps PF taps in flight so the ~0.5 us L2 round trip hides behind MT*NT MFMAs per tap
-        constexpr int PF = 3;
+        constexpr int PF = NT == 2 ? 6 : 3;      // measured: deeper ring pays for NT=2 only (NT=1 loses occupancy)
         typename Mma<T>::frag bq[PF + 1][NT];
         auto wofs = [&](int s) { return CH == 32 ? s * a.Cin + cc * 32 : s * 32; };
 #pragma unroll
         for (int s = 0; s < PF && s < NSTEP; ++s)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bq[s][j] = load8(wrow[j] + wofs(s));
+            for (int j = 0; j < NT; ++j) bq[s][j] = load8(wrow[j] + ((a.dbg & 2) ? 0 : wofs(s)));
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            if (s + PF < NSTEP) {
+            if (s + PF < NSTEP && !(a.dbg & 2)) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) bq[(s + PF) % (PF + 1)][j] = load8(wrow[j] + wofs(s + PF));
             }
@@ -187,9 +191,12 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
             bool tvalid = true;
             if (CH == 32) { toff = B::tap_off(s); col = q * 8; }
             else {
-                const int t = 2 * s + (q >> 1);
-                tvalid = t < B::NTAP;
-                toff = B::tap_off(tvalid ? t : 0);
+                // lanes q = 0,1 take tap 2s, q = 2,3 tap 2s+1: both offsets are compile-time constants
+                constexpr int dummy = 0; (void)dummy;
+                const int t1 = 2 * s + 1;
+                const int off0 = B::tap_off(2 * s), off1 = B::tap_off(t1 < B::NTAP ? t1 : 0);
+                tvalid = (q < 2) || t1 < B::NTAP;
+                toff = (q < 2) ? off0 : off1;
                 col = (q & 1) * 8;
             }
 #pragma unroll
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
         }
     }
     __syncthreads();
+    if (a.dbg & 8) { if (acc[0][0][0] == 123.f) ((T*)a.out)[0] = from_f<T>(1.f); return; }
     box_epilogue<T, B, TW, TH, MT, NT>(acc, Xs, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
 }
 
@@ -375,9 +383,11 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial
     const int tile = CP * ntap * CQ, nqt = Q / CQ;
     const int b0 = blockIdx.y * 32, b1 = (b0 + 32 < nb) ? b0 + 32 : nb;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int tap = (int)(i % ntap), qc = (int)((i / ntap) % Q), p = (int)(i / ((long long)ntap * Q));
-        const int combo = (p / CP) * nqt + qc / CQ;
-        const float* src = partial + (long long)combo * nb * tile + ((p % CP) * ntap + tap) * CQ + qc % CQ;
+        // i enumerates the partial layout [combo][p'][tap][q']: consecutive threads read consecutive floats of every
+        // partial tile (the 32..512x larger side of the traffic); the single write per element is the strided one
+        const int combo = (int)(i / tile), e = (int)(i % tile);
+        const int qq = e % CQ, tap = (e / CQ) % ntap, pp = e / (CQ * ntap);
+        const float* src = partial + (long long)combo * nb * tile + e;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int b = b0;
         for (; b + 4 <= b1; b += 4) {
@@ -386,6 +396,7 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial
         }
         for (; b < b1; ++b) s0 += src[(long long)b * tile];
         const float tot = (s0 + s1) + (s2 + s3);
+        const int p = (combo / nqt) * CP + pp, qc = (combo % nqt) * CQ + qq;
         if (gridDim.y == 1) dw[p * sP + qc * sQ + tap] += tot;
         else atomicAdd(&dw[p * sP + qc * sQ + tap], tot);
     }
@@ -618,6 +629,8 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Kpad = ((ndim == 3 ? 27 : 9) * Cin + 31) / 32 * 32;
+    static const int dbg = getenv("SEG_CONV3_DBG") ? atoi(getenv("SEG_CONV3_DBG")) : 0;
+    a.dbg = dbg;
     if (dtype == DT_F32) conv3_dispatch<float>(a, ndim, s);
     else if (dtype == DT_F16) conv3_dispatch<f16>(a, ndim, s);
     else conv3_dispatch<bf16>(a, ndim, s);

@@ -187,11 +187,12 @@ def wgrad(dr, x0, dtype, ndim, k, stride=1, pad=0, x1=None, stem=False):
     return dw
 
 
-def conv3(x, wpacked, dtype, ndim, cout, bias=None, want_stats=False):
+def conv3(x, wpacked, dtype, ndim, cout, bias=None, want_stats=False, out=None):
     """LDS halo-tile 3^d / 3^2 stride-1 pad-1 conv (forward, or data-gradient with the conv_dgrad layout)."""
     lib = _capi.lib_for(x.device)
     N, D, H, W, cin = x.shape
-    out = _alloc((N, D, H, W, cout), TORCH_DTYPE[dtype], x.device, zero=True)
+    if out is None:
+        out = _alloc((N, D, H, W, cout), TORCH_DTYPE[dtype], x.device, zero=True)
     stats = _alloc((32, N, cout, 2), torch.float64, x.device, zero=True) if want_stats else None
     lib.check(lib.seg_op_conv3(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
                                stats.data_ptr() if stats is not None else None, N, D, H, W, cin, cout, ndim, _capi.DTYPE[dtype],
