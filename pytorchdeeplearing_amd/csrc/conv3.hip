@@ -132,7 +132,10 @@ struct Conv3Args {
     int dbg;   // ablation mask (SEG_CONV3_DBG): 1 no halo loads, 2 no weight loads, 4 no MFMA loop, 8 no epilogue
 };
 
-template <class T, int TD, int TH, int TW, int KD, int CH, int NT>
+// WL = true (NT == 1 tiles): the [16][taps x CH] weight slab of the current channel chunk is staged in LDS with the
+// halo, so the tap loop never waits on L2 (the small deep levels run ~1.5 workgroups per CU and were bound by that
+// latency); WL = false: weights stream from L2 through a register ring.
+template <class T, int TD, int TH, int TW, int KD, int CH, int NT, bool WL>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
     typedef Box<TD, TH, TW, KD> B;
     constexpr int XLD = CH + 8;                         // 80 B (CH=32) / 48 B (CH=16) rows: conflict-light b128 reads
@@ -142,6 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
     __shared__ T Xs[XS_ELEMS > OS_ELEMS ? XS_ELEMS : OS_ELEMS];
     __shared__ float red[512];
     static_assert(B::V % 64 == 0, "box must hold a multiple of 64 voxels");
+    constexpr int NSTEP_ = CH == 32 ? B::NTAP : (B::NTAP + 1) / 2;
+    constexpr int WLD = NSTEP_ * 32 + 8;                  // row stride: 16 rows land on distinct 16-B slots
+    __shared__ T Ws[WL ? 16 * WLD : 8];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const BoxPos bp = box_pos<B, TD, TH, TW>(blockIdx.x, a.D, a.H, a.W);
@@ -170,6 +176,23 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
     for (int cc = 0; cc < nchunk; ++cc) {
         if (cc) __syncthreads();
         if (!(a.dbg & 1)) stage_halo<T, B, CH, XLD>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W);
+        if (WL) {
+            constexpr int PIECES = 16 * NSTEP_ * 4, WN = (PIECES + 255) / 256;
+            vec<T, 8> wv_[WN];
+#pragma unroll
+            for (int u = 0; u < WN; ++u) {
+                const int i = u * 256 + tid;
+                const int c4 = i & 3, st_ = (i >> 2) % NSTEP_, co = i / (4 * NSTEP_);
+                wv_[u] = zero8<T>();
+                if (i < PIECES) wv_[u] = load8(wp + (long long)(co0 + co) * a.Kpad + (CH == 32 ? st_ * a.Cin + cc * 32 : st_ * 32) + c4 * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < WN; ++u) {
+                const int i = u * 256 + tid;
+                const int c4 = i & 3, st_ = (i >> 2) % NSTEP_, co = i / (4 * NSTEP_);
+                if (i < PIECES) store8(&Ws[co * WLD + st_ * 32 + c4 * 8], wv_[u]);
+            }
+        }
         __syncthreads();
         if (a.dbg & 4) continue;
         // weights come straight from L2 (every workgroup reads the same few KB); a PF-deep register ring
@@ -177,13 +200,16 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
         constexpr int PF = NT == 2 ? 6 : 3;      // measured: deeper ring pays for NT=2 only (NT=1 loses occupancy)
         typename Mma<T>::frag bq[PF + 1][NT];
         auto wofs = [&](int s) { return CH == 32 ? s * a.Cin + cc * 32 : s * 32; };
+        if (!WL) {
 #pragma unroll
-        for (int s = 0; s < PF && s < NSTEP; ++s)
+            for (int s = 0; s < PF && s < NSTEP; ++s)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bq[s][j] = load8(wrow[j] + ((a.dbg & 2) ? 0 : wofs(s)));
+                for (int j = 0; j < NT; ++j) bq[s][j] = load8(wrow[j] + ((a.dbg & 2) ? 0 : wofs(s)));
+        }
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            if (s + PF < NSTEP && !(a.dbg & 2)) {
+            if (WL) bq[s % (PF + 1)][0] = load8(&Ws[l15 * WLD + s * 32 + q * 8]);
+            if (!WL && s + PF < NSTEP && !(a.dbg & 2)) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) bq[(s + PF) % (PF + 1)][j] = load8(wrow[j] + wofs(s + PF));
             }
@@ -227,7 +253,7 @@ void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
     // tiles (conv3 class 2.3 ms vs 3.4 ms per step) - the per-workgroup tap loop is latency-bound, so occupancy wins
     while (nt > 1 && nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;
     dim3 grid((unsigned)nbox, a.Cout / (16 * nt));
-#define SEG_C3(CH, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_kernel<T, TD, TH, TW, KD, CH, NT>), grid, dim3(256), 0, s, a)
+#define SEG_C3(CH, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_kernel<T, TD, TH, TW, KD, CH, NT, (NT == 1)>), grid, dim3(256), 0, s, a)
     if (a.Cin == 16) { if (nt == 1) SEG_C3(16, 1); else SEG_C3(16, 2); }
     else { if (nt == 1) SEG_C3(32, 1); else if (nt == 2) SEG_C3(32, 2); else SEG_C3(32, 4); }
 #undef SEG_C3
@@ -642,7 +668,10 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) 
     long long nb = 512 / combos;
     if (nb < 1) nb = 1;
     const long long nbox = boxes_for(ndim, N, D, H, W);
-    if (nb > nbox) nb = nbox;
+    // small levels: every workgroup writes (and the reduce re-reads) a full partial tile, so do not split the
+    // box list finer than ~3 boxes per workgroup
+    if (nb > (nbox + 2) / 3) nb = (nbox + 2) / 3;
+    if (nb < 1) nb = 1;
     return (int)nb;
 }
 
