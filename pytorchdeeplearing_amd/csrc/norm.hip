@@ -9,53 +9,37 @@
 namespace seg {
 namespace {
 
-// grid = N, block = 256 (C <= 256 handled per thread; larger C loops)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(GnFinArgs a) {
-    __shared__ double gsum[GN_GROUPS][2];
-    __shared__ float gm[GN_GROUPS], gr[GN_GROUPS];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int cpg = a.C / GN_GROUPS;
-    __shared__ double csum[256][2];
-    __shared__ double fold[256][2];
-    {   // fold the STAT_REP replicas with all 256 threads: thread -> (channel, replica group)
-        const int Cc = a.C < 256 ? a.C : 256, RG = 256 / Cc;
-        for (int cb = 0; cb < a.C; cb += 256) {
-            const int c = cb + tid % Cc, rg = tid / Cc;
-            double s = 0.0, ss = 0.0;
-            for (int rep = rg; rep < STAT_REP; rep += RG) {
-                const double* st = a.stats + (((long long)rep * a.N + n) * a.C + c) * 2;
-                s += st[0];
-                ss += st[1];
-            }
-            fold[tid][0] = s; fold[tid][1] = ss;
-            __syncthreads();
-            if (tid < Cc) {
-                for (int k = 1; k < RG; ++k) { s += fold[tid + k * Cc][0]; ss += fold[tid + k * Cc][1]; }
-                csum[cb + tid][0] = s; csum[cb + tid][1] = ss;
-            }
-            __syncthreads();
+// GroupNorm statistics are independent per (sample, group): grid = (8 groups, N), 64 threads.  Every thread folds
+// the STAT_REP replicas of (channel, replica-slice) pairs of its group; a wave reduction gives the group moments.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinArgs a) {
+    __shared__ double csum[64][2];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = a.C / GN_GROUPS;                    // 2..32 channels per group
+    const int RG = 64 / cpg;                            // replica slices per channel
+    const int cl = tid % cpg, rg = tid / cpg, c = g * cpg + cl;
+    double s = 0.0, ss = 0.0;
+    if (rg < RG)
+        for (int rep = rg; rep < STAT_REP; rep += RG) {
+            const double* st = a.stats + (((long long)rep * a.N + n) * a.C + c) * 2;
+            s += st[0];
+            ss += st[1];
         }
+    const double ts = wave_sum_d(s), tss = wave_sum_d(ss);
+    const double cnt = (double)cpg * (double)a.V;
+    const double mean = ts / cnt;
+    double var = tss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    (void)csum;
+    if (tid == 0) {
+        a.mean[n * GN_GROUPS + g] = (float)mean;
+        a.rstd[n * GN_GROUPS + g] = rstd;
     }
-    if (tid < GN_GROUPS) {
-        double s = 0.0, ss = 0.0;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += csum[c][0]; ss += csum[c][1]; }
-        const double cnt = (double)cpg * (double)a.V;
-        const double mean = s / cnt;
-        double var = ss / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-        gm[tid] = (float)mean;
-        gr[tid] = rstd;
-        a.mean[n * GN_GROUPS + tid] = (float)mean;
-        a.rstd[n * GN_GROUPS + tid] = rstd;
-    }
-    __syncthreads();
-    for (int c = tid; c < a.C; c += 256) {
-        const int g = c / cpg;
+    if (tid < cpg) {
         const float mk = a.mask ? a.mask[(long long)n * a.mask_ld + c] : 1.f;
         const float ga = a.gamma[c], be = a.beta[c];
-        a.scale[(long long)n * a.C + c] = mk * ga * gr[g];
-        a.shift[(long long)n * a.C + c] = mk * (be - ga * gm[g] * gr[g]);
+        a.scale[(long long)n * a.C + c] = mk * ga * rstd;
+        a.shift[(long long)n * a.C + c] = mk * (be - ga * (float)mean * rstd);
     }
 }
 
@@ -115,9 +99,8 @@ __device__ __forceinline__ void load_dy_sum(const GnBwdArgs& a, long long i, flo
 
 // pass 1.  grid = (slabs, N); a block reduces `rows_per_block` voxels of one sample over all channels.
 // thread = (chunk column cc, row group g); LDS tree over row groups; fp64 atomics per (n,c).
-constexpr int GNB_ROWS = 512;
 template <class T>
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a) {
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB_ROWS) {
     __shared__ float red[256 * 16];
     const int tid = threadIdx.x, n = blockIdx.y;
     const int CPR = a.C / 8;                  // 2..32 (power of two)
@@ -174,62 +157,44 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a) {
     }
 }
 
-// finalize: grid = N, block = 256
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
-    __shared__ double S1[GN_GROUPS], S2[GN_GROUPS];
-    __shared__ double sQ1[256], sR1[256];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int cpg = a.C / GN_GROUPS;
-    if (tid < GN_GROUPS) { S1[tid] = 0.0; S2[tid] = 0.0; }
-    __syncthreads();
-    __shared__ double sQ2[256];
-    __shared__ double fold3[256][3];
-    {
-        const int Cc = a.C < 256 ? a.C : 256, RG = 256 / Cc;
-        const int c = tid % Cc, rg = tid / Cc;
-        double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+// backward finalize: grid = (8 groups, N), 64 threads — same decomposition as the forward finalize
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
+    __shared__ double sh[64][3];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = a.C / GN_GROUPS, RG = 64 / cpg;
+    const int cl = tid % cpg, rg = tid / cpg, c = g * cpg + cl;
+    double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    if (rg < RG)
         for (int rep = rg; rep < STAT_REP; rep += RG) {
             const long long o = (((long long)rep * a.N + n) * a.C + c) * 2;
             f1 += a.Q[o]; f2 += a.Q[o + 1]; f3 += a.stats[o];
         }
-        fold3[tid][0] = f1; fold3[tid][1] = f2; fold3[tid][2] = f3;
-        __syncthreads();
-        if (tid < Cc) {
-            for (int k = 1; k < RG; ++k) { f1 += fold3[tid + k * Cc][0]; f2 += fold3[tid + k * Cc][1]; f3 += fold3[tid + k * Cc][2]; }
-            sQ1[tid] = f1; sQ2[tid] = f2; sR1[tid] = f3;
-        }
-        __syncthreads();
-    }
-    for (int c = tid; c < a.C; c += 256) {
-        const int g = c / cpg;
-        const double mk = a.mask ? (double)a.mask[(long long)n * a.mask_ld + c] : 1.0;
-        const double mu = a.mean[n * GN_GROUPS + g], rs = a.rstd[n * GN_GROUPS + g];
-        const double Q1 = sQ1[c], Q2 = sQ2[c];
-        const double q1 = mk * Q1;          // sum dz
-        const double q2 = mk * Q2;          // sum dz * r
-        const double qx = (q2 - mu * q1) * rs;                              // sum dz * xhat
+    sh[tid][0] = f1; sh[tid][1] = f2; sh[tid][2] = f3;
+    __syncthreads();
+    double Q1 = 0.0, Q2 = 0.0, R1 = 0.0;                 // per-channel totals (valid for tid < cpg)
+    if (tid < cpg)
+        for (int k = 0; k < RG; ++k) { Q1 += sh[tid + k * cpg][0]; Q2 += sh[tid + k * cpg][1]; R1 += sh[tid + k * cpg][2]; }
+    const double mu = a.mean[n * GN_GROUPS + g], rs = a.rstd[n * GN_GROUPS + g];
+    double mk = 1.0, ga = 0.0, q1 = 0.0, qx = 0.0;
+    if (tid < cpg) {
+        mk = a.mask ? (double)a.mask[(long long)n * a.mask_ld + c] : 1.0;
+        ga = a.gamma[c];
+        q1 = mk * Q1;                                    // sum dz
+        qx = (mk * Q2 - mu * q1) * rs;                   // sum dz * xhat
         atomicAdd(&a.dbeta[c], (float)q1);
         atomicAdd(&a.dgamma[c], (float)qx);
-        const double ga = a.gamma[c];
-        atomicAdd(&S1[g], ga * q1);
-        atomicAdd(&S2[g], ga * qx);
     }
-    __syncthreads();
-    const double Mg = (double)cpg * (double)a.V;
-    for (int c = tid; c < a.C; c += 256) {
-        const int g = c / cpg;
-        const double mk = a.mask ? (double)a.mask[(long long)n * a.mask_ld + c] : 1.0;
-        const double mu = a.mean[n * GN_GROUPS + g], rs = a.rstd[n * GN_GROUPS + g];
-        const double ga = a.gamma[c];
+    const double S1 = wave_sum_d(tid < cpg ? ga * q1 : 0.0);
+    const double S2 = wave_sum_d(tid < cpg ? ga * qx : 0.0);
+    if (tid < cpg) {
+        const double Mg = (double)cpg * (double)a.V;
         const double A = rs * ga * mk;
-        const double B = -rs * rs * S2[g] / Mg;
-        const double Cc = -rs * S1[g] / Mg + rs * rs * S2[g] * mu / Mg;
+        const double B = -rs * rs * S2 / Mg;
+        const double Cc = -rs * S1 / Mg + rs * rs * S2 * mu / Mg;
         float* co = a.coef + ((long long)n * a.C + c) * 3;
         co[0] = (float)A; co[1] = (float)B; co[2] = (float)Cc;
-        if (a.dbias) {
-            // sum_v dr = A*sum(dzr) + B*sum(r) + Cc*V   (sum(r) from the forward statistics)
-            atomicAdd(&a.dbias[c], (float)(A * sQ1[c] + B * sR1[c] + Cc * (double)a.V));
-        }
+        // sum_v dr = A*sum(dzr) + B*sum(r) + Cc*V   (sum(r) from the forward statistics)
+        if (a.dbias) atomicAdd(&a.dbias[c], (float)(A * Q1 + B * R1 + Cc * (double)a.V));
     }
 }
 
@@ -267,7 +232,7 @@ inline int ew_blocks(long long total_threads) {
 }  // namespace
 
 void launch_gn_finalize(const GnFinArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS, a.N), dim3(64), 0, s, a);
 }
 
 void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
@@ -278,14 +243,22 @@ void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
 }
 
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
+    // slab size: ~2048 workgroups in total, at least two rows per thread, at most 512 rows (small tensors were
+    // latency-bound with the fixed 512-row slabs: 16 workgroups x 16 serial round trips)
+    const int G = 256 / (a.C / 8);
+    long long rows = ((long long)a.N * a.V + 2047) / 2048;
+    rows = (rows + G - 1) / G * G;
+    if (rows < 2 * G) rows = 2 * G;
+    if (rows > 512) rows = 512;
+    const int GNB_ROWS = (int)rows;
     dim3 grid(cdiv(a.V, GNB_ROWS), a.N);
-    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<float>), grid, dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<f16>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<bf16>), grid, dim3(256), 0, s, a);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<float>), grid, dim3(256), 0, s, a, GNB_ROWS);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<f16>), grid, dim3(256), 0, s, a, GNB_ROWS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<bf16>), grid, dim3(256), 0, s, a, GNB_ROWS);
 }
 
 void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(a.N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(GN_GROUPS, a.N), dim3(64), 0, s, a);
 }
 
 void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s) {
