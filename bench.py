@@ -29,8 +29,9 @@ GB_PER_VOLUME_96 = 2.85
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 PEAK_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA
 # kernel classes whose launches are ONE kernel symbol each (so rocprofv3's per-kernel average is comparable)
-ROOFLINE_CANDIDATES = ["gn_bwd_reduce", "gn_bwd_apply", "gn_act"]
-KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel", "gn_bwd_apply": "gn_bwd_apply_kernel", "gn_act": "gn_act_kernel"}
+KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel<f16>", "gn_bwd_apply": "gn_bwd_apply_kernel<f16>", "gn_act": "gn_act_kernel<f16>",
+                 "conv3_smallbox": "conv3_kernel<f16, 3,8,8 box, KD=3, CH=32, NT=1, LDS weights>"}
+MFMA_BOUND = {"conv3_smallbox", "conv3", "wgrad3"}
 
 
 def parse():
@@ -42,7 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-kernel", default="gn_bwd_reduce", help="kernel class bracketed with HIP events in the timed region")
+    ap.add_argument("--roofline-kernel", default="conv3_smallbox", help="kernel class bracketed with HIP events in the timed region")
     ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
     return ap.parse_args()
 
@@ -157,17 +158,22 @@ def main():
         k = a.roofline_kernel
         if k in prof and prof[k]["ms"] > 0:
             p = prof[k]
-            per_launch_bytes = p["bytes"] / p["calls"]
             avg_us = p["ms"] / p["calls"] * 1e3
-            ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+            if k in MFMA_BOUND:
+                ach, peak, unit, bound = p["flops"] / (p["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS, "TFLOP/s", "mfma"
+                per_launch = {"algorithmic_flops_per_launch": int(p["flops"] / p["calls"]),
+                              "algorithmic_bytes_per_launch": int(p["bytes"] / p["calls"])}
+            else:
+                ach, peak, unit, bound = p["bytes"] / (p["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+                per_launch = {"algorithmic_bytes_per_launch": int(p["bytes"] / p["calls"])}
             line["roofline"] = {
-                "kernel": KERNEL_SYMBOL.get(k, k), "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-                "launches_per_step": p["calls"] // a.steps, "avg_launch_us": round(avg_us, 2),
-                "algorithmic_bytes_per_launch": int(per_launch_bytes),
-                "ms_per_step": round(p["ms"] / a.steps, 3),
-                "note": "HIP events on the launch stream around every launch of this kernel inside the timed region; "
-                        "bytes = (grad sources + 1) x tensor bytes per launch (DESIGN.md §5)"}
+                "kernel": KERNEL_SYMBOL.get(k, k), "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                "frac": round(ach / peak, 4), "traffic": None,
+                "launches_per_step": p["calls"] // a.steps, "avg_launch_us": round(avg_us, 2), "ms_per_step": round(p["ms"] / a.steps, 3),
+                "note": "largest kernel symbol of the step (rocprofv3 --stats); every launch bracketed by hipEventRecord on the launch "
+                        "stream inside the timed region (each bracket costs ~11 us of stream idle time, included in value); "
+                        "algorithmic flops = 2*voxels*27*Cin*Cout, bytes = input + output tensor (DESIGN.md section 5)"}
+            line["roofline"].update(per_launch)
         if table:
             line["kernel_classes"] = table
         if not a.no_cpu_baseline and world == 1:

@@ -182,7 +182,7 @@ int seg_abi_sizeof(int which);
  * synchronises the recorded events, returns per class {launch count, total ms, algorithmic bytes,
  * algorithmic flops} accumulated since the last read, and clears the records. */
 enum {
-    SEG_K_CONV3 = 0,          /* halo-tile 3^d conv, forward + data-gradient */
+    SEG_K_CONV3 = 0,          /* halo-tile 3^d conv, forward + data-gradient, wide-box levels (3x4x16 / 1x8x16) */
     SEG_K_WGRAD3 = 1,         /* halo-tile weight gradient (main kernel + partial reduce) */
     SEG_K_CONV_GENERIC = 2,   /* gather / scatter implicit GEMM */
     SEG_K_WGRAD_GENERIC = 3,
@@ -191,7 +191,8 @@ enum {
     SEG_K_GN_BWD_REDUCE = 6,
     SEG_K_GN_BWD_APPLY = 7,
     SEG_K_HEAD = 8,
-    SEG_K_COUNT = 9
+    SEG_K_CONV3_SB = 9,       /* halo-tile conv on the small-box levels (3x8x8 / 1x8x8 boxes): one kernel symbol */
+    SEG_K_COUNT = 10
 };
 int seg_profile_enable(seg_handle h, unsigned mask);
 int seg_profile_read(seg_handle h, int* calls, float* ms, double* bytes, double* flops);

@@ -18,7 +18,7 @@ LOSS_KIND = {
     "MutilCrossEntropyLoss": 4, "MutilFocalLoss": 5, "MutilDiceLoss": 6,
 }
 MASKS_EVAL, MASKS_GIVEN, MASKS_RANDOM = 0, 1, 2
-KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head"]
+KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head", "conv3_smallbox"]
 
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 

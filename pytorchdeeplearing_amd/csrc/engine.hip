@@ -51,6 +51,8 @@ struct Step {
 };
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+// profile class of a halo-conv launch: the box shape (conv3.hip wide_box) decides the kernel symbol
+inline int conv3_class(int W) { return (W % 16 == 0 || W == 12) ? SEG_K_CONV3 : SEG_K_CONV3_SB; }
 
 }  // namespace
 
@@ -471,7 +473,7 @@ struct Planner {
                         E.prof_end(st, pi);
                     } else if (s.ck == CK_K3 && s.in1 < 0) {
                         const int l = ro.lvl;
-                        const int pi = E.prof_begin(st, SEG_K_CONV3, E.tbytes(s.in0) + E.tbytes(s.raw),
+                        const int pi = E.prof_begin(st, conv3_class(E.dim_w(l)), E.tbytes(s.in0) + E.tbytes(s.raw),
                                                     2.0 * E.N * E.vol(l) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout);
                         launch_conv3(E.ws + i0.off, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l),
                                      s.Cin, s.Cout, E.ndim, E.dtype, st);
@@ -670,7 +672,7 @@ struct Planner {
                                       E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
                         E.prof_end(st, pi);
                         if (g0 >= 0) {
-                            pi = E.prof_begin(st, SEG_K_CONV3, E.tbytes(draw) + E.tbytes(g0), fl);
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g0), fl);
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);

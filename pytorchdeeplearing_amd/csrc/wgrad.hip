@@ -56,8 +56,11 @@ struct WgPlan { int TP, TQ, ntq, ntile, TB, ntg; long long Mc; int parts; };
 // partial layout per voxel slice: [P][T][Qc]  (Qc = Q, or the (tap,ci) column count of the stem)
 template <class T, bool STEM, int NTB>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, float* partial) {
-    __shared__ T Ds[WM * LDW];
-    __shared__ T Xs[NTB * WM * LDW];
+    // voxel rows per staging step: 128 for the single-tap kernels (4 MFMA K-steps per barrier pair), 32 otherwise
+    constexpr int WMT = (NTB == 1 && !STEM) ? 128 : WM;
+    constexpr int NPC = WMT * 8 / 256;                  // staging pieces (16 B) per thread, upper bound
+    __shared__ T Ds[WMT * LDW];
+    __shared__ T Xs[NTB * WMT * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tg = (int)(blockIdx.x / pl.ntile), tile = (int)(blockIdx.x % pl.ntile);
     const int tap0 = tg * NTB;
@@ -79,21 +82,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, floa
 #pragma unroll
     for (int i = 0; i < MAXW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- staging assignment: thread -> (row, 8-channel chunk) of dR, and of X for each tap slot
+    // ---- staging: piece = (row, 8-channel chunk); thread handles pieces tid, tid+256, ...
     const int cpr_p = TP / 8, cpr_q = STEM ? 8 : TQ / 8;
-    const bool dload = tid < WM * cpr_p;
-    const int drow_ = tid / cpr_p, dcc = tid % cpr_p;
-    const bool xload = STEM || tid < WM * cpr_q;
-    const int xrow_ = STEM ? (tid >> 3) : tid / cpr_q, xcc = STEM ? (tid & 7) : tid % cpr_q;
+    const int npd = WMT * cpr_p, npx = WMT * cpr_q;
 
-    vec<T, 8> dreg, xreg[NTB];
+    vec<T, 8> dreg[NPC], xreg[NTB][NPC];
     float sreg[4];
     auto gload = [&](long long ms) {
-        if (dload) {
-            const long long m = ms + drow_;
-            dreg = (m < mend) ? load8(dr + m * a.P + p0 + dcc * 8) : zero8<T>();
+#pragma unroll
+        for (int u = 0; u < NPC; ++u) {
+            const int pc = u * 256 + tid;
+            if (pc < npd) {
+                const long long m = ms + pc / cpr_p;
+                dreg[u] = (m < mend) ? load8(dr + m * a.P + p0 + (pc % cpr_p) * 8) : zero8<T>();
+            }
         }
         if (STEM) {
+            const int xrow_ = tid >> 3, xcc = tid & 7;
             const long long m = ms + xrow_;
             const bool mv = m < mend;
             const RowCoord r = decode_row(mv ? m : 0, a.OD, a.OH, a.OW);
@@ -109,51 +114,71 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, floa
                 }
                 sreg[j] = xv;
             }
-        } else if (xload) {
-            const long long m = ms + xrow_;
-            const bool mv = m < mend;
-            const RowCoord r = decode_row(mv ? m : 0, a.OD, a.OH, a.OW);
-            const int qc = q0 + xcc * 8;
+        } else {
 #pragma unroll
-            for (int t = 0; t < NTB; ++t) {
-                vec<T, 8> v = zero8<T>();
-                if (mv && t < ntb) {
-                    const int tp = tap0 + t;
-                    const int id = r.d * a.sd + a.taps.d[tp], ih = r.h * a.sh + a.taps.h[tp], iw = r.w * a.sw + a.taps.w[tp];
-                    if ((unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) {
-                        const long long vox = (((long long)r.n * a.ID + id) * a.IH + ih) * a.IW + iw;
-                        v = (qc < a.C0) ? load8(x0 + vox * a.C0 + qc) : load8(x1 + vox * a.C1 + (qc - a.C0));
+            for (int u = 0; u < NPC; ++u) {
+                const int pc = u * 256 + tid;
+                if (pc < npx) {
+                    const long long m = ms + pc / cpr_q;
+                    const bool mv = m < mend;
+                    const RowCoord r = decode_row(mv ? m : 0, a.OD, a.OH, a.OW);
+                    const int qc = q0 + (pc % cpr_q) * 8;
+#pragma unroll
+                    for (int t = 0; t < NTB; ++t) {
+                        vec<T, 8> v = zero8<T>();
+                        if (mv && t < ntb) {
+                            const int tp = tap0 + t;
+                            const int id = r.d * a.sd + a.taps.d[tp], ih = r.h * a.sh + a.taps.h[tp], iw = r.w * a.sw + a.taps.w[tp];
+                            if ((unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) {
+                                const long long vox = (((long long)r.n * a.ID + id) * a.IH + ih) * a.IW + iw;
+                                v = (qc < a.C0) ? load8(x0 + vox * a.C0 + qc) : load8(x1 + vox * a.C1 + (qc - a.C0));
+                            }
+                        }
+                        xreg[t][u] = v;
                     }
                 }
-                xreg[t] = v;
             }
         }
     };
     auto sstore = [&]() {
-        if (dload) store8(&Ds[drow_ * LDW + dcc * 8], dreg);
+#pragma unroll
+        for (int u = 0; u < NPC; ++u) {
+            const int pc = u * 256 + tid;
+            if (pc < npd) store8(&Ds[(pc / cpr_p) * LDW + (pc % cpr_p) * 8], dreg[u]);
+        }
         if (STEM) {
+            const int xrow_ = tid >> 3, xcc = tid & 7;
 #pragma unroll
             for (int j = 0; j < 4; ++j) Xs[xrow_ * LDW + xcc * 4 + j] = from_f<T>(sreg[j]);
-        } else if (xload) {
+        } else {
 #pragma unroll
-            for (int t = 0; t < NTB; ++t) store8(&Xs[(t * WM + xrow_) * LDW + xcc * 8], xreg[t]);
+            for (int u = 0; u < NPC; ++u) {
+                const int pc = u * 256 + tid;
+                if (pc < npx) {
+#pragma unroll
+                    for (int t = 0; t < NTB; ++t) store8(&Xs[(t * WMT + pc / cpr_q) * LDW + (pc % cpr_q) * 8], xreg[t][u]);
+                }
+            }
         }
     };
 
     if (mbeg < mend) gload(mbeg);
-    for (long long ms = mbeg; ms < mend; ms += WM) {
+    for (long long ms = mbeg; ms < mend; ms += WMT) {
         sstore();
         __syncthreads();
-        if (ms + WM < mend) gload(ms + WM);              // next step's loads fly while the MFMAs run
+        if (ms + WMT < mend) gload(ms + WMT);            // next step's loads fly while the MFMAs run
 #pragma unroll
         for (int i = 0; i < MAXW; ++i) {
             const int wi = wv + 4 * i;
             if (wi < nwork) {
                 const int t = wi / n16, tt = wi % n16;
                 const int pi = tt / nt_q, qi = tt % nt_q;
-                const typename Mma<T>::frag af = TFrag<T>::load(Ds, pi * 16, lane);
-                const typename Mma<T>::frag bf = TFrag<T>::load(Xs + t * WM * LDW, qi * 16, lane);
-                acc[i] = Mma<T>::run(af, bf, acc[i]);
+#pragma unroll
+                for (int kk = 0; kk < WMT / 32; ++kk) {
+                    const typename Mma<T>::frag af = TFrag<T>::load(Ds + kk * 32 * LDW, pi * 16, lane);
+                    const typename Mma<T>::frag bf = TFrag<T>::load(Xs + (t * WMT + kk * 32) * LDW, qi * 16, lane);
+                    acc[i] = Mma<T>::run(af, bf, acc[i]);
+                }
             }
         }
         __syncthreads();
@@ -225,8 +250,9 @@ WgPlan make_plan(const WgradArgs& a) {
     if (parts < 1) parts = 1;
     const long long maxp = (M + WM - 1) / WM;
     if (parts > maxp) parts = maxp;
+    const int step = (pl.TB == 1 && !a.stem) ? 128 : WM;
     long long Mc = (M + parts - 1) / parts;
-    Mc = (Mc + WM - 1) / WM * WM;
+    Mc = (Mc + step - 1) / step * step;
     pl.Mc = Mc;
     pl.parts = (int)((M + Mc - 1) / Mc);
     return pl;
