@@ -17,12 +17,13 @@ constexpr int BK = 32;    // reduction elements per step
 constexpr int LDT = BK + 8;
 
 struct RowCoord { int n, d, h, w; };
-__device__ __forceinline__ RowCoord decode_row(long long m, int D, int H, int W) {
+__device__ __forceinline__ RowCoord decode_row(long long m64, int D, int H, int W) {
+    int m = (int)m64;                                   // row counts stay below 2^31: 32-bit division
     RowCoord r;
-    r.w = (int)(m % W); m /= W;
-    r.h = (int)(m % H); m /= H;
-    r.d = (int)(m % D);
-    r.n = (int)(m / D);
+    r.w = m % W; m /= W;
+    r.h = m % H; m /= H;
+    r.d = m % D;
+    r.n = m / D;
     return r;
 }
 

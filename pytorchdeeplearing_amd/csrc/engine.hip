@@ -510,7 +510,7 @@ struct Planner {
                         launch_conv_igemm(a, E.dtype, st);
                         E.prof_end(st, pi);
                     }
-                    if (s.gn_w >= 0) {
+                    if (s.gn_w >= 0 && !gn_bwd_group_eligible(s.Cout, E.vol(ro.lvl), (int)E.esz())) {
                         GnFinArgs f;
                         f.stats = stats; f.gamma = E.p + E.params[s.gn_w].off; f.beta = E.p + E.params[s.gn_b].off;
                         f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
@@ -527,6 +527,26 @@ struct Planner {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
                     const Step& ua = E.steps[s.ua];
+                    {
+                        const Ten& ro = E.tens[ua.raw];
+                        if (s.ub < 0 && gn_bwd_group_eligible(ua.Cout, E.vol(ro.lvl), (int)E.esz())) {
+                            // small L2-resident tensor: statistics finalize + activation in one launch
+                            GnFinArgs f;
+                            f.stats = (double*)(E.ws + ua.stats);
+                            f.gamma = E.p + E.params[ua.gn_w].off; f.beta = E.p + E.params[ua.gn_b].off;
+                            f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
+                                     : (const float*)(E.ws + E.off_masks) + (size_t)ua.mask_slot * E.N * E.ld_mask();
+                            f.mask_ld = E.ld_mask();
+                            f.scale = (float*)(E.ws + ua.scale); f.shift = (float*)(E.ws + ua.shift);
+                            f.mean = (float*)(E.ws + ua.mean); f.rstd = (float*)(E.ws + ua.rstd);
+                            f.N = E.N; f.C = ua.Cout; f.V = E.vol(ro.lvl); f.eps = 1e-5f;
+                            const int pi = E.prof_begin(st, SEG_K_GN_ACT, E.tbytes(s.out) * (2 + (s.res >= 0)), 0.0);
+                            launch_gn_fwd_group(f, E.ws + ro.off, s.res >= 0 ? E.ws + E.tens[s.res].off : nullptr, E.ws + E.tens[s.out].off,
+                                                E.dtype, st);
+                            E.prof_end(st, pi);
+                            return;
+                        }
+                    }
                     ActArgs a{};
                     a.r1 = E.ws + E.tens[ua.raw].off; a.scale1 = (float*)(E.ws + ua.scale); a.shift1 = (float*)(E.ws + ua.shift);
                     if (s.ub >= 0) {
@@ -620,9 +640,6 @@ struct Planner {
                         a.Q = (double*)(E.ws + u.Q); a.coef = (float*)(E.ws + u.coef);
                         a.dr = E.ws + E.tens[u.draw].off;
                         a.N = E.N; a.C = r.C; a.V = E.vol(r.lvl);
-                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
-                        launch_gn_bwd_reduce(a, E.dtype, st);
-                        E.prof_end(st, pi);
                         GnBwdFinArgs f{};
                         f.Q = a.Q; f.stats = (double*)(E.ws + u.stats);
                         f.gamma = E.p + E.params[u.gn_w].off;
@@ -634,6 +651,15 @@ struct Planner {
                         f.dbias = u.b >= 0 ? E.g + E.params[u.b].off : nullptr;
                         f.coef = (float*)(E.ws + u.coef);
                         f.N = E.N; f.C = r.C; f.V = a.V;
+                        if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
+                            const int pg = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
+                            launch_gn_bwd_group(a, f, E.dtype, st);
+                            E.prof_end(st, pg);
+                            return;
+                        }
+                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
+                        launch_gn_bwd_reduce(a, E.dtype, st);
+                        E.prof_end(st, pi);
                         launch_gn_bwd_finalize(f, st);
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
                         launch_gn_bwd_apply(a, E.dtype, st);

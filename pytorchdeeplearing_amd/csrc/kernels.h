@@ -116,6 +116,10 @@ struct GnBwdFinArgs {
     long long V;
 };
 void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s);
+// small L2-resident tensors (C >= 64): reduce + finalize + apply in one launch, one workgroup per (sample, group)
+bool gn_bwd_group_eligible(int C, long long V, int esz);
+void launch_gn_fwd_group(const GnFinArgs& f, const void* r, const void* res, void* out, int dtype, hipStream_t s);
+void launch_gn_bwd_group(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, hipStream_t s);
 
 // Weight gradient: see seg_wgrad_args in include/segengine.h
 typedef seg_wgrad_args WgradArgs;

@@ -224,6 +224,171 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-tensor GroupNorm backward (C >= 64, i.e. the 24^3 / 12^3 / 6^3 levels whose tensors sit in L2):
+// GroupNorm is independent per (sample, group), so ONE 1024-thread workgroup per (n, g) does the
+// reduction pass, the coefficient math (incl. gamma/beta/bias gradients) and the elementwise pass
+// back to back — one launch instead of reduce + finalize + apply (3 x ~8 us of launch/latency each).
+// ------------------------------------------------------------------------------------------------
+struct GnBwdGroupArgs {
+    GnBwdArgs e;          // dy sources, r, forward scale/shift, dr
+    GnBwdFinArgs f;       // stats, gamma, mask, mean/rstd, dgamma/dbeta/dbias
+};
+
+template <class T>
+__global__ __launch_bounds__(1024) void gn_bwd_group_kernel(GnBwdGroupArgs a) {
+    __shared__ float wsum[16][4][16];        // [wave][chunk-in-group][q1 0..7 | q2 0..7]
+    __shared__ double chan[32][3];           // per channel of the group: Q1, Q2, R1
+    __shared__ float coef[32][3];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C = a.e.C, cpg = C / GN_GROUPS, CG = cpg / 8, CPR = C / 8;     // CG = 16-B chunks per voxel in this group: 1, 2 or 4
+    const long long V = a.e.V;
+    const int cg = tid % CG, c0 = g * cpg + cg * 8;
+    const T* r = (const T*)a.e.r;
+    T* dr = (T*)a.e.dr;
+    const vec<float, 8> sc = *(const vec<float, 8>*)(a.e.scale + (long long)n * C + c0);
+    const vec<float, 8> sh = *(const vec<float, 8>*)(a.e.shift + (long long)n * C + c0);
+    float q1[8], q2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
+    const long long items = V * CG;
+    for (long long it = tid; it < items; it += 1024) {
+        const long long i = ((long long)n * V + it / CG) * CPR + g * CG + cg;
+        float dy[8];
+        load_dy_sum<T>(a.e, i, dy);
+        const vec<T, 8> x = load8(r + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = to_f(x[j]);
+            const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
+            q1[j] += d;
+            q2[j] = fmaf(d, xv, q2[j]);
+        }
+    }
+    // lanes with equal (lane % CG) hold the same channels: butterfly over the remaining lane bits
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        for (int m = 32; m >= CG; m >>= 1) { q1[j] += __shfl_xor(q1[j], m); q2[j] += __shfl_xor(q2[j], m); }
+    }
+    if (lane < CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wsum[wv][lane][j] = q1[j]; wsum[wv][lane][8 + j] = q2[j]; }
+    }
+    // forward sum(r) of the group's channels (bias gradient): fold the statistic replicas
+    if (tid < cpg) {
+        double r1 = 0.0;
+        for (int rep = 0; rep < STAT_REP; ++rep) r1 += a.f.stats[(((long long)rep * a.f.N + n) * C + g * cpg + tid) * 2];
+        chan[tid][2] = r1;
+    }
+    __syncthreads();
+    if (tid < cpg) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < 16; ++w) { s1 += wsum[w][tid >> 3][tid & 7]; s2 += wsum[w][tid >> 3][8 + (tid & 7)]; }
+        chan[tid][0] = s1; chan[tid][1] = s2;
+    }
+    __syncthreads();
+    if (wv == 0) {                                       // one wave finishes the group: cpg <= 32 channels
+        const int c = g * cpg + (lane < cpg ? lane : 0);
+        const bool act = lane < cpg;
+        const double mu = a.f.mean[n * GN_GROUPS + g], rs = a.f.rstd[n * GN_GROUPS + g];
+        const double mk = act ? (a.f.mask ? (double)a.f.mask[(long long)n * a.f.mask_ld + c] : 1.0) : 0.0;
+        const double ga = act ? (double)a.f.gamma[c] : 0.0;
+        const double Q1 = act ? chan[lane][0] : 0.0, Q2 = act ? chan[lane][1] : 0.0, R1 = act ? chan[lane][2] : 0.0;
+        const double q1d = mk * Q1, qx = (mk * Q2 - mu * q1d) * rs;
+        const double S1 = wave_sum_d(ga * q1d), S2 = wave_sum_d(ga * qx);
+        if (act) {
+            atomicAdd(&a.f.dbeta[c], (float)q1d);
+            atomicAdd(&a.f.dgamma[c], (float)qx);
+            const double Mg = (double)cpg * (double)V;
+            const double A = rs * ga * mk, B = -rs * rs * S2 / Mg, Cc = -rs * S1 / Mg + rs * rs * S2 * mu / Mg;
+            coef[lane][0] = (float)A; coef[lane][1] = (float)B; coef[lane][2] = (float)Cc;
+            if (a.f.dbias) atomicAdd(&a.f.dbias[c], (float)(A * Q1 + B * R1 + Cc * (double)V));
+        }
+    }
+    __syncthreads();
+    float cA[8], cB[8], cC[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cA[j] = coef[cg * 8 + j][0]; cB[j] = coef[cg * 8 + j][1]; cC[j] = coef[cg * 8 + j][2]; }
+    for (long long it = tid; it < items; it += 1024) {
+        const long long i = ((long long)n * V + it / CG) * CPR + g * CG + cg;
+        float dy[8];
+        load_dy_sum<T>(a.e, i, dy);
+        const vec<T, 8> x = load8(r + i * 8);
+        vec<T, 8> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = to_f(x[j]);
+            const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
+            o[j] = from_f<T>(fmaf(cA[j], d, fmaf(cB[j], xv, cC[j])));
+        }
+        store8(dr + i * 8, o);
+    }
+}
+
+// forward twin: statistics fold -> mean/rstd/scale/shift (stored for the backward) -> y = relu(scale*r+shift) [+ residual]
+struct GnFwdGroupArgs {
+    GnFinArgs f;
+    const void* r; const void* res; void* out;
+};
+
+template <class T>
+__global__ __launch_bounds__(1024) void gn_fwd_group_kernel(GnFwdGroupArgs a) {
+    __shared__ float ssc[32], ssh[32];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C = a.f.C, cpg = C / GN_GROUPS, CG = cpg / 8, CPR = C / 8;
+    const long long V = a.f.V;
+    if (wv == 0) {
+        const int RG = 64 / cpg, cl = lane % cpg, rg = lane / cpg, c = g * cpg + cl;
+        double s = 0.0, ss = 0.0;
+        if (rg < RG)
+            for (int rep = rg; rep < STAT_REP; rep += RG) {
+                const double* st = a.f.stats + (((long long)rep * a.f.N + n) * C + c) * 2;
+                s += st[0];
+                ss += st[1];
+            }
+        const double ts = wave_sum_d(s), tss = wave_sum_d(ss);
+        const double cnt = (double)cpg * (double)V;
+        const double mean = ts / cnt;
+        double var = tss / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.f.eps));
+        if (lane == 0) { a.f.mean[n * GN_GROUPS + g] = (float)mean; a.f.rstd[n * GN_GROUPS + g] = rstd; }
+        if (lane < cpg) {
+            const float mk = a.f.mask ? a.f.mask[(long long)n * a.f.mask_ld + c] : 1.f;
+            const float ga = a.f.gamma[c], be = a.f.beta[c];
+            const float sc = mk * ga * rstd, sh = mk * (be - ga * (float)mean * rstd);
+            ssc[lane] = sc; ssh[lane] = sh;
+            a.f.scale[(long long)n * C + c] = sc;
+            a.f.shift[(long long)n * C + c] = sh;
+        }
+    }
+    __syncthreads();
+    const int cg = tid % CG;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = ssc[cg * 8 + j]; sh[j] = ssh[cg * 8 + j]; }
+    const T* r = (const T*)a.r;
+    const T* res = (const T*)a.res;
+    T* out = (T*)a.out;
+    const long long items = V * CG;
+    for (long long it = tid; it < items; it += 1024) {
+        const long long i = ((long long)n * V + it / CG) * CPR + g * CG + cg;
+        const vec<T, 8> x = load8(r + i * 8);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = fmaxf(fmaf(sc[j], to_f(x[j]), sh[j]), 0.f);
+        if (res) {
+            const vec<T, 8> rr = load8(res + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] += to_f(rr[j]);
+        }
+        vec<T, 8> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = from_f<T>(y[j]);
+        store8(out + i * 8, o);
+    }
+}
+
 inline int ew_blocks(long long total_threads) {
     long long b = (total_threads + 255) / 256;
     return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
@@ -255,6 +420,24 @@ void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<float>), grid, dim3(256), 0, s, a, GNB_ROWS);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<f16>), grid, dim3(256), 0, s, a, GNB_ROWS);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<bf16>), grid, dim3(256), 0, s, a, GNB_ROWS);
+}
+
+bool gn_bwd_group_eligible(int C, long long V, int esz) { return C >= 64 && C <= 256 && (long long)C * V * esz <= (8ll << 20); }
+
+void launch_gn_fwd_group(const GnFinArgs& f, const void* r, const void* res, void* out, int dtype, hipStream_t s) {
+    GnFwdGroupArgs a; a.f = f; a.r = r; a.res = res; a.out = out;
+    dim3 grid(GN_GROUPS, f.N);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_fwd_group_kernel<float>), grid, dim3(1024), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_fwd_group_kernel<f16>), grid, dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_fwd_group_kernel<bf16>), grid, dim3(1024), 0, s, a);
+}
+
+void launch_gn_bwd_group(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, hipStream_t s) {
+    GnBwdGroupArgs a; a.e = e; a.f = f;
+    dim3 grid(GN_GROUPS, e.N);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_group_kernel<float>), grid, dim3(1024), 0, s, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_group_kernel<f16>), grid, dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_group_kernel<bf16>), grid, dim3(1024), 0, s, a);
 }
 
 void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s) {

@@ -20,12 +20,13 @@ constexpr int LDW = WT + 8;
 constexpr int MAXTB = 8;      // taps handled inside one workgroup
 
 struct RowCoord { int n, d, h, w; };
-__device__ __forceinline__ RowCoord decode_row(long long m, int D, int H, int W) {
+__device__ __forceinline__ RowCoord decode_row(long long m64, int D, int H, int W) {
+    int m = (int)m64;                                   // row counts stay far below 2^31 (launcher checks); 32-bit division
     RowCoord r;
-    r.w = (int)(m % W); m /= W;
-    r.h = (int)(m % H); m /= H;
-    r.d = (int)(m % D);
-    r.n = (int)(m / D);
+    r.w = m % W; m /= W;
+    r.h = m % H; m /= H;
+    r.d = m % D;
+    r.n = m / D;
     return r;
 }
 
@@ -51,7 +52,7 @@ template <> struct TFrag<float> {
     }
 };
 
-struct WgPlan { int TP, TQ, ntq, ntile, TB, ntg; long long Mc; int parts; };
+struct WgPlan { int TP, TQ, ntq, ntile, TB, ntg; long long Mc; int parts; int direct; };   // direct: 1^d stride-1 conv, voxel == row
 
 // partial layout per voxel slice: [P][T][Qc]  (Qc = Q, or the (tap,ci) column count of the stem)
 template <class T, bool STEM, int NTB>
@@ -121,8 +122,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, floa
                 if (pc < npx) {
                     const long long m = ms + pc / cpr_q;
                     const bool mv = m < mend;
-                    const RowCoord r = decode_row(mv ? m : 0, a.OD, a.OH, a.OW);
                     const int qc = q0 + (pc % cpr_q) * 8;
+                    if (NTB == 1 && pl.direct) {        // 1^d stride-1 conv: the gathered voxel is the row itself
+                        xreg[0][u] = !mv ? zero8<T>() : (qc < a.C0) ? load8(x0 + m * a.C0 + qc) : load8(x1 + m * a.C1 + (qc - a.C0));
+                        continue;
+                    }
+                    const RowCoord r = decode_row(mv ? m : 0, a.OD, a.OH, a.OW);
 #pragma unroll
                     for (int t = 0; t < NTB; ++t) {
                         vec<T, 8> v = zero8<T>();
@@ -254,6 +259,8 @@ WgPlan make_plan(const WgradArgs& a) {
     long long Mc = (M + parts - 1) / parts;
     Mc = (Mc + step - 1) / step * step;
     pl.Mc = Mc;
+    pl.direct = (!a.stem && T == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.taps.d[0] == 0 && a.taps.h[0] == 0 && a.taps.w[0] == 0 &&
+                 a.ID == a.OD && a.IH == a.OH && a.IW == a.OW) ? 1 : 0;
     pl.parts = (int)((M + Mc - 1) / Mc);
     return pl;
 }
