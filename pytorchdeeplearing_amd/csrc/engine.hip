@@ -10,6 +10,7 @@
 // contributions (residual fan-in, skip connections) that the GroupNorm-backward kernels sum on the
 // fly, so no explicit `add` or `cat` tensor is ever materialised.
 // Reference structure: networks/VNet3d.py:25-158, networks/Unet3d.py:6-86 (+ the 2-D twins).
+#include <cstdlib>
 #include <functional>
 #include <string>
 #include <vector>
@@ -79,6 +80,25 @@ struct seg_engine {
     std::vector<std::function<void(hipStream_t)>> fwd_ops, bwd_ops;
     const float* cur_x = nullptr; float* cur_logits = nullptr; float* cur_probs = nullptr;
     const float* cur_dlogits = nullptr;
+    // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
+    hipStream_t side = nullptr;
+    bool use_side = true;
+    std::vector<hipEvent_t> ready_ev;
+    hipEvent_t side_done = nullptr;
+    size_t ready_used = 0;
+    hipStream_t wgrad_stream(hipStream_t main) {
+        if (!use_side) return main;
+        if (!side) { (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking); (void)hipEventCreateWithFlags(&side_done, hipEventDisableTiming); }
+        if (ready_used == ready_ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ready_ev.push_back(e); }
+        hipEvent_t e = ready_ev[ready_used++];
+        (void)hipEventRecord(e, main);          // everything this weight gradient reads has been produced on `main`
+        (void)hipStreamWaitEvent(side, e, 0);
+        return side;
+    }
+    void join_side(hipStream_t main) {
+        if (use_side && side && ready_used) { (void)hipEventRecord(side_done, side); (void)hipStreamWaitEvent(main, side_done, 0); }
+        ready_used = 0;
+    }
     // measurement (seg_profile_*)
     struct ProfRec { hipEvent_t a, b; int cls; double bytes, flops; };
     unsigned prof_mask = 0;
@@ -693,10 +713,11 @@ struct Planner {
                     if (s.ck == CK_K3 && s.in1 < 0) {
                         // halo-tile kernels: weight gradient (deterministic two-stage reduction) + data gradient
                         const double fl = 2.0 * E.N * E.vol(lo) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout;
-                        int pi = E.prof_begin(st, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0), fl);
+                        hipStream_t ws_ = E.wgrad_stream(st);
+                        int pi = E.prof_begin(ws_, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0), fl);
                         launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.off_partial), E.g + E.params[s.w].off,
-                                      E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
-                        E.prof_end(st, pi);
+                                      E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_);
+                        E.prof_end(ws_, pi);
                         if (g0 >= 0) {
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g0), fl);
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
@@ -706,19 +727,21 @@ struct Planner {
                         return;
                     }
                     if (s.ck == CK_STEM3 || s.ck == CK_STEM1) {
-                        const int pi = E.prof_begin(st, SEG_K_STEM, E.tbytes(draw) + E.tbytes(s.in0), 0.0);
+                        hipStream_t ws_ = E.wgrad_stream(st);
+                        const int pi = E.prof_begin(ws_, SEG_K_STEM, E.tbytes(draw) + E.tbytes(s.in0), 0.0);
                         launch_stem_wgrad(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.off_partial), E.g + E.params[s.w].off,
-                                          E.N, E.dim_d(0), E.dim_h(0), E.dim_w(0), i0.C, s.Cout, s.ck == CK_STEM1, E.ndim, E.dtype, st);
-                        E.prof_end(st, pi);
+                                          E.N, E.dim_d(0), E.dim_h(0), E.dim_w(0), i0.C, s.Cout, s.ck == CK_STEM1, E.ndim, E.dtype, ws_);
+                        E.prof_end(ws_, pi);
                         return;
                     }
                     // ---- weight gradient
                     WgradArgs w = make_wgrad_args(E, s, draw);
                     {
-                        const int pi = E.prof_begin(st, (s.ck == CK_STEM3 || s.ck == CK_STEM1) ? SEG_K_STEM : SEG_K_WGRAD_GENERIC,
+                        hipStream_t ws_ = E.wgrad_stream(st);
+                        const int pi = E.prof_begin(ws_, (s.ck == CK_STEM3 || s.ck == CK_STEM1) ? SEG_K_STEM : SEG_K_WGRAD_GENERIC,
                                                     E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
-                        launch_wgrad(w, (float*)(E.ws + E.off_partial), E.dtype, st);
-                        E.prof_end(st, pi);
+                        launch_wgrad(w, (float*)(E.ws + E.off_partial), E.dtype, ws_);
+                        E.prof_end(ws_, pi);
                     }
                     // ---- data gradient(s)
                     if (g0 < 0 && g1 < 0) return;
@@ -789,13 +812,21 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     seg_engine* e = new seg_engine();
     e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
     e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
+    e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
     Builder b(*e);
     if (net_kind == SEG_NET_VNET) b.build_vnet(); else b.build_unet();
     *out = e;
     return 0;
 }
 
-void seg_destroy(seg_handle h) { delete h; }
+void seg_destroy(seg_handle h) {
+    if (!h) return;
+    for (auto& r : h->prof_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->ready_ev) (void)hipEventDestroy(e);
+    if (h->side_done) (void)hipEventDestroy(h->side_done);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    delete h;
+}
 
 int seg_param_count(seg_handle h) { return h ? (int)h->params.size() : -1; }
 long long seg_param_numel(seg_handle h) { return h ? h->nparam : -1; }
@@ -885,7 +916,9 @@ int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* strea
     hipStream_t st = (hipStream_t)stream;
     if (zero_grads) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
+    h->ready_used = 0;
     for (auto& op : h->bwd_ops) op(st);
+    h->join_side(st);
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));
 }
 
