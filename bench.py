@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("SEG_LANES", "1")), help="intra-GPU batch lanes (pytorchdeeplearing_amd/lanes.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-kernel", default="conv3_smallbox", help="kernel class bracketed with HIP events in the timed region")
     ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
@@ -92,7 +93,11 @@ def main():
     from pytorchdeeplearing_amd.parallel import GradAllReduce
 
     S = a.size
-    e = SegEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev)
+    if a.lanes > 1:
+        from pytorchdeeplearing_amd.lanes import LaneEngine
+        e = LaneEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev, lanes=a.lanes)
+    else:
+        e = SegEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev)
     e.load_state_dict(seg.init_params("vnet", 3, 1, 1, seed=0))
     x, y = seg.synthetic_batch(a.batch, (S, S, S), 1, 1, seed=1234 + rank)
     x, y = x.to(dev), y.to(dev)
@@ -150,7 +155,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "VNet3d(1,1) binary seg, %dx1x%d^3 per GPU, BinaryDiceLoss + Dice metric, AdamW, dropout p=0.2 on, "
                                    "random-init weights (BASELINE.json configs[2])" % (a.batch, S),
-                       "global_batch": a.batch * world, "parallelism": "dp%d" % world},
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "lanes_per_gpu": a.lanes},
             "final_loss": round(loss, 5),
             "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME_96 * scale * vols / world / PEAK_HBM_GBS, 4),
                            "mfma_frac": round(GFLOP_PER_VOLUME_96 * scale * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},
