@@ -32,6 +32,20 @@ PEAK_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA
 KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel<f16>", "gn_bwd_apply": "gn_bwd_apply_kernel<f16>", "gn_act": "gn_act_kernel<f16>",
                  "conv3_smallbox": "conv3_kernel<f16, 3,8,8 box, KD=3, CH=32, NT=1, LDS weights>"}
 MFMA_BOUND = {"conv3_smallbox", "conv3", "wgrad3"}
+PMC_KEY = {"conv3_smallbox": "conv3_kernel<DF16_Li3ELi8ELi8ELi3ELi32ELi1ELb1>", "gn_bwd_reduce": "gn_bwd_reduce_kernel<DF16_>",
+           "gn_bwd_apply": "gn_bwd_apply_kernel<DF16_>", "gn_act": "gn_act_kernel<DF16_>"}
+
+
+def pmc_traffic(kclass):
+    """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes committed under profiles/
+    (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled for gfx950 as
+    MI355X_MICROARCH.md prescribes).  None when the summary is not available."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")) as f:
+            d = json.load(f)[PMC_KEY[kclass]]
+        return int((2.0 * d["fetch_kb_raw_per_launch"] + d["write_kb_per_launch"]) * 1024)
+    except Exception:
+        return None
 
 
 def parse():
@@ -173,7 +187,7 @@ def main():
                 per_launch = {"algorithmic_bytes_per_launch": int(p["bytes"] / p["calls"])}
             line["roofline"] = {
                 "kernel": KERNEL_SYMBOL.get(k, k), "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
-                "frac": round(ach / peak, 4), "traffic": None,
+                "frac": round(ach / peak, 4), "traffic": pmc_traffic(k) if a.dtype == "f16" and S == 96 and a.batch == 4 else None,
                 "launches_per_step": p["calls"] // a.steps, "avg_launch_us": round(avg_us, 2), "ms_per_step": round(p["ms"] / a.steps, 3),
                 "note": "largest kernel symbol of the step (rocprofv3 --stats); every launch bracketed by hipEventRecord on the launch "
                         "stream inside the timed region (each bracket costs ~11 us of stream idle time, included in value); "
