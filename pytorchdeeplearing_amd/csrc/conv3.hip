@@ -129,40 +129,12 @@ __device__ __forceinline__ void box_epilogue(f32x4 (&acc)[MT][NT], T* Os, float*
 struct Conv3Args {
     const void* in; const void* w; const float* bias; void* out; double* stats;
     int N, D, H, W, Cin, Cout, Kpad;
-    long long nbox;
+    int dbg;   // ablation mask (SEG_CONV3_DBG): 1 no halo loads, 2 no weight loads, 4 no MFMA loop, 8 no epilogue
 };
 
-// halo fragments of one box in registers: loads of the NEXT box are issued before the tap loop of the current one
-template <class T, class B, int CH> struct HaloRegs {
-    static constexpr int CPV = CH / 8, TOTAL = B::HV * CPV, NIT = (TOTAL + 255) / 256;
-    vec<T, 8> v[NIT];
-    __device__ __forceinline__ void load(const T* in, int C, int c0, const BoxPos& p, int D, int H, int W) {
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int i = u * 256 + threadIdx.x;
-            const int hv = i / CPV, c8 = i % CPV;
-            const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
-            const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
-            v[u] = zero8<T>();
-            if (i < TOTAL && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                v[u] = load8(in + ((((long long)p.n * D + z) * H + y) * W + x) * C + c0 + c8 * 8);
-        }
-    }
-    template <int LD> __device__ __forceinline__ void store(T* Xs) const {
-#pragma unroll
-        for (int u = 0; u < NIT; ++u) {
-            const int i = u * 256 + threadIdx.x;
-            if (i < TOTAL) store8(&Xs[(i / CPV) * LD + (i % CPV) * 8], v[u]);
-        }
-    }
-};
-
-// WL = true (NT == 1 tiles): the [16][taps x CH] weight slab of the current channel chunk lives in LDS next to the halo,
-// so the tap loop never waits on L2 (the small deep levels run ~1.5 workgroups per CU and were bound by that latency);
-// WL = false: weights stream from L2 through a register ring.
-// Single-chunk layers (Cin <= 32: the 96^3 / 48^3 levels that carry most of the bytes) run PERSISTENT workgroups over
-// a strided box list: the next box's halo is loaded into registers while the current box is on the matrix cores, and
-// the weight slab is staged once per workgroup.
+// WL = true (NT == 1 tiles): the [16][taps x CH] weight slab of the current channel chunk is staged in LDS with the
+// halo, so the tap loop never waits on L2 (the small deep levels run ~1.5 workgroups per CU and were bound by that
+// latency); WL = false: weights stream from L2 through a register ring.
 template <class T, int TD, int TH, int TW, int KD, int CH, int NT, bool WL>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
     typedef Box<TD, TH, TW, KD> B;
@@ -173,116 +145,98 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
     __shared__ T Xs[XS_ELEMS > OS_ELEMS ? XS_ELEMS : OS_ELEMS];
     __shared__ float red[512];
     static_assert(B::V % 64 == 0, "box must hold a multiple of 64 voxels");
-    constexpr int NSTEP = CH == 32 ? B::NTAP : (B::NTAP + 1) / 2;
-    constexpr int WLD = NSTEP * 32 + 8;                   // row stride: 16 rows land on distinct 16-B slots
+    constexpr int NSTEP_ = CH == 32 ? B::NTAP : (B::NTAP + 1) / 2;
+    constexpr int WLD = NSTEP_ * 32 + 8;                  // row stride: 16 rows land on distinct 16-B slots
     __shared__ T Ws[WL ? 16 * WLD : 8];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const BoxPos bp = box_pos<B, TD, TH, TW>(blockIdx.x, a.D, a.H, a.W);
     const int co0 = blockIdx.y * BN;
     const T* in = (const T*)a.in;
     const T* wp = (const T*)a.w;
-    const int nchunk = a.Cin / CH;
-    const bool pipe = nchunk == 1;
 
     int hb[MT];                                          // halo base index of this lane's voxel per M tile
 #pragma unroll
     for (int m = 0; m < MT; ++m) hb[m] = B::halo_base((wv * MT + m) * 16 + l15);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
     const T* wrow[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) wrow[j] = wp + (long long)(co0 + j * 16 + l15) * a.Kpad + q * 8;
 
-    auto stage_weights = [&](int cc) {
-        constexpr int PIECES = 16 * NSTEP * 4, WN = (PIECES + 255) / 256;
-        vec<T, 8> wv_[WN];
+    // K order of the packed weights is (tap, ci).  CH == 32: step s = (tap s) x (32 channels of chunk cc).
+    // CH == 16 (Cin == 16): step s covers taps 2s, 2s+1; lanes q = 0,1 -> tap 2s, q = 2,3 -> tap 2s+1.
+    constexpr int NSTEP = CH == 32 ? B::NTAP : (B::NTAP + 1) / 2;
+    const int nchunk = a.Cin / CH;
+    for (int cc = 0; cc < nchunk; ++cc) {
+        if (cc) __syncthreads();
+        if (!(a.dbg & 1)) stage_halo<T, B, CH, XLD>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W);
+        if (WL) {
+            constexpr int PIECES = 16 * NSTEP_ * 4, WN = (PIECES + 255) / 256;
+            vec<T, 8> wv_[WN];
 #pragma unroll
-        for (int u = 0; u < WN; ++u) {
-            const int i = u * 256 + tid;
-            const int c4 = i & 3, st_ = (i >> 2) % NSTEP, co = i / (4 * NSTEP);
-            wv_[u] = zero8<T>();
-            if (i < PIECES) wv_[u] = load8(wp + (long long)(co0 + co) * a.Kpad + (CH == 32 ? st_ * a.Cin + cc * 32 : st_ * 32) + c4 * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < WN; ++u) {
-            const int i = u * 256 + tid;
-            const int c4 = i & 3, st_ = (i >> 2) % NSTEP, co = i / (4 * NSTEP);
-            if (i < PIECES) store8(&Ws[co * WLD + st_ * 32 + c4 * 8], wv_[u]);
-        }
-    };
-
-    HaloRegs<T, B, CH> hr;
-    long long b = blockIdx.x;
-    if (b >= a.nbox) return;
-    BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
-    if (pipe) {                                          // prologue: first box + (once) the weight slab
-        hr.load(in, a.Cin, 0, bp, a.D, a.H, a.W);
-        hr.template store<XLD>(Xs);
-        if (WL) stage_weights(0);
-    }
-    for (; b < a.nbox; b += gridDim.x) {
-        bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
-        const long long bnext = b + gridDim.x;
-        f32x4 acc[MT][NT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // K order of the packed weights is (tap, ci).  CH == 32: step s = (tap s) x (32 channels of chunk cc).
-        // CH == 16 (Cin == 16): step s covers taps 2s, 2s+1; lanes q = 0,1 -> tap 2s, q = 2,3 -> tap 2s+1.
-        for (int cc = 0; cc < nchunk; ++cc) {
-            if (!pipe) {
-                if (cc) __syncthreads();
-                hr.load(in, a.Cin, cc * CH, bp, a.D, a.H, a.W);
-                hr.template store<XLD>(Xs);
-                if (WL) stage_weights(cc);
-            }
-            __syncthreads();
-            if (pipe && bnext < a.nbox)                  // next box's halo flies while this box is on the matrix cores
-                hr.load(in, a.Cin, 0, box_pos<B, TD, TH, TW>(bnext, a.D, a.H, a.W), a.D, a.H, a.W);
-            // weights without LDS residency come straight from L2 through a PF-deep register ring
-            constexpr int PF = NT == 2 ? 6 : 3;      // measured: deeper ring pays for NT=2 only (NT=1 loses occupancy)
-            typename Mma<T>::frag bq[PF + 1][NT];
-            auto wofs = [&](int s) { return CH == 32 ? s * a.Cin + cc * 32 : s * 32; };
-            if (!WL) {
-#pragma unroll
-                for (int s = 0; s < PF && s < NSTEP; ++s)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bq[s][j] = load8(wrow[j] + wofs(s));
+            for (int u = 0; u < WN; ++u) {
+                const int i = u * 256 + tid;
+                const int c4 = i & 3, st_ = (i >> 2) % NSTEP_, co = i / (4 * NSTEP_);
+                wv_[u] = zero8<T>();
+                if (i < PIECES) wv_[u] = load8(wp + (long long)(co0 + co) * a.Kpad + (CH == 32 ? st_ * a.Cin + cc * 32 : st_ * 32) + c4 * 8);
             }
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                if (WL) bq[s % (PF + 1)][0] = load8(&Ws[l15 * WLD + s * 32 + q * 8]);
-                if (!WL && s + PF < NSTEP) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bq[(s + PF) % (PF + 1)][j] = load8(wrow[j] + wofs(s + PF));
-                }
-                int toff, col;
-                bool tvalid = true;
-                if (CH == 32) { toff = B::tap_off(s); col = q * 8; }
-                else {
-                    // lanes q = 0,1 take tap 2s, q = 2,3 tap 2s+1: both offsets are compile-time constants
-                    const int t1 = 2 * s + 1;
-                    const int off0 = B::tap_off(2 * s), off1 = B::tap_off(t1 < B::NTAP ? t1 : 0);
-                    tvalid = (q < 2) || t1 < B::NTAP;
-                    toff = (q < 2) ? off0 : off1;
-                    col = (q & 1) * 8;
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    typename Mma<T>::frag af = load8(&Xs[(hb[m] + toff) * XLD + col]);
-                    if (CH == 16 && !tvalid) af = zero8<T>();
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[m][j] = Mma<T>::run(af, bq[s % (PF + 1)][j], acc[m][j]);
-                }
+            for (int u = 0; u < WN; ++u) {
+                const int i = u * 256 + tid;
+                const int c4 = i & 3, st_ = (i >> 2) % NSTEP_, co = i / (4 * NSTEP_);
+                if (i < PIECES) store8(&Ws[co * WLD + st_ * 32 + c4 * 8], wv_[u]);
             }
         }
         __syncthreads();
-        box_epilogue<T, B, TW, TH, MT, NT>(acc, Xs, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
-        if (pipe && bnext < a.nbox) {
-            __syncthreads();                             // everyone is done with the output tile that aliases the halo buffer
-            hr.template store<XLD>(Xs);
+        if (a.dbg & 4) continue;
+        // weights come straight from L2 (every workgroup reads the same few KB); a PF-deep register ring
+        // keeps PF taps in flight so the ~0.5 us L2 round trip hides behind MT*NT MFMAs per tap
+        constexpr int PF = NT == 2 ? 6 : 3;      // measured: deeper ring pays for NT=2 only (NT=1 loses occupancy)
+        typename Mma<T>::frag bq[PF + 1][NT];
+        auto wofs = [&](int s) { return CH == 32 ? s * a.Cin + cc * 32 : s * 32; };
+        if (!WL) {
+#pragma unroll
+            for (int s = 0; s < PF && s < NSTEP; ++s)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bq[s][j] = load8(wrow[j] + ((a.dbg & 2) ? 0 : wofs(s)));
+        }
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (WL) bq[s % (PF + 1)][0] = load8(&Ws[l15 * WLD + s * 32 + q * 8]);
+            if (!WL && s + PF < NSTEP && !(a.dbg & 2)) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bq[(s + PF) % (PF + 1)][j] = load8(wrow[j] + wofs(s + PF));
+            }
+            int toff, col;
+            bool tvalid = true;
+            if (CH == 32) { toff = B::tap_off(s); col = q * 8; }
+            else {
+                // lanes q = 0,1 take tap 2s, q = 2,3 tap 2s+1: both offsets are compile-time constants
+                constexpr int dummy = 0; (void)dummy;
+                const int t1 = 2 * s + 1;
+                const int off0 = B::tap_off(2 * s), off1 = B::tap_off(t1 < B::NTAP ? t1 : 0);
+                tvalid = (q < 2) || t1 < B::NTAP;
+                toff = (q < 2) ? off0 : off1;
+                col = (q & 1) * 8;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                typename Mma<T>::frag af = load8(&Xs[(hb[m] + toff) * XLD + col]);
+                if (CH == 16 && !tvalid) af = zero8<T>();
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[m][j] = Mma<T>::run(af, bq[s % (PF + 1)][j], acc[m][j]);
+            }
         }
     }
+    __syncthreads();
+    if (a.dbg & 8) { if (acc[0][0][0] == 123.f) ((T*)a.out)[0] = from_f<T>(1.f); return; }
+    box_epilogue<T, B, TW, TH, MT, NT>(acc, Xs, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
 }
 
 template <int TD, int TH, int TW>
@@ -291,19 +245,14 @@ inline long long num_boxes(int N, int D, int H, int W) {
 }
 
 template <class T, int TD, int TH, int TW, int KD>
-void conv3_launch_shape(const Conv3Args& a0, hipStream_t s) {
-    Conv3Args a = a0;
+void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
     int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     if (a.Cin == 16 && nt == 4) nt = 2;
-    a.nbox = num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W);
+    const long long nbox = num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W);
     // measured on MI355X: on the small levels more, narrower workgroups (several resident per CU) beat NT = 4
     // tiles (conv3 class 2.3 ms vs 3.4 ms per step) - the per-workgroup tap loop is latency-bound, so occupancy wins
-    while (nt > 1 && a.nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;
-    // single-chunk layers: persistent workgroups (a few per CU), each walking a strided list of boxes
-    long long gx = a.nbox, cap = 1536;
-    if (const char* e = getenv("SEG_CONV3_MAXGRID")) cap = atoll(e);      // test knob: force several boxes per workgroup
-    if (a.Cin <= 32 && gx > cap) gx = cap;
-    dim3 grid((unsigned)gx, a.Cout / (16 * nt));
+    while (nt > 1 && nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;
+    dim3 grid((unsigned)nbox, a.Cout / (16 * nt));
 #define SEG_C3(CH, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_kernel<T, TD, TH, TW, KD, CH, NT, (NT == 1)>), grid, dim3(256), 0, s, a)
     if (a.Cin == 16) { if (nt == 1) SEG_C3(16, 1); else SEG_C3(16, 2); }
     else { if (nt == 1) SEG_C3(32, 1); else if (nt == 2) SEG_C3(32, 2); else SEG_C3(32, 4); }
@@ -706,7 +655,8 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Kpad = ((ndim == 3 ? 27 : 9) * Cin + 31) / 32 * 32;
-    a.nbox = 0;
+    static const int dbg = getenv("SEG_CONV3_DBG") ? atoi(getenv("SEG_CONV3_DBG")) : 0;
+    a.dbg = dbg;
     if (dtype == DT_F32) conv3_dispatch<float>(a, ndim, s);
     else if (dtype == DT_F16) conv3_dispatch<f16>(a, ndim, s);
     else conv3_dispatch<bf16>(a, ndim, s);

@@ -226,21 +226,3 @@ def test_wgrad3_halo_exact(dev, dtype, case):
     got = ops.wgrad3(to_dev(cl(dy), dtype, dev), to_dev(cl(x), dtype, dev), dtype, ndim)
     assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
 
-
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
-def test_conv3_persistent_boxes_exact(dev, dtype, monkeypatch):
-    """single-chunk layers walk a strided box list per workgroup (register-prefetched halo, weights staged once):
-    force 3 workgroups over 12..24 boxes and compare bit-exactly, statistics included."""
-    monkeypatch.setenv("SEG_CONV3_MAXGRID", "3")
-    for ndim, N, sp, cin, cout in ((3, 2, (6, 8, 16), 16, 16), (3, 1, (6, 8, 32), 32, 32), (2, 3, (16, 32), 16, 32), (3, 2, (3, 4, 40), 32, 16)):
-        g = torch.Generator().manual_seed(cin + cout)
-        x = ints((N, cin) + sp, -2, 2, g)
-        w = ints((cout, cin) + (3,) * ndim, -1, 1, g, density=0.15)
-        b = ints((cout,), -3, 3, g)
-        ref = (F.conv3d if ndim == 3 else F.conv2d)(x, w, b, padding=1)
-        assert float(ref.abs().max()) <= 256
-        out, stats = ops.conv3(to_dev(cl(x), dtype, dev), ops.pack(w.to(dev), "conv_fwd", dtype), dtype, ndim, cout,
-                               bias=ops.aligned_like(b.to(dev)), want_stats=True)
-        assert torch.equal(ncdhw(out.float().cpu(), ndim), ref)
-        rs = torch.stack([ref.double().flatten(2).sum(2), (ref.double() ** 2).flatten(2).sum(2)], dim=2)
-        assert torch.equal(stats.cpu(), rs)
