@@ -48,8 +48,11 @@ __device__ __forceinline__ BoxPos box_pos(long long b, int D, int H, int W) {
 }
 
 // stage the halo of channels [c0, c0+CH) of tensor `in` ([N][D][H][W][C]) into LDS rows of LD elements
+// `in` may be a virtual channel concat: channels [0, C0) come from `in` (row length C0), the rest from `in1` (row length C - C0)
 template <class T, class B, int CH, int LD>
-__device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, const BoxPos& p, int D, int H, int W) {
+__device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, const BoxPos& p, int D, int H, int W,
+                                           const T* in1 = nullptr, int C0 = 0) {
+    if (!in1) C0 = C;
     // All global loads of a batch are issued before the first LDS store: a load->wait->store loop would
     // serialise ~9 HBM round trips per box (measured: the dominant cost of the first version).
     constexpr int CPV = CH / 8, TOTAL = B::HV * CPV, NIT = (TOTAL + 255) / 256;
@@ -64,8 +67,11 @@ __device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, co
             const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
             const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
             v[u] = zero8<T>();
-            if (b0 + u < NIT && i < TOTAL && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                v[u] = load8(in + ((((long long)p.n * D + z) * H + y) * W + x) * C + c0 + c8 * 8);
+            if (b0 + u < NIT && i < TOTAL && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                const long long vox = (((long long)p.n * D + z) * H + y) * W + x;
+                const int ch = c0 + c8 * 8;
+                v[u] = ch < C0 ? load8(in + vox * C0 + ch) : load8(in1 + vox * (C - C0) + (ch - C0));
+            }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -127,6 +133,7 @@ __device__ __forceinline__ void box_epilogue(f32x4 (&acc)[MT][NT], T* Os, float*
 // forward / data-gradient
 // ------------------------------------------------------------------------------------------------
 struct Conv3Args {
+    const void* in1; int C0;     // optional second concat source (channels C0..Cin-1)
     const void* in; const void* w; const float* bias; void* out; double* stats;
     int N, D, H, W, Cin, Cout, Kpad;
     int dbg;   // ablation mask (SEG_CONV3_DBG): 1 no halo loads, 2 no weight loads, 4 no MFMA loop, 8 no epilogue
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
     const int nchunk = a.Cin / CH;
     for (int cc = 0; cc < nchunk; ++cc) {
         if (cc) __syncthreads();
-        if (!(a.dbg & 1)) stage_halo<T, B, CH, XLD>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W);
+        if (!(a.dbg & 1)) stage_halo<T, B, CH, XLD>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W, (const T*)a.in1, a.C0);
         if (WL) {
             constexpr int PIECES = 16 * NSTEP_ * 4, WN = (PIECES + 255) / 256;
             vec<T, 8> wv_[WN];
@@ -277,6 +284,7 @@ void conv3_dispatch(const Conv3Args& a, int ndim, hipStream_t s) {
 // weight gradient
 // ------------------------------------------------------------------------------------------------
 struct Wgrad3Args {
+    const void* x1; int C0;      // optional second concat source of x
     const void* dr; const void* x; float* partial;
     int N, D, H, W, P, Q;       // channel counts of dr / x
     int nb;                     // workgroups per (p-tile, q-tile) combo
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(Wgrad3Args a) {
             const int i = u * 256 + tid;
             if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], dv[u]);
         }
-        stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W);
+        stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W, (const T*)a.x1, a.C0);
         __syncthreads();
 #pragma unroll 1
         for (int ks = 0; ks < B::V / 32; ++ks) {
@@ -650,8 +658,9 @@ inline long long boxes_for(int ndim, int N, int D, int H, int W) {
 
 // ---- host entry points (declared in kernels.h) -----------------------------------------------------
 void launch_conv3(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cin,
-                  int Cout, int ndim, int dtype, hipStream_t s) {
+                  int Cout, int ndim, int dtype, hipStream_t s, const void* in1, int C0) {
     Conv3Args a;
+    a.in1 = in1; a.C0 = C0;
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Kpad = ((ndim == 3 ? 27 : 9) * Cin + 31) / 32 * 32;
@@ -682,8 +691,9 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) 
 }
 
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s) {
+                   int dtype, hipStream_t s, const void* x1, int C0) {
     Wgrad3Args a;
+    a.x1 = x1; a.C0 = C0;
     a.dr = dr; a.x = x; a.partial = partial;
     a.N = N; a.D = D; a.H = H; a.W = W; a.P = P; a.Q = Q;
     a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q);

@@ -455,7 +455,7 @@ struct Planner {
         size_t pmax = 0;
         for (auto& s : E.steps)
             if (s.type == ST_UNIT) {
-                if (s.ck == CK_K3 && s.in1 < 0) {
+                if (s.ck == CK_K3) {
                     const int l = E.tens[s.raw].lvl;
                     pmax = std::max(pmax, wgrad3_partial_bytes(E.ndim, N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cout, s.Cin));
                 } else if (s.ck == CK_STEM3 || s.ck == CK_STEM1) {
@@ -491,12 +491,12 @@ struct Planner {
                         launch_stem_fwd(E.ws + i0.off, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N, E.dim_d(0), E.dim_h(0), E.dim_w(0),
                                         i0.C, s.Cout, s.ck == CK_STEM1, E.ndim, E.dtype, st);
                         E.prof_end(st, pi);
-                    } else if (s.ck == CK_K3 && s.in1 < 0) {
+                    } else if (s.ck == CK_K3) {
                         const int l = ro.lvl;
                         const int pi = E.prof_begin(st, conv3_class(E.dim_w(l)), E.tbytes(s.in0) + E.tbytes(s.raw),
                                                     2.0 * E.N * E.vol(l) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout);
                         launch_conv3(E.ws + i0.off, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l),
-                                     s.Cin, s.Cout, E.ndim, E.dtype, st);
+                                     s.Cin, s.Cout, E.ndim, E.dtype, st, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
                         E.prof_end(st, pi);
                     } else {
                         ConvArgs a{};
@@ -710,18 +710,26 @@ struct Planner {
                     // ---- bias gradient of convs without GroupNorm
                     if (s.gn_w < 0 && s.b >= 0)
                         launch_colsum(E.ws + E.tens[draw].off, E.g + E.params[s.b].off, (long long)E.N * E.vol(lo), s.Cout, E.dtype, st);
-                    if (s.ck == CK_K3 && s.in1 < 0) {
-                        // halo-tile kernels: weight gradient (deterministic two-stage reduction) + data gradient
+                    if (s.ck == CK_K3) {
+                        // halo-tile kernels: weight gradient (deterministic two-stage reduction) + data gradient(s)
                         const double fl = 2.0 * E.N * E.vol(lo) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout;
                         hipStream_t ws_ = E.wgrad_stream(st);
-                        int pi = E.prof_begin(ws_, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0), fl);
+                        int pi = E.prof_begin(ws_, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), fl);
                         launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.off_partial), E.g + E.params[s.w].off,
-                                      E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_);
+                                      E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
+                                      s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
                         E.prof_end(ws_, pi);
                         if (g0 >= 0) {
-                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g0), fl);
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
-                                         E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, st);
+                                         E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
+                            E.prof_end(st, pi);
+                        }
+                        if (g1 >= 0) {
+                            const int C1 = E.tens[s.in1].C;
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g1), fl * C1 / s.Cin);
+                            launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr, E.N,
+                                         E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);
                         }
                         return;

@@ -14,11 +14,11 @@ void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s);
 
 // LDS halo-tile kernels for 3^d stride-1 pad-1 convs (conv3.hip): forward / data-gradient and weight gradient
 void launch_conv3(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cin,
-                  int Cout, int ndim, int dtype, hipStream_t s);
+                  int Cout, int ndim, int dtype, hipStream_t s, const void* in1 = nullptr, int C0 = 0);   // in1: second concat source
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q);
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s);
+                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0);
 
 // MFMA image stem (K = taps*Cimg <= 32): forward and weight gradient on box tiles (conv3.hip)
 void launch_stem_fwd(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cimg,

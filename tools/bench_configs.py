@@ -1,0 +1,32 @@
+"""Train-step time of the BASELINE.json configs on one GPU (diagnostics; bench.py is the contract benchmark)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from oracle import seg_oracle as seg
+from pytorchdeeplearing_amd import SegEngine, _capi
+
+CONFIGS = {
+    "C2 VNet2d 16x512^2 f16 2-class": ("vnet", 2, (16, 1, 512, 512), 2, "MutilDiceLoss", "f16"),
+    "C3 VNet3d 4x96^3 f16 binary": ("vnet", 3, (4, 1, 96, 96, 96), 1, "BinaryDiceLoss", "f16"),
+    "C4 UNet3d 2x128^3 f16 4-class": ("unet", 3, (2, 1, 128, 128, 128), 4, "MutilDiceLoss", "f16"),
+    "C5 VNet3d 1x160^3 bf16 binary": ("vnet", 3, (1, 1, 160, 160, 160), 1, "BinaryCrossEntropyDiceLoss", "bf16"),
+}
+dev = torch.device("cuda")
+for name, (kind, ndim, shape, ncls, loss, dt) in CONFIGS.items():
+    e = SegEngine(kind, ndim, shape[1], ncls, dtype=dt, device=dev)
+    e.load_state_dict(seg.init_params(kind, ndim, shape[1], ncls, seed=0))
+    x, y = seg.synthetic_batch(shape[0], shape[2:], shape[1], ncls, seed=1)
+    x, y = x.to(dev), y.to(dev)
+    alpha = torch.ones(ncls, device=dev)
+    for _ in range(3): e.train_step(x, y, loss, class_alpha=alpha)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): e.train_step(x, y, loss, class_alpha=alpha)
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
+    e.profile_enable(_capi.KERNEL_CLASSES)
+    for _ in range(2): e.train_step(x, y, loss, class_alpha=alpha)
+    torch.cuda.synchronize()
+    prof = {k: round(v["ms"] / 2, 2) for k, v in e.profile_read().items()}
+    print(json.dumps({"config": name, "ms_per_step": round(ms, 2), "samples_per_s": round(shape[0] / ms * 1e3, 1), "class_ms": prof}))
+    del e
+    torch.cuda.empty_cache()
