@@ -176,6 +176,21 @@ int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int 
 /* sizeof of the structs above as compiled into the library: 0 conv, 1 wgrad, 2 pack */
 int seg_abi_sizeof(int which);
 
+/* ---- soft-clDice building blocks (model/lossescldice.py:5-59; corrected restatement).
+ * Planar fp32 tensors [planes][D][H][W]; nd = 3 pools 3x3x3 over (D,H,W), nd = 2 pools 3x3 over (H,W); stride 1, pad 1,
+ * padding ignored.  seg_op_skel_update: out = relu(x - relu(maxpool(e) - e)).  The *_bwd entry points route gradients to the
+ * first extremum of each window (ATen max_pool backward); `de` / `din` are accumulated into (zero them first). */
+int seg_op_pool3(const float* x, float* out, int planes, int d, int h, int w, int nd, int is_min, void* stream);
+int seg_op_skel_update(const float* x, const float* e, float* out, int planes, int d, int h, int w, int nd, void* stream);
+int seg_op_skel_update_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int d, int h, int w,
+                           int nd, void* stream);
+int seg_op_pool3_bwd(const float* src, const float* dout, float* din, int planes, int d, int h, int w, int nd, int is_min,
+                     void* stream);
+/* out2[p] = {sum a*b, sum a} per plane (fp64);  out = a[p]*in + b[p] (accumulate != 0: +=) */
+int seg_op_plane_dot(const float* a, const float* b, double* out2, int planes, long long v, void* stream);
+int seg_op_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long v, int accumulate,
+                      void* stream);
+
 /* ---- measurement: HIP-event timing of kernel classes inside a running forward/backward.
  * seg_profile_enable(h, mask): from now on every launch whose class bit is set in `mask` is
  * bracketed by hipEventRecord on the launch stream (0 disables).  seg_profile_read(h, ...)

@@ -109,10 +109,77 @@ def make_net(nets, losses, seg, tag, kind, ndim, ctor, shape, numclass, loss_mod
     print(tag, "logits.sum", float(logits.sum()), "loss", float(loss), "train loss", float(loss_t), "n_masks", len(masks))
 
 
+CLDICE_REPAIRS = (
+    # (reference text, repaired text, why) - applied IN MEMORY to model/lossescldice.py; nothing is written back
+    ("shape = x.size().tolist()", "shape = x.dim()", "lossescldice.py:10-11,16: rank test; torch.Size has no tolist()"),
+    ("def __int__(self):", "def __init__(self):", "lossescldice.py:43: constructor never ran"),
+    ("def __int__(self, alpha):", "def __init__(self, alpha):\n        super(Mutil_Soft_cldice_loss, self).__init__()",
+     "lossescldice.py:67: constructor never ran / nn.Module not initialised"),
+    ("y_true = y_true.view(input.size())", "y_true = y_true.reshape(input.size()).to(input.dtype)",
+     "lossescldice.py:80: permuted view + max_pool on a Long tensor"),
+)
+
+
+def load_repaired_cldice():
+    src = open(os.path.join(ref_loader.REF, "model", "lossescldice.py")).read()
+    for old, new, _why in CLDICE_REPAIRS:
+        assert src.count(old) == 1, old
+        src = src.replace(old, new)
+    ns = {}
+    exec(compile(src, "lossescldice_repaired", "exec"), ns)
+    return ns
+
+
+def cldice_inputs(shape, seed, numclass=0):
+    """vessel-like probabilities: low-pass noise through a sigmoid; target = another field thresholded."""
+    g = torch.Generator().manual_seed(seed)
+    nd = len(shape) - 2
+    pool = torch.nn.functional.avg_pool3d if nd == 3 else torch.nn.functional.avg_pool2d
+    def field(ch):
+        t = torch.randn((shape[0], ch) + tuple(shape[2:]), generator=g)
+        return pool(pool(t, 3, 1, 1), 3, 1, 1) * 6.0
+    if numclass:
+        pred = torch.softmax(field(numclass), 1)
+        target = field(numclass).argmax(1)
+    else:
+        pred = torch.sigmoid(field(shape[1]))
+        target = (field(shape[1]) > 0.3).float()
+    return pred, target
+
+
+def make_cldice():
+    ns = load_repaired_cldice()
+    out = {}
+    for tag, shape in (("b3", (2, 1, 12, 14, 16)), ("b2", (2, 2, 24, 20))):
+        pred, target = cldice_inputs(shape, 77 + len(shape))
+        pred.requires_grad_(True)
+        out[tag + "_pred"], out[tag + "_target"] = _np(pred), _np(target)
+        out[tag + "_skel_pred"] = _np(ns["soft_skeletonize"](pred))
+        out[tag + "_skel_target"] = _np(ns["soft_skeletonize"](target))
+        loss = ns["Binary_Soft_cldice_loss"]()(pred, target)
+        loss.backward()
+        out[tag + "_loss"], out[tag + "_dpred"] = _np(loss), _np(pred.grad)
+        print("cldice", tag, float(loss))
+    for tag, shape, c in (("m3", (1, 3, 8, 10, 12), 3), ("m2", (2, 3, 16, 16), 3)):
+        pred, target = cldice_inputs(shape, 91 + len(shape), c)
+        pred.requires_grad_(True)
+        alpha = torch.tensor([0.5, 1.0, 2.0])
+        loss = ns["Mutil_Soft_cldice_loss"](alpha)(pred, target)
+        loss.backward()
+        out[tag + "_pred"], out[tag + "_target"], out[tag + "_alpha"] = _np(pred), _np(target), _np(alpha)
+        out[tag + "_loss"], out[tag + "_dpred"] = _np(loss), _np(pred.grad)
+        print("cldice", tag, float(loss))
+    np.savez_compressed(os.path.join(OUT, "cldice.npz"), **out)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not available; golden fixtures can only be regenerated in the build container")
     os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    make_cldice()
+    if "--only-cldice" in sys.argv:
+        return
     nets, losses, metric = ref_loader.load()
     torch.set_num_threads(1)
     make_losses(nets, losses, metric)

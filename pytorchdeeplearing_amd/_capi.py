@@ -52,6 +52,12 @@ SIGNATURES = {
     "seg_op_wgrad3_partial_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
     "seg_op_wgrad3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "seg_abi_sizeof": (_i, [_i]),
+    "seg_op_pool3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "seg_op_skel_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "seg_op_skel_update_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "seg_op_pool3_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "seg_op_plane_dot": (_i, [_vp, _vp, _vp, _i, _ll, _vp]),
+    "seg_op_plane_axpb": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
     "seg_profile_enable": (_i, [_vp, C.c_uint]),
     "seg_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "seg_last_error": (C.c_char_p, []),

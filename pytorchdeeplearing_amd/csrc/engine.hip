@@ -1035,6 +1035,39 @@ int seg_abi_sizeof(int which) {
     return which == 0 ? (int)sizeof(seg_conv_args) : which == 1 ? (int)sizeof(seg_wgrad_args) : (int)sizeof(seg_pack_desc);
 }
 
+#define SEG_OK(what) (hipGetLastError() == hipSuccess ? 0 : fail(what ": launch failed"))
+int seg_op_pool3(const float* x, float* out, int planes, int d, int h, int w, int nd, int is_min, void* stream) {
+    if (!x || !out || (nd != 2 && nd != 3)) return fail("seg_op_pool3: bad arguments");
+    launch_pool3(x, out, planes, d, h, w, nd, is_min, (hipStream_t)stream);
+    return SEG_OK("seg_op_pool3");
+}
+int seg_op_skel_update(const float* x, const float* e, float* out, int planes, int d, int h, int w, int nd, void* stream) {
+    if (!x || !e || !out || (nd != 2 && nd != 3)) return fail("seg_op_skel_update: bad arguments");
+    launch_skel_update(x, e, out, planes, d, h, w, nd, (hipStream_t)stream);
+    return SEG_OK("seg_op_skel_update");
+}
+int seg_op_skel_update_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int d, int h, int w, int nd,
+                           void* stream) {
+    if (!g || !x || !e || !dx || !de || (nd != 2 && nd != 3)) return fail("seg_op_skel_update_bwd: bad arguments");
+    launch_skel_update_bwd(g, x, e, dx, de, planes, d, h, w, nd, (hipStream_t)stream);
+    return SEG_OK("seg_op_skel_update_bwd");
+}
+int seg_op_pool3_bwd(const float* src, const float* dout, float* din, int planes, int d, int h, int w, int nd, int is_min, void* stream) {
+    if (!src || !dout || !din || (nd != 2 && nd != 3)) return fail("seg_op_pool3_bwd: bad arguments");
+    launch_pool3_bwd(src, dout, din, planes, d, h, w, nd, is_min, (hipStream_t)stream);
+    return SEG_OK("seg_op_pool3_bwd");
+}
+int seg_op_plane_dot(const float* a, const float* b, double* out2, int planes, long long v, void* stream) {
+    if (!a || !b || !out2) return fail("seg_op_plane_dot: null pointer");
+    launch_plane_dot(a, b, out2, planes, v, (hipStream_t)stream);
+    return SEG_OK("seg_op_plane_dot");
+}
+int seg_op_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long v, int accumulate, void* stream) {
+    if (!in || !a || !b || !out) return fail("seg_op_plane_axpb: null pointer");
+    launch_plane_axpb(in, a, b, out, planes, v, accumulate, (hipStream_t)stream);
+    return SEG_OK("seg_op_plane_axpb");
+}
+
 int seg_profile_enable(seg_handle h, unsigned mask) {
     if (check_handle(h)) return -1;
     h->prof_mask = mask;

@@ -165,6 +165,14 @@ void launch_metric(const float* probs, const void* target, int label_type, int N
 // out[c] += sum_m x[m][c]   (bias gradient of a conv without GroupNorm)
 void launch_colsum(const void* x, float* out, long long M, int C, int dtype, hipStream_t s);
 
+// soft-clDice building blocks (cldice.hip): planar fp32 [planes][D][H][W]; nd = 3 pools over (D,H,W), nd = 2 over (H,W)
+void launch_pool3(const float* x, float* out, int planes, int D, int H, int W, int nd, int is_min, hipStream_t s);
+void launch_skel_update(const float* x, const float* e, float* out, int planes, int D, int H, int W, int nd, hipStream_t s);
+void launch_skel_update_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int D, int H, int W, int nd, hipStream_t s);
+void launch_pool3_bwd(const float* src, const float* dout, float* din, int planes, int D, int H, int W, int nd, int is_min, hipStream_t s);
+void launch_plane_dot(const float* a, const float* b, double* out, int planes, long long V, hipStream_t s);
+void launch_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long V, int accumulate, hipStream_t s);
+
 // Fused AdamW / Adam over the flat fp32 buffers; also clears nothing (grads are re-zeroed by the engine)
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;

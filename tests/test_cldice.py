@@ -1,0 +1,92 @@
+"""soft-clDice: oracle vs the repaired-reference golden vectors (CPU), HIP kernels vs the oracle
+(checker build on CPU, libsegengine on the GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import seg_oracle as seg
+from pytorchdeeplearing_amd import lossescldice as cl
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cldice.npz"))
+
+
+def T(name, device="cpu"):
+    return torch.from_numpy(G[name]).to(device)
+
+
+# ---- the oracle is pinned to the reference (with the documented repairs) -----------------------------------------
+@pytest.mark.parametrize("tag", ["b3", "b2"])
+def test_oracle_binary_matches_reference(tag):
+    pred, target = T(tag + "_pred").requires_grad_(True), T(tag + "_target")
+    assert torch.equal(seg.soft_skeletonize(pred.detach()), T(tag + "_skel_pred"))
+    assert torch.equal(seg.soft_skeletonize(target), T(tag + "_skel_target"))
+    loss = seg.binary_soft_cldice_loss(pred, target)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(G[tag + "_loss"])) < 1e-7
+    np.testing.assert_allclose(pred.grad.numpy(), G[tag + "_dpred"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["m3", "m2"])
+def test_oracle_multiclass_matches_reference(tag):
+    pred, target = T(tag + "_pred").requires_grad_(True), T(tag + "_target")
+    loss = seg.multi_soft_cldice_loss(pred, target, G[tag + "_alpha"])
+    loss.backward()
+    assert abs(float(loss.detach()) - float(G[tag + "_loss"])) < 1e-7
+    np.testing.assert_allclose(pred.grad.numpy(), G[tag + "_dpred"], rtol=1e-6, atol=1e-9)
+
+
+# ---- HIP path vs oracle / golden ------------------------------------------------------------------------------------
+def _binary_case(tag, dev):
+    pred, target = T(tag + "_pred", dev).requires_grad_(True), T(tag + "_target", dev)
+    # forward skeletons are pure min/max/sub/relu in fp32: bit-exact
+    assert torch.equal(cl.soft_skeletonize(pred.detach()).cpu(), T(tag + "_skel_pred"))
+    assert torch.equal(cl.soft_skeletonize(target).cpu(), T(tag + "_skel_target"))
+    loss = cl.Binary_Soft_cldice_loss()(pred, target)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(G[tag + "_loss"])) < 2e-6
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), G[tag + "_dpred"], rtol=2e-4, atol=1e-8)
+
+
+def _multi_case(tag, dev):
+    pred, target = T(tag + "_pred", dev).requires_grad_(True), T(tag + "_target", dev)
+    loss = cl.Mutil_Soft_cldice_loss(torch.from_numpy(G[tag + "_alpha"]))(pred, target)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(G[tag + "_loss"])) < 2e-6
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), G[tag + "_dpred"], rtol=2e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("tag", ["b3", "b2"])
+def test_cldice_binary(dev, tag):
+    _binary_case(tag, dev)
+
+
+@pytest.mark.parametrize("tag", ["m3", "m2"])
+def test_cldice_multiclass(dev, tag):
+    _multi_case(tag, dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 1, 40, 48, 56), (3, 2, 96, 80)])
+def test_cldice_vs_oracle_gpu(shape):
+    """larger seeded case against the oracle itself (same inputs, oracle on the host)."""
+    from oracle.make_golden import cldice_inputs
+    pred, target = cldice_inputs(shape, 5)
+    p0 = pred.clone().requires_grad_(True)
+    l0 = seg.binary_soft_cldice_loss(p0, target)
+    l0.backward()
+    p1 = pred.cuda().requires_grad_(True)
+    assert torch.equal(cl.soft_skeletonize(p1.detach()).cpu(), seg.soft_skeletonize(pred))
+    l1 = cl.Binary_Soft_cldice_loss()(p1, target.cuda())
+    l1.backward()
+    assert abs(float(l1) - float(l0)) < 2e-6
+    np.testing.assert_allclose(p1.grad.cpu().numpy(), p0.grad.numpy(), rtol=5e-4, atol=1e-8)
+
+
+def test_cldice_cpu_tensors_raise():
+    from pytorchdeeplearing_amd import _capi
+    if _capi._injected is not None:
+        pytest.skip("checker library injected in this process")
+    with pytest.raises(RuntimeError):
+        cl.soft_skeletonize(torch.rand(1, 1, 8, 8))
