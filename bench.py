@@ -58,7 +58,11 @@ def parse():
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("SEG_LANES", "1")), help="intra-GPU batch lanes (pytorchdeeplearing_amd/lanes.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-kernel", default="conv3_smallbox", help="kernel class bracketed with HIP events in the timed region")
+    ap.add_argument("--roofline-kernel", default="gn_bwd_reduce", help="kernel class bracketed with HIP events in the timed region "
+                    "(default: the largest kernel symbol of the step in the committed rocprofv3 --stats summary)")
+    ap.add_argument("--mfma-kernel", default="conv3_smallbox", help="second bracketed class, reported as \"roofline_mfma\" (largest MFMA symbol)")
+    ap.add_argument("--roofline-steps", type=int, default=5, help="timed steps whose launches carry the HIP-event brackets (each bracket "
+                    "idles the stream for ~6 us, so only the first R of the K timed steps are instrumented)")
     ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
     return ap.parse_args()
 
@@ -122,16 +126,20 @@ def main():
     def step():
         return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs)
 
-    e.profile_enable([a.roofline_kernel])
+    bracketed = [a.roofline_kernel] + ([a.mfma_kernel] if a.mfma_kernel and a.mfma_kernel != a.roofline_kernel else [])
+    e.profile_enable(bracketed)
     for _ in range(a.warmup):
         out3 = step()
     torch.cuda.synchronize()
     e.profile_read()
+    nprof = max(1, min(a.roofline_steps, a.steps))
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        if i == nprof:
+            e.profile_enable([])          # host-side flag only: no synchronisation inside the timed region
         out3 = step()
     torch.cuda.synchronize()
     if dist:
@@ -174,8 +182,9 @@ def main():
             "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME_96 * scale * vols / world / PEAK_HBM_GBS, 4),
                            "mfma_frac": round(GFLOP_PER_VOLUME_96 * scale * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},
         }
-        k = a.roofline_kernel
-        if k in prof and prof[k]["ms"] > 0:
+        def roofline_block(k):
+            if k not in prof or prof[k]["ms"] <= 0:
+                return None
             p = prof[k]
             avg_us = p["ms"] / p["calls"] * 1e3
             if k in MFMA_BOUND:
@@ -185,14 +194,25 @@ def main():
             else:
                 ach, peak, unit, bound = p["bytes"] / (p["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
                 per_launch = {"algorithmic_bytes_per_launch": int(p["bytes"] / p["calls"])}
-            line["roofline"] = {
+            blk = {
                 "kernel": KERNEL_SYMBOL.get(k, k), "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
                 "frac": round(ach / peak, 4), "traffic": pmc_traffic(k) if a.dtype == "f16" and S == 96 and a.batch == 4 else None,
-                "launches_per_step": p["calls"] // a.steps, "avg_launch_us": round(avg_us, 2), "ms_per_step": round(p["ms"] / a.steps, 3),
-                "note": "largest kernel symbol of the step (rocprofv3 --stats); every launch bracketed by hipEventRecord on the launch "
-                        "stream inside the timed region (each bracket costs ~11 us of stream idle time, included in value); "
-                        "algorithmic flops = 2*voxels*27*Cin*Cout, bytes = input + output tensor (DESIGN.md section 5)"}
-            line["roofline"].update(per_launch)
+                "launches_per_step": p["calls"] // nprof, "avg_launch_us": round(avg_us, 2), "ms_per_step": round(p["ms"] / nprof, 3),
+                "instrumented_steps": nprof}
+            blk.update(per_launch)
+            return blk
+        blk = roofline_block(a.roofline_kernel)
+        if blk:
+            blk["note"] = ("largest kernel symbol of the step (rocprofv3 --stats, profiles/); every launch of the first %d timed steps is "
+                           "bracketed by hipEventRecord on its launch stream (the brackets idle the stream ~6 us each and are part of "
+                           "value); achieved = sum of algorithmic bytes / sum of event time, algorithmic bytes per launch = "
+                           "(gradient sources + 1) x tensor bytes (DESIGN.md section 5)" % nprof)
+            line["roofline"] = blk
+        if a.mfma_kernel and a.mfma_kernel != a.roofline_kernel:
+            blk = roofline_block(a.mfma_kernel)
+            if blk:
+                blk["note"] = "largest MFMA kernel symbol; algorithmic flops = 2*voxels*27*Cin*Cout, bytes = input + output tensor"
+                line["roofline_mfma"] = blk
         if table:
             line["kernel_classes"] = table
         if not a.no_cpu_baseline and world == 1:

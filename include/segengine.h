@@ -131,6 +131,9 @@ typedef struct seg_conv_args {
     seg_taps taps;
 } seg_conv_args;
 int seg_op_conv(const seg_conv_args* a, int dtype, void* stream);
+/* which kernel seg_op_conv picks for these extents: 1 = register-resident streaming kernel (short reductions on large
+ * volumes), 0 = LDS-staged implicit GEMM */
+int seg_op_conv_kernel(const seg_conv_args* a);
 
 /* weight gradient dW[p][tap][q] += sum_m dR[m][p] * X[vox(m,tap)][q], written to
  * dw[p*sP + q*sQ + tap*sT] (fp32) through per-slice partial tiles in `partial_scratch`

@@ -45,6 +45,7 @@ SIGNATURES = {
     "seg_metric": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp]),
     "seg_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _i, _vp, _vp]),
     "seg_op_conv": (_i, [_vp, _i, _vp]),
+    "seg_op_conv_kernel": (_i, [_vp]),
     "seg_op_wgrad": (_i, [_vp, _vp, _i, _vp]),
     "seg_op_wgrad_partial_bytes": (_ll, [_vp]),
     "seg_op_pack": (_i, [_vp, _i, _ll, _i, _vp]),

@@ -6,6 +6,8 @@
 //   head_fwd/bwd                    : 1^d conv to `numclass` + sigmoid/softmax, and its backward.
 // Semantics pinned by torch.nn.Conv3d/ConvTranspose3d call sites: networks/VNet3d.py:8,28,29,49,65,70,88,
 // networks/Unet3d.py:26-34,66-80 (reference file:line).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace seg {
@@ -210,6 +212,183 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Streaming variant for the short-reduction convolutions of the two finest levels (1^d convs, 2^d stride-2 convs,
+// ConvTranspose 2^d stride 2 and their data-gradients with K <= 128): these are pure HBM streams (64 B in, 32 B out per
+// voxel), and the LDS-staged kernel above spends its time in per-workgroup latency (load -> LDS -> barrier -> 1..4
+// MFMAs -> LDS -> store: ~5 us for 4 KB; 27648 workgroups at 96^3).  Here nothing goes through LDS: the weights
+// (<= 8 MFMA fragments) live in registers for the whole kernel, every lane loads its own B fragment (8 consecutive k
+// of one voxel row = one coalesced 16-B piece) straight from HBM, and the operands are swapped (D = W * X^T) so a lane
+// ends up with 4 consecutive output channels of one voxel -> 8-B coalesced stores, no transpose.  Each wave walks a
+// strided list of 16-voxel tiles of ONE sample, keeping GroupNorm partial sums in registers.
+// ------------------------------------------------------------------------------------------------
+template <class T, int KS, int NTL, bool SCATTER>
+__global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
+    __shared__ float red[4][NTL * 16][2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int n = blockIdx.y;
+    const long long Vrow = (long long)a.OD * a.OH * a.OW;
+    const int Cin = a.C0 + a.C1;
+    const int lg = 31 - __builtin_clz(Cin);
+    const T* in0 = (const T*)a.in0;
+    const T* in1 = (const T*)a.in1;
+    const T* wp = (const T*)a.w;
+    T* out = (T*)a.out;
+
+    typename Mma<T>::frag wf[KS][NTL];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) wf[ks][j] = load8(wp + (long long)(j * 16 + l15) * a.Kpad + ks * 32 + q * 8);
+    float bs[NTL][4];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[j][r] = a.bias ? a.bias[(SCATTER ? (j * 16) % a.Cout : j * 16) + 4 * q + r] : 0.f;
+    // reduction coordinates of this lane's 8-element piece in every K step
+    int td[KS], th[KS], tw[KS], ci[KS];
+    bool kin[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k0 = ks * 32 + q * 8;
+        kin[ks] = k0 < a.K;
+        const int tap = (SCATTER || !kin[ks]) ? 0 : (k0 >> lg);
+        ci[ks] = SCATTER ? k0 : (k0 & (Cin - 1));
+        td[ks] = SCATTER ? 0 : a.taps.d[tap]; th[ks] = SCATTER ? 0 : a.taps.h[tap]; tw[ks] = SCATTER ? 0 : a.taps.w[tap];
+    }
+    float s1[NTL][4], s2[NTL][4];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+
+    const int ntile = (int)(Vrow / 16);
+    // U tiles per iteration: all their loads are issued before the first MFMA (>= 4 x 16 B in flight per lane)
+    constexpr int U = KS >= 4 ? 1 : 4 / KS;
+    const int step = gridDim.x * 4;
+    for (int t0 = blockIdx.x * 4 + wv; t0 < ntile; t0 += step * U) {
+        typename Mma<T>::frag xf[U][KS];
+        int d_[U], h_[U], w_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * step;
+            int m = (t < ntile ? t : t0) * 16 + l15;
+            w_[u] = m % a.OW; m /= a.OW;
+            h_[u] = m % a.OH;
+            d_[u] = m / a.OH;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                xf[u][ks] = zero8<T>();
+                if (kin[ks] && t < ntile) {
+                    const int id = SCATTER ? d_[u] : d_[u] * a.sd + td[ks], ih = SCATTER ? h_[u] : h_[u] * a.sh + th[ks],
+                              iw = SCATTER ? w_[u] : w_[u] * a.sw + tw[ks];
+                    const long long vox = (((long long)n * a.ID + id) * a.IH + ih) * a.IW + iw;
+                    xf[u][ks] = (ci[ks] < a.C0) ? load8(in0 + vox * a.C0 + ci[ks]) : load8(in1 + vox * a.C1 + (ci[ks] - a.C0));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * step;
+            if (t >= ntile) break;
+            f32x4 acc[NTL];
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) acc[j] = Mma<T>::run(wf[ks][j], xf[u][ks], acc[j]);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                vec<T, 4> o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = from_f<T>(acc[j][r] + bs[j][r]);
+                    const float f = to_f(o[r]);
+                    s1[j][r] += f;
+                    s2[j][r] = fmaf(f, f, s2[j][r]);
+                }
+                long long orow;
+                int co;
+                if (SCATTER) {
+                    const int tap = (j * 16) / a.Cout;
+                    co = (j * 16) % a.Cout + 4 * q;
+                    orow = (((long long)n * a.FD + d_[u] * a.sd + a.taps.d[tap]) * a.FH + h_[u] * a.sh + a.taps.h[tap]) * a.FW + w_[u] * a.sw +
+                           a.taps.w[tap];
+                } else {
+                    co = j * 16 + 4 * q;
+                    orow = (long long)n * Vrow + t * 16 + l15;
+                }
+                *(vec<T, 4>*)(out + orow * a.Cout + co) = o;
+            }
+        }
+    }
+    if (a.stats) {
+        // per-channel sums: over the 16 voxel lanes of the wave, then over waves (and taps for the scatter form)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = s1[j][r], v = s2[j][r];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) { u += __shfl_xor(u, msk); v += __shfl_xor(v, msk); }
+                if (l15 == 0) { red[wv][j * 16 + 4 * q + r][0] = u; red[wv][j * 16 + 4 * q + r][1] = v; }
+            }
+        __syncthreads();
+        if (tid < a.Cout) {
+            double ts = 0.0, tss = 0.0;
+            for (int col = tid; col < NTL * 16; col += a.Cout)      // gather form: exactly one column
+                for (int k = 0; k < 4; ++k) { ts += red[k][col][0]; tss += red[k][col][1]; }
+            double* dst = a.stats + (((long long)(blockIdx.x % STAT_REP) * a.N + n) * a.Cout + tid) * 2;
+            atomicAdd(dst, ts);
+            atomicAdd(dst + 1, tss);
+        }
+    }
+}
+
+bool stream_eligible(const ConvArgs& a) {
+    static const bool off = getenv("SEG_CONV_STREAM") && atoi(getenv("SEG_CONV_STREAM")) == 0;
+    if (off) return false;
+    const long long Vrow = (long long)a.OD * a.OH * a.OW;
+    if (Vrow % 16 || a.Kpad > 128 || a.Kpad % 32 || a.Ngemm % 16 || a.Ngemm > 128) return false;
+    const int ks = a.Kpad / 32, ntl = a.Ngemm / 16;
+    if (ks * ntl > 8 || ks == 3 || (ks == 4 && ntl > 2) || (ks == 2 && ntl > 4)) return false;
+    if (ntl != 1 && ntl != 2 && ntl != 4 && ntl != 8) return false;
+    if (a.scatter) {
+        if (a.Cout % 16 || a.K > a.Kpad) return false;
+    } else {
+        if (a.Ngemm != a.Cout) return false;
+        for (int t = 0; t < a.taps.n; ++t) {       // every tap must stay inside the source for every output voxel
+            if (a.taps.d[t] < 0 || a.taps.h[t] < 0 || a.taps.w[t] < 0) return false;
+            if ((a.OD - 1) * a.sd + a.taps.d[t] >= a.ID || (a.OH - 1) * a.sh + a.taps.h[t] >= a.IH || (a.OW - 1) * a.sw + a.taps.w[t] >= a.IW)
+                return false;
+        }
+    }
+    return true;
+}
+
+template <class T>
+bool launch_conv_stream(const ConvArgs& a, hipStream_t s) {
+    if (!stream_eligible(a)) return false;
+    const long long Vrow = (long long)a.OD * a.OH * a.OW;
+    const int ks = a.Kpad / 32, ntl = a.Ngemm / 16;
+    const int ntile = (int)(Vrow / 16);
+    int gx = ntile / 32;                              // >= 8 tiles per wave
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, a.N);
+#define SEG_STREAM(KS, NTL)                                                                                                   \
+    if (ks == KS && ntl == NTL) {                                                                                            \
+        if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, true>), grid, dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, false>), grid, dim3(256), 0, s, a);           \
+        return true;                                                                                                         \
+    }
+    SEG_STREAM(1, 1) SEG_STREAM(1, 2) SEG_STREAM(1, 4) SEG_STREAM(1, 8) SEG_STREAM(2, 1) SEG_STREAM(2, 2) SEG_STREAM(2, 4)
+    SEG_STREAM(4, 1) SEG_STREAM(4, 2)
+#undef SEG_STREAM
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------
 // stem: direct conv, Cimg in 1..4, Cout multiple of 8 (<= 64).  256 voxels per workgroup.
 // ------------------------------------------------------------------------------------------------
 template <class T>
@@ -373,10 +552,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
 
 }  // namespace
 
+bool conv_uses_stream_kernel(const ConvArgs& a) { return stream_eligible(a); }
+
 void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s) {
-    if (dtype == DT_F32) conv_dispatch<float>(a, s);
-    else if (dtype == DT_F16) conv_dispatch<f16>(a, s);
-    else conv_dispatch<bf16>(a, s);
+    if (dtype == DT_F32) { if (!launch_conv_stream<float>(a, s)) conv_dispatch<float>(a, s); }
+    else if (dtype == DT_F16) { if (!launch_conv_stream<f16>(a, s)) conv_dispatch<f16>(a, s); }
+    else { if (!launch_conv_stream<bf16>(a, s)) conv_dispatch<bf16>(a, s); }
 }
 
 void launch_conv_stem(const StemArgs& a, int dtype, hipStream_t s) {

@@ -11,6 +11,7 @@ typedef seg_taps Taps;
 // Implicit-GEMM convolution arguments: see seg_conv_args in include/segengine.h
 typedef seg_conv_args ConvArgs;
 void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s);
+bool conv_uses_stream_kernel(const ConvArgs& a);   // true: register-resident streaming kernel, false: LDS-staged implicit GEMM
 
 // LDS halo-tile kernels for 3^d stride-1 pad-1 convs (conv3.hip): forward / data-gradient and weight gradient
 void launch_conv3(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cin,

@@ -122,6 +122,9 @@ def pack(w, layout, dtype):
     return out
 
 
+last_conv_kernel = None
+
+
 def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=None, scatter=False, want_stats=False):
     """x0 (and optional concat source x1): [N,D,H,W,C] in dtype.  Gather conv (k, stride, pad) or, with
     scatter=True, the k2-s2 transposed conv.  Returns out [N,OD,OH,OW,cout] (+ stats [N,cout,2] fp64)."""
@@ -160,6 +163,8 @@ def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=
     if want_stats:
         stats = _alloc((32, N, cout, 2), torch.float64, x0.device, zero=True)
         a.stats = stats.data_ptr()
+    global last_conv_kernel
+    last_conv_kernel = lib.dll.seg_op_conv_kernel(C.byref(a))      # 1: streaming kernel, 0: LDS-staged implicit GEMM
     lib.check(lib.dll.seg_op_conv(C.byref(a), _capi.DTYPE[dtype], _capi.stream_for(x0.device)), "seg_op_conv")
     return (out, stats.sum(0)) if want_stats else out
 

@@ -41,6 +41,7 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t = nullptr
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+template <class P> inline hipError_t hipMalloc(P** p, size_t n) { *p = (P*)malloc(n); return *p ? hipSuccess : 1; }
 typedef void* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
@@ -214,6 +215,7 @@ inline WaveScratch& wsc() { return S().ws[me().wave]; }
     emu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
 
 inline void __syncthreads() { emu::yield(emu::Y_BLOCK); }
+inline unsigned long long wall_clock64() { return 0ull; }   // diagnostics only (SEG_CONV3_TRACE is a GPU tool)
 inline void __threadfence() {}
 
 // ---- atomics (blocks/fibers are serialized) ----------------------------------------------------

@@ -46,9 +46,17 @@ def test_abi_struct_sizes(dev):
     (2, 2, (9, 11), [16], 16, 3, 1, 1),
     (2, 1, (8, 12), [64, 64], 64, 1, 1, 0),
     (3, 1, (3, 4, 5), [64], 128, 3, 1, 1),
+    # short reductions on 16-row-aligned volumes -> register-resident streaming kernel (last field: expected kernel)
+    (3, 2, (4, 4, 8), [16], 32, 2, 2, 0, 1),
+    (3, 2, (2, 4, 6), [16, 16], 16, 1, 1, 0, 1),
+    (3, 1, (2, 2, 4), [16], 16, 1, 1, 0, 1),
+    (2, 2, (8, 8), [16], 32, 2, 2, 0, 1),
+    (2, 1, (4, 8), [32, 32], 16, 1, 1, 0, 1),
+    (2, 3, (8, 16), [32], 64, 2, 2, 0, 0),
 ])
 def test_conv_gather_exact(dev, dtype, case):
-    ndim, N, sp, cins, cout, k, stride, pad = case
+    want_kernel = case[8] if len(case) > 8 else 0
+    ndim, N, sp, cins, cout, k, stride, pad = case[:8]
     g = torch.Generator().manual_seed(sum(sp) * 7 + cout)
     cin = sum(cins)
     x = ints((N, cin) + sp, -2, 2, g)
@@ -62,6 +70,7 @@ def test_conv_gather_exact(dev, dtype, case):
     x1 = to_dev(cl(xs[1]), dtype, dev) if len(xs) > 1 else None
     wp = ops.pack(w.to(dev), "conv_fwd", dtype)
     out, stats = ops.conv(x0, wp, dtype, ndim, k, stride, pad, x1=x1, bias=ops.aligned_like(b.to(dev)), cout=cout, want_stats=True)
+    assert ops.last_conv_kernel == want_kernel
     got = ncdhw(out.float().cpu(), ndim)
     assert torch.equal(got, ref), float((got - ref).abs().max())
     rs = torch.stack([ref.double().flatten(2).sum(2), (ref.double() ** 2).flatten(2).sum(2)], dim=2)
@@ -69,9 +78,11 @@ def test_conv_gather_exact(dev, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("case", [(3, 2, (3, 4, 5), 32, 16), (2, 2, (6, 7), 16, 16), (3, 1, (2, 2, 3), 128, 64)])
+@pytest.mark.parametrize("case", [(3, 2, (3, 4, 5), 32, 16), (2, 2, (6, 7), 16, 16), (3, 1, (2, 2, 3), 128, 64),
+                                  (3, 2, (2, 2, 4), 32, 16, 1), (2, 2, (4, 4), 32, 16, 1), (2, 1, (4, 8), 64, 16, 1), (2, 1, (4, 8), 64, 32, 0)])
 def test_conv_transpose_scatter_exact(dev, dtype, case):
-    ndim, N, sp, cin, cout = case
+    want_kernel = case[5] if len(case) > 5 else 0
+    ndim, N, sp, cin, cout = case[:5]
     g = torch.Generator().manual_seed(7)
     x = ints((N, cin) + sp, -2, 2, g)
     w = ints((cin, cout) + (2,) * ndim, -1, 1, g, density=0.3)
@@ -82,6 +93,7 @@ def test_conv_transpose_scatter_exact(dev, dtype, case):
     wp = ops.pack(w.to(dev), "convT_fwd", dtype)
     out, stats = ops.conv(to_dev(cl(x), dtype, dev), wp, dtype, ndim, 2, scatter=True, bias=ops.aligned_like(b.to(dev)),
                           cout=cout, want_stats=True)
+    assert ops.last_conv_kernel == want_kernel
     assert torch.equal(ncdhw(out.float().cpu(), ndim), ref)
     rs = torch.stack([ref.double().flatten(2).sum(2), (ref.double() ** 2).flatten(2).sum(2)], dim=2)
     assert torch.equal(stats.cpu(), rs)
@@ -115,6 +127,23 @@ def test_data_gradients_exact(dev, dtype):
     F.conv_transpose3d(x, w, stride=2).backward(dy)
     wp = ops.pack(w.to(dev), "convT_dgrad", dtype)
     got = ops.conv(to_dev(cl(dy), dtype, dev), wp, dtype, 3, 2, 2, 0, cout=32)
+    assert torch.equal(ncdhw(got.float().cpu(), 3), x.grad)
+    # the same two forms on 16-row-aligned volumes (streaming kernel)
+    x = ints((2, 16, 4, 4, 8), -2, 2, g).requires_grad_(True)
+    w = ints((32, 16, 2, 2, 2), -1, 1, g, density=0.3)
+    dy = ints((2, 32, 2, 2, 4), -1, 1, g)
+    F.conv3d(x, w, stride=2).backward(dy)
+    wp = ops.pack(w.to(dev), "k2s2_dgrad", dtype)
+    got = ops.conv(to_dev(cl(dy), dtype, dev), wp, dtype, 3, 2, scatter=True, cout=16)
+    assert ops.last_conv_kernel == 1
+    assert torch.equal(ncdhw(got.float().cpu(), 3), x.grad)
+    x = ints((1, 32, 2, 2, 4), -2, 2, g).requires_grad_(True)
+    w = ints((32, 16, 2, 2, 2), -1, 1, g, density=0.3)
+    dy = ints((1, 16, 4, 4, 8), -1, 1, g)
+    F.conv_transpose3d(x, w, stride=2).backward(dy)
+    wp = ops.pack(w.to(dev), "convT_dgrad", dtype)
+    got = ops.conv(to_dev(cl(dy), dtype, dev), wp, dtype, 3, 2, 2, 0, cout=32)
+    assert ops.last_conv_kernel == 1
     assert torch.equal(ncdhw(got.float().cpu(), 3), x.grad)
 
 
