@@ -4,6 +4,8 @@
 // variance, eps 1e-5 (torch.nn.GroupNorm).  The conv epilogues deliver per-(n,c) sum / sum-of-squares
 // in fp64, so the whole GN forward is: finalize (tiny) + one elementwise pass; the backward is one
 // reduction pass + finalize (tiny) + one elementwise pass.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace seg {
@@ -18,12 +20,22 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinArgs a) {
     const int RG = 64 / cpg;                            // replica slices per channel
     const int cl = tid % cpg, rg = tid / cpg, c = g * cpg + cl;
     double s = 0.0, ss = 0.0;
-    if (rg < RG)
-        for (int rep = rg; rep < STAT_REP; rep += RG) {
-            const double* st = a.stats + (((long long)rep * a.N + n) * a.C + c) * 2;
-            s += st[0];
-            ss += st[1];
+    if (rg < RG) {
+        // batches of 8 independent loads: a load -> add loop serialises one L2 round trip per replica (16 for C = 256)
+        const int trips = STAT_REP / RG;
+        for (int j0 = 0; j0 < trips; j0 += 8) {
+            double v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rep = rg + (j0 + u) * RG;
+                const double* st = a.stats + (((long long)(rep < STAT_REP ? rep : rg) * a.N + n) * a.C + c) * 2;
+                v0[u] = st[0]; v1[u] = st[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < trips) { s += v0[u]; ss += v1[u]; }
         }
+    }
     const double ts = wave_sum_d(s), tss = wave_sum_d(ss);
     const double cnt = (double)cpg * (double)a.V;
     const double mean = ts / cnt;
@@ -164,11 +176,21 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
     const int cpg = a.C / GN_GROUPS, RG = 64 / cpg;
     const int cl = tid % cpg, rg = tid / cpg, c = g * cpg + cl;
     double f1 = 0.0, f2 = 0.0, f3 = 0.0;
-    if (rg < RG)
-        for (int rep = rg; rep < STAT_REP; rep += RG) {
-            const long long o = (((long long)rep * a.N + n) * a.C + c) * 2;
-            f1 += a.Q[o]; f2 += a.Q[o + 1]; f3 += a.stats[o];
+    if (rg < RG) {
+        const int trips = STAT_REP / RG;
+        for (int j0 = 0; j0 < trips; j0 += 8) {
+            double v1[8], v2[8], v3[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rep = rg + (j0 + u) * RG;
+                const long long o = (((long long)(rep < STAT_REP ? rep : rg) * a.N + n) * a.C + c) * 2;
+                v1[u] = a.Q[o]; v2[u] = a.Q[o + 1]; v3[u] = a.stats[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < trips) { f1 += v1[u]; f2 += v2[u]; f3 += v3[u]; }
         }
+    }
     sh[tid][0] = f1; sh[tid][1] = f2; sh[tid][2] = f3;
     __syncthreads();
     double Q1 = 0.0, Q2 = 0.0, R1 = 0.0;                 // per-channel totals (valid for tid < cpg)
