@@ -297,28 +297,50 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int j = 0; j < NTL; ++j) acc[j] = Mma<T>::run(wf[ks][j], xf[u][ks], acc[j]);
+            // rounded outputs + GroupNorm partial sums of every tile
+            vec<T, 4> o[NTL];
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) {
-                vec<T, 4> o;
+            for (int j = 0; j < NTL; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    o[r] = from_f<T>(acc[j][r] + bs[j][r]);
-                    const float f = to_f(o[r]);
+                    o[j][r] = from_f<T>(acc[j][r] + bs[j][r]);
+                    const float f = to_f(o[j][r]);
                     s1[j][r] += f;
                     s2[j][r] = fmaf(f, f, s2[j][r]);
                 }
-                long long orow;
-                int co;
+            // address of the 16-channel group of tile j for this lane's voxel
+            auto tile_ptr = [&](int j) -> T* {
                 if (SCATTER) {
                     const int tap = (j * 16) / a.Cout;
-                    co = (j * 16) % a.Cout + 4 * q;
-                    orow = (((long long)n * a.FD + d_[u] * a.sd + a.taps.d[tap]) * a.FH + h_[u] * a.sh + a.taps.h[tap]) * a.FW + w_[u] * a.sw +
-                           a.taps.w[tap];
-                } else {
-                    co = j * 16 + 4 * q;
-                    orow = (long long)n * Vrow + t * 16 + l15;
+                    const long long orow = (((long long)n * a.FD + d_[u] * a.sd + a.taps.d[tap]) * a.FH + h_[u] * a.sh + a.taps.h[tap]) * a.FW +
+                                           w_[u] * a.sw + a.taps.w[tap];
+                    return out + orow * a.Cout + (j * 16) % a.Cout;
                 }
-                *(vec<T, 4>*)(out + orow * a.Cout + co) = o;
+                return out + ((long long)n * Vrow + t * 16 + l15) * a.Cout + j * 16;
+            };
+            if (NTL % 2 == 0) {
+                // tiles in pairs (A, B): lanes q and q^1 swap one 4-channel piece so that even q stores 8 consecutive
+                // channels of A and odd q 8 of B: 16-B stores, and for the 2^d transposed convs (taps w-fastest) the
+                // two tiles are neighbouring voxels of one fine row -> every store instruction covers whole 64-B runs
+                const bool odd = q & 1;
+#pragma unroll
+                for (int jp = 0; jp < NTL / 2; ++jp) {
+                    const vec<T, 4> mine = odd ? o[2 * jp + 1] : o[2 * jp], send = odd ? o[2 * jp] : o[2 * jp + 1];
+                    vec<T, 4> recv;
+                    constexpr int NW = sizeof(T) * 4 / 4;
+                    int sw[NW], rw[NW];
+                    __builtin_memcpy(sw, &send, sizeof(send));
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) rw[k] = __shfl_xor(sw[k], 16);
+                    __builtin_memcpy(&recv, rw, sizeof(recv));
+                    vec<T, 8> w8;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { w8[r] = odd ? recv[r] : mine[r]; w8[4 + r] = odd ? mine[r] : recv[r]; }
+                    store8(tile_ptr(odd ? 2 * jp + 1 : 2 * jp) + (q >> 1) * 8, w8);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) *(vec<T, 4>*)(tile_ptr(j) + 4 * q) = o[j];
             }
         }
     }

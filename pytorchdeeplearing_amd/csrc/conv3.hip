@@ -493,6 +493,13 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial
         const float* src = partial + (long long)combo * nb * tile + e;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int b = b0;
+        for (; b + 16 <= b1; b += 16) {          // 16 independent loads per round trip (the loop is pure L2 latency)
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[(long long)(b + u) * tile];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+        }
         for (; b + 4 <= b1; b += 4) {
             s0 += src[(long long)b * tile]; s1 += src[(long long)(b + 1) * tile];
             s2 += src[(long long)(b + 2) * tile]; s3 += src[(long long)(b + 3) * tile];

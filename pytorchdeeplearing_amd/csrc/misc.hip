@@ -25,23 +25,45 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float* x, T* out, int
 }
 
 // ---------------------------------------------------------------- weight packing
+// One workgroup per destination row (R1 x R2 rows of Kpad elements).  The row's K = T*Cc source elements are read in
+// SOURCE order (the unit-stride index fastest: runs of T consecutive floats for PyTorch's [..][k^d] weight layout) into
+// LDS and written out as one contiguous run.  The first version walked the destination order and read the fp32
+// master weights with a 108-B stride: 670 MB of HBM fetches for a 38 MB re-layout (PMC, profiles/r01_pmc_*).
+constexpr int PACK_MAXK = 27 * 256 + 32;
 template <class T>
 __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs) {
+    __shared__ float row_s[PACK_MAXK];
     const PackDesc d = descs[blockIdx.y];
-    const long long rows = (long long)d.R1 * d.R2, total = rows * d.Kpad;
+    const long long rows = (long long)d.R1 * d.R2;
     const int K = d.T * d.Cc;
     T* dst = (T*)d.dst;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int k = (int)(i % d.Kpad);
-        const long long row = i / d.Kpad;
-        float v = 0.f;
-        if (k < K) {
-            const int t = k / d.Cc, c = k % d.Cc;
-            const int tt = d.flipT ? (d.T - 1 - t) : t;
-            const long long r1 = row / d.R2, r2 = row % d.R2;
-            v = d.src[r1 * d.s1 + r2 * d.s2 + tt * d.sT + c * d.sC];
+    const bool t_fast = d.sT == 1 || d.sC != 1;         // which source index is contiguous
+    if (K > PACK_MAXK - 32) {                            // rows too long for the LDS row buffer: destination-order walk
+        const long long total = rows * d.Kpad;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const int k = (int)(i % d.Kpad);
+            const long long row = i / d.Kpad;
+            float v = 0.f;
+            if (k < K) {
+                const int t = k / d.Cc, c = k % d.Cc;
+                const int tt = d.flipT ? (d.T - 1 - t) : t;
+                v = d.src[(row / d.R2) * d.s1 + (row % d.R2) * d.s2 + tt * d.sT + c * d.sC];
+            }
+            dst[i] = from_f<T>(v);
         }
-        dst[i] = from_f<T>(v);
+        return;
+    }
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const long long r1 = row / d.R2, r2 = row % d.R2;
+        const float* src = d.src + r1 * d.s1 + r2 * d.s2;
+        for (int j = threadIdx.x; j < K; j += 256) {
+            const int t = t_fast ? j % d.T : j / d.Cc, c = t_fast ? j / d.T : j % d.Cc;
+            const int tt = d.flipT ? (d.T - 1 - t) : t;
+            row_s[t * d.Cc + c] = src[tt * d.sT + c * d.sC];
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < d.Kpad; k += 256) dst[row * d.Kpad + k] = from_f<T>(k < K ? row_s[k] : 0.f);
+        __syncthreads();
     }
 }
 
@@ -451,7 +473,8 @@ void launch_ingest(const float* x, void* out, int N, int C, long long V, int dty
 }
 
 void launch_pack(const PackDesc* descs_dev, int ndesc, int max_elems, int dtype, hipStream_t s) {
-    dim3 grid(ew_blocks(max_elems, 512), ndesc);
+    (void)max_elems;
+    dim3 grid(64, ndesc);                                // rows are strided over 64 workgroups per descriptor
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<float>), grid, dim3(256), 0, s, descs_dev);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<f16>), grid, dim3(256), 0, s, descs_dev);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<bf16>), grid, dim3(256), 0, s, descs_dev);
