@@ -32,7 +32,7 @@ PEAK_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA
 KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel<f16>", "gn_bwd_apply": "gn_bwd_apply_kernel<f16>", "gn_act": "gn_act_kernel<f16>",
                  "conv3_smallbox": "conv3_kernel<f16, 3,8,8 box, KD=3, CH=32, NT=1, LDS weights>"}
 MFMA_BOUND = {"conv3_smallbox", "conv3", "wgrad3"}
-PMC_KEY = {"conv3_smallbox": "conv3_kernel<DF16_Li3ELi8ELi8ELi3ELi32ELi1ELb1>", "gn_bwd_reduce": "gn_bwd_reduce_kernel<DF16_>",
+PMC_KEY = {"conv3_smallbox": "conv3_kernel<DF16_Li3ELi8ELi8ELi3ELi32ELi1ELb1E>", "gn_bwd_reduce": "gn_bwd_reduce_kernel<DF16_>",
            "gn_bwd_apply": "gn_bwd_apply_kernel<DF16_>", "gn_act": "gn_act_kernel<DF16_>"}
 
 
