@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--mfma-kernel", default="conv3_smallbox", help="second bracketed class, reported as \"roofline_mfma\" (largest MFMA symbol)")
     ap.add_argument("--roofline-steps", type=int, default=5, help="timed steps whose launches carry the HIP-event brackets (each bracket "
                     "idles the stream for ~6 us, so only the first R of the K timed steps are instrumented)")
+    ap.add_argument("--single-allreduce", action="store_true", help="one blocking all-reduce after backward instead of two overlapped buckets")
     ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
     return ap.parse_args()
 
@@ -109,7 +110,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     from oracle import seg_oracle as seg   # synthetic inputs + the cpu_baseline leg only
     from pytorchdeeplearing_amd import SegEngine
-    from pytorchdeeplearing_amd.parallel import GradAllReduce
+    from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GradAllReduce
 
     S = a.size
     if a.lanes > 1:
@@ -122,7 +123,7 @@ def main():
     x, y = x.to(dev), y.to(dev)
     logits = torch.empty((a.batch, 1, S, S, S), dtype=torch.float32, device=dev)
     probs = torch.empty_like(logits)
-    allreduce = GradAllReduce(world) if world > 1 else None
+    allreduce = (GradAllReduce(world) if a.single_allreduce else BucketedGradAllReduce(world)) if world > 1 else None
 
     def step():
         return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs)

@@ -75,6 +75,14 @@ int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks,
  * flat gradient buffer (zero_grads != 0 clears it first — `opt.zero_grad()` of
  * model/modelVNet.py:593). */
 int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* stream);
+/* Bucketed gradient exchange (one process per GPU): the backward pass is a fixed list of seg_backward_ops() operations.
+ * seg_backward_bucket finds the earliest op count `op_split` after which a suffix [param_offset, numel) of the flat gradient
+ * buffer holding at least `tail_fraction` of the elements is final (gradients finish in reverse registration order);
+ * seg_backward_range runs ops [op_begin, op_end) and joins the weight-gradient side stream, so the caller can start the
+ * collective on that suffix while the remaining ops run.  seg_backward == seg_backward_range(0, seg_backward_ops()). */
+int seg_backward_ops(seg_handle h);
+int seg_backward_bucket(seg_handle h, double tail_fraction, int* op_split, long long* param_offset);
+int seg_backward_range(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, void* stream);
 
 int seg_set_loss_scale(seg_handle h, float scale);
 float seg_get_loss_scale(seg_handle h);

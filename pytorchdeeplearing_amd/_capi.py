@@ -37,6 +37,9 @@ SIGNATURES = {
     "seg_pack_weights": (_i, [_vp, _vp]),
     "seg_forward": (_i, [_vp, _vp, _i, _vp, C.c_ulonglong, _vp, _vp, _vp]),
     "seg_backward": (_i, [_vp, _vp, _i, _vp]),
+    "seg_backward_ops": (_i, [_vp]),
+    "seg_backward_bucket": (_i, [_vp, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "seg_backward_range": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "seg_set_loss_scale": (_i, [_vp, _f]),
     "seg_get_loss_scale": (_f, [_vp]),
     "seg_loss_ws_bytes": (_ll, [_i, _i]),

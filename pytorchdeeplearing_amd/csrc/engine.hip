@@ -78,6 +78,7 @@ struct seg_engine {
     float loss_scale = 1.f;
     int mask_mode = 0;
     std::vector<std::function<void(hipStream_t)>> fwd_ops, bwd_ops;
+    std::vector<std::vector<int>> bwd_writes;   // parameter indices whose gradient each backward op finishes (bucketed all-reduce)
     const float* cur_x = nullptr; float* cur_logits = nullptr; float* cur_probs = nullptr;
     const float* cur_dlogits = nullptr;
     // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
@@ -397,7 +398,7 @@ struct Planner {
     void plan() {
         seg_engine& E = e;
         const int N = E.N, dt = E.dtype;
-        E.fwd_ops.clear(); E.bwd_ops.clear(); E.packdescs.clear(); E.pack_max = 0;
+        E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_max = 0;
         // drop gradient tensors of a previous plan
         size_t nfw = 0;
         for (auto& s : E.steps) { nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1); s.draw = -1; }
@@ -618,6 +619,7 @@ struct Planner {
         }
 
         // ------------------------------------------------------------------ backward schedule
+        E.bwd_writes.push_back({});
         E.bwd_ops.push_back([this_ = &E](hipStream_t st) {
             seg_engine& E = *this_;
             (void)hipMemsetAsync(E.ws + E.off_Q, 0, E.Q_bytes, st);
@@ -627,6 +629,7 @@ struct Planner {
             if (s.type == ST_HEAD) {
                 const int gin = new_grad(s.in);
                 E.tens[s.in].grads.push_back(gin);
+                E.bwd_writes.push_back({s.w, s.b});
                 E.bwd_ops.push_back([this_ = &E, si, gin](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -643,6 +646,7 @@ struct Planner {
                 const int gin = new_grad(s.in);
                 E.tens[s.in].grads.push_back(gin);
                 const int gout = gl[0];
+                E.bwd_writes.push_back({});
                 E.bwd_ops.push_back([this_ = &E, si, gin, gout](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -661,6 +665,7 @@ struct Planner {
                     if (ui < 0) continue;
                     Step& u = E.steps[ui];
                     u.draw = new_grad(u.raw);
+                    E.bwd_writes.push_back({u.gn_w, u.gn_b, u.b});      // gamma/beta and (analytically) the conv bias
                     E.bwd_ops.push_back([this_ = &E, ui, gl](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& u = E.steps[ui];
@@ -712,6 +717,7 @@ struct Planner {
                 int g0 = -1, g1 = -1;
                 if (need_dg0) { g0 = new_grad(s.in0); E.tens[s.in0].grads.push_back(g0); }
                 if (s.in1 >= 0) { g1 = new_grad(s.in1); E.tens[s.in1].grads.push_back(g1); }
+                E.bwd_writes.push_back({s.w, s.gn_w < 0 ? s.b : -1});
                 E.bwd_ops.push_back([this_ = &E, si, draw, g0, g1](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -946,17 +952,42 @@ int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks,
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_forward: ") + hipGetErrorString(hipGetLastError()));
 }
 
-int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* stream) {
+int seg_backward_range(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, void* stream) {
     if (check_handle(h)) return -1;
     if (!h->ws || !h->g) return fail("seg_backward: gradients not bound");
     if (!dlogits) return fail("seg_backward: null dlogits");
+    const int nops = (int)h->bwd_ops.size();
+    if (op_begin < 0 || op_end > nops || op_begin > op_end) return fail("seg_backward_range: bad op range");
     hipStream_t st = (hipStream_t)stream;
-    if (zero_grads) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
+    if (zero_grads && op_begin == 0) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
     h->ready_used = 0;
-    for (auto& op : h->bwd_ops) op(st);
+    for (int i = op_begin; i < op_end; ++i) h->bwd_ops[i](st);
     h->join_side(st);
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));
+}
+int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* stream) {
+    if (check_handle(h)) return -1;
+    return seg_backward_range(h, dlogits, zero_grads, 0, (int)h->bwd_ops.size(), stream);
+}
+int seg_backward_ops(seg_handle h) { return (h && h->planned) ? (int)h->bwd_ops.size() : -1; }
+int seg_backward_bucket(seg_handle h, double tail_fraction, int* op_split, long long* param_offset) {
+    if (check_handle(h)) return -1;
+    if (!h->planned) return fail("seg_backward_bucket: call seg_plan first");
+    if (!op_split || !param_offset) return fail("seg_backward_bucket: null output");
+    // writers left per parameter; after op k the finished gradients form a suffix [S(k), nparam) of the flat buffer
+    std::vector<int> left(h->params.size(), 0);
+    for (auto& w : h->bwd_writes) for (int p : w) if (p >= 0) ++left[p];
+    const int nops = (int)h->bwd_ops.size();
+    *op_split = nops; *param_offset = 0;
+    for (int k = 0; k < nops; ++k) {
+        for (int p : h->bwd_writes[k]) if (p >= 0) --left[p];
+        int first_done = (int)h->params.size();
+        while (first_done > 0 && left[first_done - 1] == 0) --first_done;
+        const long long S = first_done < (int)h->params.size() ? h->params[first_done].off : h->nparam;
+        if ((double)(h->nparam - S) >= tail_fraction * (double)h->nparam) { *op_split = k + 1; *param_offset = S; return 0; }
+    }
+    return 0;
 }
 
 int seg_set_loss_scale(seg_handle h, float scale) {

@@ -168,10 +168,21 @@ class SegEngine:
             t[i, :, :m.shape[1]] = m.to(self.device)
         return t
 
-    def backward(self, dlogits, zero_grads=True):
-        """dlogits: fp32 NC[D]HW, already multiplied by self.loss_scale.  Accumulates into self.grads."""
+    def backward(self, dlogits, zero_grads=True, op_range=None):
+        """dlogits: fp32 NC[D]HW, already multiplied by self.loss_scale.  Accumulates into self.grads.
+        op_range = (begin, end): only that slice of the backward op list (bucketed gradient exchange)."""
         assert dlogits.dtype == torch.float32 and dlogits.is_contiguous()
-        self.lib.check(self.lib.seg_backward(self.h, _ptr(dlogits), 1 if zero_grads else 0, self.stream()), "seg_backward")
+        if op_range is None:
+            self.lib.check(self.lib.seg_backward(self.h, _ptr(dlogits), 1 if zero_grads else 0, self.stream()), "seg_backward")
+        else:
+            self.lib.check(self.lib.seg_backward_range(self.h, _ptr(dlogits), 1 if zero_grads else 0, int(op_range[0]), int(op_range[1]),
+                                                       self.stream()), "seg_backward_range")
+
+    def backward_bucket(self, tail_fraction=0.5):
+        """(op_split, param_offset, n_ops): after ops [0, op_split) the gradients [param_offset, numel) are final."""
+        k, off = C.c_int(0), C.c_longlong(0)
+        self.lib.check(self.lib.seg_backward_bucket(self.h, float(tail_fraction), C.byref(k), C.byref(off)), "seg_backward_bucket")
+        return k.value, off.value, self.lib.seg_backward_ops(self.h)
 
     # ---- losses ---------------------------------------------------------------------------------
     def loss_forward(self, logits, target, loss_name, focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, out3=None):
@@ -202,7 +213,8 @@ class SegEngine:
         self.exp_avg_sq = aligned_zeros_f32(self.numel, self.device)
         self.opt_state = torch.zeros(64, dtype=torch.int32, device=self.device)
 
-    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decoupled=True, check_finite=None):
+    def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decoupled=True, check_finite=None, grad_div=1.0):
+        """grad_div: extra divisor of the gradient (world size after a SUM all-reduce), folded into the loss-scale factor."""
         if self.exp_avg is None:
             self.init_optimizer()
         if check_finite is None:
@@ -210,7 +222,7 @@ class SegEngine:
         self.lib.check(self.lib.seg_adam_step(
             _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), self.numel,
             float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 1 if decoupled else 0,
-            1.0 / self.loss_scale, 1 if check_finite else 0, _ptr(self.opt_state), self.stream()), "seg_adam_step")
+            1.0 / (self.loss_scale * float(grad_div)), 1 if check_finite else 0, _ptr(self.opt_state), self.stream()), "seg_adam_step")
         self.packed = False
 
     # ---- measurement ------------------------------------------------------------------------------
@@ -238,9 +250,19 @@ class SegEngine:
         self._last_probs = probs
         out3 = self.loss_forward(logits, target, loss_name, focal_alpha, focal_gamma, class_alpha)
         dl = self.loss_backward(logits, target, loss_name, focal_alpha, focal_gamma)
-        self.backward(dl, zero_grads=True)
-        if allreduce is not None:
-            allreduce(self.grads)
-        self.adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled)
+        world = getattr(allreduce, "world", 1) if allreduce is not None else 1
+        if allreduce is not None and getattr(allreduce, "bucketed", False) and world > 1:
+            # two buckets: the finished suffix of the flat gradient buffer is exchanged while the fine levels still run
+            k, off, nops = self.backward_bucket(allreduce.tail_fraction)
+            self.backward(dl, zero_grads=True, op_range=(0, k))
+            w1 = allreduce.start(self.grads[off:])
+            self.backward(dl, zero_grads=False, op_range=(k, nops))
+            w0 = allreduce.start(self.grads[:off])
+            allreduce.finish([w1, w0])
+        else:
+            self.backward(dl, zero_grads=True)
+            if allreduce is not None:
+                allreduce(self.grads)
+        self.adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled, grad_div=world)
         self.pack_weights()
         return out3

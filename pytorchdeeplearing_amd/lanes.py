@@ -158,7 +158,8 @@ class LaneEngine:
             g.add_(self.engines[i].grads)
         if allreduce is not None:
             allreduce(g)
-        self.engines[0].adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled)
+        self.engines[0].adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled,
+                                  grad_div=getattr(allreduce, "world", 1) if allreduce is not None else 1)
         # re-pack the run-dtype weights of every lane from the shared master buffer
         self._fork()
         for i in range(len(sl)):

@@ -213,3 +213,64 @@ def test_cpu_tensors_fail_loudly_without_the_gpu_library():
             SegEngine("vnet", 3, 1, 1, device="cpu")
     finally:
         _capi._injected = saved
+
+
+def test_backward_op_ranges_equal_full_backward(dev):
+    """seg_backward_range over two slices (the bucketed gradient exchange) leaves exactly the gradients of seg_backward,
+    and after the first slice the reported suffix of the flat buffer is already final."""
+    tag = "unet2d_s" if dev.type == "cpu" else "vnet3d"
+    e, params, x, y, masks, alpha, loss = build(tag, "f32", dev, True)
+    xd, yd = x.to(dev), y.to(dev)
+    logits, _ = e.forward(xd, _capi.MASKS_GIVEN, masks)
+    e.loss_forward(logits, yd, loss, class_alpha=alpha.to(dev))
+    dl = e.loss_backward(logits, yd, loss)
+    e.backward(dl, zero_grads=True)
+    full = e.grads.clone()
+    k, off, nops = e.backward_bucket(0.5)
+    assert 0 < k < nops and 0 < off < e.numel and e.numel - off >= 0.5 * e.numel
+    e.backward(dl, zero_grads=True, op_range=(0, k))
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    tail = e.grads[off:].clone()
+    e.backward(dl, zero_grads=False, op_range=(k, nops))
+    # fp32 atomics in the sliced weight-gradient reduce make repeated runs agree to rounding, not bit for bit
+    scale = float(full.abs().max())
+    assert float((tail - full[off:]).abs().max()) <= 1e-5 * scale
+    assert float((e.grads - full).abs().max()) <= 1e-5 * scale
+
+
+class _LoopbackBuckets:
+    """stand-in for BucketedGradAllReduce at world 2 where both ranks hold the same shard: SUM == 2 x own gradient."""
+    bucketed, world, tail_fraction = True, 2, 0.5
+
+    def __init__(self):
+        self.sizes = []
+
+    def start(self, flat_slice):
+        self.sizes.append(flat_slice.numel())
+        flat_slice.mul_(2.0)
+        return None
+
+    @staticmethod
+    def finish(works):
+        assert len(works) == 2
+
+
+def test_bucketed_train_step_equals_plain_step(dev):
+    """the two-bucket sequencing of SegEngine.train_step (backward slice, exchange suffix, rest, exchange head, /world in the
+    optimiser) reproduces the plain step."""
+    tag = "unet2d_s" if dev.type == "cpu" else "vnet3d"
+    res = []
+    for ar in (None, _LoopbackBuckets()):
+        e, params, x, y, masks, alpha, loss = build(tag, "f32", dev, True)
+        e.train_step(x.to(dev), y.to(dev), loss, lr=1e-3, class_alpha=alpha.to(dev), mask_mode=_capi.MASKS_GIVEN, masks=masks, allreduce=ar)
+        res.append({k: v.cpu() for k, v in e.state_dict().items()})
+        if ar is not None:
+            assert len(ar.sizes) == 2 and sum(ar.sizes) == e.numel and ar.sizes[0] >= ar.sizes[1]
+    tot = bad = 0
+    for k in res[0]:
+        d = (res[0][k] - res[1][k]).abs()
+        assert float(d.max()) < 2.1e-3, k            # one Adam step moves a weight by <= lr; sign flips of ~0 gradients are rare
+        tot += d.numel()
+        bad += int((d > 1e-5).sum())
+    assert bad <= 0.002 * tot

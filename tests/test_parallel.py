@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bucketed):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -22,7 +22,7 @@ def _worker(rank, world, port, q):
     conftest.emu_library()
     from oracle import seg_oracle as seg
     from pytorchdeeplearing_amd import SegEngine, _capi
-    from pytorchdeeplearing_amd.parallel import GradAllReduce, broadcast_parameters
+    from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GradAllReduce, broadcast_parameters
     kind, shape, ncls, loss = "unet", (2, 1, 16, 16), 1, "BinaryDiceLoss"
     e = SegEngine(kind, 2, 1, ncls, dtype="f32", device="cpu")
     # rank 0 owns the initial weights; the others start from garbage and must receive them
@@ -33,23 +33,27 @@ def _worker(rank, world, port, q):
         e.params.fill_(123.0)
     broadcast_parameters(e)
     x, y = seg.synthetic_batch(shape[0], shape[2:], 1, ncls, seed=100 + rank)      # this rank's shard
-    ar = GradAllReduce()
+    ar = BucketedGradAllReduce() if bucketed else GradAllReduce()
     for it in range(2):
         g = torch.Generator().manual_seed(10 * it + rank)
         masks = seg.draw_masks(kind, shape[0], generator=g)
         e.train_step(x, y, loss, lr=1e-3, mask_mode=_capi.MASKS_GIVEN, masks=masks, allreduce=ar)
+    if bucketed:
+        k, off, nops = e.backward_bucket(ar.tail_fraction)
+        assert 0 < k < nops and 0 < off < e.numel and (e.numel - off) >= 0.5 * e.numel
     if rank == 0:
         q.put({k: v.numpy().copy() for k, v in e.state_dict().items()})      # by value: this process exits before the parent reads
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ddp_two_ranks_matches_oracle_emulation():
+@pytest.mark.parametrize("bucketed", [False, True])
+def test_ddp_two_ranks_matches_oracle_emulation(bucketed):
     from oracle import seg_oracle as seg
-    world, port = 2, 29500 + os.getpid() % 1000
+    world, port = 2, 29500 + (os.getpid() * 2 + int(bucketed)) % 1000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, bucketed)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=600)
