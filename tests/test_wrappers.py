@@ -61,6 +61,21 @@ def test_trainprocess_and_predict(dev, tmp_path, monkeypatch, cls, numclass, los
         assert set(np.unique(out)) <= {0, 255}
     else:
         assert out.max() < numclass
+    # predict() against the oracle's eval-mode forward with the same weights: identical mask (modelVNet.py:655-676:
+    # sigmoid > 0.5 -> 255 / argmax of the soft-max), differences tolerated only at numerically tied voxels
+    from oracle import seg_oracle as seg
+    kind = "vnet" if "VNet" in cls else "unet"
+    sd = {k: v.detach().cpu().float() for k, v in m.model.state_dict().items()}
+    xin = torch.from_numpy(np.load(tr_i[0]).reshape((1, 1) + shape)).float()
+    _, probs = seg.net_forward(kind, sd, xin)
+    if numclass == 1:
+        want = ((probs[0, 0] > 0.5).numpy() * 255).astype(np.uint8)
+        tied = (probs[0, 0] - 0.5).abs().numpy() < 5e-5
+    else:
+        want = probs[0].argmax(0).numpy().astype(np.uint8)
+        top2 = probs[0].topk(2, dim=0).values
+        tied = (top2[0] - top2[1]).numpy() < 1e-4
+    assert np.array_equal(out[~tied], want[~tied]) and tied.mean() < 0.01
     # the inference=True constructor path loads the checkpoint written above (inference.py:15-17)
     m2 = getattr(model, cls)(image_depth=16, image_height=16, image_width=16, image_channel=1, numclass=numclass, batch_size=1,
                              loss_name=loss, inference=True, model_path=os.path.join(log, pth), use_cuda=dev.type == "cuda")
