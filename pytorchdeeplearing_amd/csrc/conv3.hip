@@ -582,21 +582,28 @@ __device__ __forceinline__ int stem_k_to_halo(int k, int Cimg, int center, int& 
     return B::tap_off(tap);
 }
 
+// A workgroup handles STEM_NBX consecutive boxes: their (tiny) scalar halos are fetched in ONE round trip, then every box is
+// one MFMA per 16 voxels plus the epilogue.  With one box per workgroup the kernel was a 5 us latency chain per 6 KB of output
+// (18432 workgroups at 96^3: 1 TB/s).
+constexpr int STEM_NBX = 4;
 template <class T, int TD, int TH, int TW, int KD>
 __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemMArgs a) {
     typedef Box<TD, TH, TW, KD> B;
     constexpr int MT = B::V / 64, OLD = 16 + 8;
     constexpr int XS = B::HV * 3, OS = B::V * OLD;
-    __shared__ T Xs[XS > OS ? XS : OS];
+    __shared__ T Xs[STEM_NBX][XS];
+    __shared__ __attribute__((aligned(16))) T Os[OS];
     __shared__ float red[512];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const BoxPos bp = box_pos<B, TD, TH, TW>(blockIdx.x, a.D, a.H, a.W);
+    const long long nbox = (long long)a.N * ((a.D + TD - 1) / TD) * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
+    const long long b0 = (long long)blockIdx.x * STEM_NBX;
     const int co0 = blockIdx.y * 16, Cimg = a.Cimg;
     const T* in = (const T*)a.in;
     const int K = a.center ? Cimg : B::NTAP * Cimg;
-    stage_scalar_halo<T, B>(Xs, in, Cimg, bp, a.D, a.H, a.W);
+#pragma unroll
+    for (int i = 0; i < STEM_NBX; ++i)
+        if (b0 + i < nbox) stage_scalar_halo<T, B>(Xs[i], in, Cimg, box_pos<B, TD, TH, TW>(b0 + i, a.D, a.H, a.W), a.D, a.H, a.W);
     const typename Mma<T>::frag bf = load8((const T*)a.w + (long long)(co0 + l15) * 32 + q * 8);
-    __syncthreads();
     int koff[8];                                     // element offset of this lane's 8 reduction slots (-1: padding)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -605,17 +612,21 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemMArgs a) {
         const int toff = stem_k_to_halo<B>(k < K ? k : 0, Cimg, a.center, ci);
         koff[j] = k < K ? toff * Cimg + ci : -1;
     }
-    f32x4 acc[MT][1];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int hb = B::halo_base((wv * MT + m) * 16 + l15) * Cimg;
-        typename Mma<T>::frag af;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) af[j] = koff[j] >= 0 ? Xs[hb + koff[j]] : from_f<T>(0.f);
-        acc[m][0] = Mma<T>::run(af, bf, f32x4{0.f, 0.f, 0.f, 0.f});
-    }
     __syncthreads();
-    box_epilogue<T, B, TW, TH, MT, 1>(acc, Xs, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
+    for (int i = 0; i < STEM_NBX && b0 + i < nbox; ++i) {
+        const BoxPos bp = box_pos<B, TD, TH, TW>(b0 + i, a.D, a.H, a.W);
+        f32x4 acc[MT][1];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int hb = B::halo_base((wv * MT + m) * 16 + l15) * Cimg;
+            typename Mma<T>::frag af;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[j] = koff[j] >= 0 ? Xs[i][hb + koff[j]] : from_f<T>(0.f);
+            acc[m][0] = Mma<T>::run(af, bf, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        if (i) __syncthreads();                      // the previous box's epilogue is done with Os / red
+        box_epilogue<T, B, TW, TH, MT, 1>(acc, Os, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
+    }
 }
 
 // dW[co][k] = sum_v dR[v][co] * xcol[v][k]; partial tile [16][32] per workgroup (Cout == 16 per grid.y slice)
@@ -705,7 +716,8 @@ template <class T, int TD, int TH, int TW, int KD>
 void stem_launch_shape(const StemMArgs& a, bool wgrad, float* dw, hipStream_t s) {
     const long long nbox = num_boxes<TD, TH, TW>(a.N, a.D, a.H, a.W);
     if (!wgrad) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_fwd_kernel<T, TD, TH, TW, KD>), dim3((unsigned)nbox, a.Cout / 16), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_fwd_kernel<T, TD, TH, TW, KD>), dim3((unsigned)((nbox + STEM_NBX - 1) / STEM_NBX), a.Cout / 16), dim3(256), 0,
+                           s, a);
     } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(stem_wgrad_kernel<T, TD, TH, TW, KD>), dim3(a.nb, a.Cout / 16), dim3(256), 0, s, a);
         const int K = a.center ? a.Cimg : KD * 9 * a.Cimg;
