@@ -98,6 +98,9 @@ int seg_loss_backward(const float* logits, const void* target, int label_type, i
                       long long v, int loss_kind, float focal_alpha, float focal_gamma, void* ws,
                       float grad_scale, float* dlogits, void* stream);
 /* dice_coeff / iou_coeff / multiclass_* on probabilities (model/metric.py:146-215): out2 = {dice, iou} */
+/* predict() post-processing on the device (modelVNet.py:670-676): probs [N][C][V] fp32 -> uint8 mask [N][V];
+ * C == 1: (p > threshold) * scale (scale 255 or 1); C > 1: first arg-max over the class axis. */
+int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long long v, float threshold, int scale, void* stream);
 int seg_metric(const float* probs, const void* target, int label_type, int n, int c, long long v,
                void* ws, float* out2, void* stream);
 

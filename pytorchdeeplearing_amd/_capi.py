@@ -45,6 +45,7 @@ SIGNATURES = {
     "seg_loss_ws_bytes": (_ll, [_i, _i]),
     "seg_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "seg_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _f, _vp, _vp]),
+    "seg_predict_mask": (_i, [_vp, _vp, _i, _i, _ll, C.c_float, _i, _vp]),
     "seg_metric": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp]),
     "seg_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _i, _vp, _vp]),
     "seg_op_conv": (_i, [_vp, _i, _vp]),

@@ -1032,6 +1032,12 @@ int seg_loss_backward(const float* logits, const void* target, int label_type, i
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_loss_backward: launch failed");
 }
 
+int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long long v, float threshold, int scale, void* stream) {
+    if (!probs || !mask) return fail("seg_predict_mask: null pointer");
+    if (c < 1 || n < 1 || v < 1 || scale < 0 || scale > 255) return fail("seg_predict_mask: bad arguments");
+    launch_mask(probs, mask, n, c, v, threshold, scale, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_predict_mask: launch failed");
+}
 int seg_metric(const float* probs, const void* target, int label_type, int n, int c, long long v, void* ws, float* out2, void* stream) {
     if (!probs || !target || !ws || !out2) return fail("seg_metric: null pointer");
     if (c < 1 || c > 8) return fail("seg_metric: classes must be 1..8");

@@ -174,6 +174,8 @@ void launch_pool3_bwd(const float* src, const float* dout, float* din, int plane
 void launch_plane_dot(const float* a, const float* b, double* out, int planes, long long V, hipStream_t s);
 void launch_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long V, int accumulate, hipStream_t s);
 
+void launch_mask(const float* probs, unsigned char* out, int N, int C, long long V, float threshold, int scale, hipStream_t s);
+
 // Fused AdamW / Adam over the flat fp32 buffers; also clears nothing (grads are re-zeroed by the engine)
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;

@@ -472,6 +472,31 @@ void launch_ingest(const float* x, void* out, int N, int C, long long V, int dty
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<bf16>), grid, dim3(256), 0, s, x, (bf16*)out, N, C, V);
 }
 
+// predict() post-processing on the device (modelVNet.py:670-676, modelUnet.py:672-680): probs planar fp32 [N][C][V] ->
+// uint8 mask [N][V]: C == 1: (p > threshold) * scale; C > 1: index of the FIRST maximum over the class axis (np.argmax).
+__global__ __launch_bounds__(256) void mask_kernel(const float* probs, unsigned char* out, int N, int C, long long V, float threshold, int scale) {
+    const long long total = (long long)N * V;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / V, v = i % V;
+        const float* p = probs + n * C * V + v;
+        int m;
+        if (C == 1) {
+            m = p[0] > threshold ? scale : 0;
+        } else {
+            float best = p[0];
+            m = 0;
+            for (int c = 1; c < C; ++c) {
+                const float x = p[(long long)c * V];
+                if (x > best) { best = x; m = c; }
+            }
+        }
+        out[i] = (unsigned char)m;
+    }
+}
+void launch_mask(const float* probs, unsigned char* out, int N, int C, long long V, float threshold, int scale, hipStream_t s) {
+    hipLaunchKernelGGL(mask_kernel, dim3(ew_blocks((long long)N * V)), dim3(256), 0, s, probs, out, N, C, V, threshold, scale);
+}
+
 void launch_pack(const PackDesc* descs_dev, int ndesc, int max_elems, int dtype, hipStream_t s) {
     (void)max_elems;
     dim3 grid(64, ndesc);                                // rows are strided over 64 workgroups per descriptor

@@ -37,3 +37,16 @@ def multiclass_dice_coeff(input, target):
 
 def multiclass_iou_coeff(input, target):
     return _metric(input, target, input.shape[1])[1]
+
+
+def predict_mask(probs, threshold=0.5, scale=255):
+    """predict() post-processing on the device (modelVNet.py:670-676, modelUnet.py:672-680): probs (N, C, *spatial) fp32 ->
+    uint8 mask (N, *spatial); C == 1: (p > threshold) * scale, C > 1: np.argmax over the class axis (first maximum)."""
+    p = probs.float().contiguous()
+    n, c = p.shape[0], p.shape[1]
+    v = p.numel() // (n * c)
+    lib = _capi.lib_for(p.device)
+    out = torch.empty((n,) + tuple(p.shape[2:]), dtype=torch.uint8, device=p.device)
+    lib.check(lib.seg_predict_mask(p.data_ptr(), out.data_ptr(), n, c, v, float(threshold), int(scale), _capi.stream_for(p.device)),
+              "seg_predict_mask")
+    return out

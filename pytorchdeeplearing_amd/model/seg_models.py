@@ -194,12 +194,10 @@ class _SegModel(object):
             img = torch.as_tensor(full_img).float().contiguous().unsqueeze(0).to(device=self.device, dtype=torch.float32)
             with torch.no_grad():
                 _, output = self.model(img)
-                full_mask_np = output[0].detach().cpu().squeeze().numpy()
-        if self.numclass == 1:
-            out_mask = (full_mask_np > out_threshold) * self._mask_scale
-        else:
-            out_mask = np.squeeze(np.argmax(full_mask_np, axis=0))
-        return out_mask.astype(np.uint8)
+                # threshold / argmax on the device: one byte per voxel crosses PCIe instead of 4 x numclass
+                mask = M.predict_mask(output.detach(), out_threshold, self._mask_scale)
+                out_mask = mask[0].cpu().numpy()
+        return np.squeeze(out_mask).astype(np.uint8)
 
     def inference(self, image, newSize=(96, 96, 96)):
         if self._ndim == 2:

@@ -97,3 +97,19 @@ def test_module_tree_matches_live_reference():
         ta = [type(m).__name__ for m in ours.modules() if not list(m.children())]
         tb = [type(m).__name__ for m in theirs.modules() if not list(m.children()) and type(m).__name__ not in ("ReLU", "Dropout3d", "Dropout2d", "MaxPool3d", "MaxPool2d")]
         assert ta == tb
+
+
+@pytest.mark.parametrize("shape,c", [((2, 1, 5, 6, 7), 1), ((3, 4, 9, 11), 4), ((1, 3, 4, 4, 6), 3)])
+def test_predict_mask_exact(dev, shape, c):
+    """device threshold / argmax (predict post-processing) == numpy on the same probabilities, ties included."""
+    import numpy as np
+    from pytorchdeeplearing_amd.metric import predict_mask
+    g = torch.Generator().manual_seed(3)
+    p = torch.rand(shape, generator=g)
+    p[0, :, 0] = 0.5                                      # exact ties: threshold is strict, argmax takes the first maximum
+    got = predict_mask(p.to(dev), 0.5, 255).cpu().numpy()
+    if c == 1:
+        want = ((p[:, 0].numpy() > 0.5) * 255).astype(np.uint8)
+    else:
+        want = np.argmax(p.numpy(), axis=1).astype(np.uint8)
+    assert got.dtype == np.uint8 and np.array_equal(got, want)
