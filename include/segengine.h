@@ -195,13 +195,22 @@ int seg_abi_sizeof(int which);
  * padding ignored.  seg_op_skel_update: out = relu(x - relu(maxpool(e) - e)).  The *_bwd entry points route gradients to the
  * first extremum of each window (ATen max_pool backward); `de` / `din` are accumulated into (zero them first). */
 int seg_op_pool3(const float* x, float* out, int planes, int d, int h, int w, int nd, int is_min, void* stream);
+/* one whole skeleton iteration (e_out = minpool(x), x_out = relu(x - relu(maxpool(e_out) - e_out))) in one pass over LDS tiles;
+ * bit-identical to seg_op_pool3(is_min) + seg_op_skel_update */
+int seg_op_skel_iter(const float* x, float* e_out, float* x_out, int planes, int d, int h, int w, int nd, void* stream);
+/* backward of seg_op_skel_iter: dx = d loss / d x given g = d loss / d x_out (x, e as saved by the forward); two gather passes
+ * over LDS tiles - deterministic, no atomics; `de_scratch` is a tensor-sized fp32 work buffer (need not be cleared) */
+int seg_op_skel_iter_bwd(const float* g, const float* x, const float* e, float* dx, float* de_scratch, int planes, int d, int h, int w,
+                         int nd, void* stream);
 int seg_op_skel_update(const float* x, const float* e, float* out, int planes, int d, int h, int w, int nd, void* stream);
 int seg_op_skel_update_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int d, int h, int w,
                            int nd, void* stream);
 int seg_op_pool3_bwd(const float* src, const float* dout, float* din, int planes, int d, int h, int w, int nd, int is_min,
                      void* stream);
-/* out2[p] = {sum a*b, sum a} per plane (fp64);  out = a[p]*in + b[p] (accumulate != 0: +=) */
-int seg_op_plane_dot(const float* a, const float* b, double* out2, int planes, long long v, void* stream);
+/* out2[p] = {sum a*b, sum a} per plane (fp64; `scratch` = seg_op_plane_dot_scratch_bytes bytes of per-workgroup partials);
+ * out = a[p]*in + b[p] (accumulate != 0: +=) */
+long long seg_op_plane_dot_scratch_bytes(int planes, long long v);
+int seg_op_plane_dot(const float* a, const float* b, double* out2, double* scratch, int planes, long long v, void* stream);
 int seg_op_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long v, int accumulate,
                       void* stream);
 

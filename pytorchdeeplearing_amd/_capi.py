@@ -58,10 +58,13 @@ SIGNATURES = {
     "seg_op_wgrad3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "seg_abi_sizeof": (_i, [_i]),
     "seg_op_pool3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "seg_op_skel_iter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "seg_op_skel_iter_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "seg_op_skel_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "seg_op_skel_update_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "seg_op_pool3_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "seg_op_plane_dot": (_i, [_vp, _vp, _vp, _i, _ll, _vp]),
+    "seg_op_plane_dot_scratch_bytes": (_ll, [_i, _ll]),
+    "seg_op_plane_dot": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _vp]),
     "seg_op_plane_axpb": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
     "seg_profile_enable": (_i, [_vp, C.c_uint]),
     "seg_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp]),

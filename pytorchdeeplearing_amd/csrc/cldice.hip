@@ -94,8 +94,10 @@ __global__ __launch_bounds__(256) void pool3_bwd_kernel(const float* src, const 
     }
 }
 
-// out[p] = {sum a*b, sum a} over the plane (fp64)
-__global__ __launch_bounds__(256) void plane_dot_kernel(const float* a, const float* b, double* out, long long V) {
+// out[p] = {sum a*b, sum a} over the plane (fp64): per-workgroup partials (plain stores), then one small fold - atomics of
+// a thousand workgroups on two addresses per plane serialised (105 us for a 16 MB plane)
+__global__ __launch_bounds__(256) void plane_dot_kernel(const float* a, const float* b, double* partial, long long V) {
+    __shared__ double wsum[4][2];
     const int p = blockIdx.y;
     const long long v0 = (long long)blockIdx.x * 4096, v1 = (v0 + 4096 < V) ? v0 + 4096 : V;
     float s0 = 0.f, s1 = 0.f;
@@ -105,7 +107,21 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* a, const fl
         s1 += av;
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[p * 2], (double)s0); atomicAdd(&out[p * 2 + 1], (double)s1); }
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6][0] = s0; wsum[threadIdx.x >> 6][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        partial[((long long)p * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+            (wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + (wsum[2][threadIdx.x] + wsum[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void plane_dot_fold_kernel(const double* partial, double* out, int nblk) {
+    const int p = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) { s0 += partial[((long long)p * nblk + i) * 2]; s1 += partial[((long long)p * nblk + i) * 2 + 1]; }
+    __shared__ double red[4][2];
+    s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s0; red[threadIdx.x >> 6][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x < 2) out[p * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // out = a[p]*in + b[p]   (accumulate: out += ...)
@@ -119,6 +135,155 @@ __global__ __launch_bounds__(256) void plane_axpb_kernel(const float* in, const 
     }
 }
 
+// One skeleton iteration in ONE pass over HBM: e = minpool3(x), out = relu(x - relu(maxpool3(e) - e)); both are written (the
+// backward pass needs e).  A workgroup owns a TZ x TY x TX output tile: x with a 2-voxel halo sits in LDS (+inf outside the
+// volume), e is formed on the 1-voxel halo (-inf outside), then the update reads only LDS.  Pure min / max / sub / relu in
+// fp32: bit-identical to the two-kernel form (pool3_kernel + skel_update_kernel), which read every input 27 times from L2.
+template <int TZ, int TY, int TX, bool ND3>
+__global__ __launch_bounds__(256) void skel_iter_kernel(const float* x, float* e_out, float* x_out, Vol v) {
+    constexpr int HZ = ND3 ? 2 : 0;
+    constexpr int XZ = TZ + 2 * HZ, XY = TY + 4, XX = TX + 4;
+    constexpr int EZ = TZ + HZ, EY = TY + 2, EX = TX + 2;
+    __shared__ float xs[XZ * XY * XX];
+    __shared__ float es[EZ * EY * EX];
+    const float INF = __builtin_huge_valf();
+    const int ntx = (v.W + TX - 1) / TX, nty = (v.H + TY - 1) / TY, ntz = (v.D + TZ - 1) / TZ;
+    int b = blockIdx.x;
+    const int x0 = (b % ntx) * TX; b /= ntx;
+    const int y0 = (b % nty) * TY; b /= nty;
+    const int z0 = (b % ntz) * TZ;
+    const int p = b / ntz;
+    const long long V = (long long)v.D * v.H * v.W;
+    const float* xp = x + (long long)p * V;
+    for (int i = threadIdx.x; i < XZ * XY * XX; i += 256) {
+        const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
+        const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
+        xs[i] = ((unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D) ? xp[((long long)gz * v.H + gy) * v.W + gx] : INF;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < EZ * EY * EX; i += 256) {
+        const int lx = i % EX, ly = (i / EX) % EY, lz = i / (EX * EY);
+        const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - (ND3 ? 1 : 0);
+        float m = -INF;                                     // outside the volume: ignored by the max-pool below
+        if ((unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D) {
+            m = INF;
+#pragma unroll
+            for (int dz = 0; dz < (ND3 ? 3 : 1); ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) m = fminf(m, xs[((lz + dz) * XY + ly + dy) * XX + lx + dx]);
+        }
+        es[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TZ * TY * TX; i += 256) {
+        const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
+        const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+        if (gx >= v.W || gy >= v.H || gz >= v.D) continue;
+        float mx = -INF;
+#pragma unroll
+        for (int dz = 0; dz < (ND3 ? 3 : 1); ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) mx = fmaxf(mx, es[((lz + dz) * EY + ly + dy) * EX + lx + dx]);
+        const float ev = es[((lz + (ND3 ? 1 : 0)) * EY + ly + 1) * EX + lx + 1];
+        const float xv = xs[((lz + HZ) * XY + ly + 2) * XX + lx + 2];
+        const long long o = (long long)p * V + ((long long)gz * v.H + gy) * v.W + gx;
+        e_out[o] = ev;
+        x_out[o] = fmaxf(xv - fmaxf(mx - ev, 0.f), 0.f);
+    }
+}
+
+// Backward of one skeleton iteration as two GATHER passes over LDS tiles (no atomics, no zero-fill, deterministic):
+//   A: for every window w on the tile + 1 halo: u = maxpool(e)(w) - e(w), gt = g * [x - relu(u) > 0], gw = gt * [u > 0] and the
+//      position am(w) of the FIRST maximum of e in w;  dx_direct(q) = gt(q),  de(q) = gw(q) - sum_{w in N(q), am(w) = q} gw(w)
+//   B: am(w) = first minimum of x in w;  dx(q) = dx_direct(q) + sum_{w in N(q), am(w) = q} de(w)
+// (the scatter form above routes the same terms with fp32 atomics).
+template <int TZ, int TY, int TX, bool ND3, bool PASS_B>
+__global__ __launch_bounds__(256) void skel_bwd_tile_kernel(const float* g, const float* x, const float* e, float* dx, float* de, Vol v) {
+    constexpr int HZ = ND3 ? 2 : 0, H1 = ND3 ? 1 : 0;
+    constexpr int XZ = TZ + 2 * HZ, XY = TY + 4, XX = TX + 4;       // source (e in pass A, x in pass B) with a 2-voxel halo
+    constexpr int EZ = TZ + 2 * H1, EY = TY + 2, EX = TX + 2;       // windows: tile + 1 halo
+    __shared__ float src[XZ * XY * XX];
+    __shared__ float gws[EZ * EY * EX];
+    __shared__ int ams[EZ * EY * EX];
+    const float INF = __builtin_huge_valf();
+    const int ntx = (v.W + TX - 1) / TX, nty = (v.H + TY - 1) / TY, ntz = (v.D + TZ - 1) / TZ;
+    int b = blockIdx.x;
+    const int x0 = (b % ntx) * TX; b /= ntx;
+    const int y0 = (b % nty) * TY; b /= nty;
+    const int z0 = (b % ntz) * TZ;
+    const int p = b / ntz;
+    const long long V = (long long)v.D * v.H * v.W, base = (long long)p * V;
+    const float* sp = (PASS_B ? x : e) + base;
+    for (int i = threadIdx.x; i < XZ * XY * XX; i += 256) {
+        const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
+        const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
+        const bool in = (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+        src[i] = in ? sp[((long long)gz * v.H + gy) * v.W + gx] : (PASS_B ? INF : -INF);      // never the extremum
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < EZ * EY * EX; i += 256) {
+        const int lx = i % EX, ly = (i / EX) % EY, lz = i / (EX * EY);
+        const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - H1;
+        float wgt = 0.f;
+        int am = -1;
+        if ((unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D) {
+            // first extremum of the window in (z, y, x) scan order; the padding holds -/+inf and can never win the strict
+            // comparison, so no bounds tests are needed (the centre is always a finite in-volume value)
+            float best = PASS_B ? INF : -INF;
+#pragma unroll
+            for (int dz = 0; dz < (ND3 ? 3 : 1); ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx_ = 0; dx_ < 3; ++dx_) {
+                        const int li = ((lz + dz) * XY + ly + dy) * XX + lx + dx_;
+                        const float val = src[li];
+                        const bool better = PASS_B ? val < best : val > best;
+                        best = better ? val : best;
+                        am = better ? li : am;
+                    }
+            const long long o = base + ((long long)gz * v.H + gy) * v.W + gx;
+            if (PASS_B) {
+                wgt = de[o];
+            } else {
+                const float ec = src[((lz + HZ - H1) * XY + ly + 1) * XX + lx + 1];      // centre of window w
+                const float u = best - ec;
+                const float gt = (x[o] - fmaxf(u, 0.f) > 0.f) ? g[o] : 0.f;
+                wgt = u > 0.f ? gt : 0.f;
+                // tile-interior windows also publish the direct term of dx
+                const int tx = lx - 1, ty = ly - 1, tz = lz - H1;
+                if ((unsigned)tx < (unsigned)TX && (unsigned)ty < (unsigned)TY && (unsigned)tz < (unsigned)TZ) dx[o] = gt;
+            }
+        }
+        gws[i] = wgt;
+        ams[i] = am;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TZ * TY * TX; i += 256) {
+        const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
+        const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+        if (gx >= v.W || gy >= v.H || gz >= v.D) continue;
+        const int me = ((lz + HZ) * XY + ly + 2) * XX + lx + 2;          // this voxel's index in `src`
+        float acc = 0.f;
+#pragma unroll
+        for (int dz = 0; dz < (ND3 ? 3 : 1); ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx_ = 0; dx_ < 3; ++dx_) {
+                    const int wi = ((lz + dz) * EY + ly + dy) * EX + lx + dx_;
+                    if (ams[wi] == me) acc += gws[wi];
+                }
+        const long long o = base + ((long long)gz * v.H + gy) * v.W + gx;
+        if (PASS_B) dx[o] += acc;
+        else de[o] = gws[((lz + H1) * EY + ly + 1) * EX + lx + 1] - acc;
+    }
+}
+
 inline int blocks_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -128,6 +293,32 @@ void launch_pool3(const float* x, float* out, int planes, int D, int H, int W, i
     const long long n = (long long)planes * D * H * W;
     if (is_min) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool3_kernel<true>), dim3(blocks_for(n)), dim3(256), 0, s, x, out, v);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool3_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, s, x, out, v);
+}
+void launch_skel_iter(const float* x, float* e_out, float* x_out, int planes, int D, int H, int W, int nd, hipStream_t s) {
+    if (nd == 3) {
+        Vol v{planes, D, H, W, 3};
+        const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+    } else {
+        // 2-D pooling: every depth slice of every plane is an independent image
+        Vol v{planes * D, 1, H, W, 2};
+        const long long nb = (long long)planes * D * ((H + 15) / 16) * ((W + 63) / 64);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<1, 16, 64, false>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+    }
+}
+void launch_skel_iter_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int D, int H, int W, int nd,
+                          hipStream_t s) {
+    if (nd == 3) {
+        Vol v{planes, D, H, W, 3};
+        const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<4, 8, 32, true, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<4, 8, 32, true, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+    } else {
+        Vol v{planes * D, 1, H, W, 2};
+        const long long nb = (long long)planes * D * ((H + 15) / 16) * ((W + 63) / 64);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<1, 16, 64, false, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<1, 16, 64, false, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+    }
 }
 void launch_skel_update(const float* x, const float* e, float* out, int planes, int D, int H, int W, int nd, hipStream_t s) {
     Vol v{planes, D, H, W, nd};
@@ -144,9 +335,11 @@ void launch_pool3_bwd(const float* src, const float* dout, float* din, int plane
     if (is_min) hipLaunchKernelGGL(HIP_KERNEL_NAME(pool3_bwd_kernel<true>), dim3(blocks_for(n)), dim3(256), 0, s, src, dout, din, v);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool3_bwd_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, s, src, dout, din, v);
 }
-void launch_plane_dot(const float* a, const float* b, double* out, int planes, long long V, hipStream_t s) {
-    (void)hipMemsetAsync(out, 0, sizeof(double) * 2 * planes, s);
-    hipLaunchKernelGGL(plane_dot_kernel, dim3(cdiv(V, 4096), planes), dim3(256), 0, s, a, b, out, V);
+size_t plane_dot_scratch_bytes(int planes, long long V) { return (size_t)planes * cdiv(V, 4096) * 2 * sizeof(double); }
+void launch_plane_dot(const float* a, const float* b, double* out, double* scratch, int planes, long long V, hipStream_t s) {
+    const int nblk = cdiv(V, 4096);
+    hipLaunchKernelGGL(plane_dot_kernel, dim3(nblk, planes), dim3(256), 0, s, a, b, scratch, V);
+    hipLaunchKernelGGL(plane_dot_fold_kernel, dim3(planes), dim3(256), 0, s, (const double*)scratch, out, nblk);
 }
 void launch_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long V, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(plane_axpb_kernel, dim3(blocks_for(V * planes)), dim3(256), 0, s, in, a, b, out, V, planes, accumulate);

@@ -1108,6 +1108,17 @@ int seg_op_pool3(const float* x, float* out, int planes, int d, int h, int w, in
     launch_pool3(x, out, planes, d, h, w, nd, is_min, (hipStream_t)stream);
     return SEG_OK("seg_op_pool3");
 }
+int seg_op_skel_iter(const float* x, float* e_out, float* x_out, int planes, int d, int h, int w, int nd, void* stream) {
+    if (!x || !e_out || !x_out || (nd != 2 && nd != 3)) return fail("seg_op_skel_iter: bad arguments");
+    launch_skel_iter(x, e_out, x_out, planes, d, h, w, nd, (hipStream_t)stream);
+    return SEG_OK("seg_op_skel_iter");
+}
+int seg_op_skel_iter_bwd(const float* g, const float* x, const float* e, float* dx, float* de_scratch, int planes, int d, int h, int w, int nd,
+                         void* stream) {
+    if (!g || !x || !e || !dx || !de_scratch || (nd != 2 && nd != 3)) return fail("seg_op_skel_iter_bwd: bad arguments");
+    launch_skel_iter_bwd(g, x, e, dx, de_scratch, planes, d, h, w, nd, (hipStream_t)stream);
+    return SEG_OK("seg_op_skel_iter_bwd");
+}
 int seg_op_skel_update(const float* x, const float* e, float* out, int planes, int d, int h, int w, int nd, void* stream) {
     if (!x || !e || !out || (nd != 2 && nd != 3)) return fail("seg_op_skel_update: bad arguments");
     launch_skel_update(x, e, out, planes, d, h, w, nd, (hipStream_t)stream);
@@ -1124,9 +1135,10 @@ int seg_op_pool3_bwd(const float* src, const float* dout, float* din, int planes
     launch_pool3_bwd(src, dout, din, planes, d, h, w, nd, is_min, (hipStream_t)stream);
     return SEG_OK("seg_op_pool3_bwd");
 }
-int seg_op_plane_dot(const float* a, const float* b, double* out2, int planes, long long v, void* stream) {
-    if (!a || !b || !out2) return fail("seg_op_plane_dot: null pointer");
-    launch_plane_dot(a, b, out2, planes, v, (hipStream_t)stream);
+long long seg_op_plane_dot_scratch_bytes(int planes, long long v) { return (long long)plane_dot_scratch_bytes(planes, v); }
+int seg_op_plane_dot(const float* a, const float* b, double* out2, double* scratch, int planes, long long v, void* stream) {
+    if (!a || !b || !out2 || !scratch) return fail("seg_op_plane_dot: null pointer");
+    launch_plane_dot(a, b, out2, scratch, planes, v, (hipStream_t)stream);
     return SEG_OK("seg_op_plane_dot");
 }
 int seg_op_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long v, int accumulate, void* stream) {

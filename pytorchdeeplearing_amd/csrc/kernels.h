@@ -168,10 +168,14 @@ void launch_colsum(const void* x, float* out, long long M, int C, int dtype, hip
 
 // soft-clDice building blocks (cldice.hip): planar fp32 [planes][D][H][W]; nd = 3 pools over (D,H,W), nd = 2 over (H,W)
 void launch_pool3(const float* x, float* out, int planes, int D, int H, int W, int nd, int is_min, hipStream_t s);
+void launch_skel_iter(const float* x, float* e_out, float* x_out, int planes, int D, int H, int W, int nd, hipStream_t s);
+void launch_skel_iter_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int D, int H, int W, int nd,
+                          hipStream_t s);
 void launch_skel_update(const float* x, const float* e, float* out, int planes, int D, int H, int W, int nd, hipStream_t s);
 void launch_skel_update_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int D, int H, int W, int nd, hipStream_t s);
 void launch_pool3_bwd(const float* src, const float* dout, float* din, int planes, int D, int H, int W, int nd, int is_min, hipStream_t s);
-void launch_plane_dot(const float* a, const float* b, double* out, int planes, long long V, hipStream_t s);
+size_t plane_dot_scratch_bytes(int planes, long long V);
+void launch_plane_dot(const float* a, const float* b, double* out, double* scratch, int planes, long long V, hipStream_t s);
 void launch_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long V, int accumulate, hipStream_t s);
 
 void launch_mask(const float* probs, unsigned char* out, int N, int C, long long V, float threshold, int scale, hipStream_t s);

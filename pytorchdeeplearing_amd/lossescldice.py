@@ -39,8 +39,7 @@ class _SoftSkel(torch.autograd.Function):
         for _ in range(width):
             e = torch.empty_like(cur)
             nxt = torch.empty_like(cur)
-            lib.check(lib.seg_op_pool3(cur.data_ptr(), e.data_ptr(), p, d, h, w, nd, 1, st), "seg_op_pool3")
-            lib.check(lib.seg_op_skel_update(cur.data_ptr(), e.data_ptr(), nxt.data_ptr(), p, d, h, w, nd, st), "seg_op_skel_update")
+            lib.check(lib.seg_op_skel_iter(cur.data_ptr(), e.data_ptr(), nxt.data_ptr(), p, d, h, w, nd, st), "seg_op_skel_iter")
             xs.append(cur)
             es.append(e)
             cur = nxt
@@ -52,12 +51,11 @@ class _SoftSkel(torch.autograd.Function):
         g = g.float().contiguous()
         lib, st = _lib(g), _capi.stream_for(g.device)
         p, d, h, w, nd = ctx.geom
+        de = torch.empty_like(g)                       # work buffer of the gather passes (fully overwritten every iteration)
         for x, e in zip(reversed(ctx.xs), reversed(ctx.es)):
             dx = torch.empty_like(x)
-            de = torch.zeros_like(x)
-            lib.check(lib.seg_op_skel_update_bwd(g.data_ptr(), x.data_ptr(), e.data_ptr(), dx.data_ptr(), de.data_ptr(), p, d, h, w, nd, st),
-                      "seg_op_skel_update_bwd")
-            lib.check(lib.seg_op_pool3_bwd(x.data_ptr(), de.data_ptr(), dx.data_ptr(), p, d, h, w, nd, 1, st), "seg_op_pool3_bwd")
+            lib.check(lib.seg_op_skel_iter_bwd(g.data_ptr(), x.data_ptr(), e.data_ptr(), dx.data_ptr(), de.data_ptr(), p, d, h, w, nd, st),
+                      "seg_op_skel_iter_bwd")
             g = dx
         return g.to(ctx.in_dtype), None
 
@@ -78,7 +76,8 @@ class _NormIntersection(torch.autograd.Function):
         n, c = clf.shape[0], clf.shape[1]
         vol = clf.numel() // (n * c)
         sums = torch.empty((n * c, 2), dtype=torch.float64, device=clf.device)
-        lib.check(lib.seg_op_plane_dot(clf.data_ptr(), vf.data_ptr(), sums.data_ptr(), n * c, vol, st), "seg_op_plane_dot")
+        scratch = torch.empty(lib.seg_op_plane_dot_scratch_bytes(n * c, vol) // 8 + 2, dtype=torch.float64, device=clf.device)
+        lib.check(lib.seg_op_plane_dot(clf.data_ptr(), vf.data_ptr(), sums.data_ptr(), scratch.data_ptr(), n * c, vol, st), "seg_op_plane_dot")
         inter, s = sums[:, 0] + 1.0, sums[:, 1] + 1.0
         ctx.save_for_backward(clf, vf, inter, s)
         ctx.meta = (n, c, vol, cl.dtype, v.dtype)

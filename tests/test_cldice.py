@@ -94,3 +94,30 @@ def test_cldice_cpu_tensors_raise():
         pytest.skip("checker library injected in this process")
     with pytest.raises(RuntimeError):
         cl.soft_skeletonize(torch.rand(1, 1, 8, 8))
+
+
+@pytest.mark.parametrize("shape,nd", [((2, 5, 9, 11), 3), ((3, 4, 10, 13), 2), ((1, 6, 20, 40), 3)])
+def test_skel_iter_kernels_agree_with_two_kernel_forms(dev, shape, nd):
+    """the fused LDS-tile iteration and its gather backward equal the simple per-voxel kernels (pool3 + skel_update forward,
+    atomic scatter backward) on random and on tie-rich data."""
+    from pytorchdeeplearing_amd import _capi
+    lib, st = _capi.lib_for(dev), _capi.stream_for(dev)
+    planes, d, h, w = shape
+    g0 = torch.Generator().manual_seed(11)
+    for ties in (False, True):
+        x = torch.rand(shape, generator=g0)
+        if ties:
+            x = (x * 4).round() / 4                       # many equal values: exercises the first-extremum rule
+        x = x.to(dev).contiguous()
+        gup = torch.rand(shape, generator=g0).to(dev).contiguous()
+        e1, y1, e2, y2 = (torch.empty_like(x) for _ in range(4))
+        lib.check(lib.seg_op_pool3(x.data_ptr(), e1.data_ptr(), planes, d, h, w, nd, 1, st), "pool3")
+        lib.check(lib.seg_op_skel_update(x.data_ptr(), e1.data_ptr(), y1.data_ptr(), planes, d, h, w, nd, st), "update")
+        lib.check(lib.seg_op_skel_iter(x.data_ptr(), e2.data_ptr(), y2.data_ptr(), planes, d, h, w, nd, st), "iter")
+        assert torch.equal(e1, e2) and torch.equal(y1, y2)
+        dx1, de1 = torch.empty_like(x), torch.zeros_like(x)
+        lib.check(lib.seg_op_skel_update_bwd(gup.data_ptr(), x.data_ptr(), e1.data_ptr(), dx1.data_ptr(), de1.data_ptr(), planes, d, h, w, nd, st), "a")
+        lib.check(lib.seg_op_pool3_bwd(x.data_ptr(), de1.data_ptr(), dx1.data_ptr(), planes, d, h, w, nd, 1, st), "b")
+        dx2, de2 = torch.empty_like(x), torch.empty_like(x)
+        lib.check(lib.seg_op_skel_iter_bwd(gup.data_ptr(), x.data_ptr(), e1.data_ptr(), dx2.data_ptr(), de2.data_ptr(), planes, d, h, w, nd, st), "bwd")
+        assert float((de1 - de2).abs().max()) <= 1e-5 and float((dx1 - dx2).abs().max()) <= 1e-5
