@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--roofline-steps", type=int, default=5, help="timed steps whose launches carry the HIP-event brackets (each bracket "
                     "idles the stream for ~6 us, so only the first R of the K timed steps are instrumented)")
     ap.add_argument("--single-allreduce", action="store_true", help="one blocking all-reduce after backward instead of two overlapped buckets")
+    ap.add_argument("--global-loss", action="store_true", help="exact global-batch Dice across ranks (parallel.GlobalBatchLoss: 32 fp64 sums "
+                    "all-reduced between the loss reduction and its finalize; gradients summed) instead of DDP semantics")
     ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
     return ap.parse_args()
 
@@ -110,7 +112,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     from oracle import seg_oracle as seg   # synthetic inputs + the cpu_baseline leg only
     from pytorchdeeplearing_amd import SegEngine
-    from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GradAllReduce
+    from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GlobalBatchLoss, GradAllReduce
 
     S = a.size
     if a.lanes > 1:
@@ -125,8 +127,11 @@ def main():
     probs = torch.empty_like(logits)
     allreduce = (GradAllReduce(world) if a.single_allreduce else BucketedGradAllReduce(world)) if world > 1 else None
 
+    exchange = GlobalBatchLoss(world) if (a.global_loss and world > 1 and a.lanes == 1) else None
+    kw = {"loss_exchange": exchange} if exchange is not None else {}
+
     def step():
-        return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs)
+        return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs, **kw)
 
     candidates = ["gn_bwd_reduce", "gn_bwd_apply"] if a.roofline_kernel == "auto" else [a.roofline_kernel]
     bracketed = candidates + ([a.mfma_kernel] if a.mfma_kernel and a.mfma_kernel not in candidates else [])
@@ -180,7 +185,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "VNet3d(1,1) binary seg, %dx1x%d^3 per GPU, BinaryDiceLoss + Dice metric, AdamW, dropout p=0.2 on, "
                                    "random-init weights (BASELINE.json configs[2])" % (a.batch, S),
-                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "lanes_per_gpu": a.lanes},
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "lanes_per_gpu": a.lanes,
+                       "loss_semantics": "global-batch (sums exchanged)" if exchange is not None else "per-rank (DDP)"},
             "final_loss": round(loss, 5),
             "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME_96 * scale * vols / world / PEAK_HBM_GBS, 4),
                            "mfma_frac": round(GFLOP_PER_VOLUME_96 * scale * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},

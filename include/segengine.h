@@ -97,10 +97,24 @@ int seg_loss_forward(const float* logits, const void* target, int label_type, in
 int seg_loss_backward(const float* logits, const void* target, int label_type, int n, int c,
                       long long v, int loss_kind, float focal_alpha, float focal_gamma, void* ws,
                       float grad_scale, float* dlogits, void* stream);
-/* dice_coeff / iou_coeff / multiclass_* on probabilities (model/metric.py:146-215): out2 = {dice, iou} */
+/* Exact global-batch losses across data-parallel ranks (SURVEY.md section 8e mode ii).  The reference losses are
+ * batch-global ratios (model/losses.py:50-51 BinaryDiceLoss sums over the whole batch; :315-325 MutilDiceLoss reduces
+ * over dim (0,2) and counts the classes present in the batch; :259 the CE / focal means divide by the batch voxel
+ * count), so a rank-local loss is NOT the loss of the global batch.  seg_loss_forward == seg_loss_reduce followed by
+ * seg_loss_finalize(n_global = n).  Across ranks: seg_loss_reduce, SUM-all-reduce the first seg_loss_shared_doubles()
+ * doubles of `ws` (I, sum p, sum y, sum bce/nll, sum focal, per-class I_c / P_c / Y_c), seg_loss_finalize with
+ * n_global = samples over all ranks, seg_loss_backward; parameter gradients are then SUMMED over ranks (not averaged).
+ * The metrics in out3[1..2] stay per-rank (they are per-sample means, model/metric.py:146-155). */
+int seg_loss_shared_doubles(void);
+int seg_loss_reduce(const float* logits, const void* target, int label_type, int n, int c, long long v,
+                    int loss_kind, float focal_alpha, float focal_gamma, void* ws, void* stream);
+int seg_loss_finalize(const float* logits, const void* target, int label_type, int n, int c, long long v,
+                      int loss_kind, float focal_alpha, float focal_gamma, const float* class_alpha,
+                      int n_global, void* ws, float* out3, void* stream);
 /* predict() post-processing on the device (modelVNet.py:670-676): probs [N][C][V] fp32 -> uint8 mask [N][V];
  * C == 1: (p > threshold) * scale (scale 255 or 1); C > 1: first arg-max over the class axis. */
 int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long long v, float threshold, int scale, void* stream);
+/* dice_coeff / iou_coeff / multiclass_* on probabilities (model/metric.py:146-215): out2 = {dice, iou} */
 int seg_metric(const float* probs, const void* target, int label_type, int n, int c, long long v,
                void* ws, float* out2, void* stream);
 

@@ -44,6 +44,9 @@ SIGNATURES = {
     "seg_get_loss_scale": (_f, [_vp]),
     "seg_loss_ws_bytes": (_ll, [_i, _i]),
     "seg_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    "seg_loss_shared_doubles": (_i, []),
+    "seg_loss_reduce": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _vp]),
+    "seg_loss_finalize": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _i, _vp, _vp, _vp]),
     "seg_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _f, _vp, _vp]),
     "seg_predict_mask": (_i, [_vp, _vp, _i, _i, _ll, C.c_float, _i, _vp]),
     "seg_metric": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp]),

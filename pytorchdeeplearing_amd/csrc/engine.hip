@@ -1008,7 +1008,7 @@ static int fill_loss(LossArgs& a, const float* logits, const void* target, int l
     if ((c == 1) != (loss_kind <= SEG_LOSS_BINARY_CE_DICE)) return fail("loss: binary losses need C == 1, multi-class losses C > 1");
     a.logits = logits; a.target = target; a.label_type = label_type; a.N = n; a.C = c; a.V = v; a.kind = loss_kind;
     a.focal_alpha = focal_alpha; a.focal_gamma = focal_gamma; a.class_alpha = nullptr; a.sums = (double*)ws;
-    a.out = nullptr; a.dlogits = nullptr; a.grad_scale = 1.f;
+    a.out = nullptr; a.dlogits = nullptr; a.grad_scale = 1.f; a.phase = 0; a.n_global = 0;
     return 0;
 }
 
@@ -1020,6 +1020,28 @@ int seg_loss_forward(const float* logits, const void* target, int label_type, in
     a.class_alpha = class_alpha; a.out = out3;
     launch_loss_forward(a, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_loss_forward: launch failed");
+}
+
+int seg_loss_shared_doubles(void) { return loss_shared_count(); }
+
+int seg_loss_reduce(const float* logits, const void* target, int label_type, int n, int c, long long v, int loss_kind,
+                    float focal_alpha, float focal_gamma, void* ws, void* stream) {
+    LossArgs a;
+    if (fill_loss(a, logits, target, label_type, n, c, v, loss_kind, focal_alpha, focal_gamma, ws)) return -1;
+    a.phase = 1;
+    launch_loss_forward(a, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_loss_reduce: launch failed");
+}
+
+int seg_loss_finalize(const float* logits, const void* target, int label_type, int n, int c, long long v, int loss_kind,
+                      float focal_alpha, float focal_gamma, const float* class_alpha, int n_global, void* ws, float* out3, void* stream) {
+    LossArgs a;
+    if (fill_loss(a, logits, target, label_type, n, c, v, loss_kind, focal_alpha, focal_gamma, ws)) return -1;
+    if (!out3) return fail("seg_loss_finalize: out3 is null");
+    if (n_global < n) return fail("seg_loss_finalize: n_global must be >= the local sample count");
+    a.class_alpha = class_alpha; a.out = out3; a.phase = 2; a.n_global = n_global;
+    launch_loss_forward(a, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_loss_finalize: launch failed");
 }
 
 int seg_loss_backward(const float* logits, const void* target, int label_type, int n, int c, long long v, int loss_kind,

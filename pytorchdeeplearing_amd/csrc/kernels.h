@@ -156,7 +156,10 @@ struct LossArgs {
     float* out;                 // [0]=loss [1]=dice metric [2]=iou metric
     float* dlogits;             // [N][C][V] or null
     float grad_scale;           // loss scale folded into dlogits
+    int phase;                  // 0: reduce + finalize; 1: reduce + fold replicas only; 2: finalize only (sums exchanged by the caller)
+    int n_global;               // samples over ALL ranks for the mean losses (0: N)
 };
+int loss_shared_count();        // leading doubles of `sums` that are batch-global (summed across ranks in phase 1 -> 2)
 __host__ __device__ size_t loss_sums_count(int N, int C);   // doubles per replica (STAT_REP replicas)
 void launch_loss_forward(const LossArgs& a, hipStream_t s);    // reduce + finalize (writes out[], coefficient block in sums)
 void launch_loss_backward(const LossArgs& a, hipStream_t s);   // dlogits from the finalized coefficients

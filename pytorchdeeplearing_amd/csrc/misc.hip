@@ -229,16 +229,20 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
     const int C = a.C, N = a.N;
     double* S = a.sums;
     const int cnt_all = s_coef(N, C);
-    for (int i = threadIdx.x; i < cnt_all; i += 64) {          // fold the replicas into copy 0
-        double t = S[i];
-        for (int rep = 1; rep < STAT_REP; ++rep) t += S[(long long)rep * loss_sums_count(N, C) + i];
-        S[i] = t;
+    if (a.phase != 2) {
+        for (int i = threadIdx.x; i < cnt_all; i += 64) {          // fold the replicas into copy 0
+            double t = S[i];
+            for (int rep = 1; rep < STAT_REP; ++rep) t += S[(long long)rep * loss_sums_count(N, C) + i];
+            S[i] = t;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    // phase 1 stops here: the caller SUM-all-reduces the first S_METRIC doubles of copy 0 across ranks (exact
+    // global-batch loss, SURVEY section 8e mode ii), then runs phase 2 with the global sample count
+    if (threadIdx.x != 0 || a.phase == 1) return;
     double* K = S + s_coef(N, C);
     const double smooth = 1e-5, eps = 1e-7;
-    const double Ntot = (double)N * (double)a.V;
+    const double Ntot = (double)(a.n_global > 0 ? a.n_global : N) * (double)a.V;
     double loss = 0.0;
     for (int i = 0; i < 4 + 2 * MAXCLS; ++i) K[i] = 0.0;
     if (C == 1) {
@@ -520,7 +524,12 @@ void launch_maxpool_bwd(const PoolArgs& a, int dtype, hipStream_t s) {
 
 
 
+int loss_shared_count() { return S_METRIC; }
 void launch_loss_forward(const LossArgs& a, hipStream_t s) {
+    if (a.phase == 2) {                       // sums already reduced, folded (and exchanged) by a phase-1 call
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, a);
+        return;
+    }
     (void)hipMemsetAsync(a.sums, 0, loss_sums_count(a.N, a.C) * sizeof(double) * STAT_REP, s);
     dim3 grid(cdiv(a.V, LOSS_VPB), a.N);
     hipLaunchKernelGGL(loss_reduce_kernel, grid, dim3(256), 0, s, a);

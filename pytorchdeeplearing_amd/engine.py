@@ -185,10 +185,23 @@ class SegEngine:
         return k.value, off.value, self.lib.seg_backward_ops(self.h)
 
     # ---- losses ---------------------------------------------------------------------------------
-    def loss_forward(self, logits, target, loss_name, focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, out3=None):
+    def loss_forward(self, logits, target, loss_name, focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, out3=None, exchange=None):
+        """exchange: None = the reference loss on this rank's batch; a `parallel.GlobalBatchLoss` = the reference loss of the
+        batch over ALL ranks (the batch-global sums of model/losses.py:50-51,259,315-325 are SUM-all-reduced between the
+        reduction and the finalize kernel; 32 doubles)."""
         n, c = logits.shape[0], logits.shape[1]
         out3 = self._out3 if out3 is None else out3
         target = target.contiguous()
+        if exchange is not None and exchange.world > 1:
+            args = (_ptr(logits), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, c, self.V, _capi.LOSS_KIND[loss_name],
+                    float(focal_alpha), float(focal_gamma))
+            self.lib.check(self.lib.seg_loss_reduce(*args, _ptr(self._loss_ws), self.stream()), "seg_loss_reduce")
+            shared = self._loss_ws[:8 * self.lib.seg_loss_shared_doubles()].view(torch.float64)
+            n_global = exchange(shared, n)
+            self.lib.check(self.lib.seg_loss_finalize(*args, _ptr(class_alpha), int(n_global), _ptr(self._loss_ws), _ptr(out3),
+                                                      self.stream()), "seg_loss_finalize")
+            self._keep_loss = (target, class_alpha)
+            return out3
         self.lib.check(self.lib.seg_loss_forward(
             _ptr(logits), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, c, self.V, _capi.LOSS_KIND[loss_name],
             float(focal_alpha), float(focal_gamma), _ptr(class_alpha), _ptr(self._loss_ws), _ptr(out3), self.stream()),
@@ -244,13 +257,16 @@ class SegEngine:
     # ---- one optimisation step of the reference loop --------------------------------------------
     def train_step(self, x, target, loss_name="BinaryDiceLoss", lr=1e-3, weight_decay=0.01, decoupled=True,
                    focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, mask_mode=_capi.MASKS_RANDOM, masks=None,
-                   allreduce=None, logits=None, probs=None):
-        """Returns out3 = device tensor [loss, dice metric, iou metric] (no host sync)."""
+                   allreduce=None, logits=None, probs=None, loss_exchange=None):
+        """Returns out3 = device tensor [loss, dice metric, iou metric] (no host sync).
+        loss_exchange (parallel.GlobalBatchLoss): exact loss of the global batch over all ranks; the parameter gradients
+        of the ranks are then summed, not averaged (the 1/world factor is dropped)."""
         logits, probs = self.forward(x, mask_mode, masks, logits, probs)
         self._last_probs = probs
-        out3 = self.loss_forward(logits, target, loss_name, focal_alpha, focal_gamma, class_alpha)
+        out3 = self.loss_forward(logits, target, loss_name, focal_alpha, focal_gamma, class_alpha, exchange=loss_exchange)
         dl = self.loss_backward(logits, target, loss_name, focal_alpha, focal_gamma)
         world = getattr(allreduce, "world", 1) if allreduce is not None else 1
+        grad_div = 1 if (loss_exchange is not None and loss_exchange.world > 1) else world
         if allreduce is not None and getattr(allreduce, "bucketed", False) and world > 1:
             # two buckets: the finished suffix of the flat gradient buffer is exchanged while the fine levels still run
             k, off, nops = self.backward_bucket(allreduce.tail_fraction)
@@ -263,6 +279,6 @@ class SegEngine:
             self.backward(dl, zero_grads=True)
             if allreduce is not None:
                 allreduce(self.grads)
-        self.adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled, grad_div=world)
+        self.adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled, grad_div=grad_div)
         self.pack_weights()
         return out3

@@ -51,6 +51,23 @@ class BucketedGradAllReduce(GradAllReduce):
                 w.wait()                      # current stream waits for the collective; no host block on GPU backends
 
 
+class GlobalBatchLoss:
+    """Exact global-batch loss across ranks (SURVEY.md section 8e mode ii): the reference losses are ratios of sums over
+    the WHOLE batch (model/losses.py:50-51, 259, 315-325), so the loss of N volumes split over R ranks needs the sums of
+    all ranks before the ratio is taken.  Called by `SegEngine.loss_forward` between the reduction kernel and the
+    finalize kernel with the rank's batch-global sums (32 fp64 values, on the device); returns the global sample count.
+    One tiny SUM all-reduce; the parameter gradients are then summed over ranks instead of averaged."""
+
+    def __init__(self, world_size=None, group=None):
+        self.group = group
+        self.world = world_size if world_size is not None else dist.get_world_size(group)
+
+    def __call__(self, shared_sums: torch.Tensor, n_local: int):
+        if self.world > 1:
+            dist.all_reduce(shared_sums, op=dist.ReduceOp.SUM, group=self.group)
+        return n_local * self.world      # equal shards (the DataLoader drops nothing: batch_size per rank)
+
+
 def broadcast_parameters(engine, src=0, group=None):
     """make every replica start from rank `src`'s weights (call once after init / load)."""
     dist.broadcast(engine.params, src=src, group=group)

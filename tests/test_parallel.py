@@ -81,3 +81,72 @@ def test_ddp_two_ranks_matches_oracle_emulation(bucketed):
         tot += d.numel()
         bad += int((d > 1e-4).sum())
     assert bad <= 0.01 * tot, (bad, tot)
+
+
+def _worker_global(rank, world, port, q, ncls, loss):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import conftest
+    conftest.emu_library()
+    from oracle import seg_oracle as seg
+    from pytorchdeeplearing_amd import SegEngine, _capi
+    from pytorchdeeplearing_amd.parallel import GlobalBatchLoss, GradAllReduce
+    kind, shape = "unet", (2, 1, 16, 16)
+    e = SegEngine(kind, 2, 1, ncls, dtype="f32", device="cpu")
+    e.load_state_dict(seg.perturb_params(seg.init_params(kind, 2, 1, ncls, seed=0), seed=7))
+    x, y = seg.synthetic_batch(shape[0], shape[2:], 1, ncls, seed=100 + rank)
+    ar, ex = GradAllReduce(), GlobalBatchLoss()
+    losses = []
+    for it in range(2):
+        g = torch.Generator().manual_seed(10 * it + rank)
+        masks = seg.draw_masks(kind, shape[0], generator=g)
+        out3 = e.train_step(x, y, loss, lr=1e-3, mask_mode=_capi.MASKS_GIVEN, masks=masks, allreduce=ar, loss_exchange=ex)
+        losses.append(float(out3[0]))
+    if rank == 1:        # any rank holds the global loss and the same weights
+        q.put(({k: v.numpy().copy() for k, v in e.state_dict().items()}, losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ncls,loss", [(1, "BinaryCrossEntropyDiceLoss"), (3, "MutilDiceLoss"), (3, "MutilFocalLoss")])
+def test_exact_global_batch_loss_two_ranks_equals_one_process_on_the_whole_batch(ncls, loss):
+    """SURVEY 8e mode (ii): with the 32 batch-global sums exchanged, two ranks x 2 samples reproduce ONE reference process
+    training on the 4-sample batch (loss value and update), which plain DDP averaging does not."""
+    from oracle import seg_oracle as seg
+    world, port = 2, 30500 + (os.getpid() * 3 + ncls + len(loss)) % 1000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_global, args=(r, world, port, q, ncls, loss)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, got_losses = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    kind, shape = "unet", (2, 1, 16, 16)
+    cur = seg.perturb_params(seg.init_params(kind, 2, 1, ncls, seed=0), seed=7)
+    shards = [seg.synthetic_batch(shape[0], shape[2:], 1, ncls, seed=100 + r) for r in range(world)]
+    x = torch.cat([s[0] for s in shards]); y = torch.cat([s[1] for s in shards])
+    st, ref_losses, local_losses = {}, [], []
+    for it in range(2):
+        per_rank = [seg.draw_masks(kind, shape[0], generator=torch.Generator().manual_seed(10 * it + r)) for r in range(world)]
+        masks = [torch.cat([per_rank[r][i] for r in range(world)]) for i in range(len(per_rank[0]))]
+        kw = dict(alpha=torch.ones(ncls), gamma=2.0) if ncls > 1 else {}
+        r = seg.forward_backward(kind, cur, x, y, loss, masks=masks, **kw)
+        ref_losses.append(float(r["loss"]))
+        local_losses.append(float(seg.forward_backward(kind, cur, shards[1][0], shards[1][1], loss, masks=per_rank[1], **kw)["loss"]))
+        cur = seg.adamw_step(cur, r["grads"], st)
+    for a, b in zip(got_losses, ref_losses):
+        assert abs(a - b) < 2e-5, (got_losses, ref_losses)
+    assert abs(local_losses[0] - ref_losses[0]) > 1e-4      # the rank-local loss is a different number: the exchange matters
+    tot = bad = 0
+    for k in cur:
+        d = (torch.from_numpy(got[k]) - cur[k]).abs()
+        assert float(d.max()) < 2 * 2e-3, k
+        tot += d.numel()
+        bad += int((d > 1e-4).sum())
+    assert bad <= 0.01 * tot, (bad, tot)
