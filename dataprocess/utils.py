@@ -17,15 +17,15 @@ def file_name_path(file_dir, dir=True, file=False):
 
 
 def normalize(slice, bottom=95, down=5):
-    """percentile clip + z-score over the non-zero voxels (utils.py:182-204); background forced to -9."""
+    """percentile clip + z-score over the non-zero voxels (utils.py:182-204; the `tmp == tmp.min() -> -9` line is
+    commented out in the reference and is not applied).  Host-side numpy form; the wrappers use the device kernel
+    (pytorchdeeplearing_amd.prepost.normalize_percentile)."""
     b, t = np.percentile(slice, bottom), np.percentile(slice, down)
     slice = np.clip(slice, t, b)
     image_nonzero = slice[np.nonzero(slice)]
     if np.std(slice) == 0 or np.std(image_nonzero) == 0:
         return slice
-    tmp = (slice - np.mean(image_nonzero)) / np.std(image_nonzero)
-    tmp[tmp == tmp.min()] = -9
-    return tmp
+    return (slice - np.mean(image_nonzero)) / np.std(image_nonzero)
 
 
 def _sitk():
@@ -46,8 +46,6 @@ def resize_image_itkwithsize(itkimage, newSize, originSize, resamplemethod=None)
     resampler.SetTransform(sitk.Transform(3, sitk.sitkIdentity))
     resampler.SetInterpolator(sitk.sitkNearestNeighbor if resamplemethod is None else resamplemethod)
     out = resampler.Execute(itkimage)
-    if resamplemethod == sitk.sitkNearestNeighbor:
-        out = sitk.Threshold(out, 0, 1.0, 255)
     return sitk.GetArrayFromImage(out), out
 
 
@@ -58,7 +56,7 @@ def ConvertitkTrunctedValue(image, upper=200, lower=-200, normalize="maxmin"):
     if normalize == "maxmin":
         arr = (arr - arr.min()) / max(arr.max() - arr.min(), 1e-12)
     elif normalize == "meanstd":
-        arr = (arr - arr.mean()) / max(arr.std(), 1e-12)
+        arr = (arr - arr.mean()) / max(arr.std(ddof=1), 1e-12)      # itk::NormalizeImageFilter: unbiased variance
     out = sitk.GetImageFromArray(arr.astype(np.float32))
     out.SetSpacing(image.GetSpacing()); out.SetOrigin(image.GetOrigin()); out.SetDirection(image.GetDirection())
     return out

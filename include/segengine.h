@@ -114,6 +114,29 @@ int seg_loss_finalize(const float* logits, const void* target, int label_type, i
 /* predict() post-processing on the device (modelVNet.py:670-676): probs [N][C][V] fp32 -> uint8 mask [N][V];
  * C == 1: (p > threshold) * scale (scale 255 or 1); C > 1: first arg-max over the class axis. */
 int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long long v, float threshold, int scale, void* stream);
+/* ---- pre/post-processing either side of predict, planar single-channel volumes [D][H][W].
+ * seg_op_resample3d replaces the SimpleITK ResampleImageFilter calls of dataprocess/utils.py:99-145 (identity transform,
+ * same origin/direction): output voxel i along an axis samples the input at continuous index i * step, step = output
+ * spacing / input spacing (= originSize/newSize for resize_image_itkwithsize, newSpacing/originSpacing for
+ * resize_image_itk).  mode 0 = sitkLinear (f32 volumes), 1 = sitkNearestNeighbor (f32 or u8); outside the input
+ * buffer (index < -0.5 or >= size - 0.5) the value is 0, as ITK's default pixel.  elem_type 0 = f32, 1 = u8. */
+int seg_op_resample3d(const void* src, void* dst, int elem_type, int sd, int sh, int sw, int dd, int dh, int dw,
+                      double step_z, double step_y, double step_x, int mode, void* stream);
+/* workspace for the two normalisations below (bytes) */
+long long seg_op_normalize_ws_bytes(void);
+/* ConvertitkTrunctedValue(image, upper, lower, 'meanstd') (dataprocess/utils.py:148-179): optional clip to
+ * [lower, upper], then itk::NormalizeImageFilter: (x - mean) / sigma, sigma with the N-1 denominator. */
+int seg_op_normalize_meanstd(const float* x, float* out, long long n, int clip, float lower, float upper, void* ws, void* stream);
+/* normalize(slice, bottom=95, down=5) (dataprocess/utils.py:182-204): t, b = np.percentile(x, q_lo), np.percentile(x, q_hi)
+ * (float32 'linear' method, exact order statistics); x = clip(x, t, b); z-score with the mean / population std of the
+ * NON-ZERO clipped voxels; the clipped volume is returned unchanged when either std is 0. */
+int seg_op_normalize_percentile(const float* x, float* out, long long n, float q_lo, float q_hi, void* ws, void* stream);
+/* inference_patch (model/modelUnet.py:707-763): crop nb windows (origins = nb x {z,y,x} int32, device memory) of
+ * pd x ph x pw voxels into a batch [nb][pd][ph][pw]; and the reverse: out[window] = 1 wherever the window's mask is
+ * non-zero (out_mask += patch; out_mask[out_mask != 0] = 1).  `out` must be zero-initialised by the caller. */
+int seg_op_gather_patches(const float* vol, int d, int h, int w, const int* origins, int nb, int pd, int ph, int pw, float* out, void* stream);
+int seg_op_stitch_mask(const unsigned char* masks, const int* origins, int nb, int pd, int ph, int pw, unsigned char* out,
+                       int d, int h, int w, void* stream);
 /* dice_coeff / iou_coeff / multiclass_* on probabilities (model/metric.py:146-215): out2 = {dice, iou} */
 int seg_metric(const float* probs, const void* target, int label_type, int n, int c, long long v,
                void* ws, float* out2, void* stream);

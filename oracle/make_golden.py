@@ -172,11 +172,50 @@ def make_cldice():
     np.savez_compressed(os.path.join(OUT, "cldice.npz"), **out)
 
 
+def load_reference_function(relpath, name, ns):
+    """exec ONE top-level function of a reference file (its module cannot be imported here: SimpleITK / cv2 are absent);
+    the text is taken verbatim, nothing is written back."""
+    import re
+    src = open(os.path.join(ref_loader.REF, relpath)).read()
+    m = re.search(r"^def %s\(.*?(?=^def |\Z)" % name, src, re.S | re.M)
+    assert m, name
+    exec(compile(m.group(0), relpath + ":" + name, "exec"), ns)
+    return ns[name]
+
+
+def prepost_inputs():
+    """CT-like float32 volumes: smooth noise in Hounsfield-like units, a zero background slab, a constant case."""
+    rs = np.random.RandomState(5)
+    a = (rs.randn(20, 24, 28) * 300.0).astype(np.float32)
+    a[:, :6, :] = 0.0                                        # exact zeros: the "non-zero" statistics differ from the global ones
+    b = np.round(rs.randn(9, 11, 13) * 50.0).astype(np.float32)      # integer-valued (int16 CT read as float): many ties
+    c = np.full((4, 5, 6), 7.0, np.float32)                  # constant: early return
+    d = np.zeros((6, 6, 6), np.float32); d[2:4, 2:4, 2:4] = 3.0      # > 95 % zeros: t == b == 0
+    e = rs.rand(17, 3, 5).astype(np.float32) + 1.0           # no zeros at all
+    return dict(a=a, b=b, c=c, d=d, e=e)
+
+
+def make_prepost():
+    normalize = load_reference_function(os.path.join("dataprocess", "utils.py"), "normalize", {"np": np})
+    out = {}
+    import warnings
+    for k, v in prepost_inputs().items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = normalize(v.copy())
+        out["normalize_in_" + k], out["normalize_out_" + k] = v, np.asarray(r)
+        print("prepost normalize", k, r.dtype, float(np.asarray(r).mean()))
+    np.savez_compressed(os.path.join(OUT, "prepost.npz"), **out)
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference tree not available; golden fixtures can only be regenerated in the build container")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
+    make_prepost()
+    if "--only-prepost" in sys.argv:
+        return
     make_cldice()
     if "--only-cldice" in sys.argv:
         return

@@ -20,7 +20,7 @@ LOSS_KIND = {
 MASKS_EVAL, MASKS_GIVEN, MASKS_RANDOM = 0, 1, 2
 KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head", "conv3_smallbox"]
 
-_vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+_vp, _i, _ll, _f, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
 
 SIGNATURES = {
     "seg_create": (_i, [_i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
@@ -69,6 +69,12 @@ SIGNATURES = {
     "seg_op_plane_dot_scratch_bytes": (_ll, [_i, _ll]),
     "seg_op_plane_dot": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _vp]),
     "seg_op_plane_axpb": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
+    "seg_op_resample3d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _d, _d, _i, _vp]),
+    "seg_op_normalize_ws_bytes": (_ll, []),
+    "seg_op_normalize_meanstd": (_i, [_vp, _vp, _ll, _i, _f, _f, _vp, _vp]),
+    "seg_op_normalize_percentile": (_i, [_vp, _vp, _ll, _f, _f, _vp, _vp]),
+    "seg_op_gather_patches": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "seg_op_stitch_mask": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "seg_profile_enable": (_i, [_vp, C.c_uint]),
     "seg_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "seg_last_error": (C.c_char_p, []),

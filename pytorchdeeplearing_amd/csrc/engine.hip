@@ -1060,6 +1060,54 @@ int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long
     launch_mask(probs, mask, n, c, v, threshold, scale, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_predict_mask: launch failed");
 }
+int seg_op_resample3d(const void* src, void* dst, int elem_type, int sd, int sh, int sw, int dd, int dh, int dw, double step_z, double step_y,
+                      double step_x, int mode, void* stream) {
+    if (!src || !dst) return fail("seg_op_resample3d: null pointer");
+    if (sd < 1 || sh < 1 || sw < 1 || dd < 1 || dh < 1 || dw < 1) return fail("seg_op_resample3d: empty volume");
+    if (elem_type != 0 && elem_type != 1) return fail("seg_op_resample3d: elem_type must be 0 (f32) or 1 (u8)");
+    if (mode != RS_LINEAR && mode != RS_NEAREST) return fail("seg_op_resample3d: mode must be 0 (linear) or 1 (nearest)");
+    if (mode == RS_LINEAR && elem_type != 0) return fail("seg_op_resample3d: linear interpolation needs f32 volumes");
+    if (!(step_z > 0.0) || !(step_y > 0.0) || !(step_x > 0.0)) return fail("seg_op_resample3d: steps must be positive");
+    ResampleArgs a;
+    a.src = src; a.dst = dst; a.sD = sd; a.sH = sh; a.sW = sw; a.dD = dd; a.dH = dh; a.dW = dw;
+    a.fz = step_z; a.fy = step_y; a.fx = step_x; a.mode = mode;
+    launch_resample3d(a, elem_type, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_resample3d: launch failed");
+}
+long long seg_op_normalize_ws_bytes(void) { return (long long)normalize_ws_bytes(); }
+int seg_op_normalize_meanstd(const float* x, float* out, long long n, int clip, float lower, float upper, void* ws, void* stream) {
+    if (!x || !out || !ws) return fail("seg_op_normalize_meanstd: null pointer");
+    if (n < 1) return fail("seg_op_normalize_meanstd: empty volume");
+    if (clip && !(lower <= upper)) return fail("seg_op_normalize_meanstd: lower > upper");
+    launch_normalize_meanstd(x, out, n, clip, lower, upper, ws, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_normalize_meanstd: launch failed");
+}
+int seg_op_normalize_percentile(const float* x, float* out, long long n, float q_lo, float q_hi, void* ws, void* stream) {
+    if (!x || !out || !ws) return fail("seg_op_normalize_percentile: null pointer");
+    if (n < 1) return fail("seg_op_normalize_percentile: empty volume");
+    if (!(q_lo >= 0.f && q_lo <= q_hi && q_hi <= 100.f)) return fail("seg_op_normalize_percentile: need 0 <= q_lo <= q_hi <= 100");
+    launch_normalize_percentile(x, out, n, q_lo, q_hi, ws, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_normalize_percentile: launch failed");
+}
+static int check_windows(const char* what, int D, int H, int W, int nb, int pd, int ph, int pw) {
+    if (nb < 1 || pd < 1 || ph < 1 || pw < 1) return fail(std::string(what) + ": empty patch list");
+    if (pd > D || ph > H || pw > W) return fail(std::string(what) + ": patch larger than the volume");
+    return 0;
+}
+int seg_op_gather_patches(const float* vol, int d, int h, int w, const int* origins, int nb, int pd, int ph, int pw, float* out, void* stream) {
+    if (!vol || !origins || !out) return fail("seg_op_gather_patches: null pointer");
+    if (check_windows("seg_op_gather_patches", d, h, w, nb, pd, ph, pw)) return -1;
+    launch_gather_patches(vol, d, h, w, origins, nb, pd, ph, pw, out, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_gather_patches: launch failed");
+}
+int seg_op_stitch_mask(const unsigned char* masks, const int* origins, int nb, int pd, int ph, int pw, unsigned char* out, int d, int h, int w,
+                       void* stream) {
+    if (!masks || !origins || !out) return fail("seg_op_stitch_mask: null pointer");
+    if (check_windows("seg_op_stitch_mask", d, h, w, nb, pd, ph, pw)) return -1;
+    launch_stitch_mask(masks, origins, nb, pd, ph, pw, out, d, h, w, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_stitch_mask: launch failed");
+}
+
 int seg_metric(const float* probs, const void* target, int label_type, int n, int c, long long v, void* ws, float* out2, void* stream) {
     if (!probs || !target || !ws || !out2) return fail("seg_metric: null pointer");
     if (c < 1 || c > 8) return fail("seg_metric: classes must be 1..8");

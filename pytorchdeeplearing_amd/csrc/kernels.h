@@ -181,6 +181,22 @@ size_t plane_dot_scratch_bytes(int planes, long long V);
 void launch_plane_dot(const float* a, const float* b, double* out, double* scratch, int planes, long long V, hipStream_t s);
 void launch_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long V, int accumulate, hipStream_t s);
 
+// pre/post-processing around predict (prepost.hip): planar single-channel volumes [D][H][W]
+constexpr int RS_LINEAR = 0, RS_NEAREST = 1;
+struct ResampleArgs {
+    const void* src; void* dst;
+    int sD, sH, sW, dD, dH, dW;
+    double fz, fy, fx;          // continuous input index of output voxel i along an axis = i * f (output spacing / input spacing)
+    int mode;                   // RS_LINEAR | RS_NEAREST
+};
+void launch_resample3d(const ResampleArgs& a, int elem_type /* 0: f32, 1: u8 */, hipStream_t s);
+size_t normalize_ws_bytes();
+void launch_normalize_meanstd(const float* x, float* out, long long n, int clip, float lo, float hi, void* ws, hipStream_t s);
+void launch_normalize_percentile(const float* x, float* out, long long n, float q_lo, float q_hi, void* ws, hipStream_t s);
+void launch_gather_patches(const float* vol, int D, int H, int W, const int* origins, int nb, int pd, int ph, int pw, float* out, hipStream_t s);
+void launch_stitch_mask(const unsigned char* masks, const int* origins, int nb, int pd, int ph, int pw, unsigned char* out, int D, int H, int W,
+                        hipStream_t s);
+
 void launch_mask(const float* probs, unsigned char* out, int N, int C, long long V, float threshold, int scale, hipStream_t s);
 
 // Fused AdamW / Adam over the flat fp32 buffers; also clears nothing (grads are re-zeroed by the engine)

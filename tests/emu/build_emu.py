@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pytorchdeeplearing_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libsegengine_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SRCS = ["conv.hip", "conv3.hip", "wgrad.hip", "norm.hip", "misc.hip", "cldice.hip", "engine.hip"]
+SRCS = ["conv.hip", "conv3.hip", "wgrad.hip", "norm.hip", "misc.hip", "cldice.hip", "prepost.hip", "engine.hip"]
 
 
 def build(force=False):

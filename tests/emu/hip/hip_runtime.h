@@ -225,6 +225,8 @@ inline float atomicAdd(float* p, double v) { float o = *p; *p = o + (float)v; re
 template <class T>
 inline T atomicMax(T* p, T v) { T o = *p; *p = std::max(o, v); return o; }
 template <class T>
+inline T atomicMin(T* p, T v) { T o = *p; *p = std::min(o, v); return o; }
+template <class T>
 inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 
 // ---- wave shuffles ------------------------------------------------------------------------------

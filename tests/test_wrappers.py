@@ -83,3 +83,62 @@ def test_trainprocess_and_predict(dev, tmp_path, monkeypatch, cls, numclass, los
     with pytest.raises(ValueError):
         bad = getattr(model, cls)(16, 16, 16, 1, numclass, 1, loss_name="NoSuchLoss", use_cuda=dev.type == "cuda")
         bad.trainprocess(tr_i, tr_l, va_i, va_l, model_dir=log, epochs=1)
+
+
+def _oracle_net(kind, sd, scale):
+    from oracle import seg_oracle as seg
+
+    def run(vol):                      # (1, d, h, w) normalised patch -> (uint8 mask, tied voxels)
+        _, probs = seg.net_forward(kind, sd, torch.from_numpy(np.ascontiguousarray(vol[None])).float())
+        p = probs[0, 0].numpy()
+        return ((p > 0.5) * scale).astype(np.uint8), np.abs(p - 0.5) < 5e-5
+    return run
+
+
+def test_inference_and_inference_patch_on_arrays(dev, monkeypatch):
+    """3-D `inference` (modelUnet.py:684-705) and `inference_patch` (modelUnet.py:707-763) with the whole pre/post chain on
+    the device, against the CPU restatement of the same chain around the oracle network."""
+    import model
+    from oracle import prepost_oracle as po, seg_oracle as seg
+    monkeypatch.setenv("SEGENGINE_DTYPE", "f32")
+    m = model.BinaryUNet3dModel(image_depth=16, image_height=16, image_width=16, image_channel=1, numclass=1, batch_size=3,
+                                use_cuda=dev.type == "cuda")
+    sd = seg.perturb_params(seg.init_params("unet", 3, 1, 1, seed=0), seed=7)
+    m.model.load_state_dict(sd)
+    net = _oracle_net("unet", sd, 1)          # BinaryUNet3dModel.predict returns 0 / 1 (modelUnet.py:678)
+    rs = np.random.RandomState(11)
+    # ---- inference: resize to the network grid, percentile-normalise, predict, nearest-neighbour back
+    arr = (rs.randn(20, 22, 24) * 100.0).astype(np.float32)
+    arr[:, :5] = 0.0
+    got = m.inference(arr, newSize=(16, 16, 16))
+    assert got.dtype == np.uint8 and got.shape == arr.shape
+    step = tuple(a / 16.0 for a in arr.shape)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        small = po.normalize(po.itk_resample(arr, (16, 16, 16), step))
+    mask, tied = net(small[None])
+    back = tuple(16.0 / a for a in arr.shape)
+    want = po.itk_resample(mask, arr.shape, back, nearest=True)
+    tied = po.itk_resample(tied.astype(np.uint8), arr.shape, back, nearest=True).astype(bool)
+    assert np.array_equal(got[~tied], want[~tied]) and tied.mean() < 0.01
+    assert 0 < int(want.sum()) < want.size          # a non-trivial mask
+    # ---- inference_patch: resample to a finer spacing, clip + z-score, window loop, OR, back to the source grid
+    src = (13, 13, 28) if dev.type == "cpu" else (20, 24, 28)      # the host checker keeps two windows, the GPU run eight
+    ct = (-1024.0 + 224.0 * rs.rand(*src)).astype(np.float32)
+    got = m.inference_patch(ct, newSpacing=(0.8, 0.8, 0.8), spacing=(1.0, 1.0, 1.0))
+    assert got.dtype == ct.dtype and got.shape == ct.shape
+    size, st = tuple(int(s / 0.8) for s in src), (0.8, 0.8, 0.8)
+    fine = po.truncated_meanstd(po.itk_resample(ct, size, st), upper=-800, lower=-1024)
+    want = po.patch_loop(fine[None], (16, 16, 16), lambda p: net(p)[0])
+    tied = po.patch_loop(fine[None], (16, 16, 16), lambda p: net(p)[1].astype(np.uint8))
+    bsize = tuple(int(s / 1.25) for s in size)
+    want = po.itk_resample(want.astype(np.uint8), bsize, (1.25,) * 3, nearest=True)
+    tied = po.itk_resample(tied.astype(np.uint8), bsize, (1.25,) * 3, nearest=True).astype(bool)
+    final = np.zeros_like(ct)
+    mz, my, mx = (min(a, b) for a, b in zip(ct.shape, bsize))
+    final[:mz, :my, :mx] = want[:mz, :my, :mx]
+    keep = np.ones(ct.shape, bool)
+    keep[:mz, :my, :mx] = ~tied[:mz, :my, :mx]
+    assert np.array_equal(got[keep], final[keep]) and (~keep).mean() < 0.01
+    assert 0 < int(final.sum()) < final.size
