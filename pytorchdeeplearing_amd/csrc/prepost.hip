@@ -24,39 +24,53 @@ inline int pp_blocks(long long total, int cap = 4096) {
 // Linear = itk::LinearInterpolateImageFunction (double arithmetic, neighbours beyond the last index clamp to it);
 // nearest = itk::NearestNeighborInterpolateImageFunction (Math::RoundHalfIntegerUp).
 template <class T>
+__device__ __forceinline__ T resample_voxel(const ResampleArgs& a, const T* src, int z, int y, int x) {
+    const double cz = z * a.fz, cy = y * a.fy, cx = x * a.fx;
+    const bool inside = cz >= -0.5 && cz < a.sD - 0.5 && cy >= -0.5 && cy < a.sH - 0.5 && cx >= -0.5 && cx < a.sW - 0.5;
+    if (!inside) return (T)0;
+    if (a.mode == RS_NEAREST) {
+        const int iz = (int)floor(cz + 0.5), iy = (int)floor(cy + 0.5), ix = (int)floor(cx + 0.5);
+        return src[((long long)iz * a.sH + iy) * a.sW + ix];
+    }
+    int z0 = (int)floor(cz), y0 = (int)floor(cy), x0 = (int)floor(cx);
+    z0 = z0 < 0 ? 0 : z0; y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+    double dz = cz - z0, dy = cy - y0, dx = cx - x0;
+    dz = dz < 0.0 ? 0.0 : dz; dy = dy < 0.0 ? 0.0 : dy; dx = dx < 0.0 ? 0.0 : dx;
+    const int z1 = z0 + 1 < a.sD ? z0 + 1 : a.sD - 1, y1 = y0 + 1 < a.sH ? y0 + 1 : a.sH - 1, x1 = x0 + 1 < a.sW ? x0 + 1 : a.sW - 1;
+    const T* p00 = src + ((long long)z0 * a.sH + y0) * a.sW;
+    const T* p01 = src + ((long long)z0 * a.sH + y1) * a.sW;
+    const T* p10 = src + ((long long)z1 * a.sH + y0) * a.sW;
+    const T* p11 = src + ((long long)z1 * a.sH + y1) * a.sW;
+    const double v000 = (double)p00[x0], v001 = (double)p00[x1], v010 = (double)p01[x0], v011 = (double)p01[x1];
+    const double v100 = (double)p10[x0], v101 = (double)p10[x1], v110 = (double)p11[x0], v111 = (double)p11[x1];
+    const double a00 = v000 + dx * (v001 - v000), a01 = v010 + dx * (v011 - v010);
+    const double a10 = v100 + dx * (v101 - v100), a11 = v110 + dx * (v111 - v110);
+    const double b0 = a00 + dy * (a01 - a00), b1 = a10 + dy * (a11 - a10);
+    return (T)(b0 + dz * (b1 - b0));
+}
+// a thread produces VEC consecutive voxels of an output row and stores them as one 16-byte (f32 x4, u8 x16) or 4-byte vector:
+// the nearest-neighbour up-sampling of a uint8 mask is store-bound, one byte per lane wastes 15/16 of every write
+template <class T, int VEC>
 __global__ __launch_bounds__(256) void resample3d_kernel(ResampleArgs a) {
     const T* src = (const T*)a.src;
     T* dst = (T*)a.dst;
-    const long long total = (long long)a.dD * a.dH * a.dW;
+    const int wv = a.dW / VEC;                       // the launcher picks VEC so that dW % VEC == 0
+    const long long total = (long long)a.dD * a.dH * wv;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int x = (int)(i % a.dW), y = (int)((i / a.dW) % a.dH), z = (int)(i / ((long long)a.dW * a.dH));
-        const double cz = z * a.fz, cy = y * a.fy, cx = x * a.fx;
-        const bool inside = cz >= -0.5 && cz < a.sD - 0.5 && cy >= -0.5 && cy < a.sH - 0.5 && cx >= -0.5 && cx < a.sW - 0.5;
-        T out = (T)0;
-        if (inside) {
-            if (a.mode == RS_NEAREST) {
-                const int iz = (int)floor(cz + 0.5), iy = (int)floor(cy + 0.5), ix = (int)floor(cx + 0.5);
-                out = src[((long long)iz * a.sH + iy) * a.sW + ix];
-            } else {
-                int z0 = (int)floor(cz), y0 = (int)floor(cy), x0 = (int)floor(cx);
-                z0 = z0 < 0 ? 0 : z0; y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
-                double dz = cz - z0, dy = cy - y0, dx = cx - x0;
-                dz = dz < 0.0 ? 0.0 : dz; dy = dy < 0.0 ? 0.0 : dy; dx = dx < 0.0 ? 0.0 : dx;
-                const int z1 = z0 + 1 < a.sD ? z0 + 1 : a.sD - 1, y1 = y0 + 1 < a.sH ? y0 + 1 : a.sH - 1, x1 = x0 + 1 < a.sW ? x0 + 1 : a.sW - 1;
-                const T* p00 = src + ((long long)z0 * a.sH + y0) * a.sW;
-                const T* p01 = src + ((long long)z0 * a.sH + y1) * a.sW;
-                const T* p10 = src + ((long long)z1 * a.sH + y0) * a.sW;
-                const T* p11 = src + ((long long)z1 * a.sH + y1) * a.sW;
-                const double v000 = (double)p00[x0], v001 = (double)p00[x1], v010 = (double)p01[x0], v011 = (double)p01[x1];
-                const double v100 = (double)p10[x0], v101 = (double)p10[x1], v110 = (double)p11[x0], v111 = (double)p11[x1];
-                const double a00 = v000 + dx * (v001 - v000), a01 = v010 + dx * (v011 - v010);
-                const double a10 = v100 + dx * (v101 - v100), a11 = v110 + dx * (v111 - v110);
-                const double b0 = a00 + dy * (a01 - a00), b1 = a10 + dy * (a11 - a10);
-                out = (T)(b0 + dz * (b1 - b0));
-            }
-        }
-        dst[i] = out;
+        const int xv = (int)(i % wv), y = (int)((i / wv) % a.dH), z = (int)(i / ((long long)wv * a.dH));
+        vec<T, VEC> out;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) out[j] = resample_voxel<T>(a, src, z, y, xv * VEC + j);
+        *(vec<T, VEC>*)(dst + ((long long)z * a.dH + y) * a.dW + (long long)xv * VEC) = out;
     }
+}
+template <class T>
+__global__ __launch_bounds__(256) void resample3d_scalar_kernel(ResampleArgs a) {
+    const T* src = (const T*)a.src;
+    T* dst = (T*)a.dst;
+    const long long total = (long long)a.dD * a.dH * a.dW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        dst[i] = resample_voxel<T>(a, src, (int)(i / ((long long)a.dW * a.dH)), (int)((i / a.dW) % a.dH), (int)(i % a.dW));
 }
 
 // ------------------------------------------------------------------------------------------- clip + mean/std
@@ -144,12 +158,27 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* x, long long
     const int hshift = shift + bits;                     // bits above the current digit (32 on pass 0: nothing to match)
     unsigned pre[4];
     for (int r = 0; r < 4; ++r) pre[r] = pass == 0 ? 0u : (st->prefix[r] >> hshift);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const unsigned k = f2key(x[i]);
+    // uniform trip count per wave (the vote below needs every lane): `base` is the same for all lanes of a workgroup
+    for (long long base = (long long)blockIdx.x * 256; base < n; base += (long long)gridDim.x * 256) {
+        const long long i = base + threadIdx.x;
+        const bool valid = i < n;
+        const unsigned k = valid ? f2key(x[i]) : 0u;
         const unsigned d = (k >> shift) & dmask;
         if (pass == 0) {
-            atomicAdd(&lh[d], 1u);
-        } else {
+            // the leading digit is sign + exponent + 2 mantissa bits: real volumes put most of a wave into a handful of bins and
+            // 64 same-address LDS atomics serialise.  Vote per distinct digit instead: one atomic (by the leader) per digit and wave.
+            bool pending = valid;
+            for (;;) {
+                const unsigned long long pm = __ballot(pending);
+                if (!pm) break;
+                const int leader = __builtin_ctzll(pm);
+                const unsigned ld = __shfl(d, leader);
+                const bool mine = pending && d == ld;
+                const unsigned long long mm = __ballot(mine);
+                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[ld], (unsigned)__builtin_popcountll(mm));
+                pending = pending && !mine;
+            }
+        } else if (valid) {
             const unsigned hi = k >> hshift;
             for (int r = 0; r < 4; ++r)
                 if (hi == pre[r] && (r == 0 || pre[r] != pre[r - 1])) atomicAdd(&lh[r * SEL_BINS + d], 1u);   // equal prefixes share a histogram
@@ -287,9 +316,18 @@ __global__ __launch_bounds__(256) void stitch_mask_kernel(const unsigned char* m
 }  // namespace
 
 void launch_resample3d(const ResampleArgs& a, int elem_type, hipStream_t s) {
-    dim3 grid(pp_blocks((long long)a.dD * a.dH * a.dW, 16384));
-    if (elem_type == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(resample3d_kernel<float>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(resample3d_kernel<unsigned char>), grid, dim3(256), 0, s, a);
+    const long long n = (long long)a.dD * a.dH * a.dW;
+    const bool al16 = ((uintptr_t)a.dst & 15) == 0;
+    if (elem_type == 0) {
+        if (al16 && a.dW % 4 == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(resample3d_kernel<float, 4>), dim3(pp_blocks(n / 4, 16384)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(resample3d_scalar_kernel<float>), dim3(pp_blocks(n, 16384)), dim3(256), 0, s, a);
+    } else {
+        if (al16 && a.dW % 16 == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(resample3d_kernel<unsigned char, 16>), dim3(pp_blocks(n / 16, 16384)), dim3(256), 0, s, a);
+        else if (al16 && a.dW % 4 == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(resample3d_kernel<unsigned char, 4>), dim3(pp_blocks(n / 4, 16384)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(resample3d_scalar_kernel<unsigned char>), dim3(pp_blocks(n, 16384)), dim3(256), 0, s, a);
+    }
 }
 
 size_t normalize_ws_bytes() { return SEL_WS_BYTES; }

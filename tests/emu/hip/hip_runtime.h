@@ -249,6 +249,19 @@ inline T __shfl_down(T v, int d, int = 64) { int l = emu::me().lane; return emu_
 template <class T>
 inline T __shfl(T v, int src, int = 64) { return emu_shfl_idx(v, src); }
 
+// wave-wide vote: every lane of the wave must reach it (as on the hardware when EXEC is full)
+inline unsigned long long __ballot(int pred) {
+    auto& w = emu::wsc();
+    const int l = emu::me().lane;
+    const int p = pred != 0;
+    memcpy(w.a[l], &p, sizeof(int));
+    emu::yield(emu::Y_WAVE);
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) { int q; memcpy(&q, w.a[i], sizeof(int)); if (q) m |= 1ull << i; }
+    emu::yield(emu::Y_WAVE);
+    return m;
+}
+
 // ---- MFMA ---------------------------------------------------------------------------------------
 namespace emu {
 template <class T, int N>
