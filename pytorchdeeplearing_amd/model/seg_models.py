@@ -23,6 +23,7 @@ from torch.utils.data import DataLoader
 from .. import _capi, losses as L, metric as M, networks
 from . import _io
 from .dataset import datasetModelSegwithnpy, datasetModelSegwithopencv
+from .pipeline import DevicePrefetcher
 from .visualization import plot_result, save_images2d, save_images3d
 
 _BINARY_LOSSES = {"BinaryCrossEntropyLoss", "BinaryDiceLoss", "BinaryCrossEntropyDiceLoss", "BinaryFocalLoss"}
@@ -123,11 +124,8 @@ class _SegModel(object):
             self.model.train()
             tl, ta, vl, va = [], [], [], []
             trainshow = True
-            for batch in train_loader:
-                x, y = batch["image"], batch["label"]
-                if self._binary:
-                    y[y != 0] = 1
-                x, y = x.to(self.device).float().contiguous(), y.to(self.device).contiguous()
+            # reader thread + pinned staging + copy stream; labels binarised / narrowed to uint8 on the host (model/pipeline.py)
+            for x, y in DevicePrefetcher(train_loader, self.device, self._binary):
                 out3 = eng.train_step(x, y, self.loss_name, lr=lr, weight_decay=wd, decoupled=self._adamw, focal_alpha=0.25,
                                       focal_gamma=fgamma, class_alpha=class_alpha, mask_mode=_capi.MASKS_RANDOM).clone()
                 if trainshow:
@@ -137,11 +135,7 @@ class _SegModel(object):
                 ta.append(out3[metric_slot])
             self.model.eval()
             with torch.no_grad():
-                for batch in val_loader:
-                    x, y = batch["image"], batch["label"]
-                    if self._binary:
-                        y[y != 0] = 1
-                    x, y = x.to(self.device).float().contiguous(), y.to(self.device).contiguous()
+                for x, y in DevicePrefetcher(val_loader, self.device, self._binary):
                     logits, probs = eng.forward(x, _capi.MASKS_EVAL)
                     out3 = eng.loss_forward(logits, y, self.loss_name, 0.25, fgamma, class_alpha).clone()
                     self._last = (probs, y)

@@ -142,3 +142,38 @@ def test_inference_and_inference_patch_on_arrays(dev, monkeypatch):
     keep[:mz, :my, :mx] = ~tied[:mz, :my, :mx]
     assert np.array_equal(got[keep], final[keep]) and (~keep).mean() < 0.01
     assert 0 < int(final.sum()) < final.size
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_device_prefetcher_order_labels_and_early_exit(dev, tmp_path, binary):
+    """the prefetching loader hands out the DataLoader's batches in order, on the device, labels binarised
+    (`y[y != 0] = 1`, modelVNet.py:576) and narrowed to uint8; abandoning the iterator does not hang the reader thread."""
+    from torch.utils.data import DataLoader
+    from pytorchdeeplearing_amd.model.dataset import datasetModelSegwithnpy
+    from pytorchdeeplearing_amd.model.pipeline import DevicePrefetcher
+    shape = (4, 6, 8)
+    imgs, labs = _make_npy(str(tmp_path), 5, shape, 1 if binary else 3, 9)
+    ds = datasetModelSegwithnpy(imgs, labs, targetsize=(1,) + shape)
+    loader = DataLoader(ds, shuffle=False, batch_size=2, num_workers=0)
+    got = list(DevicePrefetcher(loader, dev, binary))
+    want = list(loader)
+    assert len(got) == len(want) == 3
+    for (x, y), b in zip(got, want):
+        assert x.device.type == dev.type and y.device.type == dev.type and y.dtype == torch.uint8 and x.dtype == torch.float32
+        assert torch.equal(x.cpu(), b["image"].float())
+        ref = b["label"].clone()
+        if binary:
+            ref[ref != 0] = 1
+        assert torch.equal(y.cpu().long(), ref)
+    it = iter(DevicePrefetcher(loader, dev, binary, depth=1))
+    next(it)
+    it.close()                                    # generator finaliser must stop and join the reader
+
+    class Broken(torch.utils.data.Dataset):
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            raise OSError("unreadable volume")
+    with pytest.raises(OSError):
+        list(DevicePrefetcher(DataLoader(Broken(), batch_size=1), dev, binary))
