@@ -158,27 +158,15 @@ __global__ __launch_bounds__(256) void sel_hist_kernel(const float* x, long long
     const int hshift = shift + bits;                     // bits above the current digit (32 on pass 0: nothing to match)
     unsigned pre[4];
     for (int r = 0; r < 4; ++r) pre[r] = pass == 0 ? 0u : (st->prefix[r] >> hshift);
-    // uniform trip count per wave (the vote below needs every lane): `base` is the same for all lanes of a workgroup
-    for (long long base = (long long)blockIdx.x * 256; base < n; base += (long long)gridDim.x * 256) {
-        const long long i = base + threadIdx.x;
-        const bool valid = i < n;
-        const unsigned k = valid ? f2key(x[i]) : 0u;
+    // Plain LDS atomics.  A per-digit wave vote (one atomic per distinct digit and wave) was measured and is slower on
+    // noise-like volumes: ~25 distinct leading digits per wave cost more vote rounds than the serialised atomics they replace
+    // (256^3: 0.63 -> 0.88 ms, profiles/r01_prepost_step22.jsonl vs r01_prepost_step23.jsonl).
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned k = f2key(x[i]);
         const unsigned d = (k >> shift) & dmask;
         if (pass == 0) {
-            // the leading digit is sign + exponent + 2 mantissa bits: real volumes put most of a wave into a handful of bins and
-            // 64 same-address LDS atomics serialise.  Vote per distinct digit instead: one atomic (by the leader) per digit and wave.
-            bool pending = valid;
-            for (;;) {
-                const unsigned long long pm = __ballot(pending);
-                if (!pm) break;
-                const int leader = __builtin_ctzll(pm);
-                const unsigned ld = __shfl(d, leader);
-                const bool mine = pending && d == ld;
-                const unsigned long long mm = __ballot(mine);
-                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[ld], (unsigned)__builtin_popcountll(mm));
-                pending = pending && !mine;
-            }
-        } else if (valid) {
+            atomicAdd(&lh[d], 1u);
+        } else {
             const unsigned hi = k >> hshift;
             for (int r = 0; r < 4; ++r)
                 if (hi == pre[r] && (r == 0 || pre[r] != pre[r - 1])) atomicAdd(&lh[r * SEL_BINS + d], 1u);   // equal prefixes share a histogram

@@ -6,7 +6,8 @@ import torch
 from oracle.make_golden import cldice_inputs
 from pytorchdeeplearing_amd.lossescldice import Binary_Soft_cldice_loss
 
-for shape in [(1, 1, 160, 160, 160), (4, 1, 96, 96, 96), (16, 1, 512, 512)]:
+SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(1, 1, 160, 160, 160), (4, 1, 96, 96, 96), (16, 1, 512, 512)]
+for shape in SHAPES:
     pred, target = cldice_inputs(shape, 3)
     pred, target = pred.cuda().requires_grad_(True), target.cuda()
     f = Binary_Soft_cldice_loss()
