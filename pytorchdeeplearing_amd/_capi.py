@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsegengine.so")
+# SEGENGINE_LIB: tuning builds only (tools/build_variant.py); the product library is lib/libsegengine.so
+LIB_PATH = os.environ.get("SEGENGINE_LIB") or os.path.join(HERE, "lib", "libsegengine.so")
 
 NET_KIND = {"vnet": 0, "unet": 1}
 DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "bf16": 2, "bfloat16": 2}

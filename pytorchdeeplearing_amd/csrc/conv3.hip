@@ -18,6 +18,15 @@
 
 #include "kernels.h"
 
+// waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument); tuning knobs of
+// tools/build_variant.py, the defaults are the measured choice
+#ifndef SEG_W3_OCC
+#define SEG_W3_OCC 2
+#endif
+#ifndef SEG_STEM_OCC
+#define SEG_STEM_OCC 2
+#endif
+
 namespace seg {
 namespace {
 
@@ -158,11 +167,24 @@ struct Conv3Args {
 };
 #define SEG_STAMP(k) do { if (a.trace && threadIdx.x == 0) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6 + (k)] = wall_clock64(); } while (0)
 
+// Waves per SIMD the register allocator leaves room for, per tiling (measured, profiles/r01_conv3_occupancy_step24.log):
+// the 16-channel NT=1 tiling fits four workgroups per CU in LDS (40.5 KB each) once it is held to 128 VGPRs (151 -> 135 us at
+// 96^3); the 8x8-box 32-channel NT=1 tiling gains from 184 instead of 198 VGPRs (24^3: 36.5 -> 31 us); the NT=2 tilings lose
+// when squeezed (48^3: 51 -> 77 us) and stay at 2.  SEG_C3_OCC overrides all of them (tools/build_variant.py).
+template <int CH, int NT, int TH>
+constexpr int c3_occ() {
+#ifdef SEG_C3_OCC
+    return SEG_C3_OCC;
+#else
+    return (CH == 16 && NT == 1) ? 4 : (CH == 32 && NT == 1 && TH == 8) ? 3 : 2;
+#endif
+}
+
 // WL = true (NT == 1 tiles): the [16][taps x CH] weight slab of the current channel chunk is staged in LDS with the
 // halo, so the tap loop never waits on L2 (the small deep levels run ~1.5 workgroups per CU and were bound by that
 // latency); WL = false: weights stream from L2 through a register ring.
 template <class T, int TD, int TH, int TW, int KD, int CH, int NT, bool WL>
-__global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3Args a) {
+__global__ __launch_bounds__(256, (c3_occ<CH, NT, TH>())) void conv3_kernel(Conv3Args a) {
     typedef Box<TD, TH, TW, KD> B;
     constexpr bool SWZ = sizeof(T) == 2 && CH == 32;    // swizzled unpadded 64-B rows (see halo_swz); else padded rows
     constexpr int XLD = SWZ ? CH : CH + 8;              // padded: 48 B (CH=16) / 160 B (f32) rows
@@ -384,7 +406,7 @@ template <int LD> struct TrFrag<float, LD> {
 };
 
 template <class T, int TD, int TH, int TW, int KD, int CP, int CQ>
-__global__ __launch_bounds__(256, 2) void wgrad3_kernel(Wgrad3Args a) {
+__global__ __launch_bounds__(256, SEG_W3_OCC) void wgrad3_kernel(Wgrad3Args a) {
     typedef Box<TD, TH, TW, KD> B;
     constexpr int DLD = WLd<T, CP>::v, XLD = WLd<T, CQ>::v;
     constexpr int PT = CP / 16, QT = CQ / 16;
@@ -587,7 +609,7 @@ __device__ __forceinline__ int stem_k_to_halo(int k, int Cimg, int center, int& 
 // (18432 workgroups at 96^3: 1 TB/s).
 constexpr int STEM_NBX = 4;
 template <class T, int TD, int TH, int TW, int KD>
-__global__ __launch_bounds__(256, 2) void stem_fwd_kernel(StemMArgs a) {
+__global__ __launch_bounds__(256, SEG_STEM_OCC) void stem_fwd_kernel(StemMArgs a) {
     typedef Box<TD, TH, TW, KD> B;
     constexpr int MT = B::V / 64, OLD = 16 + 8;
     constexpr int XS = B::HV * 3, OS = B::V * OLD;
