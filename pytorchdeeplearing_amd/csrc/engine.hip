@@ -84,6 +84,8 @@ struct seg_engine {
     // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
     hipStream_t side = nullptr;
     bool use_side = true;
+    bool stem_on_main = true;   // SEG_STEM_MAIN=0: 3^d stem weight gradient on the side stream (round-1 layout)
+    int side_prio = 1;          // SEG_SIDE_PRIO=0: side stream at the default priority
     std::vector<hipEvent_t> ready_ev;
     hipEvent_t side_done = nullptr;
     size_t ready_used = 0;
@@ -99,7 +101,16 @@ struct seg_engine {
     }
     void flush_side(hipStream_t main) {
         if (pending.empty()) return;
-        if (!side) { (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking); (void)hipEventCreateWithFlags(&side_done, hipEventDisableTiming); }
+        if (!side) {
+            // lowest priority: the weight gradients only have to finish before the optimiser, the main stream carries the critical
+            // path.  At equal priority the command processor kept serving the side queue's back-to-back launches while the main
+            // queue's next dispatch waited 30-125 us (profiles/r01_stream_gaps_step24.txt)
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (side_prio && lo != hi) (void)hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo);
+            else (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+            (void)hipEventCreateWithFlags(&side_done, hipEventDisableTiming);
+        }
         if (ready_used == ready_ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ready_ev.push_back(e); }
         hipEvent_t e = ready_ev[ready_used++];
         (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
@@ -765,13 +776,17 @@ struct Planner {
                             seg_engine& E = *this_;
                             const Step& s = E.steps[si];
                             const Ten& i0 = E.tens[s.in0];
-                            const size_t scratch = s.ck == CK_STEM1 ? E.off_partial_stem1 : E.off_partial;
+                            // both stems use the stem scratch when they run on the main stream (in order there); the shared
+                            // partial buffer belongs to whatever the side stream is still reducing
+                            const size_t scratch = (s.ck == CK_STEM1 || E.stem_on_main) ? E.off_partial_stem1 : E.off_partial;
                             const int pi = E.prof_begin(ws_, SEG_K_STEM, E.tbytes(draw) + E.tbytes(s.in0), 0.0);
                             launch_stem_wgrad(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + scratch), E.g + E.params[s.w].off,
                                               E.N, E.dim_d(0), E.dim_h(0), E.dim_w(0), i0.C, s.Cout, s.ck == CK_STEM1, E.ndim, E.dtype, ws_);
                             E.prof_end(ws_, pi);
                         };
-                        if (s.ck == CK_STEM1) { E.flush_side(st); run(st); }
+                        // step-24 trace: with the 3^d stem on the side stream the main stream idled 256 us at the end of every step
+                        // behind wgrad3(16ch@96^3) + the 1^d concat wgrad + this kernel; both stems now run on the main stream
+                        if (s.ck == CK_STEM1 || E.stem_on_main) { E.flush_side(st); run(st); }
                         else { E.defer_wgrad(st, run); E.flush_side(st); }
                         return;
                     }
@@ -855,6 +870,8 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
     e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
     e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
+    if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
+    if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
     if (getenv("SEG_FORK_BATCH") && atoi(getenv("SEG_FORK_BATCH")) > 0) e->fork_batch = atoi(getenv("SEG_FORK_BATCH"));
     Builder b(*e);
     if (net_kind == SEG_NET_VNET) b.build_vnet(); else b.build_unet();
