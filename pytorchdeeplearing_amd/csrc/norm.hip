@@ -430,13 +430,14 @@ void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
 }
 
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
-    // slab size: ~2048 workgroups in total, at least two rows per thread, at most 512 rows (small tensors were
+    // slab size: ~2048 workgroups in total, at least two rows per thread, at most 1024 rows (small tensors were
     // latency-bound with the fixed 512-row slabs: 16 workgroups x 16 serial round trips)
     const int G = 256 / (a.C / 8);
     long long rows = ((long long)a.N * a.V + 2047) / 2048;
     rows = (rows + G - 1) / G * G;
     if (rows < 2 * G) rows = 2 * G;
-    if (rows > 512) rows = 512;
+    static const int max_rows = getenv("SEG_GNB_MAXROWS") ? atoi(getenv("SEG_GNB_MAXROWS")) : 1024;   // measured: 256 -> 686, 512 -> 688, 1024..4096 -> 690.5 volumes/s
+    if (rows > max_rows) rows = max_rows / G * G;
     const int GNB_ROWS = (int)rows;
     dim3 grid(cdiv(a.V, GNB_ROWS), a.N);
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<float>), grid, dim3(256), 0, s, a, GNB_ROWS);
