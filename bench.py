@@ -29,11 +29,15 @@ GB_PER_VOLUME_96 = 2.85
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 PEAK_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA
 # kernel classes whose launches are ONE kernel symbol each (so rocprofv3's per-kernel average is comparable)
-KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel<f16>", "gn_bwd_apply": "gn_bwd_apply_kernel<f16>", "gn_act": "gn_act_kernel<f16>",
+KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel<f16, DUAL=0|1>", "gn_bwd_apply": "gn_bwd_apply_kernel<f16, DUAL=0|1>", "gn_act": "gn_act_kernel<f16>",
                  "conv3_smallbox": "conv3_kernel<f16, 3,8,8 box, KD=3, CH=32, NT=1, LDS weights>"}
 MFMA_BOUND = {"conv3_smallbox", "conv3", "wgrad3"}
-PMC_KEY = {"conv3_smallbox": "conv3_kernel<DF16_Li3ELi8ELi8ELi3ELi32ELi1ELb1E>", "gn_bwd_reduce": "gn_bwd_reduce_kernel<DF16_>",
-           "gn_bwd_apply": "gn_bwd_apply_kernel<DF16_>", "gn_act": "gn_act_kernel<DF16_>"}
+# PMC summary keys (profiles/summarize_pmc.py); the GroupNorm-backward classes have a single- and a dual-branch instantiation of the same
+# template (29 + 1 launches per step): the traffic figure is the launch-weighted mean over both
+PMC_KEY = {"conv3_smallbox": ["conv3_kernel<DF16_Li3ELi8ELi8ELi3ELi32ELi1ELb1E>"],
+           "gn_bwd_reduce": ["gn_bwd_reduce_kernel<DF16_>", "gn_bwd_reduce_kernel<DF16_Lb0E>", "gn_bwd_reduce_kernel<DF16_Lb1E>"],
+           "gn_bwd_apply": ["gn_bwd_apply_kernel<DF16_>", "gn_bwd_apply_kernel<DF16_Lb0E>", "gn_bwd_apply_kernel<DF16_Lb1E>"],
+           "gn_act": ["gn_act_kernel<DF16_>"]}
 
 
 def pmc_traffic(kclass):
@@ -42,8 +46,10 @@ def pmc_traffic(kclass):
     MI355X_MICROARCH.md prescribes).  None when the summary is not available."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")) as f:
-            d = json.load(f)[PMC_KEY[kclass]]
-        return int((2.0 * d["fetch_kb_raw_per_launch"] + d["write_kb_per_launch"]) * 1024)
+            table = json.load(f)
+        rows = [table[k] for k in PMC_KEY[kclass] if k in table]
+        n = sum(r["launches"] for r in rows)
+        return int(sum(r["launches"] * (2.0 * r["fetch_kb_raw_per_launch"] + r["write_kb_per_launch"]) for r in rows) / n * 1024)
     except Exception:
         return None
 

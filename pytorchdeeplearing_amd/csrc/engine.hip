@@ -84,6 +84,7 @@ struct seg_engine {
     // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
     hipStream_t side = nullptr;
     bool use_side = true;
+    bool dual_gn_bwd = true;    // SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
     bool stem_on_main = true;   // SEG_STEM_MAIN=0: 3^d stem weight gradient on the side stream (round-1 layout)
     int side_prio = 1;          // SEG_SIDE_PRIO=0: side stream at the default priority
     std::vector<hipEvent_t> ready_ev;
@@ -672,34 +673,70 @@ struct Planner {
                 std::vector<int> gl = E.tens[s.out].grads;
                 if (gl.empty() || gl.size() > 3) { g_err = "internal: unsupported gradient fan-in"; return; }
                 if (s.res >= 0) for (int gi : gl) E.tens[s.res].grads.push_back(gi);
+                // per-branch argument builders (shared by the single- and the dual-branch op)
+                auto fill = [](seg_engine& E, int ui, const std::vector<int>& gl, GnBwdArgs& a, GnBwdFinArgs& f) {
+                    const Step& u = E.steps[ui];
+                    const Ten& r = E.tens[u.raw];
+                    a = GnBwdArgs{};
+                    a.ndy = (int)gl.size();
+                    for (int i = 0; i < a.ndy; ++i) a.dy[i] = E.ws + E.tens[gl[i]].off;
+                    a.r = E.ws + r.off;
+                    a.scale = (float*)(E.ws + u.scale); a.shift = (float*)(E.ws + u.shift);
+                    a.Q = (double*)(E.ws + u.Q); a.coef = (float*)(E.ws + u.coef);
+                    a.dr = E.ws + E.tens[u.draw].off;
+                    a.N = E.N; a.C = r.C; a.V = E.vol(r.lvl);
+                    f = GnBwdFinArgs{};
+                    f.Q = a.Q; f.stats = (double*)(E.ws + u.stats);
+                    f.gamma = E.p + E.params[u.gn_w].off;
+                    f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
+                             : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                    f.mask_ld = E.ld_mask();
+                    f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
+                    f.dgamma = E.g + E.params[u.gn_w].off; f.dbeta = E.g + E.params[u.gn_b].off;
+                    f.dbias = u.b >= 0 ? E.g + E.params[u.b].off : nullptr;
+                    f.coef = (float*)(E.ws + u.coef);
+                    f.N = E.N; f.C = r.C; f.V = a.V;
+                };
+                const bool dual = s.ua >= 0 && s.ub >= 0 && E.dual_gn_bwd &&
+                                  !gn_bwd_group_eligible(E.tens[E.steps[s.ua].raw].C, E.vol(E.tens[E.steps[s.ua].raw].lvl), (int)E.esz());
+                if (dual) {
+                    // both branches of the VNet input block (one GroupNorm module applied twice, networks/VNet3d.py:36-41) receive
+                    // the SAME gradient sources: one reduce and one apply pass read them once for both (14 -> 10 tensor passes)
+                    Step& ua = E.steps[s.ua];
+                    Step& ub = E.steps[s.ub];
+                    ua.draw = new_grad(ua.raw);
+                    ub.draw = new_grad(ub.raw);
+                    E.bwd_writes.push_back({ua.gn_w, ua.gn_b, ua.b, ub.gn_w, ub.gn_b, ub.b});
+                    E.bwd_ops.push_back([this_ = &E, uia = s.ua, uib = s.ub, gl, fill](hipStream_t st) {
+                        seg_engine& E = *this_;
+                        GnBwdArgs a, b;
+                        GnBwdFinArgs fa, fb;
+                        fill(E, uia, gl, a, fa);
+                        fill(E, uib, gl, b, fb);
+                        a.r2 = b.r; a.scale2 = b.scale; a.shift2 = b.shift; a.Q2 = b.Q; a.coef2 = b.coef; a.dr2 = b.dr;
+                        const double tb = E.tbytes(E.steps[uia].raw);
+                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, tb * (a.ndy + 2), 0.0);
+                        launch_gn_bwd_reduce(a, E.dtype, st);
+                        E.prof_end(st, pi);
+                        launch_gn_bwd_finalize(fa, st);
+                        launch_gn_bwd_finalize(fb, st);
+                        pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, tb * (a.ndy + 4), 0.0);
+                        launch_gn_bwd_apply(a, E.dtype, st);
+                        E.prof_end(st, pi);
+                    });
+                } else
                 for (int ui : {s.ua, s.ub}) {
                     if (ui < 0) continue;
                     Step& u = E.steps[ui];
                     u.draw = new_grad(u.raw);
                     E.bwd_writes.push_back({u.gn_w, u.gn_b, u.b});      // gamma/beta and (analytically) the conv bias
-                    E.bwd_ops.push_back([this_ = &E, ui, gl](hipStream_t st) {
+                    E.bwd_ops.push_back([this_ = &E, ui, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& u = E.steps[ui];
                         const Ten& r = E.tens[u.raw];
-                        GnBwdArgs a{};
-                        a.ndy = (int)gl.size();
-                        for (int i = 0; i < a.ndy; ++i) a.dy[i] = E.ws + E.tens[gl[i]].off;
-                        a.r = E.ws + r.off;
-                        a.scale = (float*)(E.ws + u.scale); a.shift = (float*)(E.ws + u.shift);
-                        a.Q = (double*)(E.ws + u.Q); a.coef = (float*)(E.ws + u.coef);
-                        a.dr = E.ws + E.tens[u.draw].off;
-                        a.N = E.N; a.C = r.C; a.V = E.vol(r.lvl);
-                        GnBwdFinArgs f{};
-                        f.Q = a.Q; f.stats = (double*)(E.ws + u.stats);
-                        f.gamma = E.p + E.params[u.gn_w].off;
-                        f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                                 : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
-                        f.mask_ld = E.ld_mask();
-                        f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
-                        f.dgamma = E.g + E.params[u.gn_w].off; f.dbeta = E.g + E.params[u.gn_b].off;
-                        f.dbias = u.b >= 0 ? E.g + E.params[u.b].off : nullptr;
-                        f.coef = (float*)(E.ws + u.coef);
-                        f.N = E.N; f.C = r.C; f.V = a.V;
+                        GnBwdArgs a;
+                        GnBwdFinArgs f;
+                        fill(E, ui, gl, a, f);
                         if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
                             const int pg = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
                             launch_gn_bwd_group(a, f, E.dtype, st);
@@ -870,6 +907,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
     e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
     e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
+    if (getenv("SEG_DUAL_GN")) e->dual_gn_bwd = atoi(getenv("SEG_DUAL_GN")) != 0;
     if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
     if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
     if (getenv("SEG_FORK_BATCH") && atoi(getenv("SEG_FORK_BATCH")) > 0) e->fork_batch = atoi(getenv("SEG_FORK_BATCH"));

@@ -100,6 +100,9 @@ struct GnBwdArgs {
     void* dr;                                   // pass 2 output T
     int N, C;
     long long V;
+    // optional SECOND branch normalised by the same GroupNorm module and fed by the same gradient sources (the two convolutions
+    // of the VNet input block, networks/VNet3d.py:25-43): one pass reads the gradient sources once for both branches
+    const void* r2; const float* scale2; const float* shift2; double* Q2; const float* coef2; void* dr2;
 };
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
 void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s);

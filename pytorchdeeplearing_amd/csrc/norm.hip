@@ -111,7 +111,7 @@ __device__ __forceinline__ void load_dy_sum(const GnBwdArgs& a, long long i, flo
 
 // pass 1.  grid = (slabs, N); a block reduces `rows_per_block` voxels of one sample over all channels.
 // thread = (chunk column cc, row group g); LDS tree over row groups; fp64 atomics per (n,c).
-template <class T>
+template <class T, bool DUAL>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB_ROWS) {
     __shared__ float red[256 * 16];
     const int tid = threadIdx.x, n = blockIdx.y;
@@ -121,11 +121,17 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
     const long long v0 = (long long)blockIdx.x * GNB_ROWS;
     const long long v1 = (v0 + GNB_ROWS < a.V) ? v0 + GNB_ROWS : a.V;
     const T* r = (const T*)a.r;
+    const T* r2 = (const T*)a.r2;
     const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale + (long long)n * a.C + cc * 8);
     const vec<float, 8> sh = *(const vec<float, 8>*)(a.shift + (long long)n * a.C + cc * 8);
-    float q1[8], q2[8];
+    vec<float, 8> sc2 = sc, sh2 = sh;
+    if (DUAL) {
+        sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + cc * 8);
+        sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + cc * 8);
+    }
+    float q1[8], q2[8], p1[8], p2[8];          // p*: second branch
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; p1[j] = 0.f; p2[j] = 0.f; }
     // two rows in flight per thread: the loop is pure streaming (2-4 x 16 B loads per row)
     long long v = v0 + g;
     for (; v + G < v1; v += 2 * G) {
@@ -134,6 +140,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
         load_dy_sum<T>(a, i0, dy0);
         load_dy_sum<T>(a, i1, dy1);
         const vec<T, 8> x0 = load8(r + i0 * 8), x1 = load8(r + i1 * 8);
+        vec<T, 8> z0 = x0, z1 = x1;
+        if (DUAL) { z0 = load8(r2 + i0 * 8); z1 = load8(r2 + i1 * 8); }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xa = to_f(x0[j]), xb = to_f(x1[j]);
@@ -141,6 +149,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
             const float db = (fmaf(sc[j], xb, sh[j]) > 0.f) ? dy1[j] : 0.f;
             q1[j] += da + db;
             q2[j] = fmaf(da, xa, fmaf(db, xb, q2[j]));
+            if (DUAL) {
+                const float za = to_f(z0[j]), zb = to_f(z1[j]);
+                const float ea = (fmaf(sc2[j], za, sh2[j]) > 0.f) ? dy0[j] : 0.f;
+                const float eb = (fmaf(sc2[j], zb, sh2[j]) > 0.f) ? dy1[j] : 0.f;
+                p1[j] += ea + eb;
+                p2[j] = fmaf(ea, za, fmaf(eb, zb, p2[j]));
+            }
         }
     }
     for (; v < v1; v += G) {
@@ -148,24 +163,37 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
         float dy[8];
         load_dy_sum<T>(a, i, dy);
         const vec<T, 8> x = load8(r + i * 8);
+        vec<T, 8> z = x;
+        if (DUAL) z = load8(r2 + i * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xv = to_f(x[j]);
             const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
             q1[j] += d;
             q2[j] = fmaf(d, xv, q2[j]);
+            if (DUAL) {
+                const float zv = to_f(z[j]);
+                const float e = (fmaf(sc2[j], zv, sh2[j]) > 0.f) ? dy[j] : 0.f;
+                p1[j] += e;
+                p2[j] = fmaf(e, zv, p2[j]);
+            }
         }
     }
+#pragma unroll 1
+    for (int br = 0; br < (DUAL ? 2 : 1); ++br) {
+        if (br) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = q1[j]; red[tid * 16 + 8 + j] = q2[j]; }
-    __syncthreads();
-    // column (cc, j, which) summed over the G row groups by one thread each: CPR*16 <= 512 columns
-    for (int col = tid; col < CPR * 16; col += 256) {
-        const int ccx = col / 16, jj = col % 16;
-        double s = 0.0;
-        for (int k = 0; k < G; ++k) s += red[(k * CPR + ccx) * 16 + jj];
-        const int c = ccx * 8 + (jj & 7), which = jj >> 3;
-        atomicAdd(a.Q + (((long long)(blockIdx.x % STAT_REP) * a.N + n) * a.C + c) * 2 + which, s);
+        for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = br ? p1[j] : q1[j]; red[tid * 16 + 8 + j] = br ? p2[j] : q2[j]; }
+        __syncthreads();
+        // column (cc, j, which) summed over the G row groups by one thread each: CPR*16 <= 512 columns
+        double* Q = br ? a.Q2 : a.Q;
+        for (int col = tid; col < CPR * 16; col += 256) {
+            const int ccx = col / 16, jj = col % 16;
+            double s = 0.0;
+            for (int k = 0; k < G; ++k) s += red[(k * CPR + ccx) * 16 + jj];
+            const int c = ccx * 8 + (jj & 7), which = jj >> 3;
+            atomicAdd(Q + (((long long)(blockIdx.x % STAT_REP) * a.N + n) * a.C + c) * 2 + which, s);
+        }
     }
 }
 
@@ -220,7 +248,7 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
     }
 }
 
-template <class T>
+template <class T, bool DUAL>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
     const int CPR = a.C / 8;
     const long long per_n = a.V * CPR, total = (long long)a.N * per_n;
@@ -243,6 +271,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
             o[j] = from_f<T>(fmaf(co[j * 3], d, fmaf(co[j * 3 + 1], xv, co[j * 3 + 2])));
         }
         store8(dr + i * 8, o);
+        if (DUAL) {
+            const vec<T, 8> z = load8((const T*)a.r2 + i * 8);
+            const float* sc2 = a.scale2 + (long long)n * a.C + c0;
+            const float* sh2 = a.shift2 + (long long)n * a.C + c0;
+            const float* co2 = a.coef2 + ((long long)n * a.C + c0) * 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float zv = to_f(z[j]);
+                const float d = (fmaf(sc2[j], zv, sh2[j]) > 0.f) ? dy[j] : 0.f;
+                o[j] = from_f<T>(fmaf(co2[j * 3], d, fmaf(co2[j * 3 + 1], zv, co2[j * 3 + 2])));
+            }
+            store8((T*)a.dr2 + i * 8, o);
+        }
     }
 }
 
@@ -440,9 +481,10 @@ void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
     if (rows > max_rows) rows = max_rows / G * G;
     const int GNB_ROWS = (int)rows;
     dim3 grid(cdiv(a.V, GNB_ROWS), a.N);
-    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<float>), grid, dim3(256), 0, s, a, GNB_ROWS);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<f16>), grid, dim3(256), 0, s, a, GNB_ROWS);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<bf16>), grid, dim3(256), 0, s, a, GNB_ROWS);
+#define SEG_GNR(T_, D_) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<T_, D_>), grid, dim3(256), 0, s, a, GNB_ROWS)
+    if (a.r2) { if (dtype == DT_F32) SEG_GNR(float, true); else if (dtype == DT_F16) SEG_GNR(f16, true); else SEG_GNR(bf16, true); }
+    else { if (dtype == DT_F32) SEG_GNR(float, false); else if (dtype == DT_F16) SEG_GNR(f16, false); else SEG_GNR(bf16, false); }
+#undef SEG_GNR
 }
 
 // measured on MI355X: one workgroup per (n,g) only wins while the per-sample tensor is <= ~128 KB (the 6^3 level:
@@ -471,9 +513,10 @@ void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s) {
 
 void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s) {
     dim3 grid(ew_blocks((long long)a.N * a.V * (a.C / 8)));
-    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<float>), grid, dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<f16>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<bf16>), grid, dim3(256), 0, s, a);
+#define SEG_GNA(T_, D_) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_>), grid, dim3(256), 0, s, a)
+    if (a.r2) { if (dtype == DT_F32) SEG_GNA(float, true); else if (dtype == DT_F16) SEG_GNA(f16, true); else SEG_GNA(bf16, true); }
+    else { if (dtype == DT_F32) SEG_GNA(float, false); else if (dtype == DT_F16) SEG_GNA(f16, false); else SEG_GNA(bf16, false); }
+#undef SEG_GNA
 }
 
 }  // namespace seg

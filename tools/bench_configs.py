@@ -30,3 +30,41 @@ for name, (kind, ndim, shape, ncls, loss, dt) in CONFIGS.items():
     print(json.dumps({"config": name, "ms_per_step": round(ms, 2), "samples_per_s": round(shape[0] / ms * 1e3, 1), "class_ms": prof}))
     del e
     torch.cuda.empty_cache()
+
+# BASELINE configs[4] as worded: VNet3d 1x160^3 bf16 **+ clDice loss** (Dice on the logits + soft-clDice on the probabilities).
+# clDice is an autograd Function over the HIP skeleton kernels, so this step goes through the module (autograd) path:
+# net(x) -> losses -> loss.backward() (engine backward inside) -> fused AdamW on the engine's flat buffers.
+os.environ["SEGENGINE_DTYPE"] = "bf16"
+from pytorchdeeplearing_amd import networks as NW, losses as LS
+from pytorchdeeplearing_amd.lossescldice import Binary_Soft_cldice_loss
+net = NW.VNet3d(1, 1).to(dev)
+net.apply(NW.initialize_weights)
+net.train()
+eng = net.engine
+eng.init_optimizer()
+x, y = seg.synthetic_batch(1, (160, 160, 160), 1, 1, seed=1)
+x, y = x.to(dev), y.to(dev)
+yf = y.float().reshape(1, 1, 160, 160, 160)
+dice, cld = LS.BinaryDiceLoss(), Binary_Soft_cldice_loss()
+
+
+def cl_step():
+    for p in net.parameters():
+        p.grad = None
+    logits, probs = net(x)
+    loss = dice(logits, y) + cld(probs, yf)
+    loss.backward()
+    eng.adam_step()
+    eng.pack_weights()
+    return loss
+
+
+first = float(cl_step())
+for _ in range(2):
+    cl_step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    last = cl_step()
+torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
+print(json.dumps({"config": "C5 VNet3d 1x160^3 bf16 + Dice + soft-clDice (autograd path)", "ms_per_step": round(ms, 2),
+                  "samples_per_s": round(1e3 / ms, 1), "loss_first": round(first, 5), "loss_after_13_steps": round(float(last), 5)}))
