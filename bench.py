@@ -116,8 +116,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    from oracle import seg_oracle as seg   # synthetic inputs + the cpu_baseline leg only
-    from pytorchdeeplearing_amd import SegEngine
+    from pytorchdeeplearing_amd import SegEngine, synthetic   # oracle/ is touched by the cpu_baseline leg only
     from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GlobalBatchLoss, GradAllReduce
 
     S = a.size
@@ -126,8 +125,8 @@ def main():
         e = LaneEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev, lanes=a.lanes)
     else:
         e = SegEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev)
-    e.load_state_dict(seg.init_params("vnet", 3, 1, 1, seed=0))
-    x, y = seg.synthetic_batch(a.batch, (S, S, S), 1, 1, seed=1234 + rank)
+    synthetic.init_engine(e, seed=0)
+    x, y = synthetic.synthetic_batch(a.batch, (S, S, S), 1, 1, seed=1234 + rank)
     x, y = x.to(dev), y.to(dev)
     logits = torch.empty((a.batch, 1, S, S, S), dtype=torch.float32, device=dev)
     probs = torch.empty_like(logits)

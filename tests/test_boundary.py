@@ -132,3 +132,28 @@ def test_product_library_exports_every_symbol_the_header_declares():
     unbound = sorted(declared - set(_capi.SIGNATURES))
     undeclared = sorted(set(_capi.SIGNATURES) - declared)
     assert not unbound and not undeclared, (unbound, undeclared)
+
+
+def test_bench_and_product_do_not_touch_the_oracle_outside_the_cpu_baseline_leg():
+    """oracle/ is test infrastructure: the package never imports it, and bench.py only inside cpu_baseline()."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _dirs, files in os.walk(os.path.join(root, "pytorchdeeplearing_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                tree = ast.parse(open(os.path.join(dirpath, f)).read())
+                for node in ast.walk(tree):
+                    names = [a.name for a in node.names] if isinstance(node, ast.Import) else \
+                            [node.module or ""] if isinstance(node, ast.ImportFrom) else []
+                    assert not any(n == "oracle" or n.startswith("oracle.") for n in names), (f, names)
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                mod = node.module if isinstance(node, ast.ImportFrom) else node.names[0].name
+                if mod and mod.split(".")[0] == "oracle":
+                    assert fn.name == "cpu_baseline", fn.name
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            mod = node.module if isinstance(node, ast.ImportFrom) else node.names[0].name
+            assert not (mod and mod.split(".")[0] == "oracle")

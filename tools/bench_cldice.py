@@ -3,7 +3,7 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from oracle.make_golden import cldice_inputs
+from pytorchdeeplearing_amd.synthetic import vessel_fields as cldice_inputs
 from pytorchdeeplearing_amd.lossescldice import Binary_Soft_cldice_loss
 
 SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(1, 1, 160, 160, 160), (4, 1, 96, 96, 96), (16, 1, 512, 512)]

@@ -3,12 +3,12 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from oracle import seg_oracle as seg
+from pytorchdeeplearing_amd import synthetic as seg
 from pytorchdeeplearing_amd import SegEngine
 
 dev = torch.device("cuda")
 e = SegEngine("vnet", 3, 1, 1, dtype="f16", device=dev)
-e.load_state_dict(seg.init_params("vnet", 3, 1, 1, seed=0))
+seg.init_engine(e, seed=0)
 x, y = seg.synthetic_batch(4, (96, 96, 96), 1, 1, seed=1234)
 x, y = x.to(dev), y.to(dev)
 logits = torch.empty((4, 1, 96, 96, 96), dtype=torch.float32, device=dev)
