@@ -77,7 +77,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, seconds_budget=25.0):
+def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0):
     """The oracle (torch-CPU port of the reference path, oracle/seg_oracle.py) on this box's host cores,
     bounded sample of the same workload: VNet3d 1 x 1 x size^3 train steps (fp32, all cores, dropout on)."""
     from oracle import seg_oracle as seg
@@ -100,9 +100,37 @@ def cpu_baseline(size, seconds_budget=25.0):
         if time.time() - t_start > seconds_budget:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
+    base = {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
             "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (torch %s CPU, %d threads), best step %.3f s"
                       % (len(times), size, torch.__version__, ncores, best)}
+    return base, _dice_vs_reference(seg, trained_state, dev, dtype)
+
+
+def _dice_vs_reference(seg, trained_state, dev, dtype, size=48):
+    """BASELINE metric, second half ("Dice vs ref"): one eval forward of a 1 x 1 x 48^3 volume through the engine (run dtype and
+    f32) and through the oracle on the host, same weights; integer-mask Dice against the synthetic label must be identical
+    when the masks are (model/metric.py:146-155).  Weights: the benchmark's random init with biases / GroupNorm affine perturbed
+    (the weights after the timed steps predict all-foreground on random labels: a trivial mask).  Called from cpu_baseline only."""
+    from pytorchdeeplearing_amd import SegEngine, synthetic
+    init = synthetic.init_engine(SegEngine("vnet", 3, 1, 1, dtype="f32", device=dev), seed=0).state_dict()
+    sd = seg.perturb_params({k: v.detach().float().cpu() for k, v in init.items()}, seed=7)
+    x, y = seg.synthetic_batch(1, (size,) * 3, 1, 1, seed=4321)
+    logits_ref, probs_ref = seg.net_forward("vnet", sd, x)
+    mask_ref = probs_ref > 0.5
+    dice_ref = float(seg.dice_coeff(probs_ref, y))
+    out = {"case": "VNet3d eval forward, 1x1x%d^3, random-init weights (perturbed affine), vs the torch-CPU oracle (fp32)" % size,
+           "dice_oracle": round(dice_ref, 7), "foreground_fraction_oracle": round(float(mask_ref.float().mean()), 4)}
+    for dt in dict.fromkeys([dtype, "f32"]):
+        e = SegEngine("vnet", 3, 1, 1, dtype=dt, device=dev)
+        e.load_state_dict(sd)
+        logits, probs = e.forward(x.to(dev))
+        out3 = e.loss_forward(logits, y.to(dev), "BinaryDiceLoss").cpu()
+        mism = int(((probs.cpu() > 0.5) != mask_ref).sum())
+        out[dt] = {"dice_engine": round(float(out3[1]), 7), "mask_mismatch_voxels": mism, "voxels": int(mask_ref.numel()),
+                   "logits_max_abs_diff": float((logits.cpu() - logits_ref).abs().max())}
+        del e
+    return out
+
 
 
 def main():
@@ -258,7 +286,7 @@ def main():
         if table:
             line["kernel_classes"] = table
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(S)
+            line["cpu_baseline"], line["dice_vs_ref"] = cpu_baseline(S, e.state_dict() if a.lanes == 1 else e.engines[0].state_dict(), dev, a.dtype)
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()
