@@ -95,33 +95,54 @@ struct seg_engine {
     // optimiser), so a fork per weight gradient (35 per step) cost more than it bought.
     std::vector<std::function<void(hipStream_t)>> pending;
     int fork_batch = 6;      // measured on MI355X (VNet3d 4x96^3): 1 -> 641, 3 -> 645, 6 -> 649 volumes/s
+    // Up to two weight-gradient streams, each with its own partial-tile scratch: the kernels behind them run with 3-512 workgroups,
+    // so two of them side by side fill CUs that one alone leaves idle (SEG_WGRAD_STREAMS, default in seg_create)
+    int n_side = 1;
+    hipStream_t side2 = nullptr;
+    hipEvent_t side2_done = nullptr;
+    size_t off_partial2 = 0, cur_partial = 0;
+    int rr = 0;                 // round-robin cursor over the side streams
+    hipStream_t make_side() {
+        // lowest priority: the weight gradients only have to finish before the optimiser, the main stream carries the critical
+        // path.  At equal priority the command processor kept serving the side queue's back-to-back launches while the main
+        // queue's next dispatch waited 30-125 us (profiles/r01_stream_gaps_step25.txt)
+        hipStream_t st = nullptr;
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (side_prio && lo != hi) (void)hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo);
+        else (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        return st;
+    }
     void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> f) {
-        if (!use_side) { f(main); return; }
+        if (!use_side) { cur_partial = off_partial; f(main); return; }
         pending.push_back(std::move(f));
         if ((int)pending.size() >= fork_batch) flush_side(main);
     }
     void flush_side(hipStream_t main) {
         if (pending.empty()) return;
         if (!side) {
-            // lowest priority: the weight gradients only have to finish before the optimiser, the main stream carries the critical
-            // path.  At equal priority the command processor kept serving the side queue's back-to-back launches while the main
-            // queue's next dispatch waited 30-125 us (profiles/r01_stream_gaps_step24.txt)
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (side_prio && lo != hi) (void)hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo);
-            else (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+            side = make_side();
             (void)hipEventCreateWithFlags(&side_done, hipEventDisableTiming);
+            if (n_side > 1) { side2 = make_side(); (void)hipEventCreateWithFlags(&side2_done, hipEventDisableTiming); }
         }
         if (ready_used == ready_ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ready_ev.push_back(e); }
         hipEvent_t e = ready_ev[ready_used++];
         (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
         (void)hipStreamWaitEvent(side, e, 0);
-        for (auto& f : pending) f(side);
+        if (side2) (void)hipStreamWaitEvent(side2, e, 0);
+        for (auto& f : pending) {
+            const bool second = side2 && (rr++ & 1);
+            cur_partial = second ? off_partial2 : off_partial;
+            f(second ? side2 : side);
+        }
         pending.clear();
     }
     void join_side(hipStream_t main) {
         flush_side(main);
-        if (use_side && side && ready_used) { (void)hipEventRecord(side_done, side); (void)hipStreamWaitEvent(main, side_done, 0); }
+        if (use_side && side && ready_used) {
+            (void)hipEventRecord(side_done, side); (void)hipStreamWaitEvent(main, side_done, 0);
+            if (side2) { (void)hipEventRecord(side2_done, side2); (void)hipStreamWaitEvent(main, side2_done, 0); }
+        }
         ready_used = 0;
     }
     // measurement (seg_profile_*)
@@ -492,6 +513,7 @@ struct Planner {
                 }
             }
         E.off_partial = alloc(pmax);
+        E.off_partial2 = E.n_side > 1 ? alloc(pmax) : E.off_partial;
         E.off_partial_stem1 = alloc(stem_wgrad_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), 16 * ((E.feat + 15) / 16)));
 
         // ------------------------------------------------------------------ forward schedule
@@ -785,7 +807,7 @@ struct Planner {
                             const Step& s = E.steps[si];
                             const Ten& i0 = E.tens[s.in0];
                             const int pi = E.prof_begin(ws_, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), fl);
-                            launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.off_partial), E.g + E.params[s.w].off,
+                            launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.cur_partial), E.g + E.params[s.w].off,
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
                                           s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
                             E.prof_end(ws_, pi);
@@ -815,7 +837,7 @@ struct Planner {
                             const Ten& i0 = E.tens[s.in0];
                             // both stems use the stem scratch when they run on the main stream (in order there); the shared
                             // partial buffer belongs to whatever the side stream is still reducing
-                            const size_t scratch = (s.ck == CK_STEM1 || E.stem_on_main) ? E.off_partial_stem1 : E.off_partial;
+                            const size_t scratch = (s.ck == CK_STEM1 || E.stem_on_main) ? E.off_partial_stem1 : E.cur_partial;
                             const int pi = E.prof_begin(ws_, SEG_K_STEM, E.tbytes(draw) + E.tbytes(s.in0), 0.0);
                             launch_stem_wgrad(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + scratch), E.g + E.params[s.w].off,
                                               E.N, E.dim_d(0), E.dim_h(0), E.dim_w(0), i0.C, s.Cout, s.ck == CK_STEM1, E.ndim, E.dtype, ws_);
@@ -834,7 +856,7 @@ struct Planner {
                         WgradArgs w = make_wgrad_args(E, s, draw);
                         const int pi = E.prof_begin(ws_, SEG_K_WGRAD_GENERIC,
                                                     E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
-                        launch_wgrad(w, (float*)(E.ws + E.off_partial), E.dtype, ws_);
+                        launch_wgrad(w, (float*)(E.ws + E.cur_partial), E.dtype, ws_);
                         E.prof_end(ws_, pi);
                     });
                     // ---- data gradient(s)
@@ -910,6 +932,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (getenv("SEG_DUAL_GN")) e->dual_gn_bwd = atoi(getenv("SEG_DUAL_GN")) != 0;
     if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
     if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
+    if (getenv("SEG_WGRAD_STREAMS")) e->n_side = atoi(getenv("SEG_WGRAD_STREAMS")) >= 2 ? 2 : 1;
     if (getenv("SEG_FORK_BATCH") && atoi(getenv("SEG_FORK_BATCH")) > 0) e->fork_batch = atoi(getenv("SEG_FORK_BATCH"));
     Builder b(*e);
     if (net_kind == SEG_NET_VNET) b.build_vnet(); else b.build_unet();
@@ -923,6 +946,8 @@ void seg_destroy(seg_handle h) {
     for (auto e : h->ready_ev) (void)hipEventDestroy(e);
     if (h->side_done) (void)hipEventDestroy(h->side_done);
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side2_done) (void)hipEventDestroy(h->side2_done);
+    if (h->side2) (void)hipStreamDestroy(h->side2);
     delete h;
 }
 
