@@ -819,12 +819,15 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) {
     const int CP = P >= 32 ? 32 : 16, CQ = Q >= 32 ? 32 : 16;
     const int combos = (P / CP) * (Q / CQ);
-    long long nb = 512 / combos;
+    static const int total = getenv("SEG_W3_TOTAL") ? atoi(getenv("SEG_W3_TOTAL")) : 512;     // tuning knobs
+    static const int minbox = getenv("SEG_W3_MINBOX") ? atoi(getenv("SEG_W3_MINBOX")) : 6;
+    long long nb = total / combos;
     if (nb < 1) nb = 1;
     const long long nbox = boxes_for(ndim, N, D, H, W);
     // small levels: every workgroup writes (and the reduce re-reads) a full partial tile, so do not split the
-    // box list finer than ~3 boxes per workgroup
-    if (nb > (nbox + 2) / 3) nb = (nbox + 2) / 3;
+    // box list finer than ~6 boxes per workgroup (measured, profiles/r01_wgrad3_policy_ab_step31.log: 3 -> 694, 4 -> 698,
+    // 5 -> 698, 6 -> 700, 8 -> 690 volumes/s; 256 / 384 / 768 total workgroups instead of 512: 691 / 694 / 680)
+    if (nb > (nbox + minbox - 1) / minbox) nb = (nbox + minbox - 1) / minbox;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
