@@ -10,6 +10,7 @@
 // (deterministic, no same-address atomics).
 // Pinned by autograd of the conv call sites in networks/VNet3d.py / Unet3d.py (reference).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace seg {
 namespace {
@@ -247,11 +248,13 @@ WgPlan make_plan(const WgradArgs& a) {
     pl.ntg = (T + pl.TB - 1) / pl.TB;
     const int bx = pl.ntg * pl.ntile;
     // voxel-axis split: ~2048 workgroups in total, at most 1024 slices and 16 MB of partial tiles
-    long long parts = 2048 / bx;
+    static const long long total = getenv("SEG_WG_TOTAL") ? atoll(getenv("SEG_WG_TOTAL")) : 2048;        // tuning knobs
+    static const long long pcap = getenv("SEG_WG_CAP") ? atoll(getenv("SEG_WG_CAP")) : (4ll << 20);
+    long long parts = total / bx;
     if (parts < 1) parts = 1;
     if (parts > 1024) parts = 1024;
     const long long elems = (long long)a.P * T * a.Q;
-    if (parts * elems > (4ll << 20)) parts = (4ll << 20) / elems;
+    if (parts * elems > pcap) parts = pcap / elems;
     if (parts < 1) parts = 1;
     const long long maxp = (M + WM - 1) / WM;
     if (parts > maxp) parts = maxp;
