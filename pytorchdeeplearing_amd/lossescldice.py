@@ -34,15 +34,20 @@ class _SoftSkel(torch.autograd.Function):
         xin = x.float().contiguous()
         lib, st = _lib(xin), _capi.stream_for(xin.device)
         p, d, h, w, nd = _dims(xin)
+        # ONE work buffer for the whole iteration chain ([iteration][e | next x]) instead of 2 x width allocations per call: the
+        # caching allocator was the dominant cost whenever the tensor shape changed between calls (13-16 ms vs 2.3 ms of kernels,
+        # profiles/r01_cldice_step23_shapes.jsonl)
+        work = torch.empty((width, 2) + tuple(xin.shape), dtype=torch.float32, device=xin.device)
         xs, es = [], []
         cur = xin
-        for _ in range(width):
-            e = torch.empty_like(cur)
-            nxt = torch.empty_like(cur)
+        for it in range(width):
+            e, nxt = work[it, 0], work[it, 1]
             lib.check(lib.seg_op_skel_iter(cur.data_ptr(), e.data_ptr(), nxt.data_ptr(), p, d, h, w, nd, st), "seg_op_skel_iter")
             xs.append(cur)
             es.append(e)
             cur = nxt
+        if width == 0:
+            cur = xin.clone()
         ctx.xs, ctx.es, ctx.geom, ctx.in_dtype = xs, es, (p, d, h, w, nd), x.dtype
         return cur
 
@@ -51,12 +56,15 @@ class _SoftSkel(torch.autograd.Function):
         g = g.float().contiguous()
         lib, st = _lib(g), _capi.stream_for(g.device)
         p, d, h, w, nd = ctx.geom
-        de = torch.empty_like(g)                       # work buffer of the gather passes (fully overwritten every iteration)
-        for x, e in zip(reversed(ctx.xs), reversed(ctx.es)):
-            dx = torch.empty_like(x)
+        # work buffers: de for the gather passes (fully overwritten every iteration) and two ping-pong gradient buffers
+        buf = torch.empty((3,) + tuple(g.shape), dtype=torch.float32, device=g.device)
+        de = buf[2]
+        for i, (x, e) in enumerate(zip(reversed(ctx.xs), reversed(ctx.es))):
+            dx = buf[i & 1]
             lib.check(lib.seg_op_skel_iter_bwd(g.data_ptr(), x.data_ptr(), e.data_ptr(), dx.data_ptr(), de.data_ptr(), p, d, h, w, nd, st),
                       "seg_op_skel_iter_bwd")
             g = dx
+        g = g.clone() if len(ctx.xs) else g               # detach the result from the work buffer
         return g.to(ctx.in_dtype), None
 
 
