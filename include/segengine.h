@@ -29,7 +29,13 @@ enum {
     SEG_LOSS_BINARY_CE_DICE = 3,  /* model/losses.py:184-197 BinaryCrossEntropyDiceLoss */
     SEG_LOSS_MULTI_CE = 4,        /* model/losses.py:247-260 MutilCrossEntropyLoss */
     SEG_LOSS_MULTI_FOCAL = 5,     /* model/losses.py:263-285 MutilFocalLoss */
-    SEG_LOSS_MULTI_DICE = 6       /* model/losses.py:288-325 MutilDiceLoss */
+    SEG_LOSS_MULTI_DICE = 6,      /* model/losses.py:288-325 MutilDiceLoss */
+    /* not selectable through the reference wrappers' loss_name; same reduction, other ratios */
+    SEG_LOSS_BINARY_JACCARD = 7,  /* model/losses.py:9-30    BinaryJaccardLoss */
+    SEG_LOSS_BINARY_ELDICE = 8,   /* model/losses.py:56-74   BinaryELDiceLoss */
+    SEG_LOSS_BINARY_TVERSKY = 9,  /* model/losses.py:102-126 BinaryTverskyLoss (alpha 0.3, beta 0.7) */
+    SEG_LOSS_MULTI_CE_DICE = 10,  /* model/losses.py:328-342 MutilCrossEntropyDiceLoss */
+    SEG_LOSS_MULTI_ELDICE = 11    /* model/losses.py:345-382 MutilELDiceLoss */
 };
 enum { SEG_MASKS_EVAL = 0, SEG_MASKS_GIVEN = 1, SEG_MASKS_RANDOM = 2 };
 

@@ -51,6 +51,31 @@ def make_losses(nets, losses, metric):
     print("losses:", {k: float(v) for k, v in out.items() if k.startswith("loss_")})
 
 
+def make_losses_extra(losses):
+    """the model/losses.py classes no wrapper selects but which the engine implements from the same sums"""
+    torch.manual_seed(0)
+    z = torch.randn(2, 1, 8, 8, 8)
+    y = (torch.rand(2, 8, 8, 8) > 0.7).long()
+    z4 = torch.randn(2, 4, 8, 8, 8)
+    y4 = torch.randint(0, 4, (2, 8, 8, 8))
+    y4[y4 == 3] = 2                                   # class 3 absent: exercises the present-class mask
+    a = torch.tensor([0.5, 1.0, 1.5, 1.0])
+    out = dict(z=_np(z), y=_np(y), z4=_np(z4), y4=_np(y4), alpha=_np(a))
+    for name, f, args in (
+            ("BinaryJaccardLoss", losses.BinaryJaccardLoss(), (z, y)),
+            ("BinaryELDiceLoss", losses.BinaryELDiceLoss(), (z, y)),
+            ("BinaryTverskyLoss", losses.BinaryTverskyLoss(), (z, y)),
+            ("MutilCrossEntropyDiceLoss", losses.MutilCrossEntropyDiceLoss(a), (z4, y4)),
+            ("MutilELDiceLoss", losses.MutilELDiceLoss(a), (z4, y4))):
+        zz = args[0].clone().requires_grad_(True)
+        val = f(zz, args[1])
+        val.backward()
+        out["loss_" + name] = _np(val)
+        out["grad_" + name] = _np(zz.grad)
+    np.savez_compressed(os.path.join(OUT, "losses_extra.npz"), **out)
+    print("extra losses:", {k: float(v) for k, v in out.items() if k.startswith("loss_")})
+
+
 def grad_summary(g):
     """Compact, order-sensitive fingerprint of one gradient tensor: sum, L2 norm, and 16 entries
     at fixed pseudo-random flat positions."""
@@ -216,12 +241,17 @@ def main():
     make_prepost()
     if "--only-prepost" in sys.argv:
         return
+    if "--only-losses-extra" in sys.argv:
+        _nets, losses, _metric = ref_loader.load()
+        make_losses_extra(losses)
+        return
     make_cldice()
     if "--only-cldice" in sys.argv:
         return
     nets, losses, metric = ref_loader.load()
     torch.set_num_threads(1)
     make_losses(nets, losses, metric)
+    make_losses_extra(losses)
     from . import seg_oracle as seg
     a4 = torch.ones(4)
     make_net(nets, losses, seg, "vnet3d_bin_16", "vnet", 3, lambda: nets.VNet3d(1, 1), (2, 1, 16, 16, 16), 1,

@@ -346,7 +346,57 @@ def multi_dice_loss(logits, y, alpha):
     return (loss * alpha.to(loss.dtype)).sum() / torch.count_nonzero(mask)
 
 
+# ---- model/losses.py classes that no wrapper's loss_name selects; pinned by tests/golden/losses_extra.npz
+def _bin_sums(logits, y):
+    z, t = _flat2(logits, y)
+    p = torch.sigmoid(z)
+    return (p * t).sum(), p.sum(), t.sum()
+
+
+def binary_jaccard_loss(logits, y):
+    """model/losses.py:19-30"""
+    i, ps, ys = _bin_sums(logits, y)
+    return 1.0 - (i + 1e-5) / (ps + ys - i + 1e-5).clamp_min(1e-7)
+
+
+def binary_eldice_loss(logits, y):
+    """model/losses.py:66-74"""
+    i, ps, ys = _bin_sums(logits, y)
+    dsc = (2.0 * i + 1e-5) / (ps + ys + 1e-5).clamp_min(1e-7)
+    return torch.clamp(torch.pow(-torch.log(dsc + 1e-5), 0.3), 0, 2)
+
+
+def binary_tversky_loss(logits, y):
+    """model/losses.py:113-126 (alpha 0.3 on false positives, beta 0.7 on false negatives)"""
+    tp, ps, ys = _bin_sums(logits, y)
+    fp, fn = ps - tp, ys - tp
+    return torch.clamp(1 - (tp + 1e-5) / (tp + 0.3 * fp + 0.7 * fn + 1e-5), 0, 2)
+
+
+def multi_ce_dice_loss(logits, y, alpha):
+    """model/losses.py:337-342"""
+    return multi_ce_loss(logits, y, alpha) + multi_dice_loss(logits, y, alpha)
+
+
+def multi_eldice_loss(logits, y, alpha):
+    """model/losses.py:361-382 — absent classes enter as dice 0 (a constant term), present ones as dice * alpha"""
+    z, t = _mc_flat(logits, y)
+    p = torch.softmax(z, dim=1)
+    oh = F.one_hot(t, z.shape[1]).permute(0, 2, 1)
+    inter = torch.sum(oh * p, dim=(0, 2))
+    den = torch.sum(oh + p, dim=(0, 2))
+    dice = ((2.0 * inter + 1e-5) / (den + 1e-5)).clamp_min(1e-7)
+    mask = oh.sum((0, 2)) > 0
+    dice = dice * mask.to(dice.dtype) * alpha.to(dice.dtype)
+    return torch.clamp(torch.pow(-torch.log(dice + 1e-5), 0.3).sum() / torch.count_nonzero(mask), 0, 2)
+
+
 LOSSES = {
+    "BinaryJaccardLoss": binary_jaccard_loss,
+    "BinaryELDiceLoss": binary_eldice_loss,
+    "BinaryTverskyLoss": binary_tversky_loss,
+    "MutilCrossEntropyDiceLoss": multi_ce_dice_loss,
+    "MutilELDiceLoss": multi_eldice_loss,
     "BinaryDiceLoss": binary_dice_loss,
     "BinaryCrossEntropyLoss": binary_ce_loss,
     "BinaryFocalLoss": binary_focal_loss,
@@ -359,7 +409,7 @@ LOSSES = {
 
 def loss_fn(name, alpha=None, gamma=None):
     f = LOSSES[name]
-    if name == "MutilDiceLoss":
+    if name in ("MutilDiceLoss", "MutilCrossEntropyDiceLoss", "MutilELDiceLoss"):
         return lambda z, y: f(z, y, alpha)
     if name == "MutilFocalLoss":
         return lambda z, y: f(z, y, alpha, 2 if gamma is None else gamma)

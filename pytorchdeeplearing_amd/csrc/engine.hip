@@ -1084,8 +1084,9 @@ static int fill_loss(LossArgs& a, const float* logits, const void* target, int l
                      int loss_kind, float focal_alpha, float focal_gamma, void* ws) {
     if (!logits || !target || !ws) return fail("loss: null pointer");
     if (c < 1 || c > 8) return fail("loss: classes must be 1..8");
-    if (loss_kind < 0 || loss_kind > 6) return fail("loss: unknown loss kind");
-    if ((c == 1) != (loss_kind <= SEG_LOSS_BINARY_CE_DICE)) return fail("loss: binary losses need C == 1, multi-class losses C > 1");
+    if (loss_kind < 0 || loss_kind >= L_KIND_COUNT) return fail("loss: unknown loss kind");
+    const bool binary_kind = loss_kind <= SEG_LOSS_BINARY_CE_DICE || (loss_kind >= L_BIN_JACCARD && loss_kind <= L_BIN_TVERSKY);
+    if ((c == 1) != binary_kind) return fail("loss: binary losses need C == 1, multi-class losses C > 1");
     a.logits = logits; a.target = target; a.label_type = label_type; a.N = n; a.C = c; a.V = v; a.kind = loss_kind;
     a.focal_alpha = focal_alpha; a.focal_gamma = focal_gamma; a.class_alpha = nullptr; a.sums = (double*)ws;
     a.out = nullptr; a.dlogits = nullptr; a.grad_scale = 1.f; a.phase = 0; a.n_global = 0;

@@ -258,6 +258,30 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
         K[0] = -2.0 / D;      // d dice / d p_i = K0*y_i + K1
         K[1] = c0;
         K[2] = 1.0 / Ntot;
+        // losses that are other ratios of the same three sums: d L / d p_i = K0*y_i + K1 with K0 = dL/dI, K1 = dL/dP
+        if (a.kind == L_BIN_JACCARD) {              // model/losses.py:9-30
+            double U = P + Y - I + smooth;
+            const bool cl = U < eps;
+            if (cl) U = eps;
+            loss = 1.0 - (I + smooth) / U;
+            K[0] = cl ? -1.0 / U : -(1.0 / U + (I + smooth) / (U * U));
+            K[1] = cl ? 0.0 : (I + smooth) / (U * U);
+        } else if (a.kind == L_BIN_ELDICE) {        // model/losses.py:56-74: clamp((-log(dsc + smooth))^0.3, 0, 2)
+            const double dsc = (2.0 * I + smooth) / D;
+            const double t = -log(dsc + smooth), v = pow(t, 0.3);
+            loss = v < 0.0 ? 0.0 : (v > 2.0 ? 2.0 : v);               // NaN (dsc + smooth > 1) propagates as in the reference
+            const double g = (v >= 0.0 && v <= 2.0) ? 0.3 * pow(t, -0.7) * (-1.0 / (dsc + smooth)) : 0.0;
+            K[0] = g * 2.0 / D;
+            K[1] = (P + Y + smooth < eps) ? 0.0 : -g * (2.0 * I + smooth) / (D * D);
+        } else if (a.kind == L_BIN_TVERSKY) {       // model/losses.py:102-126: alpha = 0.3 (false positives), beta = 0.7 (false negatives)
+            const double al = 0.3, be = 0.7;
+            const double den = I + al * (P - I) + be * (Y - I) + smooth;
+            const double v = 1.0 - (I + smooth) / den;
+            loss = v < 0.0 ? 0.0 : (v > 2.0 ? 2.0 : v);
+            const bool in = v >= 0.0 && v <= 2.0;
+            K[0] = in ? -(den - (I + smooth) * (1.0 - al - be)) / (den * den) : 0.0;
+            K[1] = in ? (I + smooth) * al / (den * den) : 0.0;
+        }
     } else {
         int cnt = 0;
         for (int c = 0; c < C; ++c) cnt += S[S_CLASS + 3 * c + 2] > 0.0;
@@ -280,7 +304,28 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
         }
         if (a.kind == L_MC_DICE) loss = dl;
         else if (a.kind == L_MC_CE) loss = S[3] / Ntot;
-        else loss = S[4] / Ntot;
+        else if (a.kind == L_MC_CE_DICE) loss = dl + S[3] / Ntot;         // model/losses.py:328-342
+        else if (a.kind == L_MC_ELDICE) {
+            // model/losses.py:345-382: dice_c (0 for absent classes) * alpha_c -> clamp(sum_c (-log(. + smooth))^0.3 / present, 0, 2)
+            double tot = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const double I = S[S_CLASS + 3 * c], P = S[S_CLASS + 3 * c + 1], Y = S[S_CLASS + 3 * c + 2];
+                const double al = a.class_alpha ? (double)a.class_alpha[c] : 1.0;
+                const double D = Y + P + smooth;
+                double dice = (2.0 * I + smooth) / D;
+                const bool live = Y > 0.0 && dice >= eps;
+                if (dice < eps) dice = eps;
+                const double d = (Y > 0.0 ? dice : 0.0) * al;
+                const double t = -log(d + smooth);
+                tot += pow(t, 0.3);
+                const double g = live ? 0.3 * pow(t, -0.7) * (-1.0 / (d + smooth)) * al / cnt : 0.0;     // d(sum/cnt) / d dice_c
+                K[4 + c] = g * 2.0 / D;
+                K[4 + MAXCLS + c] = -g * (2.0 * I + smooth) / (D * D);
+            }
+            const double v = tot / cnt;
+            loss = v < 0.0 ? 0.0 : (v > 2.0 ? 2.0 : v);
+            if (!(v >= 0.0 && v <= 2.0)) for (int c = 0; c < C; ++c) { K[4 + c] = 0.0; K[4 + MAXCLS + c] = 0.0; }
+        } else loss = S[4] / Ntot;
         K[2] = 1.0 / Ntot;
     }
     // metrics: model/metric.py:146-181 (binary: class 0; multi-class: classes 1..C-1)
@@ -313,7 +358,7 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
             const float y = (float)load_label(a.target, a.label_type, i);
             const float p = 1.f / (1.f + expf(-z));
             float dz = 0.f;
-            if (a.kind == L_BIN_DICE || a.kind == L_BIN_CE_DICE) dz += (k0 * y + k1) * p * (1.f - p);
+            if (a.kind == L_BIN_DICE || a.kind == L_BIN_CE_DICE || a.kind >= L_BIN_JACCARD) dz += (k0 * y + k1) * p * (1.f - p);
             if (a.kind == L_BIN_CE || a.kind == L_BIN_CE_DICE) dz += (p - y) * kn;
             if (a.kind == L_BIN_FOCAL) {
                 const float b = bce_with_logits(z, y);
@@ -333,23 +378,28 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
             for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - mx); se += p[c]; }
             const float inv = 1.f / se;
             for (int c = 0; c < C; ++c) p[c] *= inv;
-            if (a.kind == L_MC_DICE) {
+            const bool dice_like = a.kind == L_MC_DICE || a.kind == L_MC_CE_DICE || a.kind == L_MC_ELDICE;
+            const bool ce_like = a.kind == L_MC_CE || a.kind == L_MC_FOCAL || a.kind == L_MC_CE_DICE;
+            float dz[MAXCLS];
+            for (int c = 0; c < C; ++c) dz[c] = 0.f;
+            if (dice_like) {
                 float gsum = 0.f, gc[MAXCLS];
                 for (int c = 0; c < C; ++c) {
                     gc[c] = (float)K[4 + c] * ((c == t) ? 1.f : 0.f) + (float)K[4 + MAXCLS + c];
                     gsum += p[c] * gc[c];
                 }
-                for (int c = 0; c < C; ++c) a.dlogits[(n * C + c) * a.V + v] = p[c] * (gc[c] - gsum) * gs;
-            } else {
+                for (int c = 0; c < C; ++c) dz[c] += p[c] * (gc[c] - gsum);
+            }
+            if (ce_like) {
                 float w = kn;
                 if (a.kind == L_MC_FOCAL) {
                     const float nll = (mx + logf(se)) - z[t];
                     const float pt = expf(-nll), om = 1.f - pt;
                     w *= powf(om, a.focal_gamma) + a.focal_gamma * powf(om, a.focal_gamma - 1.f) * pt * nll;
                 }
-                for (int c = 0; c < C; ++c)
-                    a.dlogits[(n * C + c) * a.V + v] = w * (p[c] - ((c == t) ? 1.f : 0.f)) * gs;
+                for (int c = 0; c < C; ++c) dz[c] += w * (p[c] - ((c == t) ? 1.f : 0.f));
             }
+            for (int c = 0; c < C; ++c) a.dlogits[(n * C + c) * a.V + v] = dz[c] * gs;
         }
     }
 }

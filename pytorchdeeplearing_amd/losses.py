@@ -113,3 +113,29 @@ class MutilDiceLoss(_Loss):
         super().__init__()
         self.alpha = alpha
         self.class_alpha = alpha if torch.is_tensor(alpha) else torch.as_tensor(alpha, dtype=torch.float32)
+
+
+# ---- losses of model/losses.py that no wrapper's `loss_name` selects: ratios of the same sums ----
+class BinaryJaccardLoss(_Loss):
+    """model/losses.py:9-30"""
+    kind = "BinaryJaccardLoss"
+
+
+class BinaryELDiceLoss(_Loss):
+    """model/losses.py:56-74"""
+    kind = "BinaryELDiceLoss"
+
+
+class BinaryTverskyLoss(_Loss):
+    """model/losses.py:102-126 (alpha = 0.3 on false positives, beta = 0.7 on false negatives)"""
+    kind = "BinaryTverskyLoss"
+
+
+class MutilCrossEntropyDiceLoss(MutilDiceLoss):
+    """model/losses.py:328-342: MutilDiceLoss(alpha) + MutilCrossEntropyLoss(alpha)"""
+    kind = "MutilCrossEntropyDiceLoss"
+
+
+class MutilELDiceLoss(MutilDiceLoss):
+    """model/losses.py:345-382"""
+    kind = "MutilELDiceLoss"
