@@ -170,3 +170,20 @@ def test_patch_origins_gather_stitch_equal_the_reference_loop(dev, vol_shape, pa
 def test_patch_origins_rejects_small_volumes():
     with pytest.raises(ValueError):
         pp.patch_origins((4, 20, 20), (8, 8, 8))
+
+
+def test_prepost_rejects_empty_volumes_and_oversized_patches(dev):
+    """error behaviour of the C-ABI entry points (no kernel is launched): int return < 0 -> RuntimeError with seg_last_error()."""
+    empty = torch.zeros((0, 4, 4), dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError):
+        pp.normalize_meanstd(empty, -1.0, 1.0)
+    with pytest.raises(RuntimeError):
+        pp.normalize_percentile(empty)
+    v = torch.zeros((4, 4, 4), dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError):
+        pp.normalize_meanstd(v, 1.0, -1.0)                      # lower > upper
+    o = torch.zeros((1, 3), dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError):
+        pp.gather_patches(v, o, (8, 8, 8))                      # patch larger than the volume
+    with pytest.raises(RuntimeError):
+        pp.stitch_mask(torch.zeros((1, 8, 8, 8), dtype=torch.uint8, device=dev), o, torch.zeros((4, 4, 4), dtype=torch.uint8, device=dev))
