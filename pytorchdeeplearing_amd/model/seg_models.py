@@ -68,7 +68,9 @@ class _SegModel(object):
             ds = datasetModelSegwithnpy(images, labels, targetsize=(self.image_channel, self.image_depth, self.image_height, self.image_width))
         else:
             ds = datasetModelSegwithopencv(images, labels, targetsize=(self.image_channel, self.image_height, self.image_width))
-        return DataLoader(ds, shuffle=shuffle, batch_size=self.batch_size, num_workers=0, pin_memory=self.device.type == "cuda")
+        # num_workers=0 as in the reference (modelVNet.py:508); SEGENGINE_LOADER_WORKERS > 0 adds reader processes behind the prefetcher
+        workers = int(os.environ.get("SEGENGINE_LOADER_WORKERS", "0"))
+        return DataLoader(ds, shuffle=shuffle, batch_size=self.batch_size, num_workers=workers, pin_memory=self.device.type == "cuda")
 
     def _loss_function(self, lossname):
         if lossname == "BinaryCrossEntropyLoss":
