@@ -329,6 +329,103 @@ __global__ __launch_bounds__(256, (c3_occ<CH, NT, TH>())) void conv3_kernel(Conv
     SEG_STAMP(5);
 }
 
+// Register-blocked variant of the 32-channel tiling (opt-in: SEG_CONV3_RB=1; 16-bit types).  The tap loop of conv3_kernel
+// reads one B and MT A fragments from LDS per MT MFMAs (1.33 KB per MFMA with MT = 3) and is capped by the 128 B/clk LDS port
+// well below the MFMA rate.  Here every A fragment feeds TWO 16-channel output tiles: the weight slabs of both tiles are
+// resident for one kd plane at a time ([2][9 taps][16 co][32 k] = 18.4 KB, next plane prefetched into registers), so a tap
+// step is 2 B + MT A reads for 2*MT MFMAs (0.83 KB per MFMA).  Same halo staging, swizzles and epilogue as conv3_kernel;
+// bit-identical results on integer-valued data (tests/test_ops.py with the knob set).
+template <class T, int TD, int TH, int TW, int KD>
+__global__ __launch_bounds__(256, 2) void conv3_rb_kernel(Conv3Args a) {
+    typedef Box<TD, TH, TW, KD> B;
+    static_assert(sizeof(T) == 2, "register-blocked tiling: 16-bit types only");
+    constexpr int CH = 32, NT = 2, XLD = CH, HWP = (B::HW + 3) / 4 * 4, MT = B::V / 64, BN = NT * 16, OLD = BN + 8;
+    constexpr int XS_ELEMS = B::HD * B::HH * HWP * XLD, OS_ELEMS = B::V * OLD, RED_ELEMS = 2048 / sizeof(T);
+    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS];
+    float* red = (float*)(Xs + OS_ELEMS);
+    constexpr int WSLAB = 9 * 16 * 32;                     // one (kd plane, output tile) slab: [tap][co][k], pieces swizzled by 3*((co>>2)&1)
+    __shared__ __attribute__((aligned(16))) T Ws[NT * WSLAB];
+    static_assert(B::V % 64 == 0, "box must hold a multiple of 64 voxels");
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const BoxPos bp = box_pos<B, TD, TH, TW>(blockIdx.x, a.D, a.H, a.W);
+    const int co0 = blockIdx.y * BN;
+    const T* in = (const T*)a.in;
+    const T* wp = (const T*)a.w;
+
+    int hb[MT], pq[MT][3];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int v = (wv * MT + m) * 16 + l15;
+        const int vx = v % TW, vy = (v / TW) % TH, vz = v / (TW * TH);
+        hb[m] = (vz * B::HH + vy) * HWP + vx;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) pq[m][kw] = (q ^ halo_swz(vz * B::HH + vy, vx + kw)) * 8;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int PIECES = NT * 9 * 16 * 4, WN = (PIECES + 255) / 256;
+    const int nchunk = a.Cin / CH;
+    for (int cc = 0; cc < nchunk; ++cc) {
+        if (cc) __syncthreads();
+        stage_halo<T, B, CH, XLD, HWP, true>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W, (const T*)a.in1, a.C0);
+        vec<T, 8> wv_[WN];
+        auto wload = [&](int kd) {
+#pragma unroll
+            for (int u = 0; u < WN; ++u) {
+                const int i = u * 256 + tid;
+                const int c4 = i & 3, tap = (i >> 2) % 9, co = (i / 36) % 16, j = i / (36 * 16);
+                wv_[u] = zero8<T>();
+                if (i < PIECES) wv_[u] = load8(wp + (long long)(co0 + j * 16 + co) * a.Kpad + (kd * 9 + tap) * a.Cin + cc * 32 + c4 * 8);
+            }
+        };
+        auto wstore = [&]() {
+#pragma unroll
+            for (int u = 0; u < WN; ++u) {
+                const int i = u * 256 + tid;
+                const int c4 = i & 3, tap = (i >> 2) % 9, co = (i / 36) % 16, j = i / (36 * 16);
+                if (i < PIECES) store8(&Ws[j * WSLAB + (tap * 16 + co) * 32 + ((c4 ^ (((co >> 2) & 1) * 3)) * 8)], wv_[u]);
+            }
+        };
+        wload(0);
+        wstore();
+        __syncthreads();
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+            if (kd + 1 < KD) wload(kd + 1);
+#pragma unroll
+            for (int s9 = 0; s9 < 9; ++s9) {
+                const int woff = (s9 * 16 + l15) * 32 + ((q ^ (((l15 >> 2) & 1) * 3)) * 8);
+                const typename Mma<T>::frag b0 = load8(&Ws[woff]), b1 = load8(&Ws[WSLAB + woff]);
+                const int skw = s9 % 3, srow = kd * B::HH + s9 / 3;
+                const int toff = srow * HWP + skw;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const typename Mma<T>::frag af = load8(&Xs[(hb[m] + toff) * XLD + (pq[m][skw] ^ ((srow & 1) << 4))]);
+                    acc[m][0] = Mma<T>::run(af, b0, acc[m][0]);
+                    acc[m][1] = Mma<T>::run(af, b1, acc[m][1]);
+                }
+            }
+            if (kd + 1 < KD) { __syncthreads(); wstore(); __syncthreads(); }
+        }
+    }
+    __syncthreads();
+    box_epilogue<T, B, TW, TH, MT, NT>(acc, Xs, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
+}
+
+template <class T, int TD, int TH, int TW, int KD> struct Conv3Rb {
+    static void launch(const Conv3Args& a, dim3 grid, hipStream_t s) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_rb_kernel<T, TD, TH, TW, KD>), grid, dim3(256), 0, s, a);
+    }
+};
+template <int TD, int TH, int TW, int KD> struct Conv3Rb<float, TD, TH, TW, KD> {
+    static void launch(const Conv3Args&, dim3, hipStream_t) {}
+};
+
 template <int TD, int TH, int TW>
 inline long long num_boxes(int N, int D, int H, int W) {
     return (long long)N * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
@@ -344,6 +441,14 @@ void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
     while (nt > 1 && nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;
     static const int force_nt = getenv("SEG_CONV3_NT") ? atoi(getenv("SEG_CONV3_NT")) : 0;     // tuning knob (tools/bench_conv3.py)
     if (force_nt && a.Cout % (16 * force_nt) == 0 && !(a.Cin == 16 && force_nt == 4)) nt = force_nt;
+    // opt-in register-blocked tiling (32 output channels per workgroup): 1 = wherever NT >= 2 was chosen, 2 = every 32-channel-aligned layer
+    static const int rb = getenv("SEG_CONV3_RB") ? atoi(getenv("SEG_CONV3_RB")) : 0;
+    if (rb && sizeof(T) == 2 && a.Cin % 32 == 0 && a.Cout % 32 == 0 && (nt >= 2 || rb >= 2) && !force_nt) {
+        static const bool verbose = getenv("SEG_CONV3_RB_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[segengine] conv3_rb box %dx%dx%d  %dx%dx%dx%d  Cin %d Cout %d\n", TD, TH, TW, a.N, a.D, a.H, a.W, a.Cin, a.Cout);
+        Conv3Rb<T, TD, TH, TW, KD>::launch(a, dim3((unsigned)nbox, a.Cout / 32), s);
+        return;
+    }
     dim3 grid((unsigned)nbox, a.Cout / (16 * nt));
     static const int force_wl = getenv("SEG_CONV3_WL") ? atoi(getenv("SEG_CONV3_WL")) : -1;   // tuning knob
     // LDS weight slab (one 16-channel output tile at a time over the resident halo) for every 16-bit tiling; the f32
