@@ -83,7 +83,7 @@ def test_ddp_two_ranks_matches_oracle_emulation(bucketed):
     assert bad <= 0.01 * tot, (bad, tot)
 
 
-def _worker_global(rank, world, port, q, ncls, loss):
+def _worker_global(rank, world, port, q, ncls, loss, bucketed=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -94,12 +94,12 @@ def _worker_global(rank, world, port, q, ncls, loss):
     conftest.emu_library()
     from oracle import seg_oracle as seg
     from pytorchdeeplearing_amd import SegEngine, _capi
-    from pytorchdeeplearing_amd.parallel import GlobalBatchLoss, GradAllReduce
+    from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GlobalBatchLoss, GradAllReduce
     kind, shape = "unet", (2, 1, 16, 16)
     e = SegEngine(kind, 2, 1, ncls, dtype="f32", device="cpu")
     e.load_state_dict(seg.perturb_params(seg.init_params(kind, 2, 1, ncls, seed=0), seed=7))
     x, y = seg.synthetic_batch(shape[0], shape[2:], 1, ncls, seed=100 + rank)
-    ar, ex = GradAllReduce(), GlobalBatchLoss()
+    ar, ex = (BucketedGradAllReduce() if bucketed else GradAllReduce()), GlobalBatchLoss()
     losses = []
     for it in range(2):
         g = torch.Generator().manual_seed(10 * it + rank)
@@ -112,15 +112,16 @@ def _worker_global(rank, world, port, q, ncls, loss):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ncls,loss", [(1, "BinaryCrossEntropyDiceLoss"), (3, "MutilDiceLoss")])
-def test_exact_global_batch_loss_two_ranks_equals_one_process_on_the_whole_batch(ncls, loss):
+@pytest.mark.parametrize("ncls,loss,bucketed", [(1, "BinaryCrossEntropyDiceLoss", True), (3, "MutilDiceLoss", False)])
+def test_exact_global_batch_loss_two_ranks_equals_one_process_on_the_whole_batch(ncls, loss, bucketed):
     """SURVEY 8e mode (ii): with the 32 batch-global sums exchanged, two ranks x 2 samples reproduce ONE reference process
-    training on the 4-sample batch (loss value and update), which plain DDP averaging does not."""
+    training on the 4-sample batch (loss value and update), which plain DDP averaging does not.  One case runs the gradient
+    exchange in the two overlapped buckets (bench.py's default) to show the two mechanisms compose."""
     from oracle import seg_oracle as seg
     world, port = 2, 30500 + (os.getpid() * 3 + ncls + len(loss)) % 1000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_global, args=(r, world, port, q, ncls, loss)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_global, args=(r, world, port, q, ncls, loss, bucketed)) for r in range(world)]
     for p in procs:
         p.start()
     got, got_losses = q.get(timeout=600)
