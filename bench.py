@@ -54,7 +54,7 @@ def pmc_traffic(kclass):
         return None
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--global-loss", action="store_true", help="exact global-batch Dice across ranks (parallel.GlobalBatchLoss: 32 fp64 sums "
                     "all-reduced between the loss reduction and its finalize; gradients summed) instead of DDP semantics")
     ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0):
@@ -133,17 +133,28 @@ def _dice_vs_reference(seg, trained_state, dev, dtype, size=48):
 
 
 
-def main():
-    a = parse()
+def main(argv=None, checker_device=None):
+    """checker_device: TEST-ONLY (tests/test_parallel.py): run the control flow of this file on the host-side kernel checker
+    with the gloo backend, so the N > 1 path (barriers, bucketed exchange, MAX over ranks, the JSON line) is exercised on
+    the GPU-less build box.  None = the real thing: one process per GPU, RCCL."""
+    a = parse(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    on_gpu = checker_device is None
+    if on_gpu:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        dev = torch.device(checker_device)
+    gpu_sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     from pytorchdeeplearing_amd import SegEngine, synthetic   # oracle/ is touched by the cpu_baseline leg only
     from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GlobalBatchLoss, GradAllReduce
 
@@ -173,32 +184,34 @@ def main():
     e.profile_enable(bracketed)
     for _ in range(a.warmup):
         out3 = step()
-    torch.cuda.synchronize()
+    gpu_sync()
     e.profile_read()
     nprof = max(1, min(a.roofline_steps, a.steps))
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    gpu_sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         if i == nprof:
             e.profile_enable([])          # host-side flag only: no synchronisation inside the timed region
         out3 = step()
-    torch.cuda.synchronize()
+    gpu_sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    gpu_sync()
     dt = time.perf_counter() - t0
     prof = e.profile_read()
     e.profile_enable([])
     # an EMPTY bracket (two event records back to back on the launch stream) is not zero: each record is a barrier packet
     # with a timestamp.  Measured live and subtracted per launch below, so that the event-based average can be compared
     # with rocprofv3's kernel durations (which carry no brackets); both the raw and the corrected figures are reported.
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
-    for ea, eb in pairs:
-        ea.record(); eb.record()
-    torch.cuda.synchronize()
-    bracket_us = sorted(ea.elapsed_time(eb) for ea, eb in pairs)[len(pairs) // 2] * 1e3
+    bracket_us = 0.0
+    if on_gpu:
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+        for ea, eb in pairs:
+            ea.record(); eb.record()
+        gpu_sync()
+        bracket_us = sorted(ea.elapsed_time(eb) for ea, eb in pairs)[len(pairs) // 2] * 1e3
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -213,7 +226,7 @@ def main():
         e.profile_enable(_capi.KERNEL_CLASSES)
         for _ in range(3):
             step()
-        torch.cuda.synchronize()
+        gpu_sync()
         table = {k: {"calls_per_step": v["calls"] // 3, "ms_per_step": round(v["ms"] / 3, 3),
                      "GBs": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None,
                      "TFLOPs": round(v["flops"] / v["ms"] / 1e9, 1) if v["flops"] else None}

@@ -151,3 +151,47 @@ def test_exact_global_batch_loss_two_ranks_equals_one_process_on_the_whole_batch
         tot += d.numel()
         bad += int((d > 1e-4).sum())
     assert bad <= 0.01 * tot, (bad, tot)
+
+
+def _worker_bench(rank, world, port, q, extra):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import contextlib
+    import io
+    import conftest
+    conftest.emu_library()
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--size", "16", "--batch", "1", "--dtype", "f32",
+                    "--no-cpu-baseline"] + list(extra), checker_device="cpu")
+    q.put((rank, buf.getvalue()))
+
+
+@pytest.mark.parametrize("extra", [("--global-loss",)])          # bucketed exchange (the default) + the loss-sum exchange: one ~1 min case
+def test_bench_control_flow_two_ranks_on_the_checker(extra):
+    """bench.py's own N > 1 path (process-group set-up, barriers around the timed region, bucketed / single exchange, optional
+    global-batch loss, MAX of the rank times, ONE JSON line from rank 0) on the host checker with gloo: the driver launches
+    exactly this file with torch.distributed.run on the 8-GPU node, where this session cannot run it."""
+    import json
+    world, port = 2, 31500 + (os.getpid() * 5 + len(extra) + sum(len(e) for e in extra)) % 1000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bench, args=(r, world, port, q, extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert outs[1].strip() == ""                       # only rank 0 prints
+    lines = [l for l in outs[0].splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["warmup"] == 0 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 2 and line["config"]["parallelism"] == "dp2"
+    assert line["config"]["loss_semantics"].startswith("global-batch" if "--global-loss" in extra else "per-rank")
+    assert line["ms_per_step"] > 0 and abs(line["value"] - 2 * 1 * 1e3 / line["ms_per_step"]) <= 0.006      # whole-job volumes/s (2 decimals)
+    assert 0.0 < line["final_loss"] < 1.5 and "cpu_baseline" not in line
