@@ -217,6 +217,8 @@ typedef struct seg_pack_desc {
     int Kpad;
     long long s1, s2, sT, sC;
     int flipT;
+    int frag;   /* 0: rows [R1*R2][Kpad]; 1: MFMA-fragment-major [Cc/32][T][rows/16][64 lanes][8] (Cc % 32 == 0, rows % 16 == 0):
+                   lane = 16*((c%32)/8) + row%16 holds k = c%8 .. — one 16x32 B fragment is one contiguous 1 KB line */
 } seg_pack_desc;
 int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int dtype, void* stream);
 /* LDS halo-tile kernels for the 3^d (ndim 3) / 3^2 (ndim 2, D = 1) stride-1 pad-1 convolutions.
@@ -230,6 +232,16 @@ int seg_op_conv3(const void* in, const void* w, const float* bias, void* out, do
 long long seg_op_wgrad3_partial_bytes(int ndim, int n, int d, int h, int wid, int p, int q);
 int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int n, int d, int h, int wid, int p,
                   int q, int ndim, int dtype, void* stream);
+/* Register-blocked halo conv for 16-bit tensors with Cin % 32 == 0 (csrc/conv3x.hip): same operator as seg_op_conv3, the
+ * weights packed with seg_pack_desc.frag = 1 ("conv_fwd" / "conv_dgrad" element order), `in1` an optional second source of a
+ * virtual channel concat (channels c0..cin-1).  cfg selects a tiling (seg_op_conv3x_cfg_info enumerates them; -1 = the
+ * engine's default for the shape).  Returns <0 when the tiling does not fit the shape. */
+int seg_op_conv3x(int cfg, const void* in0, const void* in1, int c0, const void* w, const float* bias, void* out, double* stats,
+                  int n, int d, int h, int wid, int cin, int cout, int ndim, int dtype, void* stream);
+int seg_op_conv3x_num_cfgs(void);
+/* index in [0, num_cfgs): tiling id, ndim, box {d,h,w}, output channels per workgroup, resident 32-channel chunks, description */
+int seg_op_conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, char* name, int name_cap);
+int seg_op_conv3x_default_cfg(int ndim, int n, int d, int h, int wid, int cin, int cout, int dtype);
 /* sizeof of the structs above as compiled into the library: 0 conv, 1 wgrad, 2 pack */
 int seg_abi_sizeof(int which);
 

@@ -76,6 +76,42 @@ def make_losses_extra(losses):
     print("extra losses:", {k: float(v) for k, v in out.items() if k.startswith("loss_")})
 
 
+METRIC_REPAIRS = (
+    # model/metric.py:210 — `assert input.size() == target.size()` can never hold next to the F.one_hot of index labels two
+    # lines above it (one-hot needs (N, V) indices, the assert needs (N, C, V)); with it removed the function body runs as written
+    ("    assert input.size() == target.size()\n", "", "metric.py:210: unsatisfiable size assert"),
+)
+
+
+def make_metric_extra(metric):
+    """M4 multiclass_iou_coeff (model/metric.py:204-215): the reference's own function text with METRIC_REPAIRS applied in
+    memory, on the section-8(c) recipe inputs (+ a case with an absent class)."""
+    import re
+    src = open(os.path.join(ref_loader.REF, "model", "metric.py")).read()
+    m = re.search(r"^def multiclass_iou_coeff\(.*?(?=^def |\Z)", src, re.S | re.M)
+    text = m.group(0)
+    for old, new, _why in METRIC_REPAIRS:
+        assert text.count(old) == 1, old
+        text = text.replace(old, new)
+    ns = {"torch": torch, "F": torch.nn.functional, "Tensor": torch.Tensor, "iou_coeff": metric.iou_coeff}
+    exec(compile(text, "metric_repaired", "exec"), ns)
+    torch.manual_seed(0)
+    _z = torch.randn(2, 1, 8, 8, 8)
+    _y = (torch.rand(2, 8, 8, 8) > 0.7).long()
+    z4 = torch.randn(2, 4, 8, 8, 8) * 3.0              # sharper soft-max: a good share of voxels passes the 0.5 threshold
+    y4 = torch.randint(0, 4, (2, 8, 8, 8))
+    y4b = y4.clone(); y4b[y4b == 3] = 1
+    z3 = torch.randn(3, 3, 6, 10) * 3.0
+    y3 = torch.randint(0, 3, (3, 6, 10))
+    out = dict(z4=_np(z4), y4=_np(y4), y4b=_np(y4b), z3=_np(z3), y3=_np(y3))
+    out["miou_a"] = _np(ns["multiclass_iou_coeff"](torch.softmax(z4, 1), y4))
+    out["miou_b"] = _np(ns["multiclass_iou_coeff"](torch.softmax(z4, 1), y4b))
+    out["miou_2d"] = _np(ns["multiclass_iou_coeff"](torch.softmax(z3, 1), y3))
+    out["mdice_a"] = _np(metric.multiclass_dice_coeff(torch.softmax(z4, 1), y4))
+    np.savez_compressed(os.path.join(OUT, "metric_extra.npz"), **out)
+    print("metric extra:", {k: float(v) for k, v in out.items() if k.startswith("m")})
+
+
 def grad_summary(g):
     """Compact, order-sensitive fingerprint of one gradient tensor: sum, L2 norm, and 16 entries
     at fixed pseudo-random flat positions."""
@@ -238,6 +274,10 @@ def main():
         sys.exit("reference tree not available; golden fixtures can only be regenerated in the build container")
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
+    if "--only-metric-extra" in sys.argv:
+        _nets, _losses, metric = ref_loader.load()
+        make_metric_extra(metric)
+        return
     make_prepost()
     if "--only-prepost" in sys.argv:
         return
@@ -252,6 +292,7 @@ def main():
     torch.set_num_threads(1)
     make_losses(nets, losses, metric)
     make_losses_extra(losses)
+    make_metric_extra(metric)
     from . import seg_oracle as seg
     a4 = torch.ones(4)
     make_net(nets, losses, seg, "vnet3d_bin_16", "vnet", 3, lambda: nets.VNet3d(1, 1), (2, 1, 16, 16, 16), 1,

@@ -6,13 +6,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsegengine.so")
-SRCS = ["conv.hip", "conv3.hip", "wgrad.hip", "norm.hip", "misc.hip", "cldice.hip", "prepost.hip", "engine.hip"]
+SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "wgrad.hip", "norm.hip", "misc.hip", "cldice.hip", "prepost.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
 
 
 def _deps():
-    d = [os.path.join(CSRC, f) for f in SRCS + ["common.h", "kernels.h"]]
+    d = [os.path.join(CSRC, f) for f in SRCS + ["common.h", "kernels.h", "conv3x_impl.h"]]
     d.append(os.path.join(os.path.dirname(HERE), "include", "segengine.h"))
     return d
 

@@ -82,6 +82,41 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+
+// ---- direct global -> LDS copies (gfx950 buffer_load_dwordx4 ... lds) -----------------------------------------------
+// One wave-instruction moves 64 x 16 B: lane l copies the 16 bytes at (resource base + voffset_l) to
+// (lds_wave_base + 16*l) without touching a VGPR; a voffset at or beyond the resource's byte range stores ZEROS
+// (raw-buffer out-of-range semantics), which is how the zero padding of a halo is produced.  The LDS image of a
+// wave-instruction is therefore lane-linear; layouts are swizzled by choosing which global piece a lane fetches.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned DMA_OOB = 0x80000000u;     // any offset >= the resource range (ranges are kept below 2 GB)
+#ifndef SEG_EMU
+__device__ void seg_raw_buffer_load_lds(i32x4 rsrc, __attribute__((address_space(3))) unsigned* lds, int size, int voffset, int soffset,
+                                        int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+#endif
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4 r;
+    r[0] = (int)(unsigned)(p & 0xffffffffull);
+    r[1] = (int)(unsigned)((p >> 32) & 0xffffull);    // base[47:32], stride 0
+    r[2] = (int)bytes;                                // num_records (bytes)
+    r[3] = 0x00020000;                                // gfx9 raw buffer: 32-bit data format
+    return r;
+}
+// 16-B load through a buffer resource: address = base + voffset (per lane) + soffset (wave-uniform, an SGPR); out-of-range
+// reads return zeros, so prefetching past the end of a weight array needs neither a branch nor a clamp
+#ifndef SEG_EMU
+__device__ i32x4 seg_raw_buffer_load_b128(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+#endif
+template <class T> __device__ __forceinline__ vec<T, 8> buffer_load8(i32x4 rsrc, unsigned voffset, unsigned soffset) {
+    return __builtin_bit_cast(vec<T, 8>, seg_raw_buffer_load_b128(rsrc, (int)voffset, (int)soffset, 0));
+}
+template <class T> __device__ __forceinline__ void dma16(i32x4 rsrc, T* lds_wave_base, unsigned voffset) {
+    seg_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) unsigned*)(lds_wave_base), 16, (int)voffset, 0, 0, 0);
+}
+// all of this wave's outstanding global loads / LDS copies have landed (s_waitcnt vmcnt(0); expcnt / lgkmcnt untouched)
+__device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // labels arrive as u8 / i32 / i64 / f32 class ids (the reference's datasets hand out int64)
 enum LabelType { LT_U8 = 0, LT_I32 = 1, LT_I64 = 2, LT_F32 = 3 };
 __device__ __forceinline__ int load_label(const void* p, int lt, long long i) {

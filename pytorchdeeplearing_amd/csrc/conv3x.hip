@@ -1,0 +1,129 @@
+// Host side of the register-blocked halo conv (kernel: conv3x_impl.h; instantiations: conv3x_<dtype>_<nd>.hip): the table of
+// tilings, the default choice per layer shape and the launch entry points declared in kernels.h.
+#include "conv3x_impl.h"
+
+namespace seg {
+namespace {
+using c3x::Conv3xArgs;
+
+struct Cfg { int id, ndim, td, th, tw, bn, nres; const char* name; };
+
+// id, ndim, box, BN, resident chunks — kept in sync with SEG_C3X_3D_BODY / SEG_C3X_2D_BODY (conv3x_impl.h)
+const Cfg kCfgs[] = {
+    // 3-D
+    {0, 3, 2, 8, 16, 32, 1, "2x8x16 t16 4x1 waves 4x2 tiles"},
+    {1, 3, 4, 8, 16, 32, 1, "4x8x16 t16 4x1 waves 8x2 tiles"},
+    {2, 3, 2, 8, 16, 64, 2, "2x8x16 t16 2x2 waves 8x2 tiles"},
+    {3, 3, 2, 8, 8, 64, 2, "2x8x8 t8 2x2 waves 4x2 tiles"},
+    {4, 3, 4, 8, 8, 64, 2, "4x8x8 t8 2x2 waves 8x2 tiles"},
+    {5, 3, 4, 8, 8, 64, 2, "4x8x8 t8 4x1 waves 4x4 tiles"},
+    {6, 3, 2, 8, 8, 64, 2, "2x8x8 t8 4x1 waves 2x4 tiles"},
+    {7, 3, 2, 4, 12, 64, 4, "2x4x12 t4 2x2 waves 3x2 tiles"},
+    {8, 3, 4, 4, 12, 64, 4, "4x4x12 t4 2x2 waves 6x2 tiles"},
+    {9, 3, 2, 4, 12, 128, 4, "2x4x12 t4 2x2 waves 3x4 tiles"},
+    {10, 3, 2, 8, 16, 16, 1, "2x8x16 t16 4x1 waves 4x1 tiles"},
+    {11, 3, 2, 8, 8, 64, 4, "2x8x8 t8 2x2 waves 4x2 tiles, 4 resident chunks"},
+    {12, 3, 2, 8, 8, 128, 4, "2x8x8 t8 2x2 waves 4x4 tiles, 4 resident chunks"},
+    {13, 3, 2, 8, 8, 32, 2, "2x8x8 t8 4x1 waves 2x2 tiles"},
+    {14, 3, 4, 8, 8, 32, 1, "4x8x8 t8 4x1 waves 4x2 tiles"},
+    {15, 3, 2, 8, 16, 32, 2, "2x8x16 t16 4x1 waves 4x2 tiles, 2 resident chunks"},
+    {16, 3, 2, 8, 16, 32, 1, "2x8x16 t16 4x1 waves 4x2 tiles, deep B ring, 2 workgroups/CU"},
+    {17, 3, 4, 8, 8, 32, 1, "4x8x8 t8 4x1 waves 4x2 tiles, deep B ring, 2 workgroups/CU"},
+    // 2-D
+    {32, 2, 1, 16, 16, 32, 1, "16x16 t16 4x1 waves 4x2 tiles"},
+    {33, 2, 1, 16, 16, 64, 2, "16x16 t16 2x2 waves 8x2 tiles"},
+    {34, 2, 1, 8, 16, 64, 2, "8x16 t16 2x2 waves 4x2 tiles"},
+    {35, 2, 1, 8, 16, 64, 4, "8x16 t16 2x2 waves 4x2 tiles, 4 resident chunks"},
+    {36, 2, 1, 8, 16, 128, 4, "8x16 t16 2x2 waves 4x4 tiles, 4 resident chunks"},
+    {37, 2, 1, 16, 16, 16, 1, "16x16 t16 4x1 waves 4x1 tiles"},
+    {38, 2, 1, 8, 8, 64, 4, "8x8 t8 2x2 waves 2x2 tiles, 4 resident chunks"},
+    {39, 2, 1, 8, 16, 32, 2, "8x16 t16 4x1 waves 2x2 tiles, 2 resident chunks"},
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+const Cfg* find_cfg(int id) {
+    for (int i = 0; i < kNumCfgs; ++i)
+        if (kCfgs[i].id == id) return &kCfgs[i];
+    return nullptr;
+}
+
+bool cfg_fits(const Cfg& c, int ndim, int Cout) { return c.ndim == ndim && Cout % c.bn == 0; }
+
+}  // namespace
+
+// ---- host entry points (declared in kernels.h) -----------------------------------------------------
+bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, int Cout, int C0, bool has_in1) {
+    (void)N;
+    if (dtype == DT_F32) return false;
+    if (Cin % 32 || Cout % 16) return false;
+    if (has_in1 && (C0 % 8 || C0 <= 0 || C0 >= Cin)) return false;
+    const long long vol = (long long)(ndim == 3 ? D : 1) * H * W;
+    if (vol * Cin * 2 >= (1ll << 31) || vol * 4 >= (1ll << 31)) return false;    // buffer ranges and the packed granule index stay below 2^31
+    return true;
+}
+
+// default tiling per problem.  Overrides: SEG_C3X_CFG=<id> (one tiling wherever it fits), SEG_C3X_MAP="cin:cout:w=id,..."
+// (per layer shape; tools/tune_conv3x.py prints the measured table).  Otherwise: least padding waste of the box grid, then
+// output tiles of min(Cout, 64) channels, then just enough resident chunks for Cin, then the box size that gives the
+// chip at least ~2 workgroups per CU.
+int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
+    static const int force = getenv("SEG_C3X_CFG") ? atoi(getenv("SEG_C3X_CFG")) : -1;
+    if (force >= 0) {
+        const Cfg* c = find_cfg(force);
+        if (c && cfg_fits(*c, ndim, Cout)) return force;
+    }
+    static const char* map = getenv("SEG_C3X_MAP");
+    if (map) {
+        for (const char* p = map; *p;) {
+            int ci = 0, co = 0, w = 0, id = -1;
+            if (sscanf(p, "%d:%d:%d=%d", &ci, &co, &w, &id) == 4 && ci == Cin && co == Cout && w == W) {
+                const Cfg* c = find_cfg(id);
+                if (c && cfg_fits(*c, ndim, Cout)) return id;
+            }
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+    }
+    const int nchunk = Cin / 32, want_bn = Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16);
+    int best = -1;
+    double best_score = 1e30;
+    for (int i = 0; i < kNumCfgs; ++i) {
+        const Cfg& c = kCfgs[i];
+        if (!cfg_fits(c, ndim, Cout) || c.bn > 64) continue;
+        auto up = [](int v, int t) { return (double)((v + t - 1) / t * t) / v; };
+        const double waste = up(ndim == 3 ? D : 1, c.td) * up(H, c.th) * up(W, c.tw);
+        const long long wgs = (long long)N * ((D + c.td - 1) / c.td) * ((H + c.th - 1) / c.th) * ((W + c.tw - 1) / c.tw) * (Cout / c.bn);
+        double score = waste * 1000.0;
+        score += c.bn == want_bn ? 0.0 : 100.0 * (want_bn > c.bn ? want_bn / c.bn : c.bn / want_bn);
+        score += c.nres >= nchunk ? 10.0 * (c.nres - nchunk) : 40.0 * ((nchunk + c.nres - 1) / c.nres);
+        score += wgs >= 512 ? -1.0 * (c.td * c.th * c.tw) / 256.0 : 5.0 * (c.td * c.th * c.tw) / 256.0;   // big boxes only when the chip stays full
+        if (score < best_score) { best_score = score; best = c.id; }
+    }
+    return best;
+}
+
+int conv3x_num_cfgs() { return kNumCfgs; }
+int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name) {
+    if (index < 0 || index >= kNumCfgs) return -1;
+    const Cfg& c = kCfgs[index];
+    if (id) *id = c.id;
+    if (ndim) *ndim = c.ndim;
+    if (box3) { box3[0] = c.td; box3[1] = c.th; box3[2] = c.tw; }
+    if (bn) *bn = c.bn;
+    if (nres) *nres = c.nres;
+    if (name) *name = c.name;
+    return 0;
+}
+
+bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s) {
+    const Cfg* c = find_cfg(cfg);
+    if (!c || !cfg_fits(*c, ndim, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
+    Conv3xArgs a;
+    a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
+    a.N = N; a.D = ndim == 3 ? D : 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d<f16>(cfg, a, s) : c3x::launch_3d<bf16>(cfg, a, s);
+    return dtype == DT_F16 ? c3x::launch_2d<f16>(cfg, a, s) : c3x::launch_2d<bf16>(cfg, a, s);
+}
+
+}  // namespace seg

@@ -1,0 +1,306 @@
+// Register-blocked LDS halo-tile kernel for the 3^d / 3^2 stride-1 pad-1 convolutions on 16-bit tensors with
+// Cin % 32 == 0 (the LUConv / _block layers from the second level down, networks/VNet3d.py:8, networks/Unet3d.py:66-80)
+// — forward and data-gradient (same kernel, flipped fragment-major weights).
+//
+// What it changes against conv3_kernel (conv3.hip), following the round-1 profile (VERDICT r01 "What's weak"):
+//   * ONE workgroup computes up to 64 / 128 output channels of a box from one staged halo (conv3_kernel re-staged the
+//     halo once per 16 output channels: 2.8x HBM/L2 traffic, 4 - 16x the staging latency chains per box);
+//   * every wave owns a TM x TN grid of 16x16 output tiles, so an A fragment read from LDS feeds TN MFMAs and a B
+//     fragment TM MFMAs: (TM + TN) / (TM * TN) KB of operand traffic per MFMA instead of 1.33 KB;
+//   * the halo is staged by direct global -> LDS copies (buffer_load_dwordx4 ... lds, common.h dma16): no VGPR round trip,
+//     no ds_write pass, zero padding from the buffer's out-of-range rule; the conflict-free XOR swizzle of conv3.hip is
+//     kept by choosing which 16-B channel piece each lane fetches;
+//   * weights are packed FRAGMENT-MAJOR ([chunk][tap][16-channel tile][lane][8]): a wave's B fragment is one contiguous
+//     1 KB line, loaded straight from L2 into a register ring PF steps ahead — no LDS slab, no barrier in the tap loop.
+// All 32-channel chunks of a group (NRES resident chunks) are staged before the tap loops start; staging latency is
+// hidden by the other workgroup(s) resident on the CU.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace seg {
+namespace c3x {
+
+__device__ __forceinline__ int halo_swz_x(int row, int x) { return ((row & 1) << 1) ^ (((x >> 2) & 1) * 3); }   // = conv3.hip halo_swz
+
+// Box of TD x TH x TW output voxels cut into 16-voxel M tiles of TY x TX (1x16, 2x8 or 4x4) voxels; voxel order is tile-major.
+template <int TD_, int TH_, int TW_, int KD_, int TX_> struct XBox {
+    static constexpr int TD = TD_, TH = TH_, TW = TW_, KD = KD_, TX = TX_, TY = 16 / TX_;
+    static_assert(TX_ == 16 || TX_ == 8 || TX_ == 4, "tile width");
+    static_assert(TW_ % TX_ == 0 && TH_ % (16 / TX_) == 0, "box must be cut into whole tiles");
+    static constexpr int V = TD * TH * TW, NTILE = V / 16;
+    static constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2, HWP = (HW + 3) / 4 * 4;   // row pitch: multiple of 4 voxels (swizzle)
+    static constexpr int PD = (KD - 1) / 2, NTAP = KD * 9;
+    static constexpr int ROWS = HD * HH;
+    static constexpr int GRAN = ROWS * HWP * 4;              // 16-B granules of one 32-channel chunk image
+    static constexpr int NINSTR = (GRAN + 63) / 64;          // wave-instructions (1 KB each) per chunk
+    static constexpr int CHUNK_ELEMS = NINSTR * 64 * 8;      // 16-bit elements of one resident chunk
+    static __device__ __forceinline__ void vox(int v, int& vz, int& vy, int& vx) {
+        constexpr int ntx = TW / TX, nty = TH / TY;
+        const int t = v >> 4, l = v & 15;
+        vx = (t % ntx) * TX + (l % TX);
+        vy = ((t / ntx) % nty) * TY + l / TX;
+        vz = t / (ntx * nty);
+    }
+};
+
+struct Conv3xArgs {
+    const void* in0; const void* in1; int C0;     // in1: second source of a virtual channel concat (channels C0..Cin-1), or null
+    const void* w;                                // fragment-major weights [Cin/32][taps][Cout/16][64 lanes][8]
+    const float* bias; void* out; double* stats;
+    int N, D, H, W, Cin, Cout;
+};
+
+template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
+    static_assert(WM * WN == 4 && WM * TM == B::NTILE, "wave grid must cover the box");
+    static_assert(B::NTAP % (PF + 1) == 0, "register ring must divide the tap count");
+    constexpr int BN = WN * TN * 16, OLD = BN + 8;
+    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 2048 / sizeof(T), XS_ELEMS = NRES * B::CHUNK_ELEMS;
+    // ONE LDS object: resident chunk images; the epilogue's output tile + reduction slots alias it
+    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS];
+    constexpr int NI = (B::NINSTR + 3) / 4;               // copy instructions per wave and chunk
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int wm = wv % WM, wn = wv / WM;
+    // box position
+    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
+    int bb = blockIdx.x;
+    const int x0 = (bb % nbx) * B::TW; bb /= nbx;
+    const int y0 = (bb % nby) * B::TH; bb /= nby;
+    const int z0 = (bb % nbz) * B::TD;
+    const int n = bb / nbz;
+    const int co0 = blockIdx.y * BN;
+    const int NT_total = a.Cout >> 4;
+
+    // ---- per-lane source of every granule this lane copies (the same for every chunk): voxel index inside the sample * 4
+    //      + channel piece, or -1 for padding
+    int src[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = u * 4 + wv;                          // instruction index inside the chunk image (wave-uniform)
+        const int g = i * 64 + lane;
+        const int row = g / (B::HWP * 4), rem = g % (B::HWP * 4);
+        const int hx = rem >> 2, slot = rem & 3;
+        const int hz = row / B::HH, hy = row % B::HH;
+        const int z = z0 + hz - B::PD, y = y0 + hy - 1, x = x0 + hx - 1;
+        const bool ok = i < B::NINSTR && row < B::ROWS && hx < B::HW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
+                        (unsigned)x < (unsigned)a.W;
+        src[u] = ok ? ((((z * a.H) + y) * a.W + x) << 2) + (slot ^ halo_swz_x(row, hx)) : -1;
+    }
+    const long long vol = (long long)a.D * a.H * a.W;
+    const int C1 = a.Cin - a.C0;
+    const i32x4 r0 = make_rsrc((const T*)a.in0 + (long long)n * vol * a.C0, (unsigned)(vol * a.C0 * 2));
+    const i32x4 r1 = a.in1 ? make_rsrc((const T*)a.in1 + (long long)n * vol * C1, (unsigned)(vol * C1 * 2)) : r0;
+    const bool straddle = (a.C0 & 31) != 0;                // a 32-channel chunk may take pieces from both concat sources
+
+    auto issue_chunk = [&](int cc, int buf) {
+        T* dst = Xs + buf * B::CHUNK_ELEMS;
+        const int ch0 = cc * 32;
+        if (!straddle) {
+            const bool second = ch0 >= a.C0;
+            const i32x4 rs = second ? r1 : r0;
+            const unsigned rowb = (unsigned)(second ? C1 : a.C0) * 2u, cho = (unsigned)(second ? ch0 - a.C0 : ch0) * 2u;
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int i = u * 4 + wv;
+                if (i < B::NINSTR) {
+                    const unsigned off = src[u] >= 0 ? (unsigned)(src[u] >> 2) * rowb + cho + (unsigned)(src[u] & 3) * 16u : DMA_OOB;
+                    dma16(rs, dst + i * 512, off);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int i = u * 4 + wv;
+                if (i < B::NINSTR) {
+                    const int ch = ch0 + (src[u] & 3) * 8;
+                    const bool second = src[u] >= 0 && ch >= a.C0;
+                    // lanes of one instruction may read different sources: two exec-masked copies into the same 1 KB line
+                    if (!second) {
+                        const unsigned off = src[u] >= 0 ? (unsigned)(src[u] >> 2) * (unsigned)(a.C0 * 2) + (unsigned)ch * 2u : DMA_OOB;
+                        dma16(r0, dst + i * 512, off);
+                    } else {
+                        const unsigned off = (unsigned)(src[u] >> 2) * (unsigned)(C1 * 2) + (unsigned)(ch - a.C0) * 2u;
+                        dma16(r1, dst + i * 512, off);
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- A-fragment addressing: element offset of this lane's 16-B piece per M tile and kw shift (tap offsets are
+    //      compile-time immediates; an odd tap row flips the swizzle bit)
+    int ab[TM][3];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        int vz, vy, vx;
+        B::vox((wm * TM + m) * 16 + l15, vz, vy, vx);
+        const int row = vz * B::HH + vy;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) ab[m][kw] = (row * B::HWP + vx) * 32 + ((q ^ halo_swz_x(row, vx + kw)) << 3);
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // B fragments: buffer loads with a per-lane base offset and a wave-uniform step offset (no address VALU in the tap loop;
+    // the PF steps fetched past the last tap read zeros)
+    const unsigned wstep = (unsigned)NT_total * 1024u;     // bytes between consecutive (chunk, tap) steps
+    const i32x4 wr = make_rsrc(a.w, (unsigned)(a.Cin >> 5) * B::NTAP * wstep);
+    const unsigned wl = ((unsigned)(blockIdx.y * (BN / 16) + wn * TN) * 64u + lane) * 16u;
+
+    const int nchunk = a.Cin >> 5;
+    for (int g0 = 0; g0 < nchunk; g0 += NRES) {
+        const int nres = nchunk - g0 < NRES ? nchunk - g0 : NRES;
+        if (g0) __syncthreads();                           // every wave is done reading the previous group
+#pragma unroll
+        for (int b = 0; b < NRES; ++b)
+            if (b < nres) issue_chunk(g0 + b, b);
+        // B fragments of the first PF steps travel together with the halo
+        typename Mma<T>::frag bq[PF + 1][TN];
+        const unsigned wg = (unsigned)g0 * B::NTAP * wstep;
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, wg + s * wstep);
+        wait_vmem();
+        __syncthreads();
+        unsigned wo = wg + PF * wstep;                     // byte offset of the step being prefetched
+        for (int b = 0; b < nres; ++b) {
+            // Software pipeline, written out: while the MFMAs of tap t run, the A fragments of tap t + 1 travel from LDS and
+            // the B fragments of step t + PF from L2.  Every tap offset is an immediate of the ds_read; the swizzle flip of an
+            // odd tap row is folded into the per-lane base (ab ^ 16).  sched_group_barrier pins that order in the emitted code.
+            const T* Xc = Xs + b * B::CHUNK_ELEMS;
+            typename Mma<T>::frag af[2][TM];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xc[ab[m][0]]);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);               // tap 0's fragments first (they would otherwise fill tap 1's slot)
+#pragma unroll
+            for (int t = 0; t < B::NTAP; ++t) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bq[(t + PF) % (PF + 1)][j] = buffer_load8<T>(wr, wl + j * 1024, wo);
+                wo += wstep;
+                if (t + 1 < B::NTAP) {
+                    const int t1 = t + 1, kw = t1 % 3, srow = (t1 / 9) * B::HH + (t1 / 3) % 3;
+                    const int toff = (srow * B::HWP + kw) * 32, flip = (srow & 1) << 4;
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) af[t1 & 1][m] = load8(&Xc[toff + (ab[m][kw] ^ flip)]);
+                }
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(af[t & 1][m], bq[t % (PF + 1)][j], acc[m][j]);
+                __builtin_amdgcn_sched_group_barrier(0x020, TN, 0);           // VMEM reads: B fragments of step t + PF
+                if (t + 1 < B::NTAP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);   // DS reads: A fragments of tap t + 1
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);      // the MFMAs of tap t
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: bias -> LDS tile [voxel][co] -> coalesced channels-last stores + GroupNorm partial sums
+    T* Os = Xs;
+    float* red = (float*)(Xs + OS_ELEMS);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 16 + l15;
+        const float bsv = a.bias ? a.bias[co0 + col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Os[((wm * TM + m) * 16 + q * 4 + r) * OLD + col] = from_f<T>(acc[m][j][r] + bsv);
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    T* out = (T*)a.out;
+    for (int i = tid; i < B::V * CPR; i += 256) {
+        const int v = i / CPR, c8 = i % CPR;
+        int vz, vy, vx;
+        B::vox(v, vz, vy, vx);
+        const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+        if (x < a.W && y < a.H && z < a.D)
+            store8(out + ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8, load8(&Os[v * OLD + c8 * 8]));
+    }
+    if (a.stats) {
+        constexpr int G = 256 / BN;
+        const int col = tid % BN, g = tid / BN;
+        float s = 0.f, ss = 0.f;
+        for (int v = g; v < B::V; v += G) {
+            int vz, vy, vx;
+            B::vox(v, vz, vy, vx);
+            if (x0 + vx < a.W && y0 + vy < a.H && z0 + vz < a.D) {
+                const float f = to_f(Os[v * OLD + col]);
+                s += f; ss += f * f;
+            }
+        }
+        red[(g * BN + col) * 2] = s;
+        red[(g * BN + col) * 2 + 1] = ss;
+        __syncthreads();
+        if (tid < BN) {
+            double ts = 0.0, tss = 0.0;
+            for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
+            double* dst = a.stats + ((long long)(blockIdx.x % STAT_REP) * a.N * a.Cout + (long long)n * a.Cout + co0 + col) * 2;
+            atomicAdd(dst, ts);
+            atomicAdd(dst + 1, tss);
+        }
+    }
+}
+
+
+template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC>
+void launch_cfg(const Conv3xArgs& a, hipStream_t s) {
+    constexpr int BN = WN * TN * 16;
+    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
+    dim3 grid((unsigned)nbox, a.Cout / BN);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x_kernel<T, B, TM, TN, WM, WN, NRES, PF, OCC>), grid, dim3(256), 0, s, a);
+}
+
+// one translation unit per (dtype, ndim): the tap loops are fully unrolled and each instantiation takes ~10 s to compile
+template <class T> bool launch_3d(int id, const Conv3xArgs& a, hipStream_t s);
+template <class T> bool launch_2d(int id, const Conv3xArgs& a, hipStream_t s);
+
+#define SEG_C3X_3D_BODY                                                                                       \
+    switch (id) {                                                                                             \
+        /*                       box (TD,TH,TW,KD,TX)      TM TN WM WN NRES PF OCC */                         \
+        case 0: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 2, 2>(a, s); return true;               \
+        case 1: launch_cfg<T, XBox<4, 8, 16, 3, 16>, 8, 2, 4, 1, 1, 2, 1>(a, s); return true;               \
+        case 2: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 8, 2, 2, 2, 2, 8, 1>(a, s); return true;               \
+        case 3: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 2, 8, 2>(a, s); return true;                 \
+        case 4: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 8, 2, 2, 2, 2, 8, 1>(a, s); return true;                 \
+        case 5: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 4, 4, 1, 2, 2, 1>(a, s); return true;                 \
+        case 6: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 4, 4, 1, 2, 2, 2>(a, s); return true;                 \
+        case 7: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 2, 2, 2, 4, 8, 1>(a, s); return true;                \
+        case 8: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 2, 2, 2, 4, 8, 1>(a, s); return true;                \
+        case 9: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 4, 2, 2, 4, 2, 1>(a, s); return true;                \
+        case 10: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 1, 4, 1, 1, 8, 2>(a, s); return true;              \
+        case 11: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 4, 8, 1>(a, s); return true;                \
+        case 12: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 4, 2, 2, 4, 2, 1>(a, s); return true;                \
+        case 13: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 2, 8, 2>(a, s); return true;                \
+        case 14: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 2>(a, s); return true;                \
+        case 15: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 2, 8, 1>(a, s); return true;              \
+        case 16: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;              \
+        case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;                \
+        default: return false;                                                                                \
+    }
+#define SEG_C3X_2D_BODY                                                                                       \
+    switch (id) {                                                                                             \
+        case 32: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;             \
+        case 33: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 8, 2, 2, 2, 2, 2, 2>(a, s); return true;             \
+        case 34: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 2, 8, 2>(a, s); return true;              \
+        case 35: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 4, 8, 2>(a, s); return true;              \
+        case 36: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 4, 2, 2, 4, 2, 2>(a, s); return true;              \
+        case 37: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 1, 4, 1, 1, 8, 3>(a, s); return true;             \
+        case 38: launch_cfg<T, XBox<1, 8, 8, 1, 8>, 2, 2, 2, 2, 4, 8, 2>(a, s); return true;                \
+        case 39: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 2, 2, 4, 1, 2, 8, 2>(a, s); return true;              \
+        default: return false;                                                                                \
+    }
+
+}  // namespace c3x
+}  // namespace seg

@@ -44,6 +44,7 @@ struct Step {
     int mask_slot = -1;
     size_t stats = 0, scale = 0, shift = 0, mean = 0, rstd = 0, Q = 0, coef = 0;
     size_t wp_fwd = 0, wp_dg0 = 0, wp_dg1 = 0;
+    int x_fwd = -1, x_dg0 = -1, x_dg1 = -1;   // conv3x tiling of the forward / data-gradient launches (-1: conv3_kernel, row-major weights)
     int draw = -1;           // gradient wrt raw
     // ACT
     int ua = -1, ub = -1, res = -1, out = -1;
@@ -84,6 +85,7 @@ struct seg_engine {
     // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
     hipStream_t side = nullptr;
     bool use_side = true;
+    bool use_conv3x = true;     // SEG_CONV3X=0: conv3_kernel for every halo conv (round-1 path)
     bool dual_gn_bwd = true;    // SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
     bool stem_on_main = true;   // SEG_STEM_MAIN=0: 3^d stem weight gradient on the side stream (round-1 layout)
     int side_prio = 1;          // SEG_SIDE_PRIO=0: side stream at the default priority
@@ -415,8 +417,10 @@ struct Planner {
         const int k = (ck == CK_K3 || ck == CK_STEM3) ? 3 : (ck == CK_K2S2 || ck == CK_KT) ? 2 : 1;
         return e.ndim == 3 ? k * k * k : k * k;
     }
-    void add_pack(size_t dst, long long src_off, int R1, int R2, int T, int Cc, long long s1, long long s2, long long sT, long long sC, int flip) {
+    void add_pack(size_t dst, long long src_off, int R1, int R2, int T, int Cc, long long s1, long long s2, long long sT, long long sC, int flip,
+                  int frag = 0) {
         PackDesc d;
+        d.frag = frag;
         d.src = (const float*)(uintptr_t)src_off;   // offsets; resolved in seg_bind
         d.dst = (void*)(uintptr_t)dst;
         d.R1 = R1; d.R2 = R2; d.T = T; d.Cc = Cc;
@@ -468,19 +472,28 @@ struct Planner {
             const int C0 = E.tens[s.in0].C, C1 = s.in1 >= 0 ? E.tens[s.in1].C : 0;
             switch (s.ck) {
                 case CK_K3: case CK_K1: case CK_K2S2:
+                    s.x_fwd = s.x_dg0 = s.x_dg1 = -1;
+                    if (s.ck == CK_K3 && E.use_conv3x) {
+                        // register-blocked halo kernel (conv3x.hip) wherever the shape allows: fragment-major weights
+                        const int l = E.tens[s.raw].lvl, d_ = E.dim_d(l), h_ = E.dim_h(l), w_ = E.dim_w(l);
+                        if (conv3x_supported(dt, E.ndim, N, d_, h_, w_, Ci, Co, C0, C1 > 0)) s.x_fwd = conv3x_pick(E.ndim, N, d_, h_, w_, Ci, Co);
+                        if (!E.tens[s.in0].image && conv3x_supported(dt, E.ndim, N, d_, h_, w_, Co, C0, 0, false))
+                            s.x_dg0 = conv3x_pick(E.ndim, N, d_, h_, w_, Co, C0);
+                        if (C1 && conv3x_supported(dt, E.ndim, N, d_, h_, w_, Co, C1, 0, false)) s.x_dg1 = conv3x_pick(E.ndim, N, d_, h_, w_, Co, C1);
+                    }
                     s.wp_fwd = alloc_pack(Co, T * Ci);
-                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0);
+                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0, s.x_fwd >= 0);
                     if (s.ck == CK_K2S2) {       // data-gradient = scatter GEMM, rows (a, ci), K = Cout
                         s.wp_dg0 = alloc_pack(T * Ci, Co);
                         add_pack(s.wp_dg0, woff, T, Ci, 1, Co, 1, T, 0, (long long)Ci * T, 0);
                     } else {                     // data-gradient = gather conv with flipped taps, rows ci, k = (tap, co)
                         if (!E.tens[s.in0].image) {
                             s.wp_dg0 = alloc_pack(C0, T * Co);
-                            add_pack(s.wp_dg0, woff, C0, 1, T, Co, T, 0, 1, (long long)Ci * T, 1);
+                            add_pack(s.wp_dg0, woff, C0, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg0 >= 0);
                         }
                         if (C1) {
                             s.wp_dg1 = alloc_pack(C1, T * Co);
-                            add_pack(s.wp_dg1, woff + (long long)C0 * T, C1, 1, T, Co, T, 0, 1, (long long)Ci * T, 1);
+                            add_pack(s.wp_dg1, woff + (long long)C0 * T, C1, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg1 >= 0);
                         }
                     }
                     break;
@@ -543,6 +556,10 @@ struct Planner {
                         const int l = ro.lvl;
                         const int pi = E.prof_begin(st, conv3_class(E.dim_w(l)), E.tbytes(s.in0) + E.tbytes(s.raw),
                                                     2.0 * E.N * E.vol(l) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout);
+                        if (s.x_fwd >= 0)
+                            launch_conv3x(s.x_fwd, E.ws + i0.off, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, E.ws + s.wp_fwd, bias,
+                                          E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st);
+                        else
                         launch_conv3(E.ws + i0.off, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l),
                                      s.Cin, s.Cout, E.ndim, E.dtype, st, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
                         E.prof_end(st, pi);
@@ -815,6 +832,10 @@ struct Planner {
                         int pi;
                         if (g0 >= 0) {
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
+                            if (s.x_dg0 >= 0)
+                                launch_conv3x(s.x_dg0, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr,
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
+                            else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);
@@ -822,6 +843,10 @@ struct Planner {
                         if (g1 >= 0) {
                             const int C1 = E.tens[s.in1].C;
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g1), fl * C1 / s.Cin);
+                            if (s.x_dg1 >= 0)
+                                launch_conv3x(s.x_dg1, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr,
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);
+                            else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);
@@ -929,6 +954,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
     e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
     e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
+    if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;
     if (getenv("SEG_DUAL_GN")) e->dual_gn_bwd = atoi(getenv("SEG_DUAL_GN")) != 0;
     if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
     if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
@@ -1238,6 +1264,30 @@ int seg_op_conv3(const void* in, const void* w, const float* bias, void* out, do
     if (cin < 16 || (cin & (cin - 1)) || cout % 16) return fail("seg_op_conv3: Cin must be a power of two >= 16, Cout a multiple of 16");
     launch_conv3(in, w, bias, out, stats, n, ndim == 3 ? d : 1, h, wid, cin, cout, ndim, dtype, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_conv3: launch failed");
+}
+int seg_op_conv3x(int cfg, const void* in0, const void* in1, int c0, const void* w, const float* bias, void* out, double* stats, int n, int d,
+                  int h, int wid, int cin, int cout, int ndim, int dtype, void* stream) {
+    if (!in0 || !w || !out) return fail("seg_op_conv3x: null pointer");
+    if (ndim != 2 && ndim != 3) return fail("seg_op_conv3x: ndim must be 2 or 3");
+    const int dd = ndim == 3 ? d : 1;
+    if (!conv3x_supported(dtype, ndim, n, dd, h, wid, cin, cout, c0, in1 != nullptr))
+        return fail("seg_op_conv3x: needs a 16-bit dtype, Cin % 32 == 0, Cout % 16 == 0 and tensors below 2 GB per sample");
+    if (cfg < 0) cfg = conv3x_pick(ndim, n, dd, h, wid, cin, cout);
+    if (cfg < 0 || !launch_conv3x(cfg, in0, in1, c0, w, bias, out, stats, n, dd, h, wid, cin, cout, ndim, dtype, (hipStream_t)stream))
+        return fail("seg_op_conv3x: the tiling does not fit this shape");
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_conv3x: launch failed");
+}
+int seg_op_conv3x_num_cfgs(void) { return conv3x_num_cfgs(); }
+int seg_op_conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, char* name, int name_cap) {
+    const char* nm = nullptr;
+    if (conv3x_cfg_info(index, id, ndim, box3, bn, nres, &nm)) return fail("seg_op_conv3x_cfg_info: index out of range");
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", nm);
+    return 0;
+}
+int seg_op_conv3x_default_cfg(int ndim, int n, int d, int h, int wid, int cin, int cout, int dtype) {
+    const int dd = ndim == 3 ? d : 1;
+    if (!conv3x_supported(dtype, ndim, n, dd, h, wid, cin, cout, 0, false)) return -1;
+    return conv3x_pick(ndim, n, dd, h, wid, cin, cout);
 }
 long long seg_op_wgrad3_partial_bytes(int ndim, int n, int d, int h, int wid, int p, int q) {
     return (long long)wgrad3_partial_bytes(ndim, n, ndim == 3 ? d : 1, h, wid, p, q);

@@ -16,6 +16,13 @@ bool conv_uses_stream_kernel(const ConvArgs& a);   // true: register-resident st
 // LDS halo-tile kernels for 3^d stride-1 pad-1 convs (conv3.hip): forward / data-gradient and weight gradient
 void launch_conv3(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cin,
                   int Cout, int ndim, int dtype, hipStream_t s, const void* in1 = nullptr, int C0 = 0);   // in1: second concat source
+// register-blocked variant for 16-bit tensors, Cin % 32 == 0 (conv3x.hip); weights fragment-major (PackDesc.frag = 1)
+bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, int Cout, int C0, bool has_in1);
+int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout);    // tiling id for the shape, -1: none
+int conv3x_num_cfgs();
+int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name);
+bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s);
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q);
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,

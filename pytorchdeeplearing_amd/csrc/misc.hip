@@ -62,7 +62,20 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs) {
             row_s[t * d.Cc + c] = src[tt * d.sT + c * d.sC];
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < d.Kpad; k += 256) dst[row * d.Kpad + k] = from_f<T>(k < K ? row_s[k] : 0.f);
+        if (d.frag) {
+            // fragment-major: the 8 consecutive channels (t, c8*8 ..) of this row are lane 16*(c8%4) + row%16 of the
+            // (chunk c8/4, tap t, tile row/16) fragment
+            for (int k8 = threadIdx.x; k8 < K / 8; k8 += 256) {
+                const int t = k8 / (d.Cc / 8), c8 = k8 % (d.Cc / 8);
+                vec<T, 8> v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = from_f<T>(row_s[t * d.Cc + c8 * 8 + j]);
+                const long long f = ((long long)(c8 >> 2) * d.T + t) * (rows >> 4) + (row >> 4);
+                store8(dst + (f * 64 + (c8 & 3) * 16 + (row & 15)) * 8, v);
+            }
+        } else {
+            for (int k = threadIdx.x; k < d.Kpad; k += 256) dst[row * d.Kpad + k] = from_f<T>(k < K ? row_s[k] : 0.f);
+        }
         __syncthreads();
     }
 }

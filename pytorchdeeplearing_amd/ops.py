@@ -39,7 +39,7 @@ class WgradArgs(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R1", C.c_int), ("R2", C.c_int), ("T", C.c_int),
                 ("Cc", C.c_int), ("Kpad", C.c_int), ("s1", C.c_longlong), ("s2", C.c_longlong),
-                ("sT", C.c_longlong), ("sC", C.c_longlong), ("flipT", C.c_int)]
+                ("sT", C.c_longlong), ("sC", C.c_longlong), ("flipT", C.c_int), ("frag", C.c_int)]
 
 
 def check_abi(lib):
@@ -82,10 +82,11 @@ def aligned_like(t, dtype=None):
     return o
 
 
-def pack(w, layout, dtype):
+def pack(w, layout, dtype, frag=False):
     """Re-layout an fp32 PyTorch-layout conv / conv-transpose weight for the GEMM kernels.
     layouts: conv_fwd [co][(t,ci)] | conv_dgrad [ci][(flip t,co)] | k2s2_dgrad [(a,ci)][co] |
-             convT_fwd [(a,co)][ci] | convT_dgrad [ci][(a,co)]"""
+             convT_fwd [(a,co)][ci] | convT_dgrad [ci][(a,co)]
+    frag=True: the same elements in MFMA-fragment-major order (conv3x)."""
     lib = _capi.lib_for(w.device)
     w = aligned_like(w.float().contiguous())
     A, B = w.shape[0], w.shape[1]
@@ -112,6 +113,9 @@ def pack(w, layout, dtype):
     else:
         raise ValueError(layout)
     d.Kpad = _kpad(d.T * d.Cc)
+    d.frag = 1 if frag else 0
+    if frag:
+        assert d.Cc % 32 == 0 and rows % 16 == 0, "fragment-major packing needs Cc % 32 == 0 and rows % 16 == 0"
     out = _alloc((rows, d.Kpad), TORCH_DTYPE[dtype], w.device)
     d.dst = out.data_ptr()
     raw = bytes(d)
@@ -216,3 +220,31 @@ def wgrad3(dr, x, dtype, ndim):
     lib.check(lib.seg_op_wgrad3(dr.data_ptr(), x.data_ptr(), partial.data_ptr(), dw.data_ptr(), N, D, H, W, P, Q, ndim,
                                 _capi.DTYPE[dtype], _capi.stream_for(dr.device)), "seg_op_wgrad3")
     return dw
+
+
+def conv3x_cfgs(device):
+    """The tilings of the register-blocked halo conv: list of dicts (id, ndim, box, bn, nres, name)."""
+    lib = _capi.lib_for(device)
+    out = []
+    for i in range(lib.seg_op_conv3x_num_cfgs()):
+        cid, nd, bn, nres = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        box = (C.c_int * 3)()
+        name = C.create_string_buffer(96)
+        lib.check(lib.seg_op_conv3x_cfg_info(i, C.byref(cid), C.byref(nd), box, C.byref(bn), C.byref(nres), name, 96), "cfg_info")
+        out.append(dict(id=cid.value, ndim=nd.value, box=tuple(box), bn=bn.value, nres=nres.value, name=name.value.decode()))
+    return out
+
+
+def conv3x(x, wfrag, dtype, ndim, cout, bias=None, want_stats=False, out=None, x1=None, cfg=-1):
+    """Register-blocked halo conv (16-bit, Cin % 32 == 0); wfrag = pack(..., frag=True).  x1: second concat source."""
+    lib = _capi.lib_for(x.device)
+    N, D, H, W, c0 = x.shape
+    cin = c0 + (x1.shape[-1] if x1 is not None else 0)
+    if out is None:
+        out = _alloc((N, D, H, W, cout), TORCH_DTYPE[dtype], x.device, zero=True)
+    stats = _alloc((32, N, cout, 2), torch.float64, x.device, zero=True) if want_stats else None
+    lib.check(lib.seg_op_conv3x(cfg, x.data_ptr(), x1.data_ptr() if x1 is not None else None, c0, wfrag.data_ptr(),
+                                bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                stats.data_ptr() if stats is not None else None, N, D, H, W, cin, cout, ndim, _capi.DTYPE[dtype],
+                                _capi.stream_for(x.device)), "seg_op_conv3x")
+    return (out, stats.sum(0)) if want_stats else out

@@ -335,7 +335,31 @@ inline vec<short, 4> ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+// direct global -> LDS copy (buffer_load_dwordx4 ... lds): lane l copies `size` bytes from base + voffset to lds + size*l;
+// offsets at or beyond the resource's byte range store zeros.  Executed synchronously (the checker has no memory latency).
+typedef int emu_i32x4 __attribute__((ext_vector_type(4)));
+inline void seg_raw_buffer_load_lds(emu_i32x4 rsrc, __attribute__((address_space(3))) unsigned* lds, int size, int voffset, int soffset, int offset, int aux) {
+    (void)aux;
+    const unsigned long long base = (unsigned long long)(unsigned)rsrc[0] | ((unsigned long long)((unsigned)rsrc[1] & 0xffffu) << 32);
+    const unsigned range = (unsigned)rsrc[2];
+    const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned)soffset + (unsigned)offset;
+    unsigned char* dst = (unsigned char*)(uintptr_t)lds + (size_t)size * emu::me().lane;
+    assert(((uintptr_t)dst & (size >= 16 ? 15 : 3)) == 0 && "LDS destination of a direct load must be aligned");
+    if (off + size > range) memset(dst, 0, size);
+    else memcpy(dst, (const unsigned char*)base + off, size);
+}
+inline emu_i32x4 seg_raw_buffer_load_b128(emu_i32x4 rsrc, int voffset, int soffset, int aux) {
+    (void)aux;
+    const unsigned long long base = (unsigned long long)(unsigned)rsrc[0] | ((unsigned long long)((unsigned)rsrc[1] & 0xffffu) << 32);
+    const unsigned range = (unsigned)rsrc[2];
+    const unsigned long long off = (unsigned long long)(unsigned)voffset + (unsigned)soffset;
+    emu_i32x4 r = {0, 0, 0, 0};
+    if (off + 16 <= range) memcpy(&r, (const unsigned char*)base + off, 16);
+    return r;
+}
 #define HIP_KERNEL_NAME(...) __VA_ARGS__

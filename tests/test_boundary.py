@@ -34,6 +34,22 @@ def test_losses_metrics_modules_vs_reference_golden(dev, golden_dir):
         assert abs(float(losses.BinaryDiceLoss()(z, y.to(dt))) - float(G["loss_BinaryDiceLoss"])) < 2e-6
 
 
+def test_multiclass_iou_coeff_vs_reference_golden(dev, golden_dir):
+    """M4 (model/metric.py:204-215): golden values come from the reference's own function text with its unsatisfiable size
+    assert removed (oracle/make_golden.py:METRIC_REPAIRS); 3-D with every class present, with an absent class, and 2-D."""
+    G = np.load(os.path.join(golden_dir, "metric_extra.npz"))
+    z4, z3 = torch.from_numpy(G["z4"]), torch.from_numpy(G["z3"])
+    for key, z, y in (("miou_a", z4, G["y4"]), ("miou_b", z4, G["y4b"]), ("miou_2d", z3, G["y3"])):
+        y = torch.from_numpy(y)
+        p = torch.softmax(z, 1)
+        assert abs(float(seg.multiclass_iou_coeff(p, y)) - float(G[key])) < 1e-7, key                 # the restatement
+        assert abs(float(metric.multiclass_iou_coeff(p.to(dev), y.to(dev))) - float(G[key])) < 1e-7, key      # the kernel
+        for dt in (torch.uint8, torch.int32):
+            assert abs(float(metric.multiclass_iou_coeff(p.to(dev), y.to(dev).to(dt))) - float(G[key])) < 1e-7
+    assert abs(float(metric.multiclass_dice_coeff(torch.softmax(z4, 1).to(dev), torch.from_numpy(G["y4"]).to(dev))) - float(G["mdice_a"])) < 1e-7
+    assert float(G["miou_a"]) > 0.05          # the fixture is not the trivial all-background case
+
+
 EXTRA_LOSSES = ["BinaryJaccardLoss", "BinaryELDiceLoss", "BinaryTverskyLoss", "MutilCrossEntropyDiceLoss", "MutilELDiceLoss"]
 
 

@@ -85,6 +85,69 @@ def test_trainprocess_and_predict(dev, tmp_path, monkeypatch, cls, numclass, los
         bad.trainprocess(tr_i, tr_l, va_i, va_l, model_dir=log, epochs=1)
 
 
+def _make_png(tmp, n, hw, numclass, seed):
+    from PIL import Image
+    g = np.random.RandomState(seed)
+    imgs, labs = [], []
+    for i in range(n):
+        ip, lp = os.path.join(tmp, "img%d_%d.png" % (seed, i)), os.path.join(tmp, "lab%d_%d.png" % (seed, i))
+        Image.fromarray((g.rand(*hw) * 255).astype(np.uint8)).save(ip)
+        lab = (g.rand(*hw) > 0.6).astype(np.uint8) * 255 if numclass == 1 else g.randint(0, numclass, hw).astype(np.uint8)
+        Image.fromarray(lab).save(lp)
+        imgs.append(ip); labs.append(lp)
+    return np.array(imgs), np.array(labs)
+
+
+@pytest.mark.parametrize("cls,numclass,loss,pth", [("BinaryVNet2dModel", 1, "BinaryCrossEntropyDiceLoss", "BinaryVNet2dModel.pth"),
+                                                    ("MutilUNet2dModel", 3, "MutilFocalLoss", "MutilUNet2d.pth")])
+def test_2d_wrappers_trainprocess_and_inference_on_image_files(dev, tmp_path, monkeypatch, cls, numclass, loss, pth):
+    """The 2-D wrappers (modelVNet.py:90-242, modelUnet.py:90-242): image FILES through datasetModelSegwithopencv (grey read,
+    resize to the network size, z-score), trainprocess, checkpoint, predict against the oracle, `inference(image)`
+    (resize -> /255 -> predict -> resize back, modelVNet.py:231-242)."""
+    import model
+    from pytorchdeeplearing_amd.model import _io
+    from pytorchdeeplearing_amd.model.dataset import datasetModelSegwithopencv
+    monkeypatch.setenv("SEGENGINE_DTYPE", "f32")
+    if dev.type == "cpu" and cls != "BinaryVNet2dModel":
+        pytest.skip("host-checker run keeps one 2-D wrapper (the GPU run covers both)")
+    tmp = str(tmp_path)
+    H = W = 32
+    tr_i, tr_l = _make_png(tmp, 2, (40, 36), numclass, 3)          # files are NOT at the network size: the dataset resizes
+    va_i, va_l = _make_png(tmp, 1, (32, 32), numclass, 4)
+    # the dataset item format of model/dataset.py:119-159
+    item = datasetModelSegwithopencv(tr_i, tr_l, targetsize=(1, H, W))[0]
+    assert item["image"].shape == (1, H, W) and item["image"].dtype == torch.float32 and item["label"].shape == (H, W)
+    assert item["label"].dtype == torch.int64 and abs(float(item["image"].mean())) < 1e-5 and abs(float(item["image"].std(unbiased=False)) - 1) < 1e-4
+    m = getattr(model, cls)(image_height=H, image_width=W, image_channel=1, numclass=numclass, batch_size=2, loss_name=loss,
+                            use_cuda=dev.type == "cuda")
+    log = os.path.join(tmp, "log2d")
+    m.trainprocess(tr_i, tr_l, va_i, va_l, model_dir=log, epochs=1 if dev.type == "cpu" else 2)
+    assert os.path.isfile(os.path.join(log, pth)) and np.isfinite(m.history["train_loss"]).all()
+    assert os.path.isfile(os.path.join(log, "1_Train_EPOCH_pdmask.bmp"))
+    m.model.load_state_dict(torch.load(os.path.join(log, pth)))
+    # inference(): a grey image of another size in, a mask of the SAME size out
+    # (square: the reference hands image.shape = (H, W) to cv2.resize as (w, h), modelVNet.py:241 - kept as is)
+    img = (np.random.RandomState(8).rand(48, 48) * 255).astype(np.uint8)
+    out = m.inference(img)
+    assert out.shape == img.shape[:2] and out.dtype == np.uint8
+    # predict() on the resized, /255 image equals the oracle's eval forward with the trained weights
+    from oracle import seg_oracle as seg
+    small = _io.resize(img, (W, H)) / 255.0
+    got = m.predict(np.reshape(small, (1, H, W)))
+    kind = "vnet" if "VNet" in cls else "unet"
+    sd = {k: v.detach().cpu().float() for k, v in m.model.state_dict().items()}
+    _, probs = seg.net_forward(kind, sd, torch.from_numpy(np.reshape(small, (1, 1, H, W))).float())
+    if numclass == 1:
+        want = ((probs[0, 0] > 0.5).numpy() * 255).astype(np.uint8)
+        tied = (probs[0, 0] - 0.5).abs().numpy() < 5e-5
+    else:
+        want = probs[0].argmax(0).numpy().astype(np.uint8)
+        top2 = probs[0].topk(2, dim=0).values
+        tied = (top2[0] - top2[1]).numpy() < 1e-4
+    assert np.array_equal(got[~tied], want[~tied]) and tied.mean() < 0.02
+    assert np.array_equal(out, _io.resize(got, img.shape[:2], nearest=False))
+
+
 def _oracle_net(kind, sd, scale):
     from oracle import seg_oracle as seg
 
