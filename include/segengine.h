@@ -232,6 +232,10 @@ int seg_op_conv3(const void* in, const void* w, const float* bias, void* out, do
 long long seg_op_wgrad3_partial_bytes(int ndim, int n, int d, int h, int wid, int p, int q);
 int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int n, int d, int h, int wid, int p,
                   int q, int ndim, int dtype, void* stream);
+/* seg_op_wgrad3 with x a virtual channel concat: channels [0, c0) of x come from x0 ([..][c0]), the rest from x1 ([..][q - c0])
+ * (the UNet decoder blocks read cat(up, skip), networks/Unet3d.py:50-62, without materialising it). */
+int seg_op_wgrad3_cat(const void* dr, const void* x0, const void* x1, int c0, float* partial, float* dw, int n, int d, int h,
+                      int wid, int p, int q, int ndim, int dtype, void* stream);
 /* Register-blocked halo conv for 16-bit tensors with Cin % 32 == 0 (csrc/conv3x.hip): same operator as seg_op_conv3, the
  * weights packed with seg_pack_desc.frag = 1 ("conv_fwd" / "conv_dgrad" element order), `in1` an optional second source of a
  * virtual channel concat (channels c0..cin-1).  cfg selects a tiling (seg_op_conv3x_cfg_info enumerates them; -1 = the

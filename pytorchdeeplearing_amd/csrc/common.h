@@ -114,6 +114,23 @@ template <class T> __device__ __forceinline__ vec<T, 8> buffer_load8(i32x4 rsrc,
 template <class T> __device__ __forceinline__ void dma16(i32x4 rsrc, T* lds_wave_base, unsigned voffset) {
     seg_raw_buffer_load_lds(rsrc, (__attribute__((address_space(3))) unsigned*)(lds_wave_base), 16, (int)voffset, 0, 0, 0);
 }
+// The same copy, invisible to the compiler's s_waitcnt bookkeeping: hipcc drains a dma16 (it may alias any ds_read of the same
+// LDS array) before the next LDS read, which serialises "copy box i + 1 while box i is multiplied".  Written as one asm statement
+// the copy stays in flight until the caller's own wait_vmem() + barrier.  M0 (the LDS destination base) is saved and restored
+// inside the statement; the leading s_nop covers an SGPR operand freshly written by a VALU readfirstlane
+// (cdna_hip_programming.md section 5.7).  The host checker has no asynchrony to model and runs the plain copy.
+#ifndef SEG_EMU
+template <class T> __device__ __forceinline__ void dma16_async(i32x4 rsrc, T* lds_wave_base, unsigned voffset) {
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voffset), "s"(lds_addr), "s"(rsrc)
+                 : "memory");
+}
+#else
+template <class T> __device__ __forceinline__ void dma16_async(i32x4 rsrc, T* lds_wave_base, unsigned voffset) { dma16(rsrc, lds_wave_base, voffset); }
+#endif
 // all of this wave's outstanding global loads / LDS copies have landed (s_waitcnt vmcnt(0); expcnt / lgkmcnt untouched)
 __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 

@@ -945,12 +945,36 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) 
 
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
                    int dtype, hipStream_t s, const void* x1, int C0) {
+    const int T = ndim == 3 ? 27 : 9;
+    // 16-bit tensors: double-buffered kernel (wgrad3x.hip), same partial-tile layout and reduce
+    static const bool use_x = !(getenv("SEG_WGRAD3X") && atoi(getenv("SEG_WGRAD3X")) == 0);
+    if (use_x && wgrad3x_supported(dtype, N, ndim == 3 ? D : 1, H, W, P, Q, C0, x1 != nullptr)) {
+        int CP, CQ;
+        wgrad3x_tiles(P, Q, C0, x1 != nullptr, &CP, &CQ);
+        const int combos = (P / CP) * (Q / CQ);
+        // one resident round of workgroups (one 512-thread workgroup per CU); at least `minbox` boxes per workgroup. The scratch
+        // sized by wgrad3_partial_bytes (512 tiles of 32 x taps x 32) covers every choice below
+        static const int total = getenv("SEG_W3X_TOTAL") ? atoi(getenv("SEG_W3X_TOTAL")) : 256;
+        static const int minbox = getenv("SEG_W3X_MINBOX") ? atoi(getenv("SEG_W3X_MINBOX")) : 4;
+        const long long nbox = boxes_for(ndim, N, D, H, W);
+        long long nb = total / combos;
+        if (nb > (nbox + minbox - 1) / minbox) nb = (nbox + minbox - 1) / minbox;
+        const long long cap = (long long)(wgrad3_partial_bytes(ndim, N, D, H, W, P, Q) / ((size_t)combos * CP * T * CQ * sizeof(float)));
+        if (nb > cap) nb = cap;
+        if (nb < 1) nb = 1;
+        launch_wgrad3x(dr, x, x1, C0, partial, (int)nb, N, D, H, W, P, Q, ndim, dtype, wide_box(W), s);
+        const long long tot = (long long)P * Q * T;
+        int blocks = (int)((tot + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, ((int)nb + 31) / 32), dim3(256), 0, s, (const float*)partial, dw, P, Q, CP, CQ, T, (int)nb,
+                           (long long)Q * T, (long long)T);
+        return;
+    }
     Wgrad3Args a;
     a.x1 = x1; a.C0 = C0;
     a.dr = dr; a.x = x; a.partial = partial;
     a.N = N; a.D = D; a.H = H; a.W = W; a.P = P; a.Q = Q;
     a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q);
-    const int T = ndim == 3 ? 27 : 9;
     if (dtype == DT_F32) wgrad3_dispatch<float>(a, ndim, dw, (long long)Q * T, T, s);
     else if (dtype == DT_F16) wgrad3_dispatch<f16>(a, ndim, dw, (long long)Q * T, T, s);
     else wgrad3_dispatch<bf16>(a, ndim, dw, (long long)Q * T, T, s);

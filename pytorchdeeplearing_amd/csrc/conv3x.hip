@@ -63,9 +63,7 @@ bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, 
 }
 
 // default tiling per problem.  Overrides: SEG_C3X_CFG=<id> (one tiling wherever it fits), SEG_C3X_MAP="cin:cout:w=id,..."
-// (per layer shape; tools/tune_conv3x.py prints the measured table).  Otherwise: least padding waste of the box grid, then
-// output tiles of min(Cout, 64) channels, then just enough resident chunks for Cin, then the box size that gives the
-// chip at least ~2 workgroups per CU.
+// (per layer shape; tools/tune_conv3x.py prints the measured table).
 int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
     static const int force = getenv("SEG_C3X_CFG") ? atoi(getenv("SEG_C3X_CFG")) : -1;
     if (force >= 0) {
@@ -84,22 +82,27 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
             if (*p == ',') ++p;
         }
     }
-    const int nchunk = Cin / 32, want_bn = Cout % 64 == 0 ? 64 : (Cout % 32 == 0 ? 32 : 16);
-    int best = -1;
-    double best_score = 1e30;
-    for (int i = 0; i < kNumCfgs; ++i) {
-        const Cfg& c = kCfgs[i];
-        if (!cfg_fits(c, ndim, Cout) || c.bn > 64) continue;
-        auto up = [](int v, int t) { return (double)((v + t - 1) / t * t) / v; };
-        const double waste = up(ndim == 3 ? D : 1, c.td) * up(H, c.th) * up(W, c.tw);
-        const long long wgs = (long long)N * ((D + c.td - 1) / c.td) * ((H + c.th - 1) / c.th) * ((W + c.tw - 1) / c.tw) * (Cout / c.bn);
-        double score = waste * 1000.0;
-        score += c.bn == want_bn ? 0.0 : 100.0 * (want_bn > c.bn ? want_bn / c.bn : c.bn / want_bn);
-        score += c.nres >= nchunk ? 10.0 * (c.nres - nchunk) : 40.0 * ((nchunk + c.nres - 1) / c.nres);
-        score += wgs >= 512 ? -1.0 * (c.td * c.th * c.tw) / 256.0 : 5.0 * (c.td * c.th * c.tw) / 256.0;   // big boxes only when the chip stays full
-        if (score < best_score) { best_score = score; best = c.id; }
+    // measured choice per layer class (profiles/r02_tune_conv3x.jsonl: MI355X, every tiling on the halo-conv shapes of BASELINE
+    // configs C2 - C5): 64 output channels per workgroup wherever Cout allows; 128-voxel boxes with all of Cin resident for the
+    // wide levels, 96-voxel 4x4-tile boxes (3 x 2 register tiles) once the volume is small enough that workgroup count matters
+    // more than operand reuse; for 32 output channels a 256-voxel box and 4 x 2 register tiles.
+    const long long vox = (long long)N * D * H * W;
+    int id;
+    if (ndim == 3) {
+        if (Cout % 32) id = 10;
+        else if (Cout % 64) id = Cin <= 32 ? 14 : (Cin == 64 ? (W >= 48 ? 17 : 15) : 14);
+        else if (vox <= 16384) id = Cout >= 2 * Cin ? 13 : 7;
+        else id = Cin >= 128 ? 5 : 3;
+    } else {
+        if (Cout % 32) id = 37;
+        else if (Cout % 64) id = 32;
+        else id = Cin >= 256 ? 35 : 33;
     }
-    return best;
+    const Cfg* c = find_cfg(id);
+    if (c && cfg_fits(*c, ndim, Cout)) return id;
+    for (int i = 0; i < kNumCfgs; ++i)
+        if (cfg_fits(kCfgs[i], ndim, Cout)) return kCfgs[i].id;
+    return -1;
 }
 
 int conv3x_num_cfgs() { return kNumCfgs; }

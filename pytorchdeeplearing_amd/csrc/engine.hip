@@ -1299,6 +1299,14 @@ int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int 
     launch_wgrad3(dr, x, partial, dw, n, ndim == 3 ? d : 1, h, wid, p, q, ndim, dtype, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_wgrad3: launch failed");
 }
+int seg_op_wgrad3_cat(const void* dr, const void* x0, const void* x1, int c0, float* partial, float* dw, int n, int d, int h, int wid, int p,
+                      int q, int ndim, int dtype, void* stream) {
+    if (!dr || !x0 || !x1 || !partial || !dw) return fail("seg_op_wgrad3_cat: null pointer");
+    if (p % 16 || q % 16 || (p > 16 && p % 32) || (q > 16 && q % 32)) return fail("seg_op_wgrad3_cat: channel counts must be 16 or multiples of 32");
+    if (c0 <= 0 || c0 >= q || c0 % 16) return fail("seg_op_wgrad3_cat: c0 must be a multiple of 16 inside (0, q)");
+    launch_wgrad3(dr, x0, partial, dw, n, ndim == 3 ? d : 1, h, wid, p, q, ndim, dtype, (hipStream_t)stream, x1, c0);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_wgrad3_cat: launch failed");
+}
 int seg_abi_sizeof(int which) {
     return which == 0 ? (int)sizeof(seg_conv_args) : which == 1 ? (int)sizeof(seg_wgrad_args) : (int)sizeof(seg_pack_desc);
 }

@@ -23,6 +23,11 @@ int conv3x_num_cfgs();
 int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name);
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
                    int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s);
+// double-buffered weight gradient for 16-bit tensors (wgrad3x.hip); partial tiles in the layout wgrad3_reduce_kernel sums
+bool wgrad3x_supported(int dtype, int N, int D, int H, int W, int P, int Q, int C0, bool has_x1);
+void wgrad3x_tiles(int P, int Q, int C0, bool has_x1, int* CP, int* CQ);
+bool launch_wgrad3x(const void* dr, const void* x0, const void* x1, int C0, float* partial, int nb, int N, int D, int H, int W, int P, int Q,
+                    int ndim, int dtype, bool wide, hipStream_t s);
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q);
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,

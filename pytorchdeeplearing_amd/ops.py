@@ -209,11 +209,18 @@ def conv3(x, wpacked, dtype, ndim, cout, bias=None, want_stats=False, out=None):
     return (out, stats.sum(0)) if want_stats else out
 
 
-def wgrad3(dr, x, dtype, ndim):
-    """weight gradient of the 3^d / 3^2 stride-1 pad-1 conv in PyTorch layout (P, Q, k..)."""
+def wgrad3(dr, x, dtype, ndim, x1=None):
+    """weight gradient of the 3^d / 3^2 stride-1 pad-1 conv in PyTorch layout (P, Q, k..); x1: second concat source of x."""
     lib = _capi.lib_for(dr.device)
     N, D, H, W, P = dr.shape
-    Q = x.shape[-1]
+    Q = x.shape[-1] + (x1.shape[-1] if x1 is not None else 0)
+    if x1 is not None:
+        nbytes = lib.seg_op_wgrad3_partial_bytes(ndim, N, D, H, W, P, Q)
+        partial = aligned_empty(nbytes, dr.device).view(torch.float32)
+        dw = _alloc((P, Q) + (3,) * ndim, torch.float32, dr.device, zero=True)
+        lib.check(lib.seg_op_wgrad3_cat(dr.data_ptr(), x.data_ptr(), x1.data_ptr(), x.shape[-1], partial.data_ptr(), dw.data_ptr(), N, D, H, W,
+                                        P, Q, ndim, _capi.DTYPE[dtype], _capi.stream_for(dr.device)), "seg_op_wgrad3_cat")
+        return dw
     nbytes = lib.seg_op_wgrad3_partial_bytes(ndim, N, D, H, W, P, Q)
     partial = aligned_empty(nbytes, dr.device).view(torch.float32)
     dw = _alloc((P, Q) + (3,) * ndim, torch.float32, dr.device, zero=True)

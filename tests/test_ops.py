@@ -255,3 +255,23 @@ def test_wgrad3_halo_exact(dev, dtype, case):
     got = ops.wgrad3(to_dev(cl(dy), dtype, dev), to_dev(cl(x), dtype, dev), dtype, ndim)
     assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
 
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(3, 1, (3, 8, 16), [16, 16], 16), (3, 2, (4, 6, 8), [32, 32], 32), (2, 1, (8, 16), [64, 64], 64),
+                                  (3, 1, (7, 9, 17), [32, 32], 64), (2, 2, (11, 13), [16, 16], 32)])
+def test_wgrad3_concat_exact(dev, dtype, case):
+    """x = virtual concat of two tensors (UNet decoder blocks): q-tiles never straddle the sources; partial boxes; several
+    boxes per workgroup on the double-buffered 16-bit kernel."""
+    ndim, N, sp, cins, cout = case
+    g = torch.Generator().manual_seed(sum(sp) + cout + 5)
+    x = ints((N, sum(cins)) + sp, -2, 2, g)
+    w = torch.zeros((cout, sum(cins)) + (3,) * ndim, requires_grad=True)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    y = conv(x, w, padding=1)
+    dy = ints(tuple(y.shape), -2, 2, g, density=0.6)
+    y.backward(dy)
+    assert float(w.grad.abs().max()) < 2 ** 20
+    xs = torch.split(x, cins, dim=1)
+    got = ops.wgrad3(to_dev(cl(dy), dtype, dev), to_dev(cl(xs[0]), dtype, dev), dtype, ndim, x1=to_dev(cl(xs[1]), dtype, dev))
+    assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
