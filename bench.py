@@ -2,15 +2,17 @@
 [RCCL grad all-reduce] + AdamW + weight re-pack) at 4 x 1 x 96^3 fp16 per GPU — BASELINE.json
 configs[2], the configuration the metric is quoted on.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One process per GPU; the batch shards on the batch axis (weak scaling: 4 volumes per GPU); the flat
 fp32 gradient buffer is all-reduced over RCCL (sum, then 1/N) before the fused optimiser step.  Inputs
 are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with the extra objects
-  "roofline"     – the dominant kernel class, timed live with HIP events inside the timed region
-  "cpu_baseline" – the oracle (torch-CPU port of the reference path) on this box's host cores.
+  "roofline"           – the dominant kernel class, timed live with HIP events inside the timed region
+  "cpu_baseline"       – the oracle (torch-CPU port of the reference path) on this box's host cores
+  "gpu_torch_baseline" – the same oracle functions on this GPU through stock PyTorch-ROCm / MIOpen (fp32 and autocast f16):
+                         the number the hand-written engine has to beat.
 """
 import argparse
 import json
@@ -40,12 +42,15 @@ PMC_KEY = {"conv3_smallbox": ["conv3_kernel<DF16_Li3ELi8ELi8ELi3ELi32ELi1ELb1E>"
            "gn_act": ["gn_act_kernel<DF16_>"]}
 
 
+PMC_FILE = "r02_pmc_fetch_write_per_kernel.json"      # regenerated from the final binary of the round (tools/gpu_final.sh)
+
+
 def pmc_traffic(kclass):
     """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes committed under profiles/
     (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled for gfx950 as
     MI355X_MICROARCH.md prescribes).  None when the summary is not available."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             table = json.load(f)
         rows = [table[k] for k in PMC_KEY[kclass] if k in table]
         n = sum(r["launches"] for r in rows)
@@ -57,13 +62,13 @@ def pmc_traffic(kclass):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("SEG_LANES", "1")), help="intra-GPU batch lanes (pytorchdeeplearing_amd/lanes.py)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline / dice_vs_ref / gpu_torch_baseline legs")
     ap.add_argument("--roofline-kernel", default="auto", help="kernel class bracketed with HIP events in the timed region; auto = "
                     "whichever of the two largest kernel symbols of the step (gn_bwd_reduce / gn_bwd_apply, rocprofv3 --stats summary "
                     "under profiles/) accumulates more event time in this run")
@@ -75,6 +80,54 @@ def parse(argv=None):
                     "all-reduced between the loss reduction and its finalize; gradients summed) instead of DDP semantics")
     ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
     return ap.parse_args(argv)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
+
+
+def gpu_torch_baseline(batch, size, dev, steps=3):
+    """Stock PyTorch-ROCm on the SAME GPU: the oracle's functional restatement of the reference
+    path (F.conv3d / group_norm / dropout3d-style masks / AdamW as torch ops, NCDHW) on `dev`, fp32 and autocast-f16, the full
+    batch x 1 x size^3 workload, dropout on.  MIOpen picks the convolution kernels; first calls include its search."""
+    from oracle import seg_oracle as seg
+    out = {}
+    x, y = seg.synthetic_batch(batch, (size,) * 3, 1, 1, seed=1234)
+    x, y = x.to(dev), y.to(dev)
+    for mode in ("fp32", "autocast_f16"):
+        try:
+            params = {k: v.to(dev) for k, v in seg.init_params("vnet", 3, 1, 1, seed=0).items()}
+            g = torch.Generator().manual_seed(0)
+            st = {}
+            times = []
+            for it in range(steps + 2):
+                masks = [m.to(dev) for m in seg.draw_masks("vnet", batch, generator=g)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if mode == "fp32":
+                    r = seg.forward_backward("vnet", params, x, y, "BinaryDiceLoss", masks=masks)
+                else:
+                    with torch.autocast("cuda", dtype=torch.float16):
+                        r = seg.forward_backward("vnet", params, x, y, "BinaryDiceLoss", masks=masks)
+                params = seg.adamw_step(params, r["grads"], st)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            best = min(times[2:])
+            out[mode] = {"value": round(batch / best, 2), "unit": "volumes/s", "ms_per_step": round(best * 1e3, 2),
+                         "sample": "%d timed train steps (2 warm-up) of VNet3d %dx1x%d^3, oracle functions on %s, torch %s"
+                                   % (steps, batch, size, torch.cuda.get_device_name(dev), torch.__version__)}
+            del params, st, r
+            torch.cuda.empty_cache()
+        except Exception as ex:      # a baseline that cannot run must not take the contract line down
+            out[mode] = {"error": str(ex)[:200]}
+    return out
 
 
 def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0):
@@ -101,8 +154,8 @@ def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0):
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
     base = {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
-            "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (torch %s CPU, %d threads), best step %.3f s"
-                      % (len(times), size, torch.__version__, ncores, best)}
+            "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (one volume, not the 4-volume batch), torch %s CPU, %d of the %d hardware "
+                      "threads of %s, best step %.3f s" % (len(times), size, torch.__version__, ncores, os.cpu_count() or 1, cpu_model(), best)}
     return base, _dice_vs_reference(seg, trained_state, dev, dtype)
 
 
@@ -165,13 +218,16 @@ def main(argv=None, checker_device=None):
     else:
         e = SegEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev)
     synthetic.init_engine(e, seed=0)
+    if world > 1 and a.lanes == 1:
+        from pytorchdeeplearing_amd.parallel import broadcast_parameters
+        broadcast_parameters(e, src=0)          # every replica starts from rank 0's weights (the dropout streams differ per rank)
     x, y = synthetic.synthetic_batch(a.batch, (S, S, S), 1, 1, seed=1234 + rank)
     x, y = x.to(dev), y.to(dev)
     logits = torch.empty((a.batch, 1, S, S, S), dtype=torch.float32, device=dev)
     probs = torch.empty_like(logits)
     allreduce = (GradAllReduce(world) if a.single_allreduce else BucketedGradAllReduce(world)) if world > 1 else None
 
-    exchange = GlobalBatchLoss(world) if (a.global_loss and world > 1 and a.lanes == 1) else None
+    exchange = GlobalBatchLoss(world, equal_shards=True) if (a.global_loss and world > 1 and a.lanes == 1) else None
     kw = {"loss_exchange": exchange} if exchange is not None else {}
 
     def step():
@@ -263,17 +319,18 @@ def main(argv=None, checker_device=None):
                 per_launch = {"algorithmic_bytes_per_launch": int(p["bytes"] / p["calls"])}
             blk = {
                 "kernel": KERNEL_SYMBOL.get(k, k), "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
-                "frac": round(ach / peak, 4), "traffic": pmc_traffic(k) if a.dtype == "f16" and S == 96 and a.batch == 4 else None,
-                "launches_per_step": p["calls"] // nprof, "avg_launch_us": round(avg_us, 2), "ms_per_step": round(p["ms"] / nprof, 3),
-                "avg_launch_us_raw": round(raw_ms / p["calls"] * 1e3, 2), "bracket_overhead_us": round(bracket_us, 2),
-                "frac_raw": round(ach * p["ms"] / raw_ms / peak, 4), "instrumented_steps": nprof}
+                "frac": round(ach * p["ms"] / raw_ms / peak, 4), "traffic": pmc_traffic(k) if a.dtype == "f16" and S == 96 and a.batch == 4 else None,
+                "launches_per_step": p["calls"] // nprof, "avg_launch_us": round(raw_ms / p["calls"] * 1e3, 2), "ms_per_step": round(raw_ms / nprof, 3),
+                "avg_launch_us_minus_bracket": round(avg_us, 2), "bracket_overhead_us": round(bracket_us, 2),
+                "frac_minus_bracket": round(ach / peak, 4), "instrumented_steps": nprof}
+            blk["achieved"] = round(ach * p["ms"] / raw_ms, 1)
             blk.update(per_launch)
             return blk
         corrected = lambda k: prof.get(k, {}).get("ms", 0.0) - prof.get(k, {}).get("calls", 0) * bracket_us * 1e-3
         a.roofline_kernel = max(candidates, key=corrected)
         NOTE_HBM = ("every launch of the first %d timed steps is bracketed by hipEventRecord on its launch stream (the brackets idle the "
-                    "stream and are part of value); achieved = sum of algorithmic bytes / (sum of event time - launches x the empty-bracket "
-                    "time measured live, bracket_overhead_us; frac_raw keeps the uncorrected event time); algorithmic bytes per launch = "
+                    "stream and are part of value); achieved = sum of algorithmic bytes / sum of event time (frac_minus_bracket subtracts the "
+                    "empty-bracket time measured live, bracket_overhead_us, per launch); algorithmic bytes per launch = "
                     "(gradient sources + 1 [+ 1 for the apply pass]) x tensor bytes (DESIGN.md section 5)" % nprof)
         NOTE_MFMA = ("small-box halo conv (24^3 and 6^3 levels, forward and data-gradient); algorithmic flops = 2*voxels*27*Cin*Cout, "
                      "bytes = input + output tensor; same bracket correction")
@@ -300,6 +357,10 @@ def main(argv=None, checker_device=None):
             line["kernel_classes"] = table
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"], line["dice_vs_ref"] = cpu_baseline(S, e.state_dict() if a.lanes == 1 else e.engines[0].state_dict(), dev, a.dtype)
+            if on_gpu:
+                del e
+                torch.cuda.empty_cache()
+                line["gpu_torch_baseline"] = gpu_torch_baseline(a.batch, S, dev)
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

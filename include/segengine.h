@@ -148,8 +148,9 @@ int seg_metric(const float* probs, const void* target, int label_type, int n, in
                void* ws, float* out2, void* stream);
 
 /* torch.optim.AdamW (model/modelVNet.py:548) / Adam (model/modelUnet.py:849) over flat buffers.
- * `state` = int[2] on the device: {step, found_inf}.  Gradients are multiplied by inv_scale first;
- * with check_finite the update is skipped (and state[1] set) when any gradient is inf/nan. */
+ * `state` = int[3] on the device: {step, found_inf, skipped}.  Gradients are multiplied by inv_scale first;
+ * with check_finite the update is skipped (state[1] set for this call, state[2] += 1) when any gradient is inf/nan;
+ * the caller reads state[2] now and then to back its loss scale off (no per-step host sync). */
 int seg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                   long long numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int decoupled, float inv_scale, int check_finite, int* state, void* stream);

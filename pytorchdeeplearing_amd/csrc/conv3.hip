@@ -946,8 +946,12 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) 
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
                    int dtype, hipStream_t s, const void* x1, int C0) {
     const int T = ndim == 3 ? 27 : 9;
-    // 16-bit tensors: double-buffered kernel (wgrad3x.hip), same partial-tile layout and reduce
-    static const bool use_x = !(getenv("SEG_WGRAD3X") && atoi(getenv("SEG_WGRAD3X")) == 0);
+    // 16-bit tensors, opt-in (SEG_WGRAD3X=1, read per call): double-buffered kernel (wgrad3x.hip), same partial-tile layout and
+    // reduce.  Measured on MI355X (profiles/r02_wgrad3x_ab.log): op-level 67 vs 67 us at 32ch@48^3, 62 vs 52 us at 64ch@24^3, train
+    // step 689 vs 712 volumes/s - one box in flight per CU is still latency-bound and its 112 KB / 512-thread workgroups crowd the
+    // main stream's kernels out of the CU, so wgrad3_kernel (three 44 KB workgroups per CU) stays the default.
+    const char* envx = getenv("SEG_WGRAD3X");
+    const bool use_x = envx && atoi(envx) != 0;
     if (use_x && wgrad3x_supported(dtype, N, ndim == 3 ? D : 1, H, W, P, Q, C0, x1 != nullptr)) {
         int CP, CQ;
         wgrad3x_tiles(P, Q, C0, x1 != nullptr, &CP, &CQ);

@@ -78,6 +78,8 @@ struct seg_engine {
     float* p = nullptr; float* g = nullptr; char* ws = nullptr;
     float loss_scale = 1.f;
     int mask_mode = 0;
+    int draws = 0;              // SEG_MASKS_RANDOM forwards issued so far: the device-side draw counter is restored from it at every
+                                // seg_bind, so a re-plan (partial last batch, validation batch size, predict) does not restart the mask sequence
     std::vector<std::function<void(hipStream_t)>> fwd_ops, bwd_ops;
     std::vector<std::vector<int>> bwd_writes;   // parameter indices whose gradient each backward op finishes (bucketed all-reduce)
     const float* cur_x = nullptr; float* cur_logits = nullptr; float* cur_probs = nullptr;
@@ -949,7 +951,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (dtype < 0 || dtype > 2) return fail("seg_create: dtype must be SEG_F32/F16/BF16");
     if (init_features != 16) return fail("seg_create: init_features must be 16 (GroupNorm(8) tiles; the reference never overrides the default)");
     if (num_class < 1 || num_class > 8) return fail("seg_create: num_class must be in 1..8");
-    if (in_channels < 1 || in_channels > 4 || (ndim == 3 && in_channels > 1)) return fail("seg_create: in_channels must be 1 (3-D) or 1..3 (2-D)");
+    if (in_channels < 1 || in_channels > 3 || (ndim == 3 && in_channels > 1)) return fail("seg_create: in_channels must be 1 (3-D) or 1..3 (2-D)");
     seg_engine* e = new seg_engine();
     e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
     e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
@@ -1027,6 +1029,8 @@ int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
     if (hipMemcpy(h->ws + h->off_packdesc, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice) != hipSuccess)
         return fail("seg_bind: descriptor upload failed");
     if (hipMemset(h->ws + h->off_step, 0, 256) != hipSuccess) return fail("seg_bind: memset failed");
+    if (h->draws && hipMemcpy(h->ws + h->off_step, &h->draws, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        return fail("seg_bind: counter upload failed");
     return 0;
 }
 
@@ -1052,6 +1056,7 @@ int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks,
     } else if (mask_mode == SEG_MASKS_RANDOM) {
         launch_dropout_masks((float*)(h->ws + h->off_masks), (int)h->drop_ch.size(), h->N, h->ld_mask(), 0.2f, seed,
                              (const int*)(h->ws + h->off_step), st);
+        ++h->draws;
     }
     h->cur_x = x; h->cur_logits = logits; h->cur_probs = probs;
     for (auto& op : h->fwd_ops) op(st);

@@ -509,8 +509,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
         a.p[i] = p - step_size * m / (sqrtf(v) * rs_bc2 + a.eps);
     }
 }
-__global__ __launch_bounds__(64) void adam_bump_kernel(int* step, const int* found_inf) {
-    if (threadIdx.x == 0 && !(found_inf && *found_inf)) *step += 1;
+// step counter += 1 unless the step was skipped; a skipped step is tallied in found_inf[1] (= state[2] of seg_adam_step: the host
+// reads it every few dozen steps to back the loss scale off, engine.py)
+__global__ __launch_bounds__(64) void adam_bump_kernel(int* step, int* found_inf, int tally) {
+    if (threadIdx.x == 0) {
+        if (!(found_inf && *found_inf)) *step += 1;
+        else if (tally) found_inf[1] += 1;
+    }
 }
 
 // ---------------------------------------------------------------- channel dropout multipliers
@@ -620,13 +625,13 @@ void launch_grad_check(const float* g, long long n, int* found_inf, hipStream_t 
 }
 void launch_adam(const AdamArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(a.n, 4096)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, a.step, (const int*)a.found_inf);
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, a.step, a.found_inf, 1);
 }
 
 void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s) {
     const long long total = (long long)L * N * ld;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(total, 1024)), dim3(256), 0, s, masks, total, p, seed, step);
-    if (step) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, (int*)step, (const int*)nullptr);
+    if (step) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, (int*)step, (int*)nullptr, 0);
 }
 
 }  // namespace seg

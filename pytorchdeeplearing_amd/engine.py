@@ -62,8 +62,23 @@ class SegEngine:
         self._loss_ws = None
         self._out3 = None
         self._dlogits = None
+        # dropout stream: per-rank under data parallelism (sample n of rank 0 and of rank 1 must not share channel masks)
         self.seed = 0x5EEDC0DE
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.seed ^= (dist.get_rank() * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        except Exception:
+            pass
         self.packed = False
+        # dynamic loss scaling for the f16 run dtype: the fused optimiser skips a step whose gradients overflow and tallies it on
+        # the device; every `scale_check_every` steps the host reads the tally (one tiny sync) and halves the scale if anything
+        # was skipped, doubles it again after `scale_growth_steps` clean steps (torch.cuda.amp.GradScaler's policy, coarse-grained)
+        self.scale_check_every = 64
+        self.scale_growth_steps = 2048
+        self._steps_since_check = 0
+        self._clean_steps = 0
+        self.skipped_steps = 0
 
     def __del__(self):
         try:
@@ -281,4 +296,32 @@ class SegEngine:
                 allreduce(self.grads)
         self.adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled, grad_div=grad_div)
         self.pack_weights()
+        self._steps_since_check += 1
+        if self.dtype in ("f16", "fp16", "float16") and self._steps_since_check >= self.scale_check_every:
+            self.update_loss_scale()
         return out3
+
+    def update_loss_scale(self):
+        """Read the device-side tally of skipped (overflowed) optimiser steps and adapt the loss scale; returns the number of
+        steps skipped since the last call.  A run whose gradients overflow persistently is reported instead of silently
+        training nothing."""
+        n = self._steps_since_check
+        self._steps_since_check = 0
+        if self.opt_state is None:
+            return 0
+        skipped = int(self.opt_state[2].item())
+        if skipped:
+            self.opt_state[2] = 0
+            self.skipped_steps += skipped
+            self._clean_steps = 0
+            new = max(self.loss_scale * 0.5, 1.0)
+            import warnings
+            warnings.warn("segengine: %d of the last %d optimiser steps overflowed in f16 and were skipped; loss scale %g -> %g"
+                          % (skipped, n, self.loss_scale, new))
+            self.loss_scale = new
+        else:
+            self._clean_steps += n
+            if self._clean_steps >= self.scale_growth_steps and self.loss_scale < 65536.0:
+                self.loss_scale = self.loss_scale * 2.0
+                self._clean_steps = 0
+        return skipped

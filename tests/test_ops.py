@@ -241,9 +241,18 @@ def test_conv3_halo_exact(dev, dtype, case):
     assert torch.equal(ncdhw(got.float().cpu(), ndim), xr.grad)
 
 
+@pytest.fixture(params=["wgrad3_kernel", "wgrad3x_kernel"])
+def wgrad3_impl(request, monkeypatch):
+    """both halo weight-gradient kernels: wgrad3_kernel (default) and the double-buffered 16-bit wgrad3x_kernel (SEG_WGRAD3X=1)"""
+    monkeypatch.setenv("SEG_WGRAD3X", "1" if request.param == "wgrad3x_kernel" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_wgrad3_halo_exact(dev, dtype, case):
+def test_wgrad3_halo_exact(dev, dtype, case, wgrad3_impl):
+    if wgrad3_impl == "wgrad3x_kernel" and dtype == "f32":
+        pytest.skip("the double-buffered kernel is 16-bit only")
     ndim, N, sp, cin, cout = case
     g = torch.Generator().manual_seed(sum(sp) + cout)
     x = ints((N, cin) + sp, -2, 2, g)
@@ -260,9 +269,11 @@ def test_wgrad3_halo_exact(dev, dtype, case):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", [(3, 1, (3, 8, 16), [16, 16], 16), (3, 2, (4, 6, 8), [32, 32], 32), (2, 1, (8, 16), [64, 64], 64),
                                   (3, 1, (7, 9, 17), [32, 32], 64), (2, 2, (11, 13), [16, 16], 32)])
-def test_wgrad3_concat_exact(dev, dtype, case):
+def test_wgrad3_concat_exact(dev, dtype, case, wgrad3_impl):
     """x = virtual concat of two tensors (UNet decoder blocks): q-tiles never straddle the sources; partial boxes; several
     boxes per workgroup on the double-buffered 16-bit kernel."""
+    if wgrad3_impl == "wgrad3x_kernel" and dtype == "f32":
+        pytest.skip("the double-buffered kernel is 16-bit only")
     ndim, N, sp, cins, cout = case
     g = torch.Generator().manual_seed(sum(sp) + cout + 5)
     x = ints((N, sum(cins)) + sp, -2, 2, g)

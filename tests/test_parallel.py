@@ -195,3 +195,55 @@ def test_bench_control_flow_two_ranks_on_the_checker(extra):
     assert line["config"]["loss_semantics"].startswith("global-batch" if "--global-loss" in extra else "per-rank")
     assert line["ms_per_step"] > 0 and abs(line["value"] - 2 * 1 * 1e3 / line["ms_per_step"]) <= 0.006      # whole-job volumes/s (2 decimals)
     assert 0.0 < line["final_loss"] < 1.5 and "cpu_baseline" not in line
+
+
+def _seed_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import conftest
+    conftest.emu_library()
+    from oracle import seg_oracle as seg
+    from pytorchdeeplearing_amd import SegEngine, _capi
+    kind, shape, ncls = "unet", (2, 1, 16, 16), 1
+    e = SegEngine(kind, 2, 1, ncls, dtype="f32", device="cpu")
+    e.load_state_dict(seg.perturb_params(seg.init_params(kind, 2, 1, ncls, seed=0), seed=7))
+    x, _ = seg.synthetic_batch(shape[0], shape[2:], 1, ncls, seed=100)         # the SAME samples on both ranks
+    ev, _ = e.forward(x, _capi.MASKS_EVAL)
+    ev = ev.clone()
+    tr1, _ = e.forward(x, _capi.MASKS_RANDOM)
+    tr1 = tr1.clone()
+    # a re-plan (other batch size, as a partial last batch or a validation batch causes) must not restart the mask sequence
+    e.forward(x[:1].contiguous(), _capi.MASKS_EVAL)
+    tr2, _ = e.forward(x, _capi.MASKS_RANDOM)
+    q.put((rank, e.seed, ev.numpy().copy(), tr1.numpy().copy(), tr2.clone().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dropout_streams_differ_per_rank_and_survive_a_replan():
+    """SURVEY 8e / ADVICE r01: every rank draws its own channel-dropout masks (identical weights and inputs give identical
+    eval logits but different train-mode logits), and the draw counter survives seg_plan / seg_bind (a change of batch
+    shape between two training forwards does not replay the first masks)."""
+    import numpy as np
+    world, port = 2, 29500 + (os.getpid() * 2 + 7) % 1000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_seed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r = q.get(timeout=600)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] != got[1][0]                                   # seeds
+    assert np.array_equal(got[0][1], got[1][1])                     # eval forward: replicas agree
+    assert not np.array_equal(got[0][2], got[1][2])                 # train forward: different masks per rank
+    for r in range(world):
+        assert not np.array_equal(got[r][2], got[r][3])             # second draw after the re-plan is a NEW draw
