@@ -93,11 +93,11 @@ def cpu_model():
     return "unknown CPU"
 
 
-def gpu_torch_baseline(batch, size, dev, steps=3):
+def _gpu_torch_baseline(seg, batch, size, dev, steps=3):
     """Stock PyTorch-ROCm on the SAME GPU: the oracle's functional restatement of the reference
     path (F.conv3d / group_norm / dropout3d-style masks / AdamW as torch ops, NCDHW) on `dev`, fp32 and autocast-f16, the full
-    batch x 1 x size^3 workload, dropout on.  MIOpen picks the convolution kernels; first calls include its search."""
-    from oracle import seg_oracle as seg
+    batch x 1 x size^3 workload, dropout on.  MIOpen picks the convolution kernels; first calls include its search.
+    Part of the baseline leg: called from cpu_baseline() with its oracle module."""
     out = {}
     x, y = seg.synthetic_batch(batch, (size,) * 3, 1, 1, seed=1234)
     x, y = x.to(dev), y.to(dev)
@@ -130,9 +130,10 @@ def gpu_torch_baseline(batch, size, dev, steps=3):
     return out
 
 
-def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0):
+def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0, batch=4, gpu_leg=False):
     """The oracle (torch-CPU port of the reference path, oracle/seg_oracle.py) on this box's host cores,
-    bounded sample of the same workload: VNet3d 1 x 1 x size^3 train steps (fp32, all cores, dropout on)."""
+    bounded sample of the same workload: VNet3d 1 x 1 x size^3 train steps (fp32, all cores, dropout on).
+    Returns (cpu_baseline, dice_vs_ref, gpu_torch_baseline or None): the only place of this file that touches oracle/."""
     from oracle import seg_oracle as seg
     # torch-CPU convolutions stop scaling (and then collapse) beyond a few dozen threads on a many-core host:
     # 32 threads is the fastest setting for this workload on the 256-core GPU box (all 256: 134 s/step)
@@ -156,7 +157,8 @@ def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0):
     base = {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
             "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (one volume, not the 4-volume batch), torch %s CPU, %d of the %d hardware "
                       "threads of %s, best step %.3f s" % (len(times), size, torch.__version__, ncores, os.cpu_count() or 1, cpu_model(), best)}
-    return base, _dice_vs_reference(seg, trained_state, dev, dtype)
+    dice = _dice_vs_reference(seg, trained_state, dev, dtype)
+    return base, dice, (_gpu_torch_baseline(seg, batch, size, dev) if gpu_leg else None)
 
 
 def _dice_vs_reference(seg, trained_state, dev, dtype, size=48):
@@ -356,11 +358,13 @@ def main(argv=None, checker_device=None):
         if table:
             line["kernel_classes"] = table
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"], line["dice_vs_ref"] = cpu_baseline(S, e.state_dict() if a.lanes == 1 else e.engines[0].state_dict(), dev, a.dtype)
+            sd = e.state_dict() if a.lanes == 1 else e.engines[0].state_dict()
+            del e
             if on_gpu:
-                del e
                 torch.cuda.empty_cache()
-                line["gpu_torch_baseline"] = gpu_torch_baseline(a.batch, S, dev)
+            line["cpu_baseline"], line["dice_vs_ref"], gt = cpu_baseline(S, sd, dev, a.dtype, batch=a.batch, gpu_leg=on_gpu)
+            if gt is not None:
+                line["gpu_torch_baseline"] = gt
         print(json.dumps(line))
     if dist:
         dist.destroy_process_group()

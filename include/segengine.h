@@ -219,7 +219,8 @@ typedef struct seg_pack_desc {
     long long s1, s2, sT, sC;
     int flipT;
     int frag;   /* 0: rows [R1*R2][Kpad]; 1: MFMA-fragment-major [Cc/32][T][rows/16][64 lanes][8] (Cc % 32 == 0, rows % 16 == 0):
-                   lane = 16*((c%32)/8) + row%16 holds k = c%8 .. — one 16x32 B fragment is one contiguous 1 KB line */
+                   lane = 16*((c%32)/8) + row%16 holds k = c%8 .. — one 16x32 B fragment is one contiguous 1 KB line;
+                   2: the same over the flat k = t*Cc + c axis, [Kpad/32][rows/16][64 lanes][8] (Cc == 16: two taps per step) */
 } seg_pack_desc;
 int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int dtype, void* stream);
 /* LDS halo-tile kernels for the 3^d (ndim 3) / 3^2 (ndim 2, D = 1) stride-1 pad-1 convolutions.
@@ -237,8 +238,31 @@ int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int 
  * (the UNet decoder blocks read cat(up, skip), networks/Unet3d.py:50-62, without materialising it). */
 int seg_op_wgrad3_cat(const void* dr, const void* x0, const void* x1, int c0, float* partial, float* dw, int n, int d, int h,
                       int wid, int p, int q, int ndim, int dtype, void* stream);
-/* Register-blocked halo conv for 16-bit tensors with Cin % 32 == 0 (csrc/conv3x.hip): same operator as seg_op_conv3, the
- * weights packed with seg_pack_desc.frag = 1 ("conv_fwd" / "conv_dgrad" element order), `in1` an optional second source of a
+/* Fused input block (csrc/stemx.hip): y = relu(drop(GN(conv3(x)))) [+ relu(drop(GN(conv1(x))))] for a 1..3-channel image and 16
+ * output channels (InputTransition of networks/VNet3d.py:25-43 with its shared GroupNorm module applied twice; first conv of
+ * networks/Unet3d.py:64-86 with w1 = NULL).  The raw conv outputs are recomputed in every pass instead of being stored.
+ * mode 0: GroupNorm partial sums of both branches -> stats3 / stats1 ([32][N][16][2] fp64, accumulated);
+ * mode 1: out[N][D][H][W][16] from scale / shift ([N][16], dropout multiplier folded in);
+ * mode 2: Q3 / Q1 ([32][N][16][2]: sum dz, sum dz*r with dz = (sum of the ndy gradient sources) * [scale*r + shift > 0]);
+ * mode 3: weight gradients: d(raw) = coef[0]*dz + coef[1]*r + coef[2] (coef [N][16][3]) times the im2col rows, accumulated
+ *         into dw3 (16, Cimg, 3^d) / dw1 (16, Cimg, 1^d) through `partial` (seg_op_stemx_partial_bytes of scratch).
+ * w3 / w1: run-dtype [16][32] rows, k = tap*Cimg + ci / k = ci (seg_op_pack "conv_fwd" layout).  img: run dtype, channels-last. */
+typedef struct seg_stemx_args {
+    const void* img; const void* w3; const void* w1;
+    const float* bias3; const float* bias1;
+    double* stats3; double* stats1;
+    const float* scale3; const float* shift3; const float* scale1; const float* shift1;
+    void* out;
+    const void* dy[3]; int ndy;
+    double* Q3; double* Q1;
+    const float* coef3; const float* coef1;
+    float* partial;
+    int N, D, H, W, Cimg;
+} seg_stemx_args;
+long long seg_op_stemx_partial_bytes(int ndim, int n, int d, int h, int wid, int cimg);
+int seg_op_stemx(const seg_stemx_args* a, int mode, int ndim, int dtype, float* dw3, float* dw1, void* stream);
+/* Register-blocked halo conv for 16-bit tensors with Cin % 32 == 0 or Cin == 16 (csrc/conv3x.hip): same operator as seg_op_conv3, the
+ * weights packed with seg_pack_desc.frag = 1 (Cin == 16: frag = 2) ("conv_fwd" / "conv_dgrad" element order), `in1` an optional second source of a
  * virtual channel concat (channels c0..cin-1).  cfg selects a tiling (seg_op_conv3x_cfg_info enumerates them; -1 = the
  * engine's default for the shape).  Returns <0 when the tiling does not fit the shape. */
 int seg_op_conv3x(int cfg, const void* in0, const void* in1, int c0, const void* w, const float* bias, void* out, double* stats,
@@ -247,7 +271,7 @@ int seg_op_conv3x_num_cfgs(void);
 /* index in [0, num_cfgs): tiling id, ndim, box {d,h,w}, output channels per workgroup, resident 32-channel chunks, description */
 int seg_op_conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, char* name, int name_cap);
 int seg_op_conv3x_default_cfg(int ndim, int n, int d, int h, int wid, int cin, int cout, int dtype);
-/* sizeof of the structs above as compiled into the library: 0 conv, 1 wgrad, 2 pack */
+/* sizeof of the structs above as compiled into the library: 0 conv, 1 wgrad, 2 pack, 3 stemx */
 int seg_abi_sizeof(int which);
 
 /* ---- soft-clDice building blocks (model/lossescldice.py:5-59; corrected restatement).

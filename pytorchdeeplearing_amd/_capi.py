@@ -66,6 +66,8 @@ SIGNATURES = {
     "seg_op_wgrad3_partial_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
     "seg_op_wgrad3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "seg_op_wgrad3_cat": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "seg_op_stemx_partial_bytes": (_ll, [_i, _i, _i, _i, _i, _i]),
+    "seg_op_stemx": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "seg_abi_sizeof": (_i, [_i]),
     "seg_op_pool3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "seg_op_skel_iter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

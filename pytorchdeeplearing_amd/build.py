@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsegengine.so")
-SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "wgrad.hip", "wgrad3x.hip", "norm.hip", "misc.hip", "cldice.hip", "prepost.hip", "engine.hip"]
+SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "cldice.hip", "prepost.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
 
@@ -22,17 +22,22 @@ def up_to_date():
 
 
 def build(force=False, verbose=False):
-    if not force and up_to_date():
-        return LIB
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "conv3x_impl.h")] + [os.path.join(os.path.dirname(HERE), "include", "segengine.h")]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
     procs, objs = [], []
     for s in SRCS:
         o = os.path.join(objdir, s + ".o")
         objs.append(o)
+        # per-object freshness: an object compiled before an edit of its source must not hide behind a newer link step
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(os.path.join(CSRC, s)), hdr_t):
+            continue
         cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    if not procs and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(o) for o in objs):
+        return LIB
     for s, p in procs:
         out = p.communicate()[0].decode()
         if p.returncode:

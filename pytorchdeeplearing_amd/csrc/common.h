@@ -53,6 +53,31 @@ template <> struct Mma<bf16> {
     }
 };
 
+// K = 16 step (a lane owns k = 4*(lane>>4) .. +3 of row/col lane&15): the accumulator layout of a 16x16 tile (col = lane&15,
+// rows 4*(lane>>4) + r) IS the B-operand layout of this step, so a tile computed by one MFMA feeds the next without leaving
+// the registers (fused stem weight gradient, stemx.hip).  f32: four 16x16x4 steps, step j taking element j of every lane.
+template <class T> struct Mma16;
+template <> struct Mma16<float> {
+    typedef vec<float, 4> frag;
+    static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+        return c;
+    }
+};
+template <> struct Mma16<f16> {
+    typedef vec<f16, 4> frag;
+    static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<bf16> {
+    typedef vec<bf16, 4> frag;
+    static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    }
+};
+
 // LDS transposing read (gfx950 ds_read_b64_tr_b16): within each 16-lane group the lanes' 8-byte
 // reads form a [4][16] block of 16-bit values; lane t receives column t (4 consecutive rows).
 __device__ __forceinline__ s16x4 lds_read_tr16(const void* p) {

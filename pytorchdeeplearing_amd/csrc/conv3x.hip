@@ -6,7 +6,7 @@ namespace seg {
 namespace {
 using c3x::Conv3xArgs;
 
-struct Cfg { int id, ndim, td, th, tw, bn, nres; const char* name; };
+struct Cfg { int id, ndim, td, th, tw, bn, nres; const char* name; int cin16 = 0; };   // cin16: the Cin == 16 kernel (two taps per MFMA step)
 
 // id, ndim, box, BN, resident chunks — kept in sync with SEG_C3X_3D_BODY / SEG_C3X_2D_BODY (conv3x_impl.h)
 const Cfg kCfgs[] = {
@@ -29,6 +29,10 @@ const Cfg kCfgs[] = {
     {15, 3, 2, 8, 16, 32, 2, "2x8x16 t16 4x1 waves 4x2 tiles, 2 resident chunks"},
     {16, 3, 2, 8, 16, 32, 1, "2x8x16 t16 4x1 waves 4x2 tiles, deep B ring, 2 workgroups/CU"},
     {17, 3, 4, 8, 8, 32, 1, "4x8x8 t8 4x1 waves 4x2 tiles, deep B ring, 2 workgroups/CU"},
+    {24, 3, 2, 8, 16, 16, 1, "Cin16: 2x8x16 t16 4x1 waves 4x1 tiles", 1},
+    {25, 3, 4, 8, 16, 16, 1, "Cin16: 4x8x16 t16 4x1 waves 8x1 tiles", 1},
+    {26, 3, 2, 8, 16, 32, 1, "Cin16: 2x8x16 t16 4x1 waves 4x2 tiles", 1},
+    {27, 3, 4, 8, 16, 32, 1, "Cin16: 4x8x16 t16 4x1 waves 8x2 tiles", 1},
     // 2-D
     {32, 2, 1, 16, 16, 32, 1, "16x16 t16 4x1 waves 4x2 tiles"},
     {33, 2, 1, 16, 16, 64, 2, "16x16 t16 2x2 waves 8x2 tiles"},
@@ -38,6 +42,8 @@ const Cfg kCfgs[] = {
     {37, 2, 1, 16, 16, 16, 1, "16x16 t16 4x1 waves 4x1 tiles"},
     {38, 2, 1, 8, 8, 64, 4, "8x8 t8 2x2 waves 2x2 tiles, 4 resident chunks"},
     {39, 2, 1, 8, 16, 32, 2, "8x16 t16 4x1 waves 2x2 tiles, 2 resident chunks"},
+    {56, 2, 1, 16, 16, 16, 1, "Cin16: 16x16 t16 4x1 waves 4x1 tiles", 1},
+    {57, 2, 1, 16, 16, 32, 1, "Cin16: 16x16 t16 4x1 waves 4x2 tiles", 1},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -47,7 +53,7 @@ const Cfg* find_cfg(int id) {
     return nullptr;
 }
 
-bool cfg_fits(const Cfg& c, int ndim, int Cout) { return c.ndim == ndim && Cout % c.bn == 0; }
+bool cfg_fits(const Cfg& c, int ndim, int Cin, int Cout) { return c.ndim == ndim && Cout % c.bn == 0 && (c.cin16 != 0) == (Cin == 16); }
 
 }  // namespace
 
@@ -55,7 +61,8 @@ bool cfg_fits(const Cfg& c, int ndim, int Cout) { return c.ndim == ndim && Cout 
 bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, int Cout, int C0, bool has_in1) {
     (void)N;
     if (dtype == DT_F32) return false;
-    if (Cin % 32 || Cout % 16) return false;
+    if ((Cin % 32 && Cin != 16) || Cout % 16) return false;
+    if (Cin == 16 && has_in1) return false;
     if (has_in1 && (C0 % 8 || C0 <= 0 || C0 >= Cin)) return false;
     const long long vol = (long long)(ndim == 3 ? D : 1) * H * W;
     if (vol * Cin * 2 >= (1ll << 31) || vol * 4 >= (1ll << 31)) return false;    // buffer ranges and the packed granule index stay below 2^31
@@ -68,7 +75,7 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
     static const int force = getenv("SEG_C3X_CFG") ? atoi(getenv("SEG_C3X_CFG")) : -1;
     if (force >= 0) {
         const Cfg* c = find_cfg(force);
-        if (c && cfg_fits(*c, ndim, Cout)) return force;
+        if (c && cfg_fits(*c, ndim, Cin, Cout)) return force;
     }
     static const char* map = getenv("SEG_C3X_MAP");
     if (map) {
@@ -76,7 +83,7 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
             int ci = 0, co = 0, w = 0, id = -1;
             if (sscanf(p, "%d:%d:%d=%d", &ci, &co, &w, &id) == 4 && ci == Cin && co == Cout && w == W) {
                 const Cfg* c = find_cfg(id);
-                if (c && cfg_fits(*c, ndim, Cout)) return id;
+                if (c && cfg_fits(*c, ndim, Cin, Cout)) return id;
             }
             while (*p && *p != ',') ++p;
             if (*p == ',') ++p;
@@ -88,7 +95,8 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
     // more than operand reuse; for 32 output channels a 256-voxel box and 4 x 2 register tiles.
     const long long vox = (long long)N * D * H * W;
     int id;
-    if (ndim == 3) {
+    if (Cin == 16) id = ndim == 3 ? (Cout % 32 ? 24 : 26) : (Cout % 32 ? 56 : 57);
+    else if (ndim == 3) {
         if (Cout % 32) id = 10;
         else if (Cout % 64) id = Cin <= 32 ? 14 : (Cin == 64 ? (W >= 48 ? 17 : 15) : 14);
         else if (vox <= 16384) id = Cout >= 2 * Cin ? 13 : 7;
@@ -99,9 +107,9 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
         else id = Cin >= 256 ? 35 : 33;
     }
     const Cfg* c = find_cfg(id);
-    if (c && cfg_fits(*c, ndim, Cout)) return id;
+    if (c && cfg_fits(*c, ndim, Cin, Cout)) return id;
     for (int i = 0; i < kNumCfgs; ++i)
-        if (cfg_fits(kCfgs[i], ndim, Cout)) return kCfgs[i].id;
+        if (cfg_fits(kCfgs[i], ndim, Cin, Cout)) return kCfgs[i].id;
     return -1;
 }
 
@@ -121,10 +129,12 @@ int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
                    int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s) {
     const Cfg* c = find_cfg(cfg);
-    if (!c || !cfg_fits(*c, ndim, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
+    if (!c || !cfg_fits(*c, ndim, Cin, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
     Conv3xArgs a;
     a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.N = N; a.D = ndim == 3 ? D : 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    static const int remap = getenv("SEG_C3X_REMAP") ? atoi(getenv("SEG_C3X_REMAP")) : 1;      // XCD-aware box order (c3x_box_of_block)
+    a.remap = remap;
     if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d<f16>(cfg, a, s) : c3x::launch_3d<bf16>(cfg, a, s);
     return dtype == DT_F16 ? c3x::launch_2d<f16>(cfg, a, s) : c3x::launch_2d<bf16>(cfg, a, s);
 }

@@ -51,7 +51,73 @@ struct Conv3xArgs {
     const void* w;                                // fragment-major weights [Cin/32][taps][Cout/16][64 lanes][8]
     const float* bias; void* out; double* stats;
     int N, D, H, W, Cin, Cout;
+    int remap;                                    // 1: XCD-aware box order (grid.x rounded up to a multiple of 8)
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md), each with its own L2.  With the
+// natural order the x / y / z neighbours of a box - which share most of its halo - sit on other XCDs and every halo is fetched
+// from HBM / MALL once per XCD that touches it.  Remapped, XCD k walks the contiguous box range [k*per, (k+1)*per): neighbours
+// share an L2.  Returns -1 for the padding blocks of the rounded-up grid.
+__device__ __forceinline__ int c3x_box_of_block(int b, int nbox, int remap) {
+    if (!remap) return b;
+    const int per = (nbox + 7) >> 3;
+    const int box = (b & 7) * per + (b >> 3);
+    return ((b >> 3) < per && box < nbox) ? box : -1;
+}
+
+// shared epilogue of the conv3x kernels: bias -> LDS tile [voxel][co] (aliases the halo buffer; the caller has passed the barrier that
+// ends the tap loops) -> coalesced channels-last stores + per-channel sum / sum-of-squares into this workgroup's statistics replica
+template <class T, class B, int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const Conv3xArgs& a, int n, int x0, int y0, int z0, int co0) {
+    constexpr int BN = WN * TN * 16, OLD = BN + 8, OS_ELEMS = B::V * OLD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int wm = wv % WM, wn = wv / WM;
+    T* Os = Xs;
+    float* red = (float*)(Xs + OS_ELEMS);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 16 + l15;
+        const float bsv = a.bias ? a.bias[co0 + col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Os[((wm * TM + m) * 16 + q * 4 + r) * OLD + col] = from_f<T>(acc[m][j][r] + bsv);
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    T* out = (T*)a.out;
+    for (int i = tid; i < B::V * CPR; i += 256) {
+        const int v = i / CPR, c8 = i % CPR;
+        int vz, vy, vx;
+        B::vox(v, vz, vy, vx);
+        const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+        if (x < a.W && y < a.H && z < a.D)
+            store8(out + ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8, load8(&Os[v * OLD + c8 * 8]));
+    }
+    if (a.stats) {
+        constexpr int G = 256 / BN;
+        const int col = tid % BN, g = tid / BN;
+        float s = 0.f, ss = 0.f;
+        for (int v = g; v < B::V; v += G) {
+            int vz, vy, vx;
+            B::vox(v, vz, vy, vx);
+            if (x0 + vx < a.W && y0 + vy < a.H && z0 + vz < a.D) {
+                const float f = to_f(Os[v * OLD + col]);
+                s += f; ss += f * f;
+            }
+        }
+        red[(g * BN + col) * 2] = s;
+        red[(g * BN + col) * 2 + 1] = ss;
+        __syncthreads();
+        if (tid < BN) {
+            double ts = 0.0, tss = 0.0;
+            for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
+            double* dst = a.stats + ((long long)(blockIdx.x % STAT_REP) * a.N * a.Cout + (long long)n * a.Cout + co0 + col) * 2;
+            atomicAdd(dst, ts);
+            atomicAdd(dst + 1, tss);
+        }
+    }
+}
 
 template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
@@ -68,7 +134,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     const int wm = wv % WM, wn = wv / WM;
     // box position
     const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
-    int bb = blockIdx.x;
+    int bb = c3x_box_of_block(blockIdx.x, a.N * nbz * nby * nbx, a.remap);
+    if (bb < 0) return;
     const int x0 = (bb % nbx) * B::TW; bb /= nbx;
     const int y0 = (bb % nby) * B::TH; bb /= nby;
     const int z0 = (bb % nbz) * B::TD;
@@ -205,52 +272,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     }
     __syncthreads();
 
-    // ---- epilogue: bias -> LDS tile [voxel][co] -> coalesced channels-last stores + GroupNorm partial sums
-    T* Os = Xs;
-    float* red = (float*)(Xs + OS_ELEMS);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 16 + l15;
-        const float bsv = a.bias ? a.bias[co0 + col] : 0.f;
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Os[((wm * TM + m) * 16 + q * 4 + r) * OLD + col] = from_f<T>(acc[m][j][r] + bsv);
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;
-    T* out = (T*)a.out;
-    for (int i = tid; i < B::V * CPR; i += 256) {
-        const int v = i / CPR, c8 = i % CPR;
-        int vz, vy, vx;
-        B::vox(v, vz, vy, vx);
-        const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
-        if (x < a.W && y < a.H && z < a.D)
-            store8(out + ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8, load8(&Os[v * OLD + c8 * 8]));
-    }
-    if (a.stats) {
-        constexpr int G = 256 / BN;
-        const int col = tid % BN, g = tid / BN;
-        float s = 0.f, ss = 0.f;
-        for (int v = g; v < B::V; v += G) {
-            int vz, vy, vx;
-            B::vox(v, vz, vy, vx);
-            if (x0 + vx < a.W && y0 + vy < a.H && z0 + vz < a.D) {
-                const float f = to_f(Os[v * OLD + col]);
-                s += f; ss += f * f;
-            }
-        }
-        red[(g * BN + col) * 2] = s;
-        red[(g * BN + col) * 2 + 1] = ss;
-        __syncthreads();
-        if (tid < BN) {
-            double ts = 0.0, tss = 0.0;
-            for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
-            double* dst = a.stats + ((long long)(blockIdx.x % STAT_REP) * a.N * a.Cout + (long long)n * a.Cout + co0 + col) * 2;
-            atomicAdd(dst, ts);
-            atomicAdd(dst + 1, tss);
-        }
-    }
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs, a, n, x0, y0, z0, co0);
 }
 
 
@@ -258,8 +280,127 @@ template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, in
 void launch_cfg(const Conv3xArgs& a, hipStream_t s) {
     constexpr int BN = WN * TN * 16;
     const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
-    dim3 grid((unsigned)nbox, a.Cout / BN);
+    dim3 grid(a.remap ? (unsigned)((nbox + 7) / 8 * 8) : (unsigned)nbox, a.Cout / BN);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x_kernel<T, B, TM, TN, WM, WN, NRES, PF, OCC>), grid, dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cin == 16 (the full-resolution LUConv / _block layers: networks/VNet3d.py:117-125 up_tr32.ops, networks/Unet3d.py enc1 / dec1).
+// One 16x16x32 MFMA step multiplies TWO taps: lanes q = 0, 1 hold the 16 channels of tap 2s, lanes q = 2, 3 those of tap 2s + 1
+// (K order of the weights is (tap, ci) flat; seg_pack_desc.frag = 2).  Halo rows are 32 B; 16 consecutive voxels of an x row
+// are conflict-free for ds_read_b128 without a swizzle.  The per-lane difference between the two taps of a step takes three
+// values only (next kw; next kh row; next kd plane), so three per-lane bases keep every tap offset an immediate.  These layers
+// are HBM-bound (Cin = Cout = 16: 226 MB per launch at 4 x 96^3), MFMA time at 40 % of peak is about the same as the stream time.
+// ------------------------------------------------------------------------------------------------
+template <class T, class B, int TM, int TN, int PF, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
+    static_assert(B::TX == 16, "x rows of 16 voxels");
+    static_assert(4 * TM == B::NTILE, "four waves cover the box");
+    constexpr int WM = 4, WN = 1, BN = TN * 16, OLD = BN + 8;
+    constexpr int NSTEP = (B::NTAP + 1) / 2;
+    static_assert(NSTEP >= PF + 1, "ring deeper than the loop");
+    constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
+    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 2048 / sizeof(T);
+    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS];
+    constexpr int NI = (NINSTR + 3) / 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
+    int bb = c3x_box_of_block(blockIdx.x, a.N * nbz * nby * nbx, a.remap);
+    if (bb < 0) return;
+    const int x0 = (bb % nbx) * B::TW; bb /= nbx;
+    const int y0 = (bb % nby) * B::TH; bb /= nby;
+    const int z0 = (bb % nbz) * B::TD;
+    const int n = bb / nbz;
+    const int co0 = blockIdx.y * BN;
+    const long long vol = (long long)a.D * a.H * a.W;
+
+    // ---- halo: [row][HWP voxels][16 channels], two 16-B granules per voxel, copied directly (zeros outside the volume)
+    const i32x4 r0 = make_rsrc((const T*)a.in0 + (long long)n * vol * 16, (unsigned)(vol * 32));
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = u * 4 + wv;
+        if (i < NINSTR) {
+            const int g = i * 64 + lane;
+            const int row = g / (B::HWP * 2), rem = g % (B::HWP * 2);
+            const int hx = rem >> 1, piece = rem & 1;
+            const int hz = row / B::HH, hy = row % B::HH;
+            const int z = z0 + hz - B::PD, y = y0 + hy - 1, x = x0 + hx - 1;
+            const bool ok = row < B::ROWS && hx < B::HW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            dma16(r0, Xs + i * 512, ok ? (unsigned)(((z * a.H + y) * a.W + x) * 32 + piece * 16) : DMA_OOB);
+        }
+    }
+    // ---- B fragments through the register ring (weights: [step][Cout/16][64 lanes][8])
+    const unsigned wstep = (unsigned)(a.Cout >> 4) * 1024u;
+    const i32x4 wr = make_rsrc(a.w, (unsigned)NSTEP * wstep);
+    const unsigned wl = ((unsigned)(blockIdx.y * TN) * 64u + lane) * 16u;
+    typename Mma<T>::frag bq[PF + 1][TN];
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, s * wstep);
+
+    // ---- A addressing: lanes q < 2 read tap 2s, lanes q >= 2 tap 2s + 1; the second tap's extra offset is one of three values
+    constexpr int D_KW = 16, D_KH = (B::HWP - 2) * 16, D_KD = ((B::HH - 2) * B::HWP - 2) * 16;    // elements
+    const int hi = q >> 1, piece = q & 1;
+    int ab[TM][3];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        int vz, vy, vx;
+        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
+        const int base = ((vz * B::HH + vy) * B::HWP + vx) * 16 + piece * 8;
+        ab[m][0] = base + (hi ? D_KW : 0);
+        ab[m][1] = base + (hi ? D_KH : 0);
+        ab[m][2] = base + (hi ? D_KD : 0);
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wait_vmem();
+    __syncthreads();
+
+    unsigned wo = PF * wstep;
+    auto tap_off = [](int t) { return ((t / 9) * B::HH + (t / 3) % 3) * B::HWP + t % 3; };       // halo voxels
+    typename Mma<T>::frag af[2][TM];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xs[ab[m][0] + tap_off(0) * 16]);
+    __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bq[(s + PF) % (PF + 1)][j] = buffer_load8<T>(wr, wl + j * 1024, wo);
+        wo += wstep;
+        if (s + 1 < NSTEP) {
+            const int t0 = 2 * (s + 1), t1 = t0 + 1;
+            // the second tap of the step: +1 in kw, or the start of the next kh row / kd plane; past the last tap (zero weights)
+            // the lanes re-read the first tap (finite data)
+            const int d = t1 >= B::NTAP ? -1 : (tap_off(t1) - tap_off(t0) == 1 ? 0 : (t1 % 9 == 0 ? 2 : 1));
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                const int basev = d < 0 ? ab[m][0] - (hi ? D_KW : 0) : ab[m][d];
+                af[(s + 1) & 1][m] = load8(&Xs[basev + tap_off(t0) * 16]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(af[s & 1][m], bq[s % (PF + 1)][j], acc[m][j]);
+        __builtin_amdgcn_sched_group_barrier(0x020, TN, 0);
+        if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+    }
+    __syncthreads();
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs, a, n, x0, y0, z0, co0);
+}
+
+template <class T, class B, int TM, int TN, int PF, int OCC>
+void launch_cfg16(const Conv3xArgs& a, hipStream_t s) {
+    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
+    dim3 grid(a.remap ? (unsigned)((nbox + 7) / 8 * 8) : (unsigned)nbox, a.Cout / (TN * 16));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x16_kernel<T, B, TM, TN, PF, OCC>), grid, dim3(256), 0, s, a);
 }
 
 // one translation unit per (dtype, ndim): the tap loops are fully unrolled and each instantiation takes ~10 s to compile
@@ -287,6 +428,11 @@ template <class T> bool launch_2d(int id, const Conv3xArgs& a, hipStream_t s);
         case 15: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 2, 8, 1>(a, s); return true;              \
         case 16: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;              \
         case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;                \
+        /* Cin == 16:             box                    TM TN PF OCC */                                      \
+        case 24: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2, 4>(a, s); return true;                      \
+        case 25: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2, 3>(a, s); return true;                      \
+        case 26: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 2, 2, 3>(a, s); return true;                      \
+        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;                      \
         default: return false;                                                                                \
     }
 #define SEG_C3X_2D_BODY                                                                                       \
@@ -299,6 +445,8 @@ template <class T> bool launch_2d(int id, const Conv3xArgs& a, hipStream_t s);
         case 37: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 1, 4, 1, 1, 8, 3>(a, s); return true;             \
         case 38: launch_cfg<T, XBox<1, 8, 8, 1, 8>, 2, 2, 2, 2, 4, 8, 2>(a, s); return true;                \
         case 39: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 2, 2, 4, 1, 2, 8, 2>(a, s); return true;              \
+        case 56: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 1, 2, 4>(a, s); return true;                     \
+        case 57: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 2, 2, 4>(a, s); return true;                     \
         default: return false;                                                                                \
     }
 

@@ -44,6 +44,7 @@ struct Step {
     int mask_slot = -1;
     size_t stats = 0, scale = 0, shift = 0, mean = 0, rstd = 0, Q = 0, coef = 0;
     size_t wp_fwd = 0, wp_dg0 = 0, wp_dg1 = 0;
+    bool fused_stem = false;                  // image stem evaluated inside the fused input block of its ACT step (stemx.hip)
     int x_fwd = -1, x_dg0 = -1, x_dg1 = -1;   // conv3x tiling of the forward / data-gradient launches (-1: conv3_kernel, row-major weights)
     int draw = -1;           // gradient wrt raw
     // ACT
@@ -87,6 +88,8 @@ struct seg_engine {
     // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
     hipStream_t side = nullptr;
     bool use_side = true;
+    bool use_stemx = true;      // SEG_STEMX=0: separate stem / GroupNorm / stem weight-gradient kernels (round-1 path)
+    size_t off_partial_stemx = 0;
     bool use_conv3x = true;     // SEG_CONV3X=0: conv3_kernel for every halo conv (round-1 path)
     bool dual_gn_bwd = true;    // SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
     bool stem_on_main = true;   // SEG_STEM_MAIN=0: 3^d stem weight gradient on the side stream (round-1 layout)
@@ -398,6 +401,26 @@ WgradArgs make_wgrad_args(const seg_engine& E, const Step& s, int draw) {
     return w;
 }
 
+// arguments of the fused input block behind ACT step `s` (pointers valid once the engine is bound)
+seg_stemx_args stemx_args(const seg_engine& E, const Step& s) {
+    const Step& ua = E.steps[s.ua];
+    seg_stemx_args x{};
+    x.img = E.ws + E.tens[ua.in0].off;
+    x.w3 = E.ws + ua.wp_fwd; x.bias3 = ua.b >= 0 ? E.p + E.params[ua.b].off : nullptr;
+    x.stats3 = (double*)(E.ws + ua.stats); x.scale3 = (float*)(E.ws + ua.scale); x.shift3 = (float*)(E.ws + ua.shift);
+    x.Q3 = (double*)(E.ws + ua.Q); x.coef3 = (float*)(E.ws + ua.coef);
+    if (s.ub >= 0) {
+        const Step& ub = E.steps[s.ub];
+        x.w1 = E.ws + ub.wp_fwd; x.bias1 = ub.b >= 0 ? E.p + E.params[ub.b].off : nullptr;
+        x.stats1 = (double*)(E.ws + ub.stats); x.scale1 = (float*)(E.ws + ub.scale); x.shift1 = (float*)(E.ws + ub.shift);
+        x.Q1 = (double*)(E.ws + ub.Q); x.coef1 = (float*)(E.ws + ub.coef);
+    }
+    x.out = E.ws + E.tens[s.out].off;
+    x.partial = (float*)(E.ws + E.off_partial_stemx);
+    x.N = E.N; x.D = E.dim_d(0); x.H = E.dim_h(0); x.W = E.dim_w(0); x.Cimg = E.tens[ua.in0].C;
+    return x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // planning: workspace layout + forward / backward schedules
 // ------------------------------------------------------------------------------------------------
@@ -444,6 +467,15 @@ struct Planner {
         E.tens.resize(std::max<size_t>(nfw, (size_t)E.image_ten + 1));
         for (auto& t : E.tens) t.grads.clear();
 
+        // ---- fused input block: an ACT whose unit(s) are image stems (3^d [+ 1^d]) without a residual
+        for (auto& st_ : E.steps) st_.fused_stem = false;
+        if (E.use_stemx && E.feat == 16 && (long long)E.vol(0) * 16 * 4 < (1ll << 31))
+            for (auto& st_ : E.steps)
+                if (st_.type == ST_ACT && st_.res < 0 && E.steps[st_.ua].ck == CK_STEM3 && E.steps[st_.ua].gn_w >= 0 &&
+                    (st_.ub < 0 || (E.steps[st_.ub].ck == CK_STEM1 && E.steps[st_.ub].gn_w >= 0))) {
+                    E.steps[st_.ua].fused_stem = true;
+                    if (st_.ub >= 0) E.steps[st_.ub].fused_stem = true;
+                }
         // ---- small persistent regions
         E.off_step = alloc(256);
         E.off_masks = alloc((size_t)E.drop_ch.size() * N * E.ld_mask() * 4);
@@ -484,18 +516,18 @@ struct Planner {
                         if (C1 && conv3x_supported(dt, E.ndim, N, d_, h_, w_, Co, C1, 0, false)) s.x_dg1 = conv3x_pick(E.ndim, N, d_, h_, w_, Co, C1);
                     }
                     s.wp_fwd = alloc_pack(Co, T * Ci);
-                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0, s.x_fwd >= 0);
+                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0, s.x_fwd >= 0 ? (Ci == 16 ? 2 : 1) : 0);
                     if (s.ck == CK_K2S2) {       // data-gradient = scatter GEMM, rows (a, ci), K = Cout
                         s.wp_dg0 = alloc_pack(T * Ci, Co);
                         add_pack(s.wp_dg0, woff, T, Ci, 1, Co, 1, T, 0, (long long)Ci * T, 0);
                     } else {                     // data-gradient = gather conv with flipped taps, rows ci, k = (tap, co)
                         if (!E.tens[s.in0].image) {
                             s.wp_dg0 = alloc_pack(C0, T * Co);
-                            add_pack(s.wp_dg0, woff, C0, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg0 >= 0);
+                            add_pack(s.wp_dg0, woff, C0, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg0 >= 0 ? (Co == 16 ? 2 : 1) : 0);
                         }
                         if (C1) {
                             s.wp_dg1 = alloc_pack(C1, T * Co);
-                            add_pack(s.wp_dg1, woff + (long long)C0 * T, C1, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg1 >= 0);
+                            add_pack(s.wp_dg1, woff + (long long)C0 * T, C1, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg1 >= 0 ? (Co == 16 ? 2 : 1) : 0);
                         }
                     }
                     break;
@@ -529,6 +561,7 @@ struct Planner {
             }
         E.off_partial = alloc(pmax);
         E.off_partial2 = E.n_side > 1 ? alloc(pmax) : E.off_partial;
+        E.off_partial_stemx = alloc(stemx_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), E.in_ch));
         E.off_partial_stem1 = alloc(stem_wgrad_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), 16 * ((E.feat + 15) / 16)));
 
         // ------------------------------------------------------------------ forward schedule
@@ -544,6 +577,7 @@ struct Planner {
                 E.fwd_ops.push_back([this_ = &E, si](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
+                    if (s.fused_stem) return;              // evaluated by the fused input block of its ACT step
                     const Ten& i0 = E.tens[s.in0];
                     const Ten& ro = E.tens[s.raw];
                     double* stats = s.gn_w >= 0 ? (double*)(E.ws + s.stats) : nullptr;
@@ -614,6 +648,28 @@ struct Planner {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
                     const Step& ua = E.steps[s.ua];
+                    if (ua.fused_stem) {
+                        // fused input block: statistics of both branches from the image, finalize, then recompute + normalise + add
+                        seg_stemx_args x = stemx_args(E, s);
+                        const int pi = E.prof_begin(st, SEG_K_STEM, E.tbytes(ua.in0) * 2 + E.tbytes(s.out), 0.0);
+                        launch_stemx(x, 0, E.ndim, E.dtype, nullptr, nullptr, st);
+                        for (int ui : {s.ua, s.ub}) {
+                            if (ui < 0) continue;
+                            const Step& u = E.steps[ui];
+                            GnFinArgs f;
+                            f.stats = (double*)(E.ws + u.stats); f.gamma = E.p + E.params[u.gn_w].off; f.beta = E.p + E.params[u.gn_b].off;
+                            f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
+                                     : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                            f.mask_ld = E.ld_mask();
+                            f.scale = (float*)(E.ws + u.scale); f.shift = (float*)(E.ws + u.shift);
+                            f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
+                            f.N = E.N; f.C = u.Cout; f.V = E.vol(0); f.eps = 1e-5f;
+                            launch_gn_finalize(f, st);
+                        }
+                        launch_stemx(x, 1, E.ndim, E.dtype, nullptr, nullptr, st);
+                        E.prof_end(st, pi);
+                        return;
+                    }
                     {
                         const Ten& ro = E.tens[ua.raw];
                         if (s.ub < 0 && gn_bwd_group_eligible(ua.Cout, E.vol(ro.lvl), (int)E.esz())) {
@@ -738,6 +794,46 @@ struct Planner {
                     f.coef = (float*)(E.ws + u.coef);
                     f.N = E.N; f.C = r.C; f.V = a.V;
                 };
+                if (E.steps[s.ua].fused_stem) {
+                    // fused input block: reduce (recomputing r), finalize per branch, then d(raw) in registers -> stem weight gradients
+                    std::vector<int> wr;
+                    for (int ui : {s.ua, s.ub})
+                        if (ui >= 0) { const Step& u = E.steps[ui]; wr.push_back(u.gn_w); wr.push_back(u.gn_b); wr.push_back(u.b); wr.push_back(u.w); }
+                    E.bwd_writes.push_back(wr);
+                    E.bwd_ops.push_back([this_ = &E, si, gl](hipStream_t st) {
+                        seg_engine& E = *this_;
+                        const Step& s = E.steps[si];
+                        seg_stemx_args x = stemx_args(E, s);
+                        x.ndy = (int)gl.size();
+                        for (int i = 0; i < x.ndy; ++i) x.dy[i] = E.ws + E.tens[gl[i]].off;
+                        E.flush_side(st);
+                        const double tb = E.tbytes(s.out);
+                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, tb * x.ndy, 0.0);
+                        launch_stemx(x, 2, E.ndim, E.dtype, nullptr, nullptr, st);
+                        E.prof_end(st, pi);
+                        for (int ui : {s.ua, s.ub}) {
+                            if (ui < 0) continue;
+                            const Step& u = E.steps[ui];
+                            GnBwdFinArgs f{};
+                            f.Q = (double*)(E.ws + u.Q); f.stats = (double*)(E.ws + u.stats);
+                            f.gamma = E.p + E.params[u.gn_w].off;
+                            f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
+                                     : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                            f.mask_ld = E.ld_mask();
+                            f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
+                            f.dgamma = E.g + E.params[u.gn_w].off; f.dbeta = E.g + E.params[u.gn_b].off;
+                            f.dbias = u.b >= 0 ? E.g + E.params[u.b].off : nullptr;
+                            f.coef = (float*)(E.ws + u.coef);
+                            f.N = E.N; f.C = u.Cout; f.V = E.vol(0);
+                            launch_gn_bwd_finalize(f, st);
+                        }
+                        pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, tb * x.ndy, 0.0);
+                        launch_stemx(x, 3, E.ndim, E.dtype, E.g + E.params[E.steps[s.ua].w].off,
+                                     s.ub >= 0 ? E.g + E.params[E.steps[s.ub].w].off : nullptr, st);
+                        E.prof_end(st, pi);
+                    });
+                    continue;
+                }
                 const bool dual = s.ua >= 0 && s.ub >= 0 && E.dual_gn_bwd &&
                                   !gn_bwd_group_eligible(E.tens[E.steps[s.ua].raw].C, E.vol(E.tens[E.steps[s.ua].raw].lvl), (int)E.esz());
                 if (dual) {
@@ -794,6 +890,7 @@ struct Planner {
                     });
                 }
             } else {   // UNIT: weight gradient + data gradient given d(raw)
+                if (s.fused_stem) continue;      // weight gradients come out of the fused input block (the ACT op above)
                 int draw = s.draw;
                 if (s.gn_w < 0) {
                     // plain ConvTranspose (UNet up-conv): d(raw) is the (single) gradient of its output tensor
@@ -957,6 +1054,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
     e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
     if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;
+    if (getenv("SEG_STEMX")) e->use_stemx = atoi(getenv("SEG_STEMX")) != 0;
     if (getenv("SEG_DUAL_GN")) e->dual_gn_bwd = atoi(getenv("SEG_DUAL_GN")) != 0;
     if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
     if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
@@ -1276,7 +1374,7 @@ int seg_op_conv3x(int cfg, const void* in0, const void* in1, int c0, const void*
     if (ndim != 2 && ndim != 3) return fail("seg_op_conv3x: ndim must be 2 or 3");
     const int dd = ndim == 3 ? d : 1;
     if (!conv3x_supported(dtype, ndim, n, dd, h, wid, cin, cout, c0, in1 != nullptr))
-        return fail("seg_op_conv3x: needs a 16-bit dtype, Cin % 32 == 0, Cout % 16 == 0 and tensors below 2 GB per sample");
+        return fail("seg_op_conv3x: needs a 16-bit dtype, Cin % 32 == 0 (or Cin == 16 without a concat), Cout % 16 == 0 and tensors below 2 GB per sample");
     if (cfg < 0) cfg = conv3x_pick(ndim, n, dd, h, wid, cin, cout);
     if (cfg < 0 || !launch_conv3x(cfg, in0, in1, c0, w, bias, out, stats, n, dd, h, wid, cin, cout, ndim, dtype, (hipStream_t)stream))
         return fail("seg_op_conv3x: the tiling does not fit this shape");
@@ -1312,8 +1410,27 @@ int seg_op_wgrad3_cat(const void* dr, const void* x0, const void* x1, int c0, fl
     launch_wgrad3(dr, x0, partial, dw, n, ndim == 3 ? d : 1, h, wid, p, q, ndim, dtype, (hipStream_t)stream, x1, c0);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_wgrad3_cat: launch failed");
 }
+long long seg_op_stemx_partial_bytes(int ndim, int n, int d, int h, int wid, int cimg) {
+    return (long long)stemx_partial_bytes(ndim, n, ndim == 3 ? d : 1, h, wid, cimg);
+}
+int seg_op_stemx(const seg_stemx_args* a, int mode, int ndim, int dtype, float* dw3, float* dw1, void* stream) {
+    if (!a || !a->img || !a->w3) return fail("seg_op_stemx: null pointer");
+    if (mode < 0 || mode > 3) return fail("seg_op_stemx: mode must be 0..3");
+    if (ndim != 2 && ndim != 3) return fail("seg_op_stemx: ndim must be 2 or 3");
+    if (a->Cimg < 1 || a->Cimg > 3 || (ndim == 3 && a->Cimg != 1)) return fail("seg_op_stemx: image channels must be 1 (3-D) or 1..3 (2-D)");
+    if ((long long)(ndim == 3 ? a->D : 1) * a->H * a->W * 16 * 4 >= (1ll << 31)) return fail("seg_op_stemx: volume too large for one buffer range");
+    if (mode == 0 && (!a->stats3 || (a->w1 && !a->stats1))) return fail("seg_op_stemx: statistics pointers");
+    if (mode >= 1 && (!a->scale3 || !a->shift3 || (a->w1 && (!a->scale1 || !a->shift1)))) return fail("seg_op_stemx: scale / shift pointers");
+    if (mode == 1 && !a->out) return fail("seg_op_stemx: out is null");
+    if (mode >= 2 && (a->ndy < 1 || a->ndy > 3 || !a->dy[0])) return fail("seg_op_stemx: gradient sources");
+    if (mode == 2 && (!a->Q3 || (a->w1 && !a->Q1))) return fail("seg_op_stemx: Q pointers");
+    if (mode == 3 && (!a->coef3 || (a->w1 && !a->coef1) || !a->partial || !dw3 || (a->w1 && !dw1))) return fail("seg_op_stemx: weight-gradient pointers");
+    launch_stemx(*a, mode, ndim, dtype, dw3, dw1, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_stemx: launch failed");
+}
 int seg_abi_sizeof(int which) {
-    return which == 0 ? (int)sizeof(seg_conv_args) : which == 1 ? (int)sizeof(seg_wgrad_args) : (int)sizeof(seg_pack_desc);
+    return which == 0 ? (int)sizeof(seg_conv_args) : which == 1 ? (int)sizeof(seg_wgrad_args) : which == 2 ? (int)sizeof(seg_pack_desc)
+                                                                                                           : (int)sizeof(seg_stemx_args);
 }
 
 #define SEG_OK(what) (hipGetLastError() == hipSuccess ? 0 : fail(what ": launch failed"))

@@ -23,6 +23,10 @@ int conv3x_num_cfgs();
 int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name);
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
                    int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s);
+// fused input block (stemx.hip): modes 0 forward statistics, 1 forward apply, 2 backward reduce, 3 backward apply + weight gradients
+int stemx_workgroups(int ndim, int N, int D, int H, int W);
+size_t stemx_partial_bytes(int ndim, int N, int D, int H, int W, int Cimg);
+void launch_stemx(const seg_stemx_args& a, int mode, int ndim, int dtype, float* dw3, float* dw1, hipStream_t s);
 // double-buffered weight gradient for 16-bit tensors (wgrad3x.hip); partial tiles in the layout wgrad3_reduce_kernel sums
 bool wgrad3x_supported(int dtype, int N, int D, int H, int W, int P, int Q, int C0, bool has_x1);
 void wgrad3x_tiles(int P, int Q, int C0, bool has_x1, int* CP, int* CQ);

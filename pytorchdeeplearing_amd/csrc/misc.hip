@@ -62,7 +62,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs) {
             row_s[t * d.Cc + c] = src[tt * d.sT + c * d.sC];
         }
         __syncthreads();
-        if (d.frag) {
+        if (d.frag == 2) {
+            // fragment-major over the FLAT k = t*Cc + c axis (Cc = 16: two taps per 32-deep MFMA step), zero-padded to Kpad
+            for (int k8 = threadIdx.x; k8 < d.Kpad / 8; k8 += 256) {
+                vec<T, 8> v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = from_f<T>(k8 * 8 + j < K ? row_s[k8 * 8 + j] : 0.f);
+                const long long f = (long long)(k8 >> 2) * (rows >> 4) + (row >> 4);
+                store8(dst + (f * 64 + (k8 & 3) * 16 + (row & 15)) * 8, v);
+            }
+        } else if (d.frag) {
             // fragment-major: the 8 consecutive channels (t, c8*8 ..) of this row are lane 16*(c8%4) + row%16 of the
             // (chunk c8/4, tap t, tile row/16) fragment
             for (int k8 = threadIdx.x; k8 < K / 8; k8 += 256) {

@@ -42,7 +42,17 @@ class PackDesc(C.Structure):
                 ("sT", C.c_longlong), ("sC", C.c_longlong), ("flipT", C.c_int), ("frag", C.c_int)]
 
 
+class StemxArgs(C.Structure):
+    _fields_ = [("img", C.c_void_p), ("w3", C.c_void_p), ("w1", C.c_void_p), ("bias3", C.c_void_p), ("bias1", C.c_void_p),
+                ("stats3", C.c_void_p), ("stats1", C.c_void_p),
+                ("scale3", C.c_void_p), ("shift3", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
+                ("out", C.c_void_p), ("dy", C.c_void_p * 3), ("ndy", C.c_int),
+                ("Q3", C.c_void_p), ("Q1", C.c_void_p), ("coef3", C.c_void_p), ("coef1", C.c_void_p), ("partial", C.c_void_p),
+                ("N", C.c_int), ("D", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cimg", C.c_int)]
+
+
 def check_abi(lib):
+    assert lib.dll.seg_abi_sizeof(3) == C.sizeof(StemxArgs), (lib.dll.seg_abi_sizeof(3), C.sizeof(StemxArgs))
     assert lib.dll.seg_abi_sizeof(0) == C.sizeof(ConvArgs), (lib.dll.seg_abi_sizeof(0), C.sizeof(ConvArgs))
     assert lib.dll.seg_abi_sizeof(1) == C.sizeof(WgradArgs)
     assert lib.dll.seg_abi_sizeof(2) == C.sizeof(PackDesc)
@@ -113,9 +123,9 @@ def pack(w, layout, dtype, frag=False):
     else:
         raise ValueError(layout)
     d.Kpad = _kpad(d.T * d.Cc)
-    d.frag = 1 if frag else 0
+    d.frag = (2 if d.Cc == 16 else 1) if frag else 0
     if frag:
-        assert d.Cc % 32 == 0 and rows % 16 == 0, "fragment-major packing needs Cc % 32 == 0 and rows % 16 == 0"
+        assert (d.Cc % 32 == 0 or d.Cc == 16) and rows % 16 == 0, "fragment-major packing needs Cc % 32 == 0 (or 16) and rows % 16 == 0"
     out = _alloc((rows, d.Kpad), TORCH_DTYPE[dtype], w.device)
     d.dst = out.data_ptr()
     raw = bytes(d)
@@ -255,3 +265,52 @@ def conv3x(x, wfrag, dtype, ndim, cout, bias=None, want_stats=False, out=None, x
                                 stats.data_ptr() if stats is not None else None, N, D, H, W, cin, cout, ndim, _capi.DTYPE[dtype],
                                 _capi.stream_for(x.device)), "seg_op_conv3x")
     return (out, stats.sum(0)) if want_stats else out
+
+
+def stemx(mode, img, w3p, dtype, ndim, w1p=None, bias3=None, bias1=None, scale=None, shift=None, dys=(), coef=None):
+    """Fused input block (csrc/stemx.hip).  img [N,D,H,W,Cimg] run dtype; w3p / w1p packed "conv_fwd" rows; scale / shift / coef:
+    pairs (branch 3, branch 1) of fp32 [N,16] / [N,16,3] tensors.  Returns per mode:
+    0 -> (stats3, stats1) fp64 [N,16,2];  1 -> out [N,D,H,W,16];  2 -> (Q3, Q1) fp64 [N,16,2];  3 -> (dw3, dw1) fp32 PyTorch layout."""
+    lib = _capi.lib_for(img.device)
+    N, D, H, W, cimg = img.shape
+    dev = img.device
+    a = StemxArgs()
+    a.img, a.w3, a.w1 = img.data_ptr(), w3p.data_ptr(), (w1p.data_ptr() if w1p is not None else None)
+    a.bias3 = bias3.data_ptr() if bias3 is not None else None
+    a.bias1 = bias1.data_ptr() if bias1 is not None else None
+    a.N, a.D, a.H, a.W, a.Cimg = N, D, H, W, cimg
+    keep = []
+    two = w1p is not None
+    if scale is not None:
+        a.scale3, a.shift3 = scale[0].data_ptr(), shift[0].data_ptr()
+        if two:
+            a.scale1, a.shift1 = scale[1].data_ptr(), shift[1].data_ptr()
+    a.ndy = len(dys)
+    for i, d in enumerate(dys):
+        a.dy[i] = d.data_ptr()
+    dw3 = dw1 = None
+    if mode == 0:
+        st = [_alloc((32, N, 16, 2), torch.float64, dev, zero=True) for _ in range(2)]
+        a.stats3, a.stats1 = st[0].data_ptr(), st[1].data_ptr()
+        res = lambda: (st[0].sum(0), st[1].sum(0))
+    elif mode == 1:
+        out = _alloc((N, D, H, W, 16), TORCH_DTYPE[dtype], dev, zero=True)
+        a.out = out.data_ptr()
+        res = lambda: out
+    elif mode == 2:
+        qs = [_alloc((32, N, 16, 2), torch.float64, dev, zero=True) for _ in range(2)]
+        a.Q3, a.Q1 = qs[0].data_ptr(), qs[1].data_ptr()
+        res = lambda: (qs[0].sum(0), qs[1].sum(0))
+    else:
+        a.coef3 = coef[0].data_ptr()
+        if two:
+            a.coef1 = coef[1].data_ptr()
+        part = aligned_empty(lib.seg_op_stemx_partial_bytes(ndim, N, D, H, W, cimg), dev)
+        a.partial = part.data_ptr()
+        keep.append(part)
+        dw3 = _alloc((16, cimg) + (3,) * ndim, torch.float32, dev, zero=True)
+        dw1 = _alloc((16, cimg) + (1,) * ndim, torch.float32, dev, zero=True)
+        res = lambda: (dw3, dw1)
+    lib.check(lib.seg_op_stemx(C.byref(a), mode, ndim, _capi.DTYPE[dtype], dw3.data_ptr() if dw3 is not None else None,
+                               dw1.data_ptr() if (dw1 is not None and two) else None, _capi.stream_for(dev)), "seg_op_stemx")
+    return res()

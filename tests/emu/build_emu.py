@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pytorchdeeplearing_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libsegengine_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "wgrad.hip", "wgrad3x.hip", "norm.hip", "misc.hip", "cldice.hip", "prepost.hip", "engine.hip"]
+SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "cldice.hip", "prepost.hip", "engine.hip"]
 
 
 def build(force=False):
@@ -25,14 +25,16 @@ def _build(force=False):
     srcs = [os.path.join(CSRC, s) for s in SRCS]
     deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv3x_impl.h"),
                    os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "segengine.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
+    hdr_t = max(os.path.getmtime(d) for d in deps[len(srcs):])
+    # per-object freshness (an object compiled BEFORE an edit of its source must not hide behind a newer link step)
+    stale = lambda s, o: force or not os.path.exists(o) or os.path.getmtime(o) <= max(os.path.getmtime(s), hdr_t)
+    objs = [os.path.join(HERE, "_build", os.path.basename(s) + ".o") for s in srcs]
+    todo = [(s, o) for s, o in zip(srcs, objs) if stale(s, o)]
+    if not todo and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(o) for o in objs):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    objs = []
     procs = []
-    for s in srcs:
-        o = os.path.join(HERE, "_build", os.path.basename(s) + ".o")
-        objs.append(o)
+    for s, o in todo:
         cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I", HERE, "-I", CSRC, "-Wno-unused-value",
                "-Wno-vla-cxx-extension", "-c", s, "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -331,6 +331,9 @@ inline vec<short, 4> ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma<32, 8, _Float16, 16>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma<32, 8, __bf16, 16>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, x, y, z) emu::mfma<16, 4, _Float16, 4>(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, x, y, z) \
+    emu::mfma<16, 4, __bf16, 4>(__builtin_bit_cast(emu::vec<__bf16, 4>, a), __builtin_bit_cast(emu::vec<__bf16, 4>, b), c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2f32(a, b, c)
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

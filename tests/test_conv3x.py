@@ -19,6 +19,10 @@ CASES = [
     (3, 1, (2, 6, 16), [16, 16], 32, [0]),                  # concat straddling one 32-channel chunk
     (3, 1, (2, 5, 8), [32, 32], 64, [3]),                   # concat on a chunk boundary
     (3, 1, (2, 4, 8), [64, 64], 64, [None]),
+    (3, 1, (3, 9, 18), [16], 16, [24, 25]),                 # Cin == 16: two taps per MFMA step, flat-K weights
+    (3, 2, (2, 8, 32), [16], 32, [26, 27]),
+    (2, 1, (19, 24), [16], 16, [56]),
+    (2, 2, (16, 16), [16], 32, [57, None]),
     (2, 2, (17, 20), [32], 32, [32, 39]),
     (2, 1, (16, 32), [64], 64, [33, 34, 35, 38]),
     (2, 1, (9, 16), [128], 128, [36]),
@@ -57,8 +61,8 @@ def test_conv3x_exact(dev, dtype, case):
         got = ncdhw(out.float().cpu(), ndim)
         assert torch.equal(got, ref.detach()), (cfg, float((got - ref.detach()).abs().max()))
         assert torch.equal(stats.cpu(), rs), cfg
-    # data-gradient: K = Cout (must be a multiple of 32), one launch per concat source with its own flipped weights
-    if cout % 32 == 0:
+    # data-gradient: K = Cout (a multiple of 32, or 16), one launch per concat source with its own flipped weights
+    if cout % 32 == 0 or cout == 16:
         dyd = to_dev(cl(dy), dtype, dev)
         c_lo = 0
         for ci in cins:
@@ -73,8 +77,9 @@ def test_conv3x_exact(dev, dtype, case):
 def test_conv3x_rejects_what_it_cannot_run(dev):
     x = to_dev(torch.zeros(1, 2, 4, 8, 16), "f16", dev)
     w = to_dev(torch.zeros(16, 27 * 16), "f16", dev)
+    x1 = to_dev(torch.zeros(1, 2, 4, 8, 8), "f16", dev)
     with pytest.raises(RuntimeError):
-        ops.conv3x(x, w, "f16", 3, 16)              # Cin = 16
+        ops.conv3x(x1, w, "f16", 3, 16, x1=x1)      # Cin = 16 as a concat of 8 + 8
     x = to_dev(torch.zeros(1, 2, 4, 8, 32), "f16", dev)
     w = to_dev(torch.zeros(32, 27 * 32), "f16", dev)
     with pytest.raises(RuntimeError):
