@@ -546,10 +546,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
                 dw[c][j] = fmaf(dl, to_f(x[j]), dw[c][j]);
             }
         }
-        vec<T, 8> o;
+        if (din) {
+            vec<T, 8> o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = from_f<T>(g[j]);
-        store8(din + m * a.Cin + cc * 8, o);
+            for (int j = 0; j < 8; ++j) o[j] = from_f<T>(g[j]);
+            store8(din + m * a.Cin + cc * 8, o);
+        }
     }
     // block reduction: for each class, 8 dw columns (+ db) per thread -> sum over threads with equal cc
     for (int c = 0; c < a.C; ++c) {
@@ -604,7 +606,8 @@ void launch_head_bwd(const HeadBwdArgs& a, int dtype, hipStream_t s) {
     const long long M = (long long)a.N * a.V;
     const int VPB = 256 / (a.Cin / 8);
     int blocks = cdiv(M, VPB);
-    if (blocks > 512) blocks = 512;
+    static const int cap = getenv("SEG_HEAD_BWD_WGS") ? atoi(getenv("SEG_HEAD_BWD_WGS")) : 1024;      // tuning knob
+    if (blocks > cap) blocks = cap;
     dim3 grid(blocks);
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<float>), grid, dim3(256), 0, s, a);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<f16>), grid, dim3(256), 0, s, a);

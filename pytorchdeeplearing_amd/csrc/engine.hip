@@ -33,6 +33,7 @@ struct Ten {
     int C, lvl;
     size_t off = 0;          // workspace byte offset
     bool image = false;
+    bool virt = false;       // gradient of the head's input kept virtual (evaluated from dlogits and the head weights by its readers)
     std::vector<int> grads;  // gradient contribution tensors (ids)
 };
 
@@ -88,6 +89,9 @@ struct seg_engine {
     // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
     hipStream_t side = nullptr;
     bool use_side = true;
+    bool use_vhead = true;      // SEG_VHEAD=0: head_bwd writes its data-gradient tensor (round-1 path)
+    bool head_din_needed = false;   // planning: some reader of the head's data-gradient cannot evaluate it on the fly
+    int head_step = -1;
     bool use_stemx = true;      // SEG_STEMX=0: separate stem / GroupNorm / stem weight-gradient kernels (round-1 path)
     size_t off_partial_stemx = 0;
     bool use_conv3x = true;     // SEG_CONV3X=0: conv3_kernel for every halo conv (round-1 path)
@@ -737,6 +741,9 @@ struct Planner {
             Step& s = E.steps[si];
             if (s.type == ST_HEAD) {
                 const int gin = new_grad(s.in);
+                E.tens[gin].virt = E.use_vhead;
+                E.head_din_needed = !E.use_vhead;
+                E.head_step = si;
                 E.tens[s.in].grads.push_back(gin);
                 E.bwd_writes.push_back({s.w, s.b});
                 E.bwd_ops.push_back([this_ = &E, si, gin](hipStream_t st) {
@@ -744,7 +751,8 @@ struct Planner {
                     const Step& s = E.steps[si];
                     HeadBwdArgs a;
                     a.in = E.ws + E.tens[s.in].off; a.w = E.p + E.params[s.w].off; a.dlogits = E.cur_dlogits;
-                    a.din = E.ws + E.tens[gin].off;
+                    // rank-K gradient: its readers (GroupNorm-backward passes) rebuild it from dlogits unless one of them cannot
+                    a.din = E.head_din_needed ? E.ws + E.tens[gin].off : nullptr;
                     a.dw = E.g + E.params[s.w].off; a.db = E.g + E.params[s.b].off;
                     a.N = E.N; a.V = (int)E.vol(0); a.Cin = s.Cin; a.C = s.Cout;
                     launch_head_bwd(a, E.dtype, st);
@@ -752,6 +760,7 @@ struct Planner {
             } else if (s.type == ST_POOL) {
                 std::vector<int> gl = E.tens[s.out].grads;
                 if (gl.size() != 1) { g_err = "internal: pool output needs exactly one gradient"; return; }
+                if (E.tens[gl[0]].virt) E.head_din_needed = true;
                 const int gin = new_grad(s.in);
                 E.tens[s.in].grads.push_back(gin);
                 const int gout = gl[0];
@@ -770,13 +779,25 @@ struct Planner {
                 std::vector<int> gl = E.tens[s.out].grads;
                 if (gl.empty() || gl.size() > 3) { g_err = "internal: unsupported gradient fan-in"; return; }
                 if (s.res >= 0) for (int gi : gl) E.tens[s.res].grads.push_back(gi);
+                {
+                    // the fused input block, the dual-branch and the one-launch small-tensor passes read real tensors only
+                    const Step& ua_ = E.steps[s.ua];
+                    const bool generic = !ua_.fused_stem && s.ub < 0 &&
+                                         !gn_bwd_group_eligible(E.tens[ua_.raw].C, E.vol(E.tens[ua_.raw].lvl), (int)E.esz());
+                    for (int gi : gl) if (E.tens[gi].virt && !generic) E.head_din_needed = true;
+                }
                 // per-branch argument builders (shared by the single- and the dual-branch op)
                 auto fill = [](seg_engine& E, int ui, const std::vector<int>& gl, GnBwdArgs& a, GnBwdFinArgs& f) {
                     const Step& u = E.steps[ui];
                     const Ten& r = E.tens[u.raw];
                     a = GnBwdArgs{};
-                    a.ndy = (int)gl.size();
-                    for (int i = 0; i < a.ndy; ++i) a.dy[i] = E.ws + E.tens[gl[i]].off;
+                    a.ndy = 0;
+                    for (int gi : gl) {
+                        if (E.tens[gi].virt && !E.head_din_needed) {
+                            const Step& hs = E.steps[E.head_step];
+                            a.vdl = E.cur_dlogits; a.vw = E.p + E.params[hs.w].off; a.vK = hs.Cout;
+                        } else a.dy[a.ndy++] = E.ws + E.tens[gi].off;
+                    }
                     a.r = E.ws + r.off;
                     a.scale = (float*)(E.ws + u.scale); a.shift = (float*)(E.ws + u.shift);
                     a.Q = (double*)(E.ws + u.Q); a.coef = (float*)(E.ws + u.coef);
@@ -897,6 +918,7 @@ struct Planner {
                     std::vector<int> gl = E.tens[s.raw].grads;
                     if (gl.size() != 1) { g_err = "internal: plain conv output needs exactly one gradient"; return; }
                     draw = gl[0];
+                    if (E.tens[draw].virt) E.head_din_needed = true;
                 }
                 if (draw < 0) { g_err = "internal: unit without output gradient"; return; }
                 const bool need_dg0 = !E.tens[s.in0].image;
@@ -1055,6 +1077,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
     if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;
     if (getenv("SEG_STEMX")) e->use_stemx = atoi(getenv("SEG_STEMX")) != 0;
+    if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
     if (getenv("SEG_DUAL_GN")) e->dual_gn_bwd = atoi(getenv("SEG_DUAL_GN")) != 0;
     if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
     if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));

@@ -71,7 +71,7 @@ struct HeadBwdArgs {
     const void* in;        // activated input [M][Cin] T
     const float* w;        // [C][Cin]
     const float* dlogits;  // [N][C][V] fp32 (already multiplied by the loss scale)
-    void* din;             // [M][Cin] T
+    void* din;             // [M][Cin] T, or null: the data-gradient stays virtual (GnBwdArgs::vdl)
     float* dw;             // [C][Cin] +=
     float* db;             // [C] +=
     int N, V, Cin, C;
@@ -119,6 +119,10 @@ struct GnBwdArgs {
     // optional SECOND branch normalised by the same GroupNorm module and fed by the same gradient sources (the two convolutions
     // of the VNet input block, networks/VNet3d.py:25-43): one pass reads the gradient sources once for both branches
     const void* r2; const float* scale2; const float* shift2; double* Q2; const float* coef2; void* dr2;
+    // optional VIRTUAL gradient source: the data-gradient of the 1^d head, dy[v][c] += sum_k vdl[n][k][v] * vw[k][c], evaluated on
+    // the fly from the loss gradient (planar fp32) and the head weights instead of being written as a 16-channel tensor and read
+    // back by every GroupNorm-backward pass it feeds
+    const float* vdl; const float* vw; int vK;
 };
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
 void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s);

@@ -92,11 +92,24 @@ __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
     }
 }
 
+// i = 8-channel chunk index ((n*V + v)*C/8 + c0/8); (n, v, c0) only matter for the virtual head source
 template <class T>
-__device__ __forceinline__ void load_dy_sum(const GnBwdArgs& a, long long i, float* g) {
-    const vec<T, 8> d0 = load8((const T*)a.dy[0] + i * 8);
+__device__ __forceinline__ void load_dy_sum(const GnBwdArgs& a, long long i, float* g, int n = 0, long long v = 0, int c0 = 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = to_f(d0[j]);
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    if (a.vdl) {
+        for (int k = 0; k < a.vK; ++k) {
+            const float dl = a.vdl[((long long)n * a.vK + k) * a.V + v];
+            const vec<float, 8> w = *(const vec<float, 8>*)(a.vw + (long long)k * a.C + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = fmaf(dl, w[j], g[j]);
+        }
+    }
+    if (a.ndy > 0) {
+        const vec<T, 8> d0 = load8((const T*)a.dy[0] + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += to_f(d0[j]);
+    }
     if (a.ndy > 1) {
         const vec<T, 8> d1 = load8((const T*)a.dy[1] + i * 8);
 #pragma unroll
@@ -137,8 +150,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
     for (; v + G < v1; v += 2 * G) {
         const long long i0 = ((long long)n * a.V + v) * CPR + cc, i1 = i0 + (long long)G * CPR;
         float dy0[8], dy1[8];
-        load_dy_sum<T>(a, i0, dy0);
-        load_dy_sum<T>(a, i1, dy1);
+        load_dy_sum<T>(a, i0, dy0, n, v, cc * 8);
+        load_dy_sum<T>(a, i1, dy1, n, v + G, cc * 8);
         const vec<T, 8> x0 = load8(r + i0 * 8), x1 = load8(r + i1 * 8);
         vec<T, 8> z0 = x0, z1 = x1;
         if (DUAL) { z0 = load8(r2 + i0 * 8); z1 = load8(r2 + i1 * 8); }
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
     for (; v < v1; v += G) {
         const long long i = ((long long)n * a.V + v) * CPR + cc;
         float dy[8];
-        load_dy_sum<T>(a, i, dy);
+        load_dy_sum<T>(a, i, dy, n, v, cc * 8);
         const vec<T, 8> x = load8(r + i * 8);
         vec<T, 8> z = x;
         if (DUAL) z = load8(r2 + i * 8);
@@ -258,11 +271,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
         const int n = (int)(i / per_n);
         const int c0 = (int)(i % CPR) * 8;
         float dy[8];
-        load_dy_sum<T>(a, i, dy);
+        load_dy_sum<T>(a, i, dy, n, (i % per_n) / CPR, c0);
         const vec<T, 8> x = load8(r + i * 8);
-        const float* sc = a.scale + (long long)n * a.C + c0;
-        const float* sh = a.shift + (long long)n * a.C + c0;
-        const float* co = a.coef + ((long long)n * a.C + c0) * 3;
+        // per-(n, c) coefficients as wide loads (10 x 16 B instead of 40 scalar loads per thread: the small levels are latency-bound)
+        const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale + (long long)n * a.C + c0);
+        const vec<float, 8> sh = *(const vec<float, 8>*)(a.shift + (long long)n * a.C + c0);
+        const vec<float, 8>* cop = (const vec<float, 8>*)(a.coef + ((long long)n * a.C + c0) * 3);
+        const vec<float, 8> ca = cop[0], cb = cop[1], cc = cop[2];
+        float co[24];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { co[j] = ca[j]; co[8 + j] = cb[j]; co[16 + j] = cc[j]; }
         vec<T, 8> o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -273,9 +291,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
         store8(dr + i * 8, o);
         if (DUAL) {
             const vec<T, 8> z = load8((const T*)a.r2 + i * 8);
-            const float* sc2 = a.scale2 + (long long)n * a.C + c0;
-            const float* sh2 = a.shift2 + (long long)n * a.C + c0;
-            const float* co2 = a.coef2 + ((long long)n * a.C + c0) * 3;
+            const vec<float, 8> sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + c0);
+            const vec<float, 8> sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
+            const vec<float, 8>* cop2 = (const vec<float, 8>*)(a.coef2 + ((long long)n * a.C + c0) * 3);
+            const vec<float, 8> da = cop2[0], db = cop2[1], dc = cop2[2];
+            float co2[24];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { co2[j] = da[j]; co2[8 + j] = db[j]; co2[16 + j] = dc[j]; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float zv = to_f(z[j]);

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
     constexpr bool BWD = MODE == SX_BWD_REDUCE || MODE == SX_BWD_APPLY;
     static_assert(B::NTILE % 4 == 0, "tiles must split over the four waves");
     constexpr int XELEMS = (SX_MAXCI * NCOPY + 1) * B::HVP;       // + one all-zero plane: the padding k slots (k >= K) read it at the tile's offset
-    constexpr int DELEMS = BWD ? 3 * B::V * SX_C : 8;
+    constexpr int DELEMS = BWD ? 2 * 3 * B::V * SX_C : 8;           // two buffers of up to three gradient-source tiles
     __shared__ __attribute__((aligned(16))) T Xc[XELEMS];
     __shared__ __attribute__((aligned(16))) T Dy[DELEMS];
     __shared__ float red[4 * 2 * 2 * SX_C * 2];                   // [wave][branch][which][co] partial sums / weight-gradient tiles (2 KB)
@@ -123,61 +123,82 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
         }
     };
 
+    // ---- box pipeline: while box b is multiplied, the image halo of the next box travels to registers and its gradient-source
+    //      tiles to the other LDS buffer (asynchronous direct copies); the only exposed latency is the first box's
+    constexpr int NIT = (B::HD * B::HH * B::HW * SX_MAXCI + 255) / 256;
+    const int total = B::HD * B::HH * B::HW * Cimg;
+    T himg[NIT];
+    struct BoxAt { int x0, y0, z0, n; };
+    auto box_at = [&](long long b) {
+        BoxAt p;
+        p.x0 = (int)(b % nbx) * 16; b /= nbx;
+        p.y0 = (int)(b % nby) * B::TH; b /= nby;
+        p.z0 = (int)(b % nbz) * B::TD;
+        p.n = (int)(b / nbz);
+        return p;
+    };
+    auto load_img = [&](const BoxAt& p) {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = u * 256 + tid;
+            const int hv = i / Cimg, ci = i % Cimg;
+            const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
+            const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
+            himg[u] = from_f<T>(0.f);
+            if (i < total && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                himg[u] = img[((((long long)p.n * a.D + z) * a.H + y) * a.W + x) * Cimg + ci];
+        }
+    };
+    auto issue_dy = [&](const BoxAt& p, int buf) {
+        constexpr int GPV = SX_C * (int)sizeof(T) / 16;                          // 16-B granules per voxel row: 2 (16-bit) or 4 (f32)
+        constexpr int NG = B::V * GPV, NI = (NG + 255) / 256;
+        for (int sidx = 0; sidx < a.ndy; ++sidx) {
+            const i32x4 rs = make_rsrc((const T*)a.dy[sidx] + (long long)p.n * vol * SX_C, (unsigned)(vol * SX_C * sizeof(T)));
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int g = (u * 4 + wv) * 64 + lane;
+                const int v = g / GPV, piece = g % GPV;
+                const int vx = v % 16, vy = (v / 16) % B::TH, vz = v / (16 * B::TH);
+                const int z = p.z0 + vz, y = p.y0 + vy, x = p.x0 + vx;
+                const bool ok = v < B::V && z < a.D && y < a.H && x < a.W;
+                const unsigned off = ok ? (unsigned)((((long long)z * a.H + y) * a.W + x) * SX_C * sizeof(T)) + piece * 16u : DMA_OOB;
+                if ((u * 4 + wv) * 64 < B::V * GPV)
+                    dma16_async(rs, (T*)((char*)(Dy + (buf * 3 + sidx) * B::V * SX_C) + (size_t)(u * 4 + wv) * 1024), off);
+            }
+        }
+    };
+    int cur = 0;
+    if ((long long)blockIdx.x < nbox) {
+        const BoxAt p0 = box_at(blockIdx.x);
+        load_img(p0);
+        if (BWD) issue_dy(p0, 0);
+    }
     for (long long b = blockIdx.x; b < nbox; b += gridDim.x) {
-        long long bb = b;
-        const int x0 = (int)(bb % nbx) * 16; bb /= nbx;
-        const int y0 = (int)(bb % nby) * B::TH; bb /= nby;
-        const int z0 = (int)(bb % nbz) * B::TD;
-        const int n = (int)(bb / nbz);
+        const BoxAt bp = box_at(b);
+        const int x0 = bp.x0, y0 = bp.y0, z0 = bp.z0, n = bp.n;
         if (n != cur_n) { if (cur_n >= 0) flush(cur_n); cur_n = n; }
-        __syncthreads();                                 // the previous box is done with the LDS tiles
-        // ---- image halo -> LDS (all loads first, then the stores of every shifted copy)
-        {
-            constexpr int NIT = (B::HD * B::HH * B::HW * SX_MAXCI + 255) / 256;
-            const int total = B::HD * B::HH * B::HW * Cimg;
-            T v[NIT];
+        __syncthreads();                                 // the previous box is done with the image copies and the other gradient buffer
+        // ---- image halo (loaded during the previous box) -> every shifted copy
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int i = u * 256 + tid;
+        for (int u = 0; u < NIT; ++u) {
+            const int i = u * 256 + tid;
+            if (i < total) {
                 const int hv = i / Cimg, ci = i % Cimg;
-                const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
-                const int z = z0 + hz - B::PD, y = y0 + hy - 1, x = x0 + hx - 1;
-                v[u] = from_f<T>(0.f);
-                if (i < total && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-                    v[u] = img[((((long long)n * a.D + z) * a.H + y) * a.W + x) * Cimg + ci];
-            }
+                const int L = (hv / B::HW) * B::HWP + hv % B::HW;
 #pragma unroll
-            for (int u = 0; u < NIT; ++u) {
-                const int i = u * 256 + tid;
-                if (i < total) {
-                    const int hv = i / Cimg, ci = i % Cimg;
-                    const int L = (hv / B::HW) * B::HWP + hv % B::HW;
-#pragma unroll
-                    for (int c = 0; c < NCOPY; ++c)
-                        if (L - c >= 0) Xc[(ci * NCOPY + c) * B::HVP + L - c] = v[u];
-                }
+                for (int c = 0; c < NCOPY; ++c)
+                    if (L - c >= 0) Xc[(ci * NCOPY + c) * B::HVP + L - c] = himg[u];
             }
         }
-        // ---- gradient sources of this box -> LDS [source][voxel][16] (direct copies; voxels outside the volume read zeros)
-        if (BWD) {
-            constexpr int GPV = SX_C * (int)sizeof(T) / 16;                          // 16-B granules per voxel row: 2 (16-bit) or 4 (f32)
-            constexpr int NG = B::V * GPV, NI = (NG + 255) / 256;
-            for (int sidx = 0; sidx < a.ndy; ++sidx) {
-                const i32x4 rs = make_rsrc((const T*)a.dy[sidx] + (long long)n * vol * SX_C, (unsigned)(vol * SX_C * sizeof(T)));
-#pragma unroll
-                for (int u = 0; u < NI; ++u) {
-                    const int g = (u * 4 + wv) * 64 + lane;
-                    const int v = g / GPV, piece = g % GPV;
-                    const int vx = v % 16, vy = (v / 16) % B::TH, vz = v / (16 * B::TH);
-                    const int z = z0 + vz, y = y0 + vy, x = x0 + vx;
-                    const bool ok = v < B::V && z < a.D && y < a.H && x < a.W;
-                    const unsigned off = ok ? (unsigned)((((long long)z * a.H + y) * a.W + x) * SX_C * sizeof(T)) + piece * 16u : DMA_OOB;
-                    if ((u * 4 + wv) * 64 < B::V * GPV) dma16(rs, (T*)((char*)(Dy + sidx * B::V * SX_C) + (size_t)(u * 4 + wv) * 1024), off);
-                }
-            }
-            wait_vmem();
-        }
+        if (BWD) wait_vmem();                            // this wave's copies of the gradient tiles of box b have landed
         __syncthreads();
+        if (b + gridDim.x < nbox) {
+            const BoxAt pn = box_at(b + gridDim.x);
+            load_img(pn);
+            if (BWD) issue_dy(pn, cur ^ 1);
+        }
+        const T* DyB = Dy + cur * 3 * B::V * SX_C;
+        cur ^= 1;
 
         // per-sample coefficients of this lane's channel(s)
         const long long nc = (long long)n * SX_C;
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
             // sum of the gradient sources in the same layout: one transposing read per source
             float dy[4] = {0.f, 0.f, 0.f, 0.f};
             for (int sidx = 0; sidx < a.ndy; ++sidx) {
-                const T* tile = Dy + sidx * B::V * SX_C + m * 16 * SX_C;
+                const T* tile = DyB + sidx * B::V * SX_C + m * 16 * SX_C;
                 if constexpr (H16) {
                     const s16x4 t = lds_read_tr16(tile + (4 * q + (l15 >> 2)) * SX_C + 4 * (l15 & 3));
                     const vec<T, 4> tv = __builtin_bit_cast(vec<T, 4>, t);
