@@ -77,12 +77,15 @@ __device__ __forceinline__ void tile_stats(const T* Os, int ldo, int rows_valid,
     }
 }
 
-template <class T, int NT, bool SCATTER>
+// KS = 32-wide reduction slices per pipeline stage.  The deep levels launch 28..432 workgroups whose time is the serial
+// chain of stages (one global-load latency each): KS = 2 halves the chain with twice the loads in flight.
+template <class T, int NT, bool SCATTER, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BN = 16 * NT;
-    __shared__ T As[2 * BM * LDT];
-    __shared__ T Bs[2 * BN * LDT];
+    __shared__ T As[2 * KS * BM * LDT];
+    __shared__ T Bs[2 * KS * BN * LDT];
     __shared__ float red[512];
+    __shared__ int tapoff[32];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
@@ -109,33 +112,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     const bool bload = tid < BN * 4;
     const int brow = tid >> 2;
+    // tap offsets through LDS: read from the argument segment they were vector-memory loads whose `s_waitcnt vmcnt(0)` also drained the
+    // operand loads in flight, one round trip after the other
+    if (tid < 32) {
+        const int t = tid < a.taps.n ? tid : 0;
+        tapoff[tid] = (a.taps.d[t] & 255) | ((a.taps.h[t] & 255) << 8) | ((a.taps.w[t] & 255) << 16);
+    }
+    __syncthreads();
 
-    vec<T, 8> areg[2], breg;
-    auto gload = [&](int ks) {
-        const int k0 = ks * BK + ac * 8;
-        const int tap = SCATTER ? 0 : (k0 >> lg);
-        const int ci = SCATTER ? k0 : (k0 & (Cin - 1));
-        const bool kin = k0 < a.K;
-        int td = 0, th = 0, tw = 0;
-        if (!SCATTER && kin) { td = a.taps.d[tap]; th = a.taps.h[tap]; tw = a.taps.w[tap]; }
+    vec<T, 8> areg[KS][2], breg[KS];
+    bool aok[KS][2];
+    auto gload = [&](int st) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = rc[i].d + td, ih = rc[i].h + th, iw = rc[i].w + tw;
-            const bool ok = kin && rvalid[i] && (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH &&
-                            (unsigned)iw < (unsigned)a.IW;
-            if (ok) {
+        for (int u = 0; u < KS; ++u) {
+            const int k0 = (st * KS + u) * BK + ac * 8;
+            const int tap = SCATTER ? 0 : (k0 >> lg);
+            const int ci = SCATTER ? k0 : (k0 & (Cin - 1));
+            const bool kin = k0 < a.K;
+            int td = 0, th = 0, tw = 0;
+            if (!SCATTER) { const int tp = tapoff[kin ? tap : 0]; td = (signed char)tp; th = (signed char)(tp >> 8); tw = (signed char)(tp >> 16); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int id = rc[i].d + td, ih = rc[i].h + th, iw = rc[i].w + tw;
+                const bool ok = kin && rvalid[i] && (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH &&
+                                (unsigned)iw < (unsigned)a.IW;
+                // branch-free: a load under a divergent `if` has to land before the paths re-join, which serialised the loads of a
+                // stage at one L2 round trip each (r02 trace: 2 us per stage, 11 GB/s per CU).  Out-of-range rows read a safe address
+                // and are zeroed on the way into LDS (sstore), after the MFMAs of the current stage.
                 const long long vox = (((long long)rc[i].n * a.ID + id) * a.IH + ih) * a.IW + iw;
-                areg[i] = (ci < a.C0) ? load8(in0 + vox * a.C0 + ci) : load8(in1 + vox * a.C1 + (ci - a.C0));
-            } else {
-                areg[i] = zero8<T>();
+                const T* src = (ci < a.C0) ? in0 + vox * a.C0 + ci : in1 + vox * a.C1 + (ci - a.C0);
+                areg[u][i] = load8(ok ? src : in0);
+                aok[u][i] = ok;
             }
+            breg[u] = load8(wp + (long long)(cog0 + (bload ? brow : 0)) * a.Kpad + (st * KS + u) * BK + ac * 8);
         }
-        if (bload) breg = load8(wp + (long long)(cog0 + brow) * a.Kpad + ks * BK + ac * 8);
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) store8(&As[(buf * BM + ar0 + 64 * i) * LDT + ac * 8], areg[i]);
-        if (bload) store8(&Bs[(buf * BN + brow) * LDT + ac * 8], breg);
+        for (int u = 0; u < KS; ++u) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) store8(&As[((buf * KS + u) * BM + ar0 + 64 * i) * LDT + ac * 8], aok[u][i] ? areg[u][i] : zero8<T>());
+            if (bload) store8(&Bs[((buf * KS + u) * BN + brow) * LDT + ac * 8], breg[u]);
+        }
     };
 
     f32x4 acc[2][NT];
@@ -144,22 +162,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.Kpad / BK;
+    const int nk = a.Kpad / (BK * KS);
     gload(0);
     sstore(0);
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nk) gload(ks + 1);
-        typename Mma<T>::frag af[2], bf[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = load8(&As[(buf * BM + wv * 32 + i * 16 + l15) * LDT + q * 8]);
+        for (int u = 0; u < KS; ++u) {
+            typename Mma<T>::frag af[2], bf[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = load8(&Bs[(buf * BN + j * 16 + l15) * LDT + q * 8]);
+            for (int i = 0; i < 2; ++i) af[i] = load8(&As[((buf * KS + u) * BM + wv * 32 + i * 16 + l15) * LDT + q * 8]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NT; ++j) bf[j] = load8(&Bs[((buf * KS + u) * BN + j * 16 + l15) * LDT + q * 8]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = Mma<T>::run(af[i], bf[j], acc[i][j]);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = Mma<T>::run(af[i], bf[j], acc[i][j]);
+        }
         if (ks + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
     }
@@ -204,9 +225,15 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s) {
     const long long M = (long long)a.N * a.OD * a.OH * a.OW;
     const int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     dim3 grid(cdiv(M, BM), a.Ngemm / (16 * nt));
+    // two reduction slices per stage where the launch is a latency chain (fewer than two workgroups per CU) and K allows it
+    static const int ks_env = getenv("SEG_IGEMM_KS") ? atoi(getenv("SEG_IGEMM_KS")) : 0;
+    const bool ks2 = a.Kpad % (2 * BK) == 0 && a.Kpad >= 4 * BK && (ks_env ? ks_env == 2 : (long long)grid.x * grid.y <= 512);
 #define SEG_LAUNCH_CONV(NT)                                                                          \
-    if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true>), grid, dim3(256), 0, s, a);  \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false>), grid, dim3(256), 0, s, a);
+    if (ks2) {                                                                                        \
+        if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 2>), grid, dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 2>), grid, dim3(256), 0, s, a);           \
+    } else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 1>), grid, dim3(256), 0, s, a);  \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 1>), grid, dim3(256), 0, s, a);
     if (nt == 4) { SEG_LAUNCH_CONV(4) } else if (nt == 2) { SEG_LAUNCH_CONV(2) } else { SEG_LAUNCH_CONV(1) }
 #undef SEG_LAUNCH_CONV
 }
@@ -516,60 +543,87 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
 }
 
 // backward: din[m][ci] = sum_c dlogit[n][c][v] w[c][ci]; dw[c][ci] += sum_m dlogit*in; db[c] += sum dlogit.
-// Thread = (voxel, 8-channel chunk); dw partials are reduced over the block in LDS.
-template <class T>
+// grid = (slabs, N); thread = (voxel, 8-channel chunk), two voxels in flight; dw partials are reduced over the block in LDS.
+// NC = compile-time class count (0: runtime a.C <= MAXCLS, guarded full unroll so dw/db stay in registers); DIN = the data
+// gradient is materialised (the engine keeps it virtual: the consumer recomputes it from dlogits and the head weights).
+template <class T, int NC, bool DIN>
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
+    constexpr int CM = NC > 0 ? NC : MAXCLS;
     __shared__ float ws[MAXCLS * 64];
     __shared__ float red[256 * 9];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < a.C * a.Cin; i += 256) ws[i] = a.w[i];
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int C = NC > 0 ? NC : a.C;
+    for (int i = tid; i < C * a.Cin; i += 256) ws[i] = a.w[i];
     __syncthreads();
     const int CPR = a.Cin / 8;                 // chunks per voxel (power of two, <= 8)
     const int cc = tid % CPR, vslot = tid / CPR, VPB = 256 / CPR;
-    const long long M = (long long)a.N * a.V;
-    const T* in = (const T*)a.in;
-    T* din = (T*)a.din;
-    float dw[MAXCLS][8], db[MAXCLS];
-    for (int c = 0; c < MAXCLS; ++c) { db[c] = 0.f; for (int j = 0; j < 8; ++j) dw[c][j] = 0.f; }
-    for (long long m = (long long)blockIdx.x * VPB + vslot; m < M; m += (long long)gridDim.x * VPB) {
-        const long long n = m / a.V, v = m % a.V;
-        const vec<T, 8> x = load8(in + m * a.Cin + cc * 8);
-        float g[8];
+    const int V = (int)a.V;
+    const T* in = (const T*)a.in + (long long)n * V * a.Cin + cc * 8;
+    T* din = DIN ? (T*)a.din + (long long)n * V * a.Cin + cc * 8 : nullptr;
+    const float* dlog = a.dlogits + (long long)n * C * V;
+    float dw[CM][8], db[CM];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = 0.f;
-        for (int c = 0; c < a.C; ++c) {
-            const float dl = a.dlogits[(n * a.C + c) * a.V + v];
-            db[c] += dl;
+    for (int c = 0; c < CM; ++c) { db[c] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                g[j] = fmaf(dl, ws[c * a.Cin + cc * 8 + j], g[j]);
-                dw[c][j] = fmaf(dl, to_f(x[j]), dw[c][j]);
+        for (int j = 0; j < 8; ++j) dw[c][j] = 0.f; }
+    const int stride = gridDim.x * VPB;
+    for (int v = blockIdx.x * VPB + vslot; v < V; v += 2 * stride) {
+        const int vb = v + stride;
+        const bool two = vb < V;
+        const vec<T, 8> x0 = load8(in + (long long)v * a.Cin);
+        const vec<T, 8> x1 = two ? load8(in + (long long)vb * a.Cin) : zero8<T>();
+        float d0[CM], d1[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            d0[c] = (c < C) ? dlog[(long long)c * V + v] : 0.f;
+            d1[c] = (c < C && two) ? dlog[(long long)c * V + vb] : 0.f;
+        }
+        float g0[8], g1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { g0[j] = 0.f; g1[j] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            if (c < C) {
+                db[c] += d0[c] + d1[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dw[c][j] = fmaf(d0[c], to_f(x0[j]), fmaf(d1[c], to_f(x1[j]), dw[c][j]));
+                    if (DIN) {
+                        const float wv = ws[c * a.Cin + cc * 8 + j];
+                        g0[j] = fmaf(d0[c], wv, g0[j]);
+                        g1[j] = fmaf(d1[c], wv, g1[j]);
+                    }
+                }
             }
         }
-        if (din) {
-            vec<T, 8> o;
+        if (DIN) {
+            vec<T, 8> o0, o1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = from_f<T>(g[j]);
-            store8(din + m * a.Cin + cc * 8, o);
+            for (int j = 0; j < 8; ++j) { o0[j] = from_f<T>(g0[j]); o1[j] = from_f<T>(g1[j]); }
+            store8(din + (long long)v * a.Cin, o0);
+            if (two) store8(din + (long long)vb * a.Cin, o1);
         }
     }
     // block reduction: for each class, 8 dw columns (+ db) per thread -> sum over threads with equal cc
-    for (int c = 0; c < a.C; ++c) {
-        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[tid * 9 + j] = dw[c][j];
-        red[tid * 9 + 8] = db[c];
-        __syncthreads();
-        if (tid < CPR * 8) {
-            const int ccx = tid / 8, j = tid % 8;
-            float s = 0.f;
-            for (int t = ccx; t < 256; t += CPR) s += red[t * 9 + j];
-            atomicAdd(&a.dw[c * a.Cin + ccx * 8 + j], s);
-        }
-        if (tid == 255) {
-            float s = 0.f;
-            for (int t = 0; t < 256; t += CPR) s += red[t * 9 + 8];   // db counted once per voxel (cc == 0 lanes)
-            atomicAdd(&a.db[c], s);
+    for (int c = 0; c < CM; ++c) {
+        if (c < C) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[tid * 9 + j] = dw[c][j];
+            red[tid * 9 + 8] = db[c];
+            __syncthreads();
+            if (tid < CPR * 8) {
+                const int ccx = tid / 8, j = tid % 8;
+                float s = 0.f;
+                for (int t = ccx; t < 256; t += CPR) s += red[t * 9 + j];
+                atomicAdd(&a.dw[c * a.Cin + ccx * 8 + j], s);
+            }
+            if (tid == 255) {
+                float s = 0.f;
+                for (int t = 0; t < 256; t += CPR) s += red[t * 9 + 8];   // db counted once per voxel (cc == 0 lanes)
+                atomicAdd(&a.db[c], s);
+            }
         }
     }
 }
@@ -602,16 +656,26 @@ void launch_head_fwd(const HeadArgs& a, int dtype, hipStream_t s) {
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(head_fwd_kernel<bf16>), grid, dim3(256), 0, s, a);
 }
 
+template <class T>
+static void head_bwd_dispatch(const HeadBwdArgs& a, dim3 grid, hipStream_t s) {
+#define SEG_HB(NC)                                                                                                       \
+    if (a.din) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<T, NC, true>), grid, dim3(256), 0, s, a);               \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<T, NC, false>), grid, dim3(256), 0, s, a);
+    if (a.C == 1) { SEG_HB(1) } else if (a.C == 2) { SEG_HB(2) } else if (a.C == 3) { SEG_HB(3) } else if (a.C == 4) { SEG_HB(4) }
+    else { SEG_HB(0) }
+#undef SEG_HB
+}
+
 void launch_head_bwd(const HeadBwdArgs& a, int dtype, hipStream_t s) {
-    const long long M = (long long)a.N * a.V;
     const int VPB = 256 / (a.Cin / 8);
-    int blocks = cdiv(M, VPB);
-    static const int cap = getenv("SEG_HEAD_BWD_WGS") ? atoi(getenv("SEG_HEAD_BWD_WGS")) : 1024;      // tuning knob
-    if (blocks > cap) blocks = cap;
-    dim3 grid(blocks);
-    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<float>), grid, dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<f16>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<bf16>), grid, dim3(256), 0, s, a);
+    int blocks = cdiv(a.V, 2 * VPB);           // per sample; two voxels per thread and trip
+    static const int cap = getenv("SEG_HEAD_BWD_WGS") ? atoi(getenv("SEG_HEAD_BWD_WGS")) : 1024;      // tuning knob: workgroups per launch
+    const int per_n = cap / a.N > 0 ? cap / a.N : 1;
+    if (blocks > per_n) blocks = per_n;
+    dim3 grid(blocks, a.N);
+    if (dtype == DT_F32) head_bwd_dispatch<float>(a, grid, s);
+    else if (dtype == DT_F16) head_bwd_dispatch<f16>(a, grid, s);
+    else head_bwd_dispatch<bf16>(a, grid, s);
 }
 
 }  // namespace seg

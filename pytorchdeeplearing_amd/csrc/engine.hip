@@ -105,7 +105,8 @@ struct seg_engine {
     // hipEventRecord idles the main stream for ~6 us, and the side stream has slack (it only has to finish before the
     // optimiser), so a fork per weight gradient (35 per step) cost more than it bought.
     std::vector<std::function<void(hipStream_t)>> pending;
-    int fork_batch = 6;      // measured on MI355X (VNet3d 4x96^3): 1 -> 641, 3 -> 645, 6 -> 649 volumes/s
+    int fork_batch = 3;      // measured on MI355X (VNet3d 4x96^3), round 1: 1 -> 641, 3 -> 645, 6 -> 649 volumes/s; round 2 with the
+                             // heavy levels released at once: 6 -> 826, 3 -> 838
     // Up to two weight-gradient streams, each with its own partial-tile scratch: the kernels behind them run with 3-512 workgroups,
     // so two of them side by side fill CUs that one alone leaves idle (SEG_WGRAD_STREAMS, default in seg_create)
     int n_side = 1;
@@ -124,10 +125,27 @@ struct seg_engine {
         else (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         return st;
     }
-    void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> f) {
+    // `bytes` = gradient tensor the kernel reads: a weight gradient over a big level is released at once (its inputs are
+    // final, and started early it overlaps the bandwidth-bound top levels instead of the latency-bound deep chain)
+    // The last `tail_wgrads` deferred weight gradients of a backward pass stay on the main stream and run after its last op:
+    // r02 trace — the main queue finished 140-210 us before the side queue and idled behind it.
+    // Measured (profiles/r02_small_kernels_ab.log): 0 -> 849, 1 -> 842, 2 -> 836, 3 -> 832 volumes/s — the main stream is the
+    // critical path once its idle time is gone, so the default keeps every weight gradient on the side stream.
+    int n_deferred = 0, wgrad_seq = 0, tail_wgrads = 0;       // SEG_TAIL_WGRADS
+    size_t off_partial_main = 0;
+    std::vector<std::function<void(hipStream_t)>> tail_pending;
+    void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> f, double bytes = 0.0) {
         if (!use_side) { cur_partial = off_partial; f(main); return; }
+        if (wgrad_seq++ >= n_deferred - tail_wgrads) { tail_pending.push_back(std::move(f)); return; }
         pending.push_back(std::move(f));
-        if ((int)pending.size() >= fork_batch) flush_side(main);
+        // a full batch is released AFTER the op that queued it has enqueued its own main-stream kernels (maybe_flush): the dozen
+        // launches + events of a batch take the host ~45 us, during which the main queue used to run dry (r02 trace: 138 us idle)
+        if ((int)pending.size() >= fork_batch || bytes >= fork_heavy_bytes) { if (flush_late) flush_due = true; else flush_side(main); }
+    }
+    double fork_heavy_bytes = 16e6;                 // SEG_FORK_HEAVY_MB
+    bool flush_due = false, flush_late = true;      // SEG_FLUSH_LATE=0: release a full batch immediately (round-1 order)
+    void maybe_flush(hipStream_t main) {
+        if (flush_due) { flush_due = false; flush_side(main); }
     }
     void flush_side(hipStream_t main) {
         if (pending.empty()) return;
@@ -150,6 +168,8 @@ struct seg_engine {
     }
     void join_side(hipStream_t main) {
         flush_side(main);
+        for (auto& f : tail_pending) { cur_partial = off_partial_main; f(main); }
+        tail_pending.clear();
         if (use_side && side && ready_used) {
             (void)hipEventRecord(side_done, side); (void)hipStreamWaitEvent(main, side_done, 0);
             if (side2) { (void)hipEventRecord(side2_done, side2); (void)hipStreamWaitEvent(main, side2_done, 0); }
@@ -464,7 +484,7 @@ struct Planner {
     void plan() {
         seg_engine& E = e;
         const int N = E.N, dt = E.dtype;
-        E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_max = 0;
+        E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_max = 0; E.n_deferred = 0;
         // drop gradient tensors of a previous plan
         size_t nfw = 0;
         for (auto& s : E.steps) { nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1); s.draw = -1; }
@@ -565,6 +585,7 @@ struct Planner {
             }
         E.off_partial = alloc(pmax);
         E.off_partial2 = E.n_side > 1 ? alloc(pmax) : E.off_partial;
+        E.off_partial_main = alloc(pmax);
         E.off_partial_stemx = alloc(stemx_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), E.in_ch));
         E.off_partial_stem1 = alloc(stem_wgrad_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), 16 * ((E.feat + 15) / 16)));
 
@@ -926,6 +947,7 @@ struct Planner {
                 if (need_dg0) { g0 = new_grad(s.in0); E.tens[s.in0].grads.push_back(g0); }
                 if (s.in1 >= 0) { g1 = new_grad(s.in1); E.tens[s.in1].grads.push_back(g1); }
                 E.bwd_writes.push_back({s.w, s.gn_w < 0 ? s.b : -1});
+                if (s.ck != CK_STEM3 && s.ck != CK_STEM1) ++E.n_deferred;
                 E.bwd_ops.push_back([this_ = &E, si, draw, g0, g1](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -949,7 +971,7 @@ struct Planner {
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
                                           s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
                             E.prof_end(ws_, pi);
-                        });
+                        }, E.tbytes(draw));
                         int pi;
                         if (g0 >= 0) {
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
@@ -1004,7 +1026,7 @@ struct Planner {
                                                     E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
                         launch_wgrad(w, (float*)(E.ws + E.cur_partial), E.dtype, ws_);
                         E.prof_end(ws_, pi);
-                    });
+                    }, E.tbytes(draw));
                     // ---- data gradient(s)
                     if (g0 < 0 && g1 < 0) return;
                     ConvArgs a{};
@@ -1078,6 +1100,9 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;
     if (getenv("SEG_STEMX")) e->use_stemx = atoi(getenv("SEG_STEMX")) != 0;
     if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
+    if (getenv("SEG_TAIL_WGRADS")) e->tail_wgrads = atoi(getenv("SEG_TAIL_WGRADS"));
+    if (getenv("SEG_FORK_HEAVY_MB")) e->fork_heavy_bytes = atof(getenv("SEG_FORK_HEAVY_MB")) * 1e6;
+    if (getenv("SEG_FLUSH_LATE")) e->flush_late = atoi(getenv("SEG_FLUSH_LATE")) != 0;
     if (getenv("SEG_DUAL_GN")) e->dual_gn_bwd = atoi(getenv("SEG_DUAL_GN")) != 0;
     if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
     if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
@@ -1194,7 +1219,8 @@ int seg_backward_range(seg_handle h, const float* dlogits, int zero_grads, int o
     if (zero_grads && op_begin == 0) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
     h->ready_used = 0;
-    for (int i = op_begin; i < op_end; ++i) h->bwd_ops[i](st);
+    if (op_begin == 0) h->wgrad_seq = 0;
+    for (int i = op_begin; i < op_end; ++i) { h->bwd_ops[i](st); h->maybe_flush(st); }
     h->join_side(st);
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));
 }

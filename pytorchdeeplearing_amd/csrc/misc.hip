@@ -181,69 +181,118 @@ __device__ __forceinline__ float bce_with_logits(float z, float y) {
     return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)));
 }
 
-// grid = (slabs, N); one block reduces LOSS_VPB voxels of one sample
+// grid = (slabs, N); one block reduces LOSS_VPB voxels of one sample, four voxels in flight per thread.  The transcendental
+// terms are only evaluated for the loss kinds that use their sums (Dice-type losses need p alone); partial sums go through a
+// wave reduction, one LDS fold over the four waves and ONE set of fp64 atomics per block.
 constexpr int LOSS_VPB = 256 * 16;
+constexpr int LOSS_NVAL = 5 + 6 * MAXCLS;
 __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
+    __shared__ float part[4][LOSS_NVAL];
     const int n = blockIdx.y, tid = threadIdx.x, C = a.C;
     const long long v0 = (long long)blockIdx.x * LOSS_VPB;
     const long long v1 = (v0 + LOSS_VPB < a.V) ? v0 + LOSS_VPB : a.V;
     float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float cls[MAXCLS][3], met[MAXCLS][3];
+#pragma unroll
     for (int c = 0; c < MAXCLS; ++c)
+#pragma unroll
         for (int j = 0; j < 3; ++j) { cls[c][j] = 0.f; met[c][j] = 0.f; }
     if (C == 1) {
-        for (long long v = v0 + tid; v < v1; v += 256) {
-            const long long i = (long long)n * a.V + v;
-            const float z = a.logits[i];
-            const float y = (float)load_label(a.target, a.label_type, i);
-            const float p = 1.f / (1.f + expf(-z));
-            g[0] += p * y; g[1] += p; g[2] += y;
-            const float b = bce_with_logits(z, y);
-            g[3] += b;
-            const float pt = expf(-b);
-            g[4] += a.focal_alpha * powf(1.f - pt, a.focal_gamma) * b;
-            const float mk = p > 0.5f ? 1.f : 0.f;
-            met[0][0] += mk * y; met[0][1] += mk; met[0][2] += y;
+        const bool need_bce = a.kind == L_BIN_CE || a.kind == L_BIN_FOCAL || a.kind == L_BIN_CE_DICE;
+        const bool need_focal = a.kind == L_BIN_FOCAL;
+        const long long base = (long long)n * a.V;
+        for (long long v = v0 + tid; v < v1; v += 1024) {
+            float z[4], y[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long vv = v + u * 256;
+                ok[u] = vv < v1;
+                z[u] = ok[u] ? a.logits[base + vv] : 0.f;
+                y[u] = ok[u] ? (float)load_label(a.target, a.label_type, base + vv) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                const float p = 1.f / (1.f + expf(-z[u]));
+                g[0] += p * y[u]; g[1] += p; g[2] += y[u];
+                if (need_bce) {
+                    const float b = bce_with_logits(z[u], y[u]);
+                    g[3] += b;
+                    if (need_focal) {
+                        const float pt = expf(-b);
+                        g[4] += a.focal_alpha * powf(1.f - pt, a.focal_gamma) * b;
+                    }
+                }
+                const float mk = p > 0.5f ? 1.f : 0.f;
+                met[0][0] += mk * y[u]; met[0][1] += mk; met[0][2] += y[u];
+            }
         }
     } else {
+        const bool need_focal = a.kind == L_MC_FOCAL;
         for (long long v = v0 + tid; v < v1; v += 256) {
             const int t = load_label(a.target, a.label_type, (long long)n * a.V + v);
             float z[MAXCLS], mx = -3.0e38f;
-            for (int c = 0; c < C; ++c) { z[c] = a.logits[((long long)n * C + c) * a.V + v]; mx = fmaxf(mx, z[c]); }
+#pragma unroll
+            for (int c = 0; c < MAXCLS; ++c) {
+                z[c] = (c < C) ? a.logits[((long long)n * C + c) * a.V + v] : -3.0e38f;
+                mx = fmaxf(mx, z[c]);
+            }
             float se = 0.f, e[MAXCLS];
-            for (int c = 0; c < C; ++c) { e[c] = expf(z[c] - mx); se += e[c]; }
+#pragma unroll
+            for (int c = 0; c < MAXCLS; ++c) { e[c] = (c < C) ? expf(z[c] - mx) : 0.f; se += e[c]; }
             const float inv = 1.f / se;
             const float lse = mx + logf(se);
             float zt = 0.f;
-            for (int c = 0; c < C; ++c) {
-                const float p = e[c] * inv;
-                const float y = (c == t) ? 1.f : 0.f;
-                if (c == t) zt = z[c];
-                cls[c][0] += y * p; cls[c][1] += p; cls[c][2] += y;
-                const float mk = p > 0.5f ? 1.f : 0.f;
-                met[c][0] += mk * y; met[c][1] += mk; met[c][2] += y;
+#pragma unroll
+            for (int c = 0; c < MAXCLS; ++c) {
+                if (c < C) {
+                    const float p = e[c] * inv;
+                    const float y = (c == t) ? 1.f : 0.f;
+                    if (c == t) zt = z[c];
+                    cls[c][0] += y * p; cls[c][1] += p; cls[c][2] += y;
+                    const float mk = p > 0.5f ? 1.f : 0.f;
+                    met[c][0] += mk * y; met[c][1] += mk; met[c][2] += y;
+                }
             }
             const float nll = lse - zt;
             g[3] += nll;
-            const float pt = expf(-nll);
-            g[4] += powf(1.f - pt, a.focal_gamma) * nll;
+            if (need_focal) {
+                const float pt = expf(-nll);
+                g[4] += powf(1.f - pt, a.focal_gamma) * nll;
+            }
         }
     }
-    const int lane = tid & 63;
-    double* sums = a.sums + (long long)((blockIdx.x * 4 + (tid >> 6)) % STAT_REP) * loss_sums_count(a.N, C);
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
     for (int j = 0; j < 5; ++j) {
         const float s = wave_sum(g[j]);
-        if (lane == 0 && s != 0.f) atomicAdd(sums + S_GLOBAL + j, (double)s);
+        if (lane == 0) part[wv][j] = s;
     }
-    for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int c = 0; c < MAXCLS; ++c)
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
-            if (C > 1) {
-                const float s = wave_sum(cls[c][j]);
-                if (lane == 0 && s != 0.f) atomicAdd(sums + S_CLASS + 3 * c + j, (double)s);
+            if (c < C) {
+                const float s = (C > 1) ? wave_sum(cls[c][j]) : 0.f;
+                const float m = wave_sum(met[c][j]);
+                if (lane == 0) { part[wv][5 + 3 * c + j] = s; part[wv][5 + 3 * MAXCLS + 3 * c + j] = m; }
             }
-            const float m = wave_sum(met[c][j]);
-            if (lane == 0 && m != 0.f) atomicAdd(sums + S_METRIC + ((long long)n * C + c) * 3 + j, (double)m);
         }
+    __syncthreads();
+    double* sums = a.sums + (long long)(blockIdx.x % STAT_REP) * loss_sums_count(a.N, C);
+    if (tid < LOSS_NVAL) {
+        const int k = tid < 5 ? 0 : (tid < 5 + 3 * MAXCLS ? 1 : 2);
+        const int r = k == 0 ? tid : (k == 1 ? tid - 5 : tid - 5 - 3 * MAXCLS);      // 3*c + j for the per-class blocks
+        if (k == 0 || r < 3 * C) {
+            const float s = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+            if (s != 0.f) {
+                if (k == 0) atomicAdd(sums + S_GLOBAL + r, (double)s);
+                else if (k == 1) atomicAdd(sums + S_CLASS + r, (double)s);
+                else atomicAdd(sums + S_METRIC + (long long)n * C * 3 + r, (double)s);
+            }
+        }
+    }
 }
 
 // single block: scalar loss, metrics and the coefficients consumed by the backward pass
@@ -580,7 +629,10 @@ void launch_mask(const float* probs, unsigned char* out, int N, int C, long long
 
 void launch_pack(const PackDesc* descs_dev, int ndesc, int max_elems, int dtype, hipStream_t s) {
     (void)max_elems;
-    dim3 grid(64, ndesc);                                // rows are strided over 64 workgroups per descriptor
+    // rows are strided over `wgs` workgroups per descriptor.  The 256-channel levels hold most of the bytes in descriptors of 256
+    // rows: at 64 workgroups each one walked four 27 KB rows back to back (67 us per step, latency-bound)
+    static const int wgs = getenv("SEG_PACK_WGS") ? atoi(getenv("SEG_PACK_WGS")) : 256;
+    dim3 grid(wgs, ndesc);
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<float>), grid, dim3(256), 0, s, descs_dev);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<f16>), grid, dim3(256), 0, s, descs_dev);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<bf16>), grid, dim3(256), 0, s, descs_dev);

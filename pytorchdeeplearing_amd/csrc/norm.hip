@@ -58,15 +58,17 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinArgs a) {
 // elementwise; one thread = one 8-channel chunk
 template <class T>
 __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
-    const int CPR = a.C / 8;
-    const long long per_n = a.V * CPR, total = (long long)a.N * per_n;
+    // grid.y = sample; chunk index inside the sample in 32 bits, C/8 a power of two: no 64-bit division per element
+    const int CPR = a.C / 8, n = blockIdx.y;
+    const int per_n = (int)(a.V * CPR);
+    const long long base = (long long)n * per_n;
     const T* r1 = (const T*)a.r1;
     const T* r2 = (const T*)a.r2;
     const T* res = (const T*)a.res;
     T* out = (T*)a.out;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int n = (int)(i / per_n);
-        const int c0 = (int)(i % CPR) * 8;
+    for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += gridDim.x * 256) {
+        const long long i = base + ii;
+        const int c0 = (ii & (CPR - 1)) * 8;
         const vec<T, 8> x = load8(r1 + i * 8);
         const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale1 + (long long)n * a.C + c0);
         const vec<float, 8> sh = *(const vec<float, 8>*)(a.shift1 + (long long)n * a.C + c0);
@@ -263,15 +265,16 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
 
 template <class T, bool DUAL>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
-    const int CPR = a.C / 8;
-    const long long per_n = a.V * CPR, total = (long long)a.N * per_n;
+    const int CPR = a.C / 8, n = blockIdx.y;       // grid.y = sample, 32-bit chunk index inside it (C/8 is a power of two)
+    const int per_n = (int)(a.V * CPR), lc = 31 - __builtin_clz(CPR);
+    const long long base = (long long)n * per_n;
     const T* r = (const T*)a.r;
     T* dr = (T*)a.dr;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int n = (int)(i / per_n);
-        const int c0 = (int)(i % CPR) * 8;
+    for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += gridDim.x * 256) {
+        const long long i = base + ii;
+        const int c0 = (ii & (CPR - 1)) * 8;
         float dy[8];
-        load_dy_sum<T>(a, i, dy, n, (i % per_n) / CPR, c0);
+        load_dy_sum<T>(a, i, dy, n, ii >> lc, c0);
         const vec<T, 8> x = load8(r + i * 8);
         // per-(n, c) coefficients as wide loads (10 x 16 B instead of 40 scalar loads per thread: the small levels are latency-bound)
         const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale + (long long)n * a.C + c0);
@@ -486,7 +489,7 @@ void launch_gn_finalize(const GnFinArgs& a, hipStream_t s) {
 }
 
 void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
-    dim3 grid(ew_blocks((long long)a.N * a.V * (a.C / 8)));
+    dim3 grid(ew_blocks(a.V * (a.C / 8)), a.N);
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<float>), grid, dim3(256), 0, s, a);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<f16>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<bf16>), grid, dim3(256), 0, s, a);
@@ -534,7 +537,7 @@ void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s) {
 }
 
 void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s) {
-    dim3 grid(ew_blocks((long long)a.N * a.V * (a.C / 8)));
+    dim3 grid(ew_blocks(a.V * (a.C / 8)), a.N);
 #define SEG_GNA(T_, D_) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_>), grid, dim3(256), 0, s, a)
     if (a.r2) { if (dtype == DT_F32) SEG_GNA(float, true); else if (dtype == DT_F16) SEG_GNA(f16, true); else SEG_GNA(bf16, true); }
     else { if (dtype == DT_F32) SEG_GNA(float, false); else if (dtype == DT_F16) SEG_GNA(f16, false); else SEG_GNA(bf16, false); }

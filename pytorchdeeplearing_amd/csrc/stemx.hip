@@ -34,27 +34,27 @@ template <int TD_, int TH_, int KD_> struct SBox {
     static __device__ __forceinline__ int tap_row(int tap) { return ((tap / 9) * HH + (tap / 3) % 3) * HWP; }   // (kd, kh) part of the halo offset
 };
 
-template <class T, class B, int MODE>
+template <class T, class B, int MODE, int CIMG, int NDY>
 __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
     constexpr bool H16 = sizeof(T) == 2;
     constexpr int NCOPY = H16 ? 3 : 1;                            // shifted copies of every image-channel plane
     constexpr int TM = B::NTILE / 4;                              // tiles per wave
     constexpr bool BWD = MODE == SX_BWD_REDUCE || MODE == SX_BWD_APPLY;
     static_assert(B::NTILE % 4 == 0, "tiles must split over the four waves");
-    constexpr int XELEMS = (SX_MAXCI * NCOPY + 1) * B::HVP;       // + one all-zero plane: the padding k slots (k >= K) read it at the tile's offset
-    constexpr int DELEMS = BWD ? 2 * 3 * B::V * SX_C : 8;           // two buffers of up to three gradient-source tiles
+    constexpr int XELEMS = (CIMG * NCOPY + 1) * B::HVP;       // + one all-zero plane: the padding k slots (k >= K) read it at the tile's offset
+    constexpr int DELEMS = BWD ? 2 * NDY * B::V * SX_C : 8;         // two buffers of NDY gradient-source tiles
     __shared__ __attribute__((aligned(16))) T Xc[XELEMS];
     __shared__ __attribute__((aligned(16))) T Dy[DELEMS];
     __shared__ float red[4 * 2 * 2 * SX_C * 2];                   // [wave][branch][which][co] partial sums / weight-gradient tiles (2 KB)
     __shared__ float wred[MODE == SX_BWD_APPLY ? 4 * 3 * 256 : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const int Cimg = a.Cimg, K = B::NTAP * Cimg, kc0 = (B::NTAP / 2) * Cimg;     // kc0: first k slot of the centre tap
+    constexpr int Cimg = CIMG, K = B::NTAP * Cimg, kc0 = (B::NTAP / 2) * Cimg;   // kc0: first k slot of the centre tap
     const int nbr = a.w1 ? 2 : 1;
     const T* img = (const T*)a.img;
-    const int ZERO = SX_MAXCI * NCOPY * B::HVP;
+    constexpr int ZERO = CIMG * NCOPY * B::HVP;
     const int nbx = a.W / 16 + (a.W % 16 != 0), nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
-    const long long nbox = (long long)a.N * nbz * nby * nbx;
+    const int nbox = a.N * nbz * nby * nbx;
     const long long vol = (long long)a.D * a.H * a.W;
 
     // ---- weight fragments (lane: co = l15, k = 8q .. 8q+7); the 1^d branch sits on the centre tap's k slots of the same im2col
@@ -125,34 +125,44 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
 
     // ---- box pipeline: while box b is multiplied, the image halo of the next box travels to registers and its gradient-source
     //      tiles to the other LDS buffer (asynchronous direct copies); the only exposed latency is the first box's
-    constexpr int NIT = (B::HD * B::HH * B::HW * SX_MAXCI + 255) / 256;
-    const int total = B::HD * B::HH * B::HW * Cimg;
+    // (all index arithmetic of the staging is box-independent and done ONCE: per box a halo element costs three adds, three
+    // compares and a load - with it inside the box loop the kernels were bound by integer division, not by memory)
+    constexpr int NIT = (B::HD * B::HH * B::HW * CIMG + 255) / 256;
+    constexpr int total = B::HD * B::HH * B::HW * CIMG;
     T himg[NIT];
+    int hsrc[NIT], hdst[NIT];                 // packed (hz, hy, hx, ci) of this thread's halo elements; LDS index in copy 0 (-1: none)
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int i = u * 256 + tid;
+        const int hv = i / CIMG, ci = i % CIMG;
+        const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
+        hsrc[u] = ((hz << 8 | hy) << 8 | hx) << 2 | ci;
+        hdst[u] = i < total ? ci * NCOPY * B::HVP + (hv / B::HW) * B::HWP + hx : -1;
+    }
     struct BoxAt { int x0, y0, z0, n; };
-    auto box_at = [&](long long b) {
+    auto box_at = [&](int b) {                   // 32-bit: the box count stays far below 2^31
         BoxAt p;
-        p.x0 = (int)(b % nbx) * 16; b /= nbx;
-        p.y0 = (int)(b % nby) * B::TH; b /= nby;
-        p.z0 = (int)(b % nbz) * B::TD;
-        p.n = (int)(b / nbz);
+        p.x0 = (b % nbx) * 16; b /= nbx;
+        p.y0 = (b % nby) * B::TH; b /= nby;
+        p.z0 = (b % nbz) * B::TD;
+        p.n = b / nbz;
         return p;
     };
     auto load_img = [&](const BoxAt& p) {
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
-            const int i = u * 256 + tid;
-            const int hv = i / Cimg, ci = i % Cimg;
-            const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
-            const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
+            const int hs = hsrc[u];
+            const int z = p.z0 + (hs >> 18) - B::PD, y = p.y0 + ((hs >> 10) & 255) - 1, x = p.x0 + ((hs >> 2) & 255) - 1;
             himg[u] = from_f<T>(0.f);
-            if (i < total && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-                himg[u] = img[((((long long)p.n * a.D + z) * a.H + y) * a.W + x) * Cimg + ci];
+            if (hdst[u] >= 0 && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+                himg[u] = img[((((long long)p.n * a.D + z) * a.H + y) * a.W + x) * CIMG + (hs & 3)];
         }
     };
     auto issue_dy = [&](const BoxAt& p, int buf) {
         constexpr int GPV = SX_C * (int)sizeof(T) / 16;                          // 16-B granules per voxel row: 2 (16-bit) or 4 (f32)
         constexpr int NG = B::V * GPV, NI = (NG + 255) / 256;
-        for (int sidx = 0; sidx < a.ndy; ++sidx) {
+#pragma unroll
+        for (int sidx = 0; sidx < NDY; ++sidx) {
             const i32x4 rs = make_rsrc((const T*)a.dy[sidx] + (long long)p.n * vol * SX_C, (unsigned)(vol * SX_C * sizeof(T)));
 #pragma unroll
             for (int u = 0; u < NI; ++u) {
@@ -163,17 +173,17 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
                 const bool ok = v < B::V && z < a.D && y < a.H && x < a.W;
                 const unsigned off = ok ? (unsigned)((((long long)z * a.H + y) * a.W + x) * SX_C * sizeof(T)) + piece * 16u : DMA_OOB;
                 if ((u * 4 + wv) * 64 < B::V * GPV)
-                    dma16_async(rs, (T*)((char*)(Dy + (buf * 3 + sidx) * B::V * SX_C) + (size_t)(u * 4 + wv) * 1024), off);
+                    dma16_async(rs, (T*)((char*)(Dy + (buf * NDY + sidx) * B::V * SX_C) + (size_t)(u * 4 + wv) * 1024), off);
             }
         }
     };
     int cur = 0;
-    if ((long long)blockIdx.x < nbox) {
-        const BoxAt p0 = box_at(blockIdx.x);
+    if ((int)blockIdx.x < nbox) {
+        const BoxAt p0 = box_at((int)blockIdx.x);
         load_img(p0);
         if (BWD) issue_dy(p0, 0);
     }
-    for (long long b = blockIdx.x; b < nbox; b += gridDim.x) {
+    for (int b = blockIdx.x; b < nbox; b += gridDim.x) {
         const BoxAt bp = box_at(b);
         const int x0 = bp.x0, y0 = bp.y0, z0 = bp.z0, n = bp.n;
         if (n != cur_n) { if (cur_n >= 0) flush(cur_n); cur_n = n; }
@@ -181,23 +191,21 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
         // ---- image halo (loaded during the previous box) -> every shifted copy
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
-            const int i = u * 256 + tid;
-            if (i < total) {
-                const int hv = i / Cimg, ci = i % Cimg;
-                const int L = (hv / B::HW) * B::HWP + hv % B::HW;
+            if (hdst[u] >= 0) {
+                const int L0 = hdst[u] - (hsrc[u] & 3) * NCOPY * B::HVP;       // index inside the plane: copy c holds halo[L + c] at L
 #pragma unroll
                 for (int c = 0; c < NCOPY; ++c)
-                    if (L - c >= 0) Xc[(ci * NCOPY + c) * B::HVP + L - c] = himg[u];
+                    if (L0 - c >= 0) Xc[hdst[u] + c * B::HVP - c] = himg[u];
             }
         }
         if (BWD) wait_vmem();                            // this wave's copies of the gradient tiles of box b have landed
         __syncthreads();
-        if (b + gridDim.x < nbox) {
-            const BoxAt pn = box_at(b + gridDim.x);
+        if (b + (int)gridDim.x < nbox) {
+            const BoxAt pn = box_at(b + (int)gridDim.x);
             load_img(pn);
             if (BWD) issue_dy(pn, cur ^ 1);
         }
-        const T* DyB = Dy + cur * 3 * B::V * SX_C;
+        const T* DyB = Dy + cur * NDY * B::V * SX_C;
         cur ^= 1;
 
         // per-sample coefficients of this lane's channel(s)
@@ -286,7 +294,8 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
             }
             // sum of the gradient sources in the same layout: one transposing read per source
             float dy[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int sidx = 0; sidx < a.ndy; ++sidx) {
+#pragma unroll
+            for (int sidx = 0; sidx < NDY; ++sidx) {
                 const T* tile = DyB + sidx * B::V * SX_C + m * 16 * SX_C;
                 if constexpr (H16) {
                     const s16x4 t = lds_read_tr16(tile + (4 * q + (l15 >> 2)) * SX_C + 4 * (l15 & 3));
@@ -377,15 +386,17 @@ __global__ __launch_bounds__(256) void stemx_wgrad_reduce_kernel(const float* pa
     }
 }
 
-template <class T, class B>
+template <class T, class B, int CIMG>
 void launch_mode(const StemxArgs& a, int mode, int nwg, hipStream_t s) {
     dim3 grid(nwg), block(256);
+#define SEG_SXK(M, ND) hipLaunchKernelGGL(HIP_KERNEL_NAME(stemx_kernel<T, B, M, CIMG, ND>), grid, block, 0, s, a)
     switch (mode) {
-        case SX_FWD_STATS: hipLaunchKernelGGL(HIP_KERNEL_NAME(stemx_kernel<T, B, SX_FWD_STATS>), grid, block, 0, s, a); break;
-        case SX_FWD_APPLY: hipLaunchKernelGGL(HIP_KERNEL_NAME(stemx_kernel<T, B, SX_FWD_APPLY>), grid, block, 0, s, a); break;
-        case SX_BWD_REDUCE: hipLaunchKernelGGL(HIP_KERNEL_NAME(stemx_kernel<T, B, SX_BWD_REDUCE>), grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(stemx_kernel<T, B, SX_BWD_APPLY>), grid, block, 0, s, a); break;
+        case SX_FWD_STATS: SEG_SXK(SX_FWD_STATS, 0); break;
+        case SX_FWD_APPLY: SEG_SXK(SX_FWD_APPLY, 0); break;
+        case SX_BWD_REDUCE: if (a.ndy == 1) SEG_SXK(SX_BWD_REDUCE, 1); else if (a.ndy == 2) SEG_SXK(SX_BWD_REDUCE, 2); else SEG_SXK(SX_BWD_REDUCE, 3); break;
+        default: if (a.ndy == 1) SEG_SXK(SX_BWD_APPLY, 1); else if (a.ndy == 2) SEG_SXK(SX_BWD_APPLY, 2); else SEG_SXK(SX_BWD_APPLY, 3); break;
     }
+#undef SEG_SXK
 }
 
 inline long long sx_boxes(int ndim, int N, int D, int H, int W) {
@@ -409,7 +420,10 @@ void launch_stemx(const seg_stemx_args& a0, int mode, int ndim, int dtype, float
     StemxArgs a = a0;
     if (ndim != 3) a.D = 1;
     const int nwg = stemx_workgroups(ndim, a.N, a.D, a.H, a.W);
-#define SEG_SX(T) do { if (ndim == 3) launch_mode<T, SBox<2, 8, 3>>(a, mode, nwg, s); else launch_mode<T, SBox<1, 16, 1>>(a, mode, nwg, s); } while (0)
+#define SEG_SX(T) do { if (ndim == 3) launch_mode<T, SBox<2, 8, 3>, 1>(a, mode, nwg, s);                    \
+                       else if (a.Cimg == 1) launch_mode<T, SBox<1, 16, 1>, 1>(a, mode, nwg, s);             \
+                       else if (a.Cimg == 2) launch_mode<T, SBox<1, 16, 1>, 2>(a, mode, nwg, s);             \
+                       else launch_mode<T, SBox<1, 16, 1>, 3>(a, mode, nwg, s); } while (0)
     if (dtype == DT_F32) SEG_SX(float);
     else if (dtype == DT_F16) SEG_SX(f16);
     else SEG_SX(bf16);

@@ -48,3 +48,10 @@ def dev(request):
     from pytorchdeeplearing_amd import _capi
     _capi.product_library()      # fail loudly if the HIP library is missing
     return torch.device("cuda:0")
+
+
+def checker_slow(dev, why="minutes on the host checker"):
+    """Cases whose host-checker run takes a minute or more are left to the GPU run (`-m gpu` executes the same test on the
+    device) so that `-m "not gpu"` stays a few-minute suite; SEG_TEST_FULL=1 runs them on the checker too."""
+    if getattr(dev, "type", str(dev)) == "cpu" and not os.environ.get("SEG_TEST_FULL"):
+        pytest.skip("%s; covered by the -m gpu run of this test (SEG_TEST_FULL=1 runs it here)" % why)

@@ -5,6 +5,8 @@ seeded inputs.  Tolerances: fp32 run dtype -> logits within 1e-3 (BASELINE.json 
 gated on Dice difference and gradient direction instead (SURVEY.md §7 'Parity target')."""
 import numpy as np
 import pytest
+
+import conftest
 import torch
 
 from oracle import seg_oracle as seg
@@ -284,6 +286,7 @@ def test_conv3x_path_matches_conv3_kernel_path_gpu(monkeypatch, tag, dtype):
 
 @pytest.mark.parametrize("tag,dtype", [("vnet3d", "f16"), ("unet2d", "bf16")])
 def test_conv3x_path_matches_conv3_kernel_path(dev, monkeypatch, tag, dtype):
+    conftest.checker_slow(dev, "two whole 16-bit train steps per case: 2-3 min on the host checker")
     check_conv3x_path(dev, monkeypatch, tag, dtype)
 
 

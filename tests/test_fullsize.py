@@ -13,6 +13,8 @@ And size-independent properties:
   * directional derivative: (L(p + eps d) - L(p - eps d)) / 2 eps == <grad, d> for the engine's own loss and gradients
     (fp32 run dtype) — a whole-network check of forward vs backward at full size;
   * f16 / bf16 run dtypes stay within the Dice tolerance of the fp32 run on the same weights."""
+import os
+
 import pytest
 import torch
 
@@ -239,9 +241,12 @@ def test_oracle_gradients_full_size_f32(tag):
 
 
 @pytest.mark.parametrize("tag", list(GRAD_CASES))
-@pytest.mark.parametrize("dtype,tol", [("f16", 0.25), ("bf16", 0.35)])
-def test_oracle_gradients_full_size_low_precision(tag, dtype, tol):
-    """per-tensor report of the 16-bit run dtypes at full size (where the error sits, and how large it is)"""
+@pytest.mark.parametrize("dtype,tol,med_tol,cos_tol", [("f16", 0.2, 0.12, 0.98), ("bf16", 0.45, 0.3, 0.9)])
+def test_oracle_gradients_full_size_low_precision(tag, dtype, tol, med_tol, cos_tol):
+    """per-tensor report of the 16-bit run dtypes at full size (where the error sits, and how large it is).
+    Bounds = the MI355X measurement (profiles/r02_fullsize_lowp_gradients.txt) + ~50 % margin: f16 worst tensor 0.127 / median 0.077 /
+    cosine >= 0.992, bf16 0.352 / 0.22 / 0.937; the worst tensors are GroupNorm affine gradients of norm 3e-5..9e-5 in the
+    deep levels (activations and gradient tensors are stored in the 16-bit type, 50+ layers deep; accumulation is fp32)."""
     kind, ndim, shape, ncls, loss = GRAD_CASES[tag]
     params, x, y, r = oracle_grads(tag)
     e = SegEngine(kind, ndim, shape[1], ncls, dtype=dtype, device=DEV)
@@ -261,6 +266,12 @@ def test_oracle_gradients_full_size_low_precision(tag, dtype, tol):
           (tag, dtype, scale, ", ".join("%s %.3f/%.4f (|g|=%.2e)" % (k, v, c, n) for v, k, n, c in rows[:6])))
     med = sorted(v for v, _, _, _ in rows)[len(rows) // 2]
     print("%s %s: median rel-L2 %.3e over %d tensors" % (tag, dtype, med, len(rows)))
+    if os.environ.get("SEG_FULLSIZE_REPORT"):      # tools/gpu_*.sh keep the per-tensor numbers under profiles/
+        with open(os.environ["SEG_FULLSIZE_REPORT"], "a") as f:
+            f.write("%s %s loss_scale=%g median_relL2=%.3e min_cos=%.4f worst: %s\n" % (
+                tag, dtype, scale, med, min(c for _, _, _, c in rows),
+                ", ".join("%s %.3f/%.4f(|g|=%.1e)" % (k, v, c, n) for v, k, n, c in rows[:5])))
     assert torch.isfinite(e.grads).all()
     assert rows[0][0] < tol, rows[0]
-    assert min(c for _, _, _, c in rows) > (0.95 if dtype == "f16" else 0.85)
+    assert med < med_tol, med
+    assert min(c for _, _, _, c in rows) > cos_tol

@@ -47,7 +47,11 @@ def _worker(rank, world, port, q, bucketed):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucketed", [False, True])
+FULL = bool(os.environ.get("SEG_TEST_FULL"))
+full_only = pytest.mark.skipif(not FULL, reason="second variant of a ~1 min two-process case; SEG_TEST_FULL=1 runs it")
+
+
+@pytest.mark.parametrize("bucketed", [pytest.param(False, marks=full_only), True])
 def test_ddp_two_ranks_matches_oracle_emulation(bucketed):
     from oracle import seg_oracle as seg
     world, port = 2, 29500 + (os.getpid() * 2 + int(bucketed)) % 1000
@@ -112,7 +116,8 @@ def _worker_global(rank, world, port, q, ncls, loss, bucketed=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ncls,loss,bucketed", [(1, "BinaryCrossEntropyDiceLoss", True), (3, "MutilDiceLoss", False)])
+@pytest.mark.parametrize("ncls,loss,bucketed", [(1, "BinaryCrossEntropyDiceLoss", True),
+                                                pytest.param(3, "MutilDiceLoss", False, marks=full_only)])
 def test_exact_global_batch_loss_two_ranks_equals_one_process_on_the_whole_batch(ncls, loss, bucketed):
     """SURVEY 8e mode (ii): with the 32 batch-global sums exchanged, two ranks x 2 samples reproduce ONE reference process
     training on the 4-sample batch (loss value and update), which plain DDP averaging does not.  One case runs the gradient

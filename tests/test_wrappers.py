@@ -5,6 +5,8 @@ import os
 
 import numpy as np
 import pytest
+
+import conftest
 import torch
 
 
@@ -42,8 +44,8 @@ def test_trainprocess_and_predict(dev, tmp_path, monkeypatch, cls, numclass, los
     monkeypatch.setenv("SEGENGINE_DTYPE", "f32")
     tmp = str(tmp_path)
     shape = (16, 16, 16)
-    if dev.type == "cpu" and cls != "MutilUNet3dModel":
-        pytest.skip("host-checker run keeps one wrapper (the GPU run covers both)")
+    # the 2-D wrapper test below keeps trainprocess/predict on the host checker; the 3-D wrappers take 1-2 min each there
+    conftest.checker_slow(dev, "a 3-D trainprocess epoch takes over a minute on the host checker")
     epochs = 1 if dev.type == "cpu" else 2
     tr_i, tr_l = _make_npy(tmp, 1 if dev.type == "cpu" else 2, shape, numclass, 1)
     va_i, va_l = _make_npy(tmp, 1, shape, numclass, 2)

@@ -73,3 +73,14 @@ for name,sel in (("FORWARD (main)",lambda r:r['s']<tl and r['Queue_Id']=='1'),("
     for r in rs: a=agg[short(r['Kernel_Name'])]; a[0]+=1; a[1]+=(r['e']-r['s'])/1e3
     print("==",name,"%d kernels busy %.0f us span %.0f us"%(len(rs),sum(v[1] for v in agg.values()),(rs[-1]['e']-rs[0]['s'])/1e3))
     for k,v in sorted(agg.items(),key=lambda kv:-kv[1][1])[:14]: print("   %7.1f us n=%3d  %s"%(v[1],v[0],k[:70]))
+
+print('---- full timeline of the step (queue, start us, duration us, idle before on the same queue, kernel, grid x*y*z / workgroup)')
+lastq = {}
+for r in sorted(step, key=lambda r: r['s']):
+    q = r['Queue_Id']
+    gap = (r['s'] - lastq[q]) / 1e3 if q in lastq else 0.0
+    lastq[q] = r['e']
+    wg = int(r.get('Workgroup_Size_X', 1) or 1)
+    gx = int(r['Grid_Size_X']) // max(wg, 1)
+    print("q%s %8.1f %7.1f %6.1f  %-58s %dx%sx%s/%d" % (q, (r['s'] - t0) / 1e3, (r['e'] - r['s']) / 1e3, gap, short(r['Kernel_Name'])[:58], gx,
+                                                      r.get('Grid_Size_Y', '1'), r.get('Grid_Size_Z', '1'), wg))
