@@ -33,9 +33,9 @@ __device__ __forceinline__ RowCoord decode_row(long long m64, int D, int H, int 
 // rows of the tile may straddle samples when the per-sample volume is not a multiple of BM.
 template <class T, int BN>
 __device__ __forceinline__ void tile_stats(const T* Os, int ldo, int rows_valid, long long m0, long long Vrow,
-                                           double* stats, int Cout, int co_base, float* red, int N) {
+                                           double* stats, int Cout, int co_base, float* red, int N, int srep = STAT_REP) {
     constexpr int G = 256 / BN;
-    stats += (long long)(blockIdx.x % STAT_REP) * N * Cout * 2;       // replica of this workgroup
+    stats += (long long)(blockIdx.x % srep) * N * Cout * 2;           // replica of this workgroup
     const int col = threadIdx.x % BN, g = threadIdx.x / BN;
     const int n_first = (int)(m0 / Vrow), n_last = (int)((m0 + rows_valid - 1) / Vrow);
     if (n_first == n_last) {
@@ -80,7 +80,7 @@ __device__ __forceinline__ void tile_stats(const T* Os, int ldo, int rows_valid,
 // KS = 32-wide reduction slices per pipeline stage.  The deep levels launch 28..432 workgroups whose time is the serial
 // chain of stages (one global-load latency each): KS = 2 halves the chain with twice the loads in flight.
 template <class T, int NT, bool SCATTER, int KS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int srep) {
     constexpr int BN = 16 * NT;
     __shared__ T As[2 * KS * BM * LDT];
     __shared__ T Bs[2 * KS * BN * LDT];
@@ -217,11 +217,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
         store8(out + orow * a.Cout + co_real0 + cc * 8, v);
     }
-    if (a.stats) tile_stats<T, BN>(Os, LDO, rows_valid, m0, Vrow, a.stats, a.Cout, co_real0, red, a.N);
+    if (a.stats) tile_stats<T, BN>(Os, LDO, rows_valid, m0, Vrow, a.stats, a.Cout, co_real0, red, a.N, srep);
 }
 
 template <class T>
-void conv_dispatch(const ConvArgs& a, hipStream_t s) {
+void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep) {
     const long long M = (long long)a.N * a.OD * a.OH * a.OW;
     const int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     dim3 grid(cdiv(M, BM), a.Ngemm / (16 * nt));
@@ -230,10 +230,10 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s) {
     const bool ks2 = a.Kpad % (2 * BK) == 0 && a.Kpad >= 4 * BK && (ks_env ? ks_env == 2 : (long long)grid.x * grid.y <= 512);
 #define SEG_LAUNCH_CONV(NT)                                                                          \
     if (ks2) {                                                                                        \
-        if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 2>), grid, dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 2>), grid, dim3(256), 0, s, a);           \
-    } else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 1>), grid, dim3(256), 0, s, a);  \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 1>), grid, dim3(256), 0, s, a);
+        if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 2>), grid, dim3(256), 0, s, a, srep);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 2>), grid, dim3(256), 0, s, a, srep);     \
+    } else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 1>), grid, dim3(256), 0, s, a, srep);  \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 1>), grid, dim3(256), 0, s, a, srep);
     if (nt == 4) { SEG_LAUNCH_CONV(4) } else if (nt == 2) { SEG_LAUNCH_CONV(2) } else { SEG_LAUNCH_CONV(1) }
 #undef SEG_LAUNCH_CONV
 }
@@ -632,10 +632,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
 
 bool conv_uses_stream_kernel(const ConvArgs& a) { return stream_eligible(a); }
 
-void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s) {
-    if (dtype == DT_F32) { if (!launch_conv_stream<float>(a, s)) conv_dispatch<float>(a, s); }
-    else if (dtype == DT_F16) { if (!launch_conv_stream<f16>(a, s)) conv_dispatch<f16>(a, s); }
-    else { if (!launch_conv_stream<bf16>(a, s)) conv_dispatch<bf16>(a, s); }
+void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep) {
+    const int srep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
+    if (dtype == DT_F32) { if (!launch_conv_stream<float>(a, s)) conv_dispatch<float>(a, s, srep); }
+    else if (dtype == DT_F16) { if (!launch_conv_stream<f16>(a, s)) conv_dispatch<f16>(a, s, srep); }
+    else { if (!launch_conv_stream<bf16>(a, s)) conv_dispatch<bf16>(a, s, srep); }
 }
 
 void launch_conv_stem(const StemArgs& a, int dtype, hipStream_t s) {

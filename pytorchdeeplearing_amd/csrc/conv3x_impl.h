@@ -49,7 +49,7 @@ template <int TD_, int TH_, int TW_, int KD_, int TX_> struct XBox {
 struct Conv3xArgs {
     const void* in0; const void* in1; int C0;     // in1: second source of a virtual channel concat (channels C0..Cin-1), or null
     const void* w;                                // fragment-major weights [Cin/32][taps][Cout/16][64 lanes][8]
-    const float* bias; void* out; double* stats;
+    const float* bias; void* out; double* stats; int stat_rep;   // stat_rep: replicas of `stats` the workgroups spread over (<= STAT_REP)
     int N, D, H, W, Cin, Cout;
     int remap;                                    // 1: XCD-aware box order (grid.x rounded up to a multiple of 8)
 };
@@ -112,7 +112,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const 
         if (tid < BN) {
             double ts = 0.0, tss = 0.0;
             for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
-            double* dst = a.stats + ((long long)(blockIdx.x % STAT_REP) * a.N * a.Cout + (long long)n * a.Cout + co0 + col) * 2;
+            double* dst = a.stats + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + col) * 2;
             atomicAdd(dst, ts);
             atomicAdd(dst + 1, tss);
         }

@@ -46,6 +46,8 @@ struct Step {
     size_t stats = 0, scale = 0, shift = 0, mean = 0, rstd = 0, Q = 0, coef = 0;
     size_t wp_fwd = 0, wp_dg0 = 0, wp_dg1 = 0;
     bool fused_stem = false;                  // image stem evaluated inside the fused input block of its ACT step (stemx.hip)
+    int stat_rep = 0;                         // replicas of the statistics buffers this unit's producers use (0 = STAT_REP)
+    bool fold_fin = false;                    // statistics finalize folded into the consuming gn_act launch (no launch of its own)
     int x_fwd = -1, x_dg0 = -1, x_dg1 = -1;   // conv3x tiling of the forward / data-gradient launches (-1: conv3_kernel, row-major weights)
     int draw = -1;           // gradient wrt raw
     // ACT
@@ -89,6 +91,7 @@ struct seg_engine {
     // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
     hipStream_t side = nullptr;
     bool use_side = true;
+    bool use_fold = true;       // SEG_GN_FOLD=0: finalize kernels between the GroupNorm passes (round-1 path)
     bool use_vhead = true;      // SEG_VHEAD=0: head_bwd writes its data-gradient tensor (round-1 path)
     bool head_din_needed = false;   // planning: some reader of the head's data-gradient cannot evaluate it on the fly
     int head_step = -1;
@@ -500,6 +503,17 @@ struct Planner {
                     E.steps[st_.ua].fused_stem = true;
                     if (st_.ub >= 0) E.steps[st_.ub].fused_stem = true;
                 }
+        // ---- statistics finalize folded into the elementwise consumer (not for the fused input block / one-launch small tensors)
+        for (auto& st_ : E.steps) st_.fold_fin = false;
+        if (E.use_fold)
+            for (auto& st_ : E.steps) {
+                if (st_.type != ST_ACT || E.steps[st_.ua].fused_stem || E.steps[st_.ua].gn_w < 0) continue;
+                const Step& ua_ = E.steps[st_.ua];
+                if (st_.ub < 0 && gn_bwd_group_eligible(ua_.Cout, E.vol(E.tens[ua_.raw].lvl), (int)E.esz())) continue;
+                if (ua_.Cout > 256) continue;
+                E.steps[st_.ua].fold_fin = true;
+                if (st_.ub >= 0) E.steps[st_.ub].fold_fin = true;
+            }
         // ---- small persistent regions
         E.off_step = alloc(256);
         E.off_masks = alloc((size_t)E.drop_ch.size() * N * E.ld_mask() * 4);
@@ -617,9 +631,12 @@ struct Planner {
                         const int l = ro.lvl;
                         const int pi = E.prof_begin(st, conv3_class(E.dim_w(l)), E.tbytes(s.in0) + E.tbytes(s.raw),
                                                     2.0 * E.N * E.vol(l) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout);
+                        // replicas this producer spreads the statistics over (read back by the folded finalize of the consumers)
+                        E.steps[si].stat_rep = (s.x_fwd >= 0 && E.use_fold) ? stat_rep_for(E.vol(l)) : STAT_REP;
                         if (s.x_fwd >= 0)
                             launch_conv3x(s.x_fwd, E.ws + i0.off, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, E.ws + s.wp_fwd, bias,
-                                          E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st);
+                                          E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st,
+                                          s.stat_rep);
                         else
                         launch_conv3(E.ws + i0.off, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l),
                                      s.Cin, s.Cout, E.ndim, E.dtype, st, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
@@ -653,11 +670,12 @@ struct Planner {
                         const int pi = E.prof_begin(st, SEG_K_CONV_GENERIC,
                                                     E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0) + E.tbytes(s.raw),
                                                     2.0 * E.N * E.vol(s.ck == CK_KT ? li : lo) * (double)a.K * a.Ngemm);
-                        launch_conv_igemm(a, E.dtype, st);
+                        E.steps[si].stat_rep = (E.use_fold && !conv_uses_stream_kernel(a)) ? stat_rep_for(E.vol(lo)) : STAT_REP;
+                        launch_conv_igemm(a, E.dtype, st, s.stat_rep);
                         E.prof_end(st, pi);
                     }
-                    if (s.gn_w >= 0 && !gn_bwd_group_eligible(s.Cout, E.vol(ro.lvl), (int)E.esz())) {
-                        GnFinArgs f;
+                    if (s.gn_w >= 0 && !s.fold_fin && !gn_bwd_group_eligible(s.Cout, E.vol(ro.lvl), (int)E.esz())) {
+                        GnFinArgs f{};
                         f.stats = stats; f.gamma = E.p + E.params[s.gn_w].off; f.beta = E.p + E.params[s.gn_b].off;
                         f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
                                  : (const float*)(E.ws + E.off_masks) + (size_t)s.mask_slot * E.N * E.ld_mask();
@@ -681,7 +699,7 @@ struct Planner {
                         for (int ui : {s.ua, s.ub}) {
                             if (ui < 0) continue;
                             const Step& u = E.steps[ui];
-                            GnFinArgs f;
+                            GnFinArgs f{};
                             f.stats = (double*)(E.ws + u.stats); f.gamma = E.p + E.params[u.gn_w].off; f.beta = E.p + E.params[u.gn_b].off;
                             f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
                                      : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
@@ -699,7 +717,7 @@ struct Planner {
                         const Ten& ro = E.tens[ua.raw];
                         if (s.ub < 0 && gn_bwd_group_eligible(ua.Cout, E.vol(ro.lvl), (int)E.esz())) {
                             // small L2-resident tensor: statistics finalize + activation in one launch
-                            GnFinArgs f;
+                            GnFinArgs f{};
                             f.stats = (double*)(E.ws + ua.stats);
                             f.gamma = E.p + E.params[ua.gn_w].off; f.beta = E.p + E.params[ua.gn_b].off;
                             f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
@@ -724,6 +742,21 @@ struct Planner {
                     a.res = s.res >= 0 ? E.ws + E.tens[s.res].off : nullptr;
                     a.out = E.ws + E.tens[s.out].off;
                     a.N = E.N; a.C = E.tens[s.out].C; a.V = E.vol(E.tens[s.out].lvl);
+                    if (ua.fold_fin) {
+                        auto fin = [&E](const Step& u, GnFinArgs& f) {
+                            f = GnFinArgs{};
+                            f.stats = (double*)(E.ws + u.stats); f.gamma = E.p + E.params[u.gn_w].off; f.beta = E.p + E.params[u.gn_b].off;
+                            f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
+                                     : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                            f.mask_ld = E.ld_mask();
+                            f.scale = (float*)(E.ws + u.scale); f.shift = (float*)(E.ws + u.shift);
+                            f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
+                            f.N = E.N; f.C = u.Cout; f.V = E.vol(E.tens[u.raw].lvl); f.eps = 1e-5f; f.rep = u.stat_rep;
+                        };
+                        a.fold = 1;
+                        fin(ua, a.fin1);
+                        if (s.ub >= 0) fin(E.steps[s.ub], a.fin2);
+                    }
                     const int pi = E.prof_begin(st, SEG_K_GN_ACT, E.tbytes(s.out) * (2 + (s.ub >= 0) + (s.res >= 0)), 0.0);
                     launch_gn_act(a, E.dtype, st);
                     E.prof_end(st, pi);
@@ -835,6 +868,8 @@ struct Planner {
                     f.dbias = u.b >= 0 ? E.g + E.params[u.b].off : nullptr;
                     f.coef = (float*)(E.ws + u.coef);
                     f.N = E.N; f.C = r.C; f.V = a.V;
+                    a.rep_q = f.rep_q = E.use_fold ? stat_rep_for(a.V) : 0;
+                    f.rep_s = u.stat_rep;
                 };
                 if (E.steps[s.ua].fused_stem) {
                     // fused input block: reduce (recomputing r), finalize per branch, then d(raw) in registers -> stem weight gradients
@@ -889,7 +924,7 @@ struct Planner {
                     E.bwd_ops.push_back([this_ = &E, uia = s.ua, uib = s.ub, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
                         GnBwdArgs a, b;
-                        GnBwdFinArgs fa, fb;
+                        GnBwdFinArgs fa{}, fb{};
                         fill(E, uia, gl, a, fa);
                         fill(E, uib, gl, b, fb);
                         a.r2 = b.r; a.scale2 = b.scale; a.shift2 = b.shift; a.Q2 = b.Q; a.coef2 = b.coef; a.dr2 = b.dr;
@@ -897,10 +932,10 @@ struct Planner {
                         int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, tb * (a.ndy + 2), 0.0);
                         launch_gn_bwd_reduce(a, E.dtype, st);
                         E.prof_end(st, pi);
-                        launch_gn_bwd_finalize(fa, st);
-                        launch_gn_bwd_finalize(fb, st);
+                        const bool fold = E.use_fold && a.C <= 256;
+                        if (!fold) { launch_gn_bwd_finalize(fa, st); launch_gn_bwd_finalize(fb, st); }
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, tb * (a.ndy + 4), 0.0);
-                        launch_gn_bwd_apply(a, E.dtype, st);
+                        launch_gn_bwd_apply(a, E.dtype, st, fold ? &fa : nullptr, fold ? &fb : nullptr);
                         E.prof_end(st, pi);
                     });
                 } else
@@ -914,7 +949,7 @@ struct Planner {
                         const Step& u = E.steps[ui];
                         const Ten& r = E.tens[u.raw];
                         GnBwdArgs a;
-                        GnBwdFinArgs f;
+                        GnBwdFinArgs f{};
                         fill(E, ui, gl, a, f);
                         if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
                             const int pg = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
@@ -925,9 +960,10 @@ struct Planner {
                         int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
                         launch_gn_bwd_reduce(a, E.dtype, st);
                         E.prof_end(st, pi);
-                        launch_gn_bwd_finalize(f, st);
+                        const bool fold = E.use_fold && a.C <= 256;
+                        if (!fold) launch_gn_bwd_finalize(f, st);
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
-                        launch_gn_bwd_apply(a, E.dtype, st);
+                        launch_gn_bwd_apply(a, E.dtype, st, fold ? &f : nullptr, nullptr);
                         E.prof_end(st, pi);
                     });
                 }
@@ -1099,6 +1135,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
     if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;
     if (getenv("SEG_STEMX")) e->use_stemx = atoi(getenv("SEG_STEMX")) != 0;
+    if (getenv("SEG_GN_FOLD")) e->use_fold = atoi(getenv("SEG_GN_FOLD")) != 0;
     if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
     if (getenv("SEG_TAIL_WGRADS")) e->tail_wgrads = atoi(getenv("SEG_TAIL_WGRADS"));
     if (getenv("SEG_FORK_HEAVY_MB")) e->fork_heavy_bytes = atof(getenv("SEG_FORK_HEAVY_MB")) * 1e6;

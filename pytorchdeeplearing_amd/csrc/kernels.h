@@ -10,7 +10,7 @@ namespace seg {
 typedef seg_taps Taps;
 // Implicit-GEMM convolution arguments: see seg_conv_args in include/segengine.h
 typedef seg_conv_args ConvArgs;
-void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s);
+void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep = STAT_REP);   // stat_rep: LDS-staged kernel only
 bool conv_uses_stream_kernel(const ConvArgs& a);   // true: register-resident streaming kernel, false: LDS-staged implicit GEMM
 
 // LDS halo-tile kernels for 3^d stride-1 pad-1 convs (conv3.hip): forward / data-gradient and weight gradient
@@ -22,7 +22,10 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout);    // 
 int conv3x_num_cfgs();
 int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name);
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s);
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep = STAT_REP);
+// replicas a statistics producer spreads its atomics over, by voxels per sample: enough to keep same-address fp64 atomics apart,
+// few enough that the consumer-side fold (gn_fold_block) reads ~8 KB
+inline int stat_rep_for(long long V) { return V >= 262144 ? 32 : V >= 65536 ? 16 : V >= 8192 ? 8 : 4; }
 // fused input block (stemx.hip): modes 0 forward statistics, 1 forward apply, 2 backward reduce, 3 backward apply + weight gradients
 int stemx_workgroups(int ndim, int N, int D, int H, int W);
 size_t stemx_partial_bytes(int ndim, int N, int D, int H, int W, int Cimg);
@@ -92,6 +95,7 @@ struct GnFinArgs {
     int N, C;
     long long V;
     float eps;
+    int rep;              // replicas of `stats` that hold data (1..STAT_REP, power of two); 0 = STAT_REP
 };
 void launch_gn_finalize(const GnFinArgs& a, hipStream_t s);
 
@@ -103,6 +107,10 @@ struct ActArgs {
     void* out;
     int N, C;
     long long V;
+    // fold != 0: scale/shift are not read; each workgroup finalizes the statistics of its sample itself (fin1, fin2 for r2) and
+    // workgroup 0 of every sample publishes scale / shift / mean / rstd for the backward pass
+    int fold;
+    GnFinArgs fin1, fin2;
 };
 void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s);
 
@@ -122,10 +130,12 @@ struct GnBwdArgs {
     // optional VIRTUAL gradient source: the data-gradient of the 1^d head, dy[v][c] += sum_k vdl[n][k][v] * vw[k][c], evaluated on
     // the fly from the loss gradient (planar fp32) and the head weights instead of being written as a 16-channel tensor and read
     // back by every GroupNorm-backward pass it feeds
-    const float* vdl; const float* vw; int vK;
+    const float* vdl; const float* vw; int vK;    int rep_q;                                  // replicas of Q the reduce pass spreads over; 0 = STAT_REP
 };
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
-void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s);
+struct GnBwdFinArgs;
+// fa != null: the backward finalize of the branch(es) runs as a prologue of this launch (no gn_bwd_finalize launch before it)
+void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s, const GnBwdFinArgs* fa = nullptr, const GnBwdFinArgs* fb = nullptr);
 
 struct GnBwdFinArgs {
     const double* Q;       // [N][C][2]
@@ -138,6 +148,7 @@ struct GnBwdFinArgs {
     float* coef;                            // [N][C][3]
     int N, C;
     long long V;
+    int rep_q, rep_s;                       // replicas of Q / stats that hold data; 0 = STAT_REP
 };
 void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s);
 // small L2-resident tensors (C >= 64): reduce + finalize + apply in one launch, one workgroup per (sample, group)

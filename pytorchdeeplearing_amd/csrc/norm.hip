@@ -55,9 +55,59 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinArgs a) {
     }
 }
 
-// elementwise; one thread = one 8-channel chunk
-template <class T>
+// The finalize of one sample inside a consumer workgroup (256 threads, C = 16..256): fold the `rep` replica partial sums,
+// reduce the channels of a group with lane butterflies (the cpg = C/8 channels of a group are neighbouring lanes) and leave
+// scale / shift of every channel in LDS.  Same formulas as gn_finalize_kernel.  `publish`: this workgroup also writes the
+// per-(n, c) coefficients and per-(n, g) moments the backward pass reads.  Ends with a barrier.
+__device__ __forceinline__ void gn_fold_block(const GnFinArgs& f, int n, bool publish, double (*part)[2], float* sc_s, float* sh_s) {
+    const int tid = threadIdx.x, C = f.C, cpg = C / GN_GROUPS;
+    const int S = 256 / C;                              // replica slices folded side by side (C <= 256)
+    const int c = tid % C, sl = tid / C;
+    const int nrep = f.rep > 0 ? f.rep : STAT_REP;
+    double s = 0.0, ss = 0.0;
+    for (int r0 = sl; r0 < nrep; r0 += 4 * S) {         // four independent 16-B loads per trip
+        double v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rep = r0 + u * S;
+            const double* st = f.stats + (((long long)(rep < nrep ? rep : sl) * f.N + n) * C + c) * 2;
+            v0[u] = st[0]; v1[u] = st[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r0 + u * S < nrep) { s += v0[u]; ss += v1[u]; }
+    }
+    part[tid][0] = s; part[tid][1] = ss;
+    __syncthreads();
+    s = 0.0; ss = 0.0;
+    if (tid < C)
+        for (int k = 0; k < S; ++k) { s += part[tid + k * C][0]; ss += part[tid + k * C][1]; }
+    for (int o = cpg >> 1; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if (tid < C) {
+        const double cnt = (double)cpg * (double)f.V;
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float mk = f.mask ? f.mask[(long long)n * f.mask_ld + c] : 1.f;
+        const float ga = f.gamma[c], be = f.beta[c];
+        const float sc = mk * ga * rstd, sh = mk * (be - ga * (float)mean * rstd);
+        sc_s[c] = sc; sh_s[c] = sh;
+        if (publish) {
+            f.scale[(long long)n * C + c] = sc;
+            f.shift[(long long)n * C + c] = sh;
+            if (c % cpg == 0) { f.mean[n * GN_GROUPS + c / cpg] = (float)mean; f.rstd[n * GN_GROUPS + c / cpg] = rstd; }
+        }
+    }
+    __syncthreads();
+}
+
+// elementwise; one thread = one 8-channel chunk.  FOLD: the statistics finalize runs as a per-workgroup prologue
+// (gn_fold_block) instead of a launch of its own - a kernel boundary costs 4-5 us on this part, the fold 1-2.
+template <class T, bool FOLD>
 __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
+    __shared__ double part[FOLD ? 256 : 1][2];
+    __shared__ float coef_s[FOLD ? 4 : 1][256];
     // grid.y = sample; chunk index inside the sample in 32 bits, C/8 a power of two: no 64-bit division per element
     const int CPR = a.C / 8, n = blockIdx.y;
     const int per_n = (int)(a.V * CPR);
@@ -66,19 +116,31 @@ __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
     const T* r2 = (const T*)a.r2;
     const T* res = (const T*)a.res;
     T* out = (T*)a.out;
+    // the grid stride is a multiple of C/8: a thread keeps its channel chunk, the coefficients live in registers
+    const int c0 = ((blockIdx.x * 256 + threadIdx.x) & (CPR - 1)) * 8;
+    vec<float, 8> sc, sh, sc2, sh2;
+    if (FOLD) {
+        gn_fold_block(a.fin1, n, blockIdx.x == 0, part, coef_s[0], coef_s[1]);
+        if (r2) gn_fold_block(a.fin2, n, blockIdx.x == 0, part, coef_s[2], coef_s[3]);
+        sc = *(const vec<float, 8>*)&coef_s[0][c0];
+        sh = *(const vec<float, 8>*)&coef_s[1][c0];
+        if (r2) { sc2 = *(const vec<float, 8>*)&coef_s[2][c0]; sh2 = *(const vec<float, 8>*)&coef_s[3][c0]; }
+    } else {
+        sc = *(const vec<float, 8>*)(a.scale1 + (long long)n * a.C + c0);
+        sh = *(const vec<float, 8>*)(a.shift1 + (long long)n * a.C + c0);
+        if (r2) {
+            sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + c0);
+            sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
+        }
+    }
     for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += gridDim.x * 256) {
         const long long i = base + ii;
-        const int c0 = (ii & (CPR - 1)) * 8;
         const vec<T, 8> x = load8(r1 + i * 8);
-        const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale1 + (long long)n * a.C + c0);
-        const vec<float, 8> sh = *(const vec<float, 8>*)(a.shift1 + (long long)n * a.C + c0);
         float y[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] = fmaxf(fmaf(sc[j], to_f(x[j]), sh[j]), 0.f);
         if (r2) {
             const vec<T, 8> x2 = load8(r2 + i * 8);
-            const vec<float, 8> sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + c0);
-            const vec<float, 8> sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] += fmaxf(fmaf(sc2[j], to_f(x2[j]), sh2[j]), 0.f);
         }
@@ -207,7 +269,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
             double s = 0.0;
             for (int k = 0; k < G; ++k) s += red[(k * CPR + ccx) * 16 + jj];
             const int c = ccx * 8 + (jj & 7), which = jj >> 3;
-            atomicAdd(Q + (((long long)(blockIdx.x % STAT_REP) * a.N + n) * a.C + c) * 2 + which, s);
+            atomicAdd(Q + (((long long)(blockIdx.x % (a.rep_q > 0 ? a.rep_q : STAT_REP)) * a.N + n) * a.C + c) * 2 + which, s);
         }
     }
 }
@@ -263,27 +325,108 @@ __global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
     }
 }
 
-template <class T, bool DUAL>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
+// The backward finalize of one sample inside a consumer workgroup (same decomposition as gn_fold_block): folds the replica
+// partials of Q (sum dz, sum dz*r) and of the forward channel sums, and leaves the A / B / Cc coefficients of every channel in
+// LDS (same formulas as gn_bwd_finalize_kernel).  `publish`: this workgroup adds the gamma / beta / conv-bias gradients of its
+// sample.  Ends with a barrier.
+__device__ __forceinline__ void gn_bwd_fold_block(const GnBwdFinArgs& f, int n, bool publish, double (*part)[3], float* A_s, float* B_s,
+                                                  float* C_s) {
+    const int tid = threadIdx.x, C = f.C, cpg = C / GN_GROUPS;
+    const int S = 256 / C;
+    const int c = tid % C, sl = tid / C;
+    const int nq = f.rep_q > 0 ? f.rep_q : STAT_REP, ns = f.rep_s > 0 ? f.rep_s : STAT_REP;
+    const int nrep = nq > ns ? nq : ns;
+    double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    for (int r0 = sl; r0 < nrep; r0 += 4 * S) {
+        double v1[4], v2[4], v3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rep = r0 + u * S;
+            const long long o = (((long long)(rep < nrep ? rep : sl) * f.N + n) * C + c) * 2;
+            v1[u] = f.Q[o]; v2[u] = f.Q[o + 1]; v3[u] = f.stats[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r0 + u * S < nrep) { f1 += v1[u]; f2 += v2[u]; f3 += v3[u]; }
+    }
+    part[tid][0] = f1; part[tid][1] = f2; part[tid][2] = f3;
+    __syncthreads();
+    double Q1 = 0.0, Q2 = 0.0, R1 = 0.0, mu = 0.0, rs = 0.0, mk = 1.0, ga = 0.0, q1 = 0.0, qx = 0.0;
+    if (tid < C) {
+        for (int k = 0; k < S; ++k) { Q1 += part[tid + k * C][0]; Q2 += part[tid + k * C][1]; R1 += part[tid + k * C][2]; }
+        mu = f.mean[n * GN_GROUPS + c / cpg]; rs = f.rstd[n * GN_GROUPS + c / cpg];
+        mk = f.mask ? (double)f.mask[(long long)n * f.mask_ld + c] : 1.0;
+        ga = f.gamma[c];
+        q1 = mk * Q1;                                    // sum dz
+        qx = (mk * Q2 - mu * q1) * rs;                   // sum dz * xhat
+        if (publish) {
+            atomicAdd(&f.dbeta[c], (float)q1);
+            atomicAdd(&f.dgamma[c], (float)qx);
+        }
+    }
+    double S1 = ga * q1, S2 = ga * qx;
+    for (int o = cpg >> 1; o >= 1; o >>= 1) { S1 += __shfl_xor(S1, o); S2 += __shfl_xor(S2, o); }
+    if (tid < C) {
+        const double Mg = (double)cpg * (double)f.V;
+        const double A = rs * ga * mk;
+        const double B = -rs * rs * S2 / Mg;
+        const double Cc = -rs * S1 / Mg + rs * rs * S2 * mu / Mg;
+        A_s[c] = (float)A; B_s[c] = (float)B; C_s[c] = (float)Cc;
+        if (publish) {
+            if (f.coef) { float* co = f.coef + ((long long)n * C + c) * 3; co[0] = (float)A; co[1] = (float)B; co[2] = (float)Cc; }
+            // sum_v dr = A*sum(dzr) + B*sum(r) + Cc*V   (sum(r) from the forward statistics)
+            if (f.dbias) atomicAdd(&f.dbias[c], (float)(A * Q1 + B * R1 + Cc * (double)f.V));
+        }
+    }
+    __syncthreads();
+}
+
+// FOLD: the backward finalize runs as a per-workgroup prologue (gn_bwd_fold_block); fa / fb are the finalize arguments of the branches
+template <class T, bool DUAL, bool FOLD>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a, GnBwdFinArgs fa, GnBwdFinArgs fb) {
+    __shared__ double part[FOLD ? 256 : 1][3];
+    __shared__ float coef_s[FOLD ? (DUAL ? 6 : 3) : 1][256];
     const int CPR = a.C / 8, n = blockIdx.y;       // grid.y = sample, 32-bit chunk index inside it (C/8 is a power of two)
     const int per_n = (int)(a.V * CPR), lc = 31 - __builtin_clz(CPR);
     const long long base = (long long)n * per_n;
     const T* r = (const T*)a.r;
     T* dr = (T*)a.dr;
+    // the grid stride is a multiple of C/8: a thread keeps its channel chunk, all coefficients live in registers
+    const int c0 = ((blockIdx.x * 256 + threadIdx.x) & (CPR - 1)) * 8;
+    float co[24], co2[24];
+    if (FOLD) {
+        gn_bwd_fold_block(fa, n, blockIdx.x == 0, part, coef_s[0], coef_s[1], coef_s[2]);
+        if (DUAL) gn_bwd_fold_block(fb, n, blockIdx.x == 0, part, coef_s[DUAL ? 3 : 0], coef_s[DUAL ? 4 : 0], coef_s[DUAL ? 5 : 0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            co[j * 3] = coef_s[0][c0 + j]; co[j * 3 + 1] = coef_s[1][c0 + j]; co[j * 3 + 2] = coef_s[2][c0 + j];
+            if (DUAL) { co2[j * 3] = coef_s[DUAL ? 3 : 0][c0 + j]; co2[j * 3 + 1] = coef_s[DUAL ? 4 : 0][c0 + j]; co2[j * 3 + 2] = coef_s[DUAL ? 5 : 0][c0 + j]; }
+        }
+    } else {
+        // per-(n, c) coefficients as wide loads (the small levels are latency-bound)
+        const vec<float, 8>* cop = (const vec<float, 8>*)(a.coef + ((long long)n * a.C + c0) * 3);
+        const vec<float, 8> ca = cop[0], cb = cop[1], cc = cop[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { co[j] = ca[j]; co[8 + j] = cb[j]; co[16 + j] = cc[j]; }
+        if (DUAL) {
+            const vec<float, 8>* cop2 = (const vec<float, 8>*)(a.coef2 + ((long long)n * a.C + c0) * 3);
+            const vec<float, 8> da = cop2[0], db = cop2[1], dc = cop2[2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { co2[j] = da[j]; co2[8 + j] = db[j]; co2[16 + j] = dc[j]; }
+        }
+    }
+    const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale + (long long)n * a.C + c0);
+    const vec<float, 8> sh = *(const vec<float, 8>*)(a.shift + (long long)n * a.C + c0);
+    vec<float, 8> sc2 = sc, sh2 = sh;
+    if (DUAL) {
+        sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + c0);
+        sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
+    }
     for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += gridDim.x * 256) {
         const long long i = base + ii;
-        const int c0 = (ii & (CPR - 1)) * 8;
         float dy[8];
         load_dy_sum<T>(a, i, dy, n, ii >> lc, c0);
         const vec<T, 8> x = load8(r + i * 8);
-        // per-(n, c) coefficients as wide loads (10 x 16 B instead of 40 scalar loads per thread: the small levels are latency-bound)
-        const vec<float, 8> sc = *(const vec<float, 8>*)(a.scale + (long long)n * a.C + c0);
-        const vec<float, 8> sh = *(const vec<float, 8>*)(a.shift + (long long)n * a.C + c0);
-        const vec<float, 8>* cop = (const vec<float, 8>*)(a.coef + ((long long)n * a.C + c0) * 3);
-        const vec<float, 8> ca = cop[0], cb = cop[1], cc = cop[2];
-        float co[24];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { co[j] = ca[j]; co[8 + j] = cb[j]; co[16 + j] = cc[j]; }
         vec<T, 8> o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -294,13 +437,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
         store8(dr + i * 8, o);
         if (DUAL) {
             const vec<T, 8> z = load8((const T*)a.r2 + i * 8);
-            const vec<float, 8> sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + c0);
-            const vec<float, 8> sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
-            const vec<float, 8>* cop2 = (const vec<float, 8>*)(a.coef2 + ((long long)n * a.C + c0) * 3);
-            const vec<float, 8> da = cop2[0], db = cop2[1], dc = cop2[2];
-            float co2[24];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { co2[j] = da[j]; co2[8 + j] = db[j]; co2[16 + j] = dc[j]; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float zv = to_f(z[j]);
@@ -489,10 +625,18 @@ void launch_gn_finalize(const GnFinArgs& a, hipStream_t s) {
 }
 
 void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
-    dim3 grid(ew_blocks(a.V * (a.C / 8)), a.N);
-    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<float>), grid, dim3(256), 0, s, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<f16>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<bf16>), grid, dim3(256), 0, s, a);
+    int bx = ew_blocks(a.V * (a.C / 8));
+    if (a.fold) {
+        // every workgroup repeats the fold: fewer, longer-running workgroups on the big levels
+        static const int cap = getenv("SEG_FOLD_WGS") ? atoi(getenv("SEG_FOLD_WGS")) : 2048;
+        const int per_n = cap / a.N > 0 ? cap / a.N : 1;
+        if (bx > per_n) bx = per_n;
+    }
+    dim3 grid(bx, a.N);
+#define SEG_ACT(T_) { if (a.fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, true>), grid, dim3(256), 0, s, a); \
+                      else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, false>), grid, dim3(256), 0, s, a); }
+    if (dtype == DT_F32) SEG_ACT(float) else if (dtype == DT_F16) SEG_ACT(f16) else SEG_ACT(bf16)
+#undef SEG_ACT
 }
 
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
@@ -536,11 +680,20 @@ void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(GN_GROUPS, a.N), dim3(64), 0, s, a);
 }
 
-void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s) {
-    dim3 grid(ew_blocks(a.V * (a.C / 8)), a.N);
-#define SEG_GNA(T_, D_) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_>), grid, dim3(256), 0, s, a)
-    if (a.r2) { if (dtype == DT_F32) SEG_GNA(float, true); else if (dtype == DT_F16) SEG_GNA(f16, true); else SEG_GNA(bf16, true); }
-    else { if (dtype == DT_F32) SEG_GNA(float, false); else if (dtype == DT_F16) SEG_GNA(f16, false); else SEG_GNA(bf16, false); }
+void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s, const GnBwdFinArgs* fa, const GnBwdFinArgs* fb) {
+    int bx = ew_blocks(a.V * (a.C / 8));
+    const bool fold = fa != nullptr;
+    if (fold) {
+        static const int cap = getenv("SEG_FOLD_WGS") ? atoi(getenv("SEG_FOLD_WGS")) : 2048;
+        const int per_n = cap / a.N > 0 ? cap / a.N : 1;
+        if (bx > per_n) bx = per_n;
+    }
+    dim3 grid(bx, a.N);
+    const GnBwdFinArgs za = fa ? *fa : GnBwdFinArgs{}, zb = fb ? *fb : GnBwdFinArgs{};
+#define SEG_GNA(T_, D_) { if (fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_, true>), grid, dim3(256), 0, s, a, za, zb); \
+                          else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_, false>), grid, dim3(256), 0, s, a, za, zb); }
+    if (a.r2) { if (dtype == DT_F32) SEG_GNA(float, true) else if (dtype == DT_F16) SEG_GNA(f16, true) else SEG_GNA(bf16, true) }
+    else { if (dtype == DT_F32) SEG_GNA(float, false) else if (dtype == DT_F16) SEG_GNA(f16, false) else SEG_GNA(bf16, false) }
 #undef SEG_GNA
 }
 
