@@ -304,7 +304,7 @@ int seg_op_plane_axpb(const float* in, const float* a, const float* b, float* ou
  * synchronises the recorded events, returns per class {launch count, total ms, algorithmic bytes,
  * algorithmic flops} accumulated since the last read, and clears the records. */
 enum {
-    SEG_K_CONV3 = 0,          /* halo-tile 3^d conv, forward + data-gradient, wide-box levels (3x4x16 / 1x8x16) */
+    SEG_K_CONV3 = 0,          /* halo-tile 3^d conv, forward + data-gradient, big-box tiling of the wide levels with >= 32 channels */
     SEG_K_WGRAD3 = 1,         /* halo-tile weight gradient (main kernel + partial reduce) */
     SEG_K_CONV_GENERIC = 2,   /* gather / scatter implicit GEMM */
     SEG_K_WGRAD_GENERIC = 3,
@@ -313,8 +313,9 @@ enum {
     SEG_K_GN_BWD_REDUCE = 6,
     SEG_K_GN_BWD_APPLY = 7,
     SEG_K_HEAD = 8,
-    SEG_K_CONV3_SB = 9,       /* halo-tile conv on the small-box levels (3x8x8 / 1x8x8 boxes): one kernel symbol */
-    SEG_K_COUNT = 10
+    SEG_K_CONV3_SB = 9,       /* every other halo-tile conv (16-channel top level, deep levels) */
+    SEG_K_GN_GROUP = 10,      /* one-launch GroupNorm passes of the small tensors (forward and backward) */
+    SEG_K_COUNT = 11
 };
 int seg_profile_enable(seg_handle h, unsigned mask);
 int seg_profile_read(seg_handle h, int* calls, float* ms, double* bytes, double* flops);

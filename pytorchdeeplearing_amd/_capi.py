@@ -20,7 +20,7 @@ LOSS_KIND = {
     "BinaryJaccardLoss": 7, "BinaryELDiceLoss": 8, "BinaryTverskyLoss": 9, "MutilCrossEntropyDiceLoss": 10, "MutilELDiceLoss": 11,
 }
 MASKS_EVAL, MASKS_GIVEN, MASKS_RANDOM = 0, 1, 2
-KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head", "conv3_smallbox"]
+KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head", "conv3_smallbox", "gn_group"]
 
 _vp, _i, _ll, _f, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
 

@@ -57,8 +57,9 @@ struct Step {
 };
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-// profile class of a halo-conv launch: the box shape (conv3.hip wide_box) decides the kernel symbol
-inline int conv3_class(int W) { return (W % 16 == 0 || W == 12) ? SEG_K_CONV3 : SEG_K_CONV3_SB; }
+// profile class of a halo-conv launch.  "conv3" = the big-box tiling of the wide 32+-channel levels (one kernel symbol per
+// network: 48^3 x 32 channels in the BASELINE VNet3d), "conv3_smallbox" = every other halo conv (16-channel top level, deep levels)
+inline int conv3_class(int W, int Cin = 32) { return (W >= 32 && Cin >= 32) ? SEG_K_CONV3 : SEG_K_CONV3_SB; }
 
 }  // namespace
 
@@ -629,7 +630,7 @@ struct Planner {
                         E.prof_end(st, pi);
                     } else if (s.ck == CK_K3) {
                         const int l = ro.lvl;
-                        const int pi = E.prof_begin(st, conv3_class(E.dim_w(l)), E.tbytes(s.in0) + E.tbytes(s.raw),
+                        const int pi = E.prof_begin(st, conv3_class(E.dim_w(l), s.Cin), E.tbytes(s.in0) + E.tbytes(s.raw),
                                                     2.0 * E.N * E.vol(l) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout);
                         // replicas this producer spreads the statistics over (read back by the folded finalize of the consumers)
                         E.steps[si].stat_rep = (s.x_fwd >= 0 && E.use_fold) ? stat_rep_for(E.vol(l)) : STAT_REP;
@@ -726,7 +727,7 @@ struct Planner {
                             f.scale = (float*)(E.ws + ua.scale); f.shift = (float*)(E.ws + ua.shift);
                             f.mean = (float*)(E.ws + ua.mean); f.rstd = (float*)(E.ws + ua.rstd);
                             f.N = E.N; f.C = ua.Cout; f.V = E.vol(ro.lvl); f.eps = 1e-5f;
-                            const int pi = E.prof_begin(st, SEG_K_GN_ACT, E.tbytes(s.out) * (2 + (s.res >= 0)), 0.0);
+                            const int pi = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(s.out) * (2 + (s.res >= 0)), 0.0);
                             launch_gn_fwd_group(f, E.ws + ro.off, s.res >= 0 ? E.ws + E.tens[s.res].off : nullptr, E.ws + E.tens[s.out].off,
                                                 E.dtype, st);
                             E.prof_end(st, pi);
@@ -885,7 +886,7 @@ struct Planner {
                         for (int i = 0; i < x.ndy; ++i) x.dy[i] = E.ws + E.tens[gl[i]].off;
                         E.flush_side(st);
                         const double tb = E.tbytes(s.out);
-                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, tb * x.ndy, 0.0);
+                        int pi = E.prof_begin(st, SEG_K_STEM, tb * x.ndy, 0.0);
                         launch_stemx(x, 2, E.ndim, E.dtype, nullptr, nullptr, st);
                         E.prof_end(st, pi);
                         for (int ui : {s.ua, s.ub}) {
@@ -904,7 +905,7 @@ struct Planner {
                             f.N = E.N; f.C = u.Cout; f.V = E.vol(0);
                             launch_gn_bwd_finalize(f, st);
                         }
-                        pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, tb * x.ndy, 0.0);
+                        pi = E.prof_begin(st, SEG_K_STEM, tb * x.ndy, 0.0);
                         launch_stemx(x, 3, E.ndim, E.dtype, E.g + E.params[E.steps[s.ua].w].off,
                                      s.ub >= 0 ? E.g + E.params[E.steps[s.ub].w].off : nullptr, st);
                         E.prof_end(st, pi);
@@ -952,7 +953,7 @@ struct Planner {
                         GnBwdFinArgs f{};
                         fill(E, ui, gl, a, f);
                         if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
-                            const int pg = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
+                            const int pg = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
                             launch_gn_bwd_group(a, f, E.dtype, st);
                             E.prof_end(st, pg);
                             return;
@@ -1010,7 +1011,7 @@ struct Planner {
                         }, E.tbytes(draw));
                         int pi;
                         if (g0 >= 0) {
-                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
                             if (s.x_dg0 >= 0)
                                 launch_conv3x(s.x_dg0, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr,
                                               E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
@@ -1021,7 +1022,7 @@ struct Planner {
                         }
                         if (g1 >= 0) {
                             const int C1 = E.tens[s.in1].C;
-                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo)), E.tbytes(draw) + E.tbytes(g1), fl * C1 / s.Cin);
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g1), fl * C1 / s.Cin);
                             if (s.x_dg1 >= 0)
                                 launch_conv3x(s.x_dg1, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr,
                                               E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);
