@@ -92,6 +92,11 @@ struct seg_engine {
     // weight gradients run on a side stream: they are off the backward critical path (only the optimiser needs them)
     hipStream_t side = nullptr;
     bool use_side = true;
+    // weight re-layouts that only the backward pass reads run on the weight-gradient stream, next to the forward pass
+    std::vector<char> pack_is_bwd;
+    int npack_fwd = 0;
+    bool pack_split = true, pack_bwd_pending = false;      // SEG_PACK_SPLIT=0: one launch on the caller's stream
+    hipEvent_t pack_fork = nullptr, pack_done = nullptr;
     bool use_fold = true;       // SEG_GN_FOLD=0: finalize kernels between the GroupNorm passes (round-1 path)
     bool use_vhead = true;      // SEG_VHEAD=0: head_bwd writes its data-gradient tensor (round-1 path)
     bool head_din_needed = false;   // planning: some reader of the head's data-gradient cannot evaluate it on the fly
@@ -151,13 +156,15 @@ struct seg_engine {
     void maybe_flush(hipStream_t main) {
         if (flush_due) { flush_due = false; flush_side(main); }
     }
+    void ensure_side() {
+        if (side) return;
+        side = make_side();
+        (void)hipEventCreateWithFlags(&side_done, hipEventDisableTiming);
+        if (n_side > 1) { side2 = make_side(); (void)hipEventCreateWithFlags(&side2_done, hipEventDisableTiming); }
+    }
     void flush_side(hipStream_t main) {
         if (pending.empty()) return;
-        if (!side) {
-            side = make_side();
-            (void)hipEventCreateWithFlags(&side_done, hipEventDisableTiming);
-            if (n_side > 1) { side2 = make_side(); (void)hipEventCreateWithFlags(&side2_done, hipEventDisableTiming); }
-        }
+        ensure_side();
         if (ready_used == ready_ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ready_ev.push_back(e); }
         hipEvent_t e = ready_ev[ready_used++];
         (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
@@ -470,6 +477,7 @@ struct Planner {
         const int k = (ck == CK_K3 || ck == CK_STEM3) ? 3 : (ck == CK_K2S2 || ck == CK_KT) ? 2 : 1;
         return e.ndim == 3 ? k * k * k : k * k;
     }
+    bool pack_bwd = false;     // the descriptors added while set feed the backward pass only (data-gradient layouts)
     void add_pack(size_t dst, long long src_off, int R1, int R2, int T, int Cc, long long s1, long long s2, long long sT, long long sC, int flip,
                   int frag = 0) {
         PackDesc d;
@@ -480,6 +488,7 @@ struct Planner {
         d.Kpad = (T * Cc + 31) / 32 * 32;
         d.s1 = s1; d.s2 = s2; d.sT = sT; d.sC = sC; d.flipT = flip;
         e.packdescs.push_back(d);
+        e.pack_is_bwd.push_back(pack_bwd ? 1 : 0);
         const long long tot = (long long)R1 * R2 * d.Kpad;
         if (tot > e.pack_max) e.pack_max = tot;
     }
@@ -488,7 +497,7 @@ struct Planner {
     void plan() {
         seg_engine& E = e;
         const int N = E.N, dt = E.dtype;
-        E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_max = 0; E.n_deferred = 0;
+        E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_is_bwd.clear(); E.pack_max = 0; E.n_deferred = 0;
         // drop gradient tensors of a previous plan
         size_t nfw = 0;
         for (auto& s : E.steps) { nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1); s.draw = -1; }
@@ -558,15 +567,21 @@ struct Planner {
                     add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0, s.x_fwd >= 0 ? (Ci == 16 ? 2 : 1) : 0);
                     if (s.ck == CK_K2S2) {       // data-gradient = scatter GEMM, rows (a, ci), K = Cout
                         s.wp_dg0 = alloc_pack(T * Ci, Co);
+                        pack_bwd = true;
                         add_pack(s.wp_dg0, woff, T, Ci, 1, Co, 1, T, 0, (long long)Ci * T, 0);
+                        pack_bwd = false;
                     } else {                     // data-gradient = gather conv with flipped taps, rows ci, k = (tap, co)
                         if (!E.tens[s.in0].image) {
                             s.wp_dg0 = alloc_pack(C0, T * Co);
+                            pack_bwd = true;
                             add_pack(s.wp_dg0, woff, C0, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg0 >= 0 ? (Co == 16 ? 2 : 1) : 0);
+                            pack_bwd = false;
                         }
                         if (C1) {
                             s.wp_dg1 = alloc_pack(C1, T * Co);
+                            pack_bwd = true;
                             add_pack(s.wp_dg1, woff + (long long)C0 * T, C1, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg1 >= 0 ? (Co == 16 ? 2 : 1) : 0);
+                            pack_bwd = false;
                         }
                     }
                     break;
@@ -574,13 +589,24 @@ struct Planner {
                     s.wp_fwd = alloc_pack(T * Co, Ci);
                     add_pack(s.wp_fwd, woff, T, Co, 1, Ci, 1, T, 0, (long long)Co * T, 0);
                     s.wp_dg0 = alloc_pack(Ci, T * Co);   // data-gradient = gather stride 2, rows ci, k = (a, co)
+                    pack_bwd = true;
                     add_pack(s.wp_dg0, woff, Ci, 1, T, Co, (long long)Co * T, 0, 1, T, 0);
+                    pack_bwd = false;
                     break;
                 default:                         // image stems: [Cout][32] with k = tap*Cimg + ci (1^d stem: k = ci)
                     s.wp_fwd = alloc_pack(Co, T * Ci);
                     add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0);
                     break;
             }
+        }
+        {   // forward layouts first, backward-only layouts behind them: the second range is packed on the weight-gradient stream
+            std::vector<PackDesc> fw, bw;
+            for (size_t i = 0; i < E.packdescs.size(); ++i) (E.pack_is_bwd[i] ? bw : fw).push_back(E.packdescs[i]);
+            E.npack_fwd = (int)fw.size();
+            E.packdescs = fw;
+            E.packdescs.insert(E.packdescs.end(), bw.begin(), bw.end());
+            E.pack_is_bwd.assign(E.packdescs.size(), 0);
+            for (size_t i = fw.size(); i < E.packdescs.size(); ++i) E.pack_is_bwd[i] = 1;
         }
         E.off_packdesc = alloc(E.packdescs.size() * sizeof(PackDesc));
         // partial-tile buffer of the halo weight-gradient kernel (largest K3 layer)
@@ -1136,6 +1162,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
     if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;
     if (getenv("SEG_STEMX")) e->use_stemx = atoi(getenv("SEG_STEMX")) != 0;
+    if (getenv("SEG_PACK_SPLIT")) e->pack_split = atoi(getenv("SEG_PACK_SPLIT")) != 0;
     if (getenv("SEG_GN_FOLD")) e->use_fold = atoi(getenv("SEG_GN_FOLD")) != 0;
     if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
     if (getenv("SEG_TAIL_WGRADS")) e->tail_wgrads = atoi(getenv("SEG_TAIL_WGRADS"));
@@ -1156,6 +1183,8 @@ void seg_destroy(seg_handle h) {
     if (!h) return;
     for (auto& r : h->prof_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->ready_ev) (void)hipEventDestroy(e);
+    if (h->pack_fork) (void)hipEventDestroy(h->pack_fork);
+    if (h->pack_done) (void)hipEventDestroy(h->pack_done);
     if (h->side_done) (void)hipEventDestroy(h->side_done);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2_done) (void)hipEventDestroy(h->side2_done);
@@ -1222,7 +1251,23 @@ int seg_pack_weights(seg_handle h, void* stream) {
     if (check_handle(h)) return -1;
     if (!h->ws) return fail("seg_pack_weights: not bound");
     hipStream_t st = (hipStream_t)stream;
-    launch_pack((const PackDesc*)(h->ws + h->off_packdesc), (int)h->packdescs.size(), (int)h->pack_max, h->dtype, st);
+    const PackDesc* descs = (const PackDesc*)(h->ws + h->off_packdesc);
+    const int nall = (int)h->packdescs.size(), nbwd = nall - h->npack_fwd;
+    if (h->use_side && h->pack_split && nbwd > 0 && h->npack_fwd > 0) {
+        h->ensure_side();
+        if (!h->pack_fork) {
+            (void)hipEventCreateWithFlags(&h->pack_fork, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&h->pack_done, hipEventDisableTiming);
+        }
+        (void)hipEventRecord(h->pack_fork, st);            // the parameters are final on `st` here
+        (void)hipStreamWaitEvent(h->side, h->pack_fork, 0);
+        launch_pack(descs + h->npack_fwd, nbwd, (int)h->pack_max, h->dtype, h->side);
+        (void)hipEventRecord(h->pack_done, h->side);
+        h->pack_bwd_pending = true;                        // seg_backward_range waits for it
+        launch_pack(descs, h->npack_fwd, (int)h->pack_max, h->dtype, st);
+    } else {
+        launch_pack(descs, nall, (int)h->pack_max, h->dtype, st);
+    }
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_pack_weights: launch failed");
 }
 
@@ -1258,6 +1303,7 @@ int seg_backward_range(seg_handle h, const float* dlogits, int zero_grads, int o
     h->cur_dlogits = dlogits;
     h->ready_used = 0;
     if (op_begin == 0) h->wgrad_seq = 0;
+    if (h->pack_bwd_pending) { (void)hipStreamWaitEvent(st, h->pack_done, 0); h->pack_bwd_pending = false; }
     for (int i = op_begin; i < op_end; ++i) { h->bwd_ops[i](st); h->maybe_flush(st); }
     h->join_side(st);
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));
