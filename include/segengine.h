@@ -298,6 +298,16 @@ int seg_op_plane_dot(const float* a, const float* b, double* out2, double* scrat
 int seg_op_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long v, int accumulate,
                       void* stream);
 
+/* Binary soft-clDice as a loss of the engine (reference: model/lossescldice.py:37-59 Binary_Soft_cldice_loss, with the repairs listed in
+ * oracle/make_golden.py:CLDICE_REPAIRS; `width` = skeleton iterations, 10 in the reference).  probs = the head's probabilities
+ * [n][1][d][h][w] fp32, target = labels of the same extent.  out1[0] = the clDice loss; when dlogits != NULL,
+ * grad_scale * d loss / d logit (sigmoid Jacobian included) is ADDED to dlogits, i.e. call it after seg_loss_backward of the
+ * companion loss (Dice) with grad_scale = weight * loss scale.  ws: seg_cldice_ws_bytes() bytes planned by the caller; no
+ * allocation, no host synchronisation.  nd = 2 (d = 1) or 3. */
+long long seg_cldice_ws_bytes(int n, int d, int h, int w, int nd, int width);
+int seg_cldice_binary(const float* probs, const void* target, int label_type, int n, int d, int h, int w, int nd, int width,
+                      float grad_scale, void* ws, float* out1, float* dlogits, void* stream);
+
 /* ---- measurement: HIP-event timing of kernel classes inside a running forward/backward.
  * seg_profile_enable(h, mask): from now on every launch whose class bit is set in `mask` is
  * bracketed by hipEventRecord on the launch stream (0 disables).  seg_profile_read(h, ...)

@@ -345,4 +345,105 @@ void launch_plane_axpb(const float* in, const float* a, const float* b, float* o
     hipLaunchKernelGGL(plane_axpb_kernel, dim3(blocks_for(V * planes)), dim3(256), 0, s, in, a, b, out, V, planes, accumulate);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Binary soft-clDice as ONE engine call (model/lossescldice.py:37-59, repaired as in oracle/make_golden.py:CLDICE_REPAIRS): both skeletons,
+// the two normalised intersections, the ratio, and the whole backward down to d loss / d logit — no host round trip, no allocation
+// (caller-planned workspace), every volume-sized pass in the kernels above.  Same arithmetic as the autograd composition in
+// pytorchdeeplearing_amd/lossescldice.py (tests/test_cldice.py compares the two).
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void cld_labels_kernel(const void* target, int lt, float* y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = (float)load_label(target, lt, i);
+}
+// sums1[p] = {sum cl_pred*y, sum cl_pred}, sums2[p] = {sum cl_tgt*pred, sum cl_tgt}.  coef = [a1 | b1 | a2 | zero] (P floats each):
+// d loss / d cl_pred = a1*y + b1, direct d loss / d pred = a2*cl_tgt, all times `gscale` (loss weight x loss scale).
+__global__ void cld_finalize_kernel(const double* sums1, const double* sums2, int P, float gscale, float* out1, float* coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double smooth = 1e-5, eps = 1e-7;
+    double I = 0.0, A = 0.0, B = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const double fi = (double)(float)((sums1[2 * p] + 1.0) / (sums1[2 * p + 1] + 1.0));     // the autograd path keeps the ratios in fp32
+        const double ft = (double)(float)((sums2[2 * p] + 1.0) / (sums2[2 * p + 1] + 1.0));
+        I += fi * ft; A += fi; B += ft;
+    }
+    double D = A + B + smooth;
+    const double live = D >= eps ? 1.0 : 0.0;            // clamp_min passes the gradient only above the floor
+    if (D < eps) D = eps;
+    const double num = 2.0 * I + smooth;
+    out1[0] = (float)(1.0 - num / D);
+    for (int p = 0; p < P; ++p) {
+        const double in1 = sums1[2 * p] + 1.0, s1 = sums1[2 * p + 1] + 1.0, s2 = sums2[2 * p + 1] + 1.0;
+        const double fi = (double)(float)(in1 / s1), ft = (double)(float)((sums2[2 * p] + 1.0) / s2);
+        const double gi = -(2.0 * ft / D - live * num / (D * D)) * gscale;      // d loss / d iflat_p
+        const double gt = -(2.0 * fi / D - live * num / (D * D)) * gscale;      // d loss / d tflat_p
+        coef[p] = (float)(gi / s1);
+        coef[P + p] = (float)(-gi * in1 / (s1 * s1));
+        coef[2 * P + p] = (float)(gt / s2);
+        coef[3 * P + p] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void cld_sigmoid_accum_kernel(const float* dprobs, const float* probs, float* dlogits, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float p = probs[i];
+        dlogits[i] += dprobs[i] * p * (1.f - p);
+    }
+}
+struct CldLayout { size_t y, work, tgt, grad, sums, scratch, coef, total; };
+CldLayout cld_layout(int P, long long V, int width) {
+    CldLayout L;
+    const size_t vol = ((size_t)P * V * sizeof(float) + 255) / 256 * 256;
+    size_t cur = 0;
+    L.y = cur; cur += vol;
+    L.work = cur; cur += (size_t)2 * (width > 0 ? width : 1) * vol;
+    L.tgt = cur; cur += 3 * vol;
+    L.grad = cur; cur += 3 * vol;
+    L.sums = cur; cur += ((size_t)4 * P * sizeof(double) + 255) / 256 * 256;
+    L.scratch = cur; cur += (plane_dot_scratch_bytes(P, V) + 255) / 256 * 256;
+    L.coef = cur; cur += ((size_t)4 * P * sizeof(float) + 255) / 256 * 256;
+    L.total = cur;
+    return L;
+}
+}  // namespace
+
+size_t cldice_binary_ws_bytes(int planes, long long V, int width) { return cld_layout(planes, V, width).total; }
+
+void launch_cldice_binary(const float* probs, const void* target, int label_type, int planes, int D, int H, int W, int nd, int width,
+                          float gscale, void* ws_, float* out1, float* dlogits, hipStream_t s) {
+    const long long V = (long long)D * H * W, n = (long long)planes * V;
+    const CldLayout L = cld_layout(planes, V, width);
+    char* ws = (char*)ws_;
+    const size_t vol = ((size_t)n * sizeof(float) + 255) / 256 * 256;
+    float* y = (float*)(ws + L.y);
+    auto work = [&](int it, int which) { return (float*)(ws + L.work + ((size_t)it * 2 + which) * vol); };     // 0: e_it, 1: x_{it+1}
+    float* t[3] = {(float*)(ws + L.tgt), (float*)(ws + L.tgt + vol), (float*)(ws + L.tgt + 2 * vol)};
+    float* g[3] = {(float*)(ws + L.grad), (float*)(ws + L.grad + vol), (float*)(ws + L.grad + 2 * vol)};
+    double* sums1 = (double*)(ws + L.sums);
+    double* sums2 = sums1 + 2 * planes;
+    double* scratch = (double*)(ws + L.scratch);
+    float* coef = (float*)(ws + L.coef);
+    hipLaunchKernelGGL(cld_labels_kernel, dim3(blocks_for(n)), dim3(256), 0, s, target, label_type, y, n);
+    // skeleton of the prediction: every iteration's input and eroded image stay for the backward pass
+    const float* cur = probs;
+    for (int it = 0; it < width; ++it) { launch_skel_iter(cur, work(it, 0), work(it, 1), planes, D, H, W, nd, s); cur = work(it, 1); }
+    const float* cl_pred = cur;
+    // skeleton of the target: nothing is kept
+    const float* tc = y;
+    for (int it = 0; it < width; ++it) { float* nx = t[1 + (it & 1)]; launch_skel_iter(tc, t[0], nx, planes, D, H, W, nd, s); tc = nx; }
+    const float* cl_tgt = tc;
+    launch_plane_dot(cl_pred, y, sums1, scratch, planes, V, s);
+    launch_plane_dot(cl_tgt, probs, sums2, scratch, planes, V, s);
+    hipLaunchKernelGGL(cld_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)sums1, (const double*)sums2, planes, gscale, out1, coef);
+    if (!dlogits) return;
+    // backward: d cl_pred (affine map of y per plane) through the skeleton iterations, plus the direct term through tflat
+    float* gc = g[0];
+    launch_plane_axpb(y, coef, coef + planes, gc, planes, V, 0, s);
+    for (int it = width - 1; it >= 0; --it) {
+        float* dx = (gc == g[0]) ? g[1] : g[0];
+        launch_skel_iter_bwd(gc, it == 0 ? probs : work(it - 1, 1), work(it, 0), dx, g[2], planes, D, H, W, nd, s);
+        gc = dx;
+    }
+    launch_plane_axpb(cl_tgt, coef + 2 * planes, coef + 3 * planes, gc, planes, V, 1, s);
+    hipLaunchKernelGGL(cld_sigmoid_accum_kernel, dim3(blocks_for(n)), dim3(256), 0, s, (const float*)gc, probs, dlogits, n);
+}
+
 }  // namespace seg

@@ -926,7 +926,10 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) 
     const int combos = (P / CP) * (Q / CQ);
     static const int total = getenv("SEG_W3_TOTAL") ? atoi(getenv("SEG_W3_TOTAL")) : 512;     // tuning knobs
     static const int minbox = getenv("SEG_W3_MINBOX") ? atoi(getenv("SEG_W3_MINBOX")) : 6;
-    long long nb = total / combos;
+    // 16 -> 16 channels (the finest level): four workgroups fit a CU (23 KB LDS, 113 VGPRs) and the partial tile is 27 KB, so the
+    // staging latency of one workgroup can hide behind the others
+    static const int total16 = getenv("SEG_W3_TOTAL16") ? atoi(getenv("SEG_W3_TOTAL16")) : 1024;   // standalone 4x96^3: 512 -> 168 us, 1024 -> 123 us, 2048 -> 137 us (r02_wgrad16_ab.log); step unchanged
+    long long nb = (P == 16 && Q == 16 ? total16 : total) / combos;
     if (nb < 1) nb = 1;
     const long long nbox = boxes_for(ndim, N, D, H, W);
     // small levels: every workgroup writes (and the reduce re-reads) a full partial tile, so do not split the

@@ -136,6 +136,14 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
     a.N = N; a.D = ndim == 3 ? D : 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     static const int remap = getenv("SEG_C3X_REMAP") ? atoi(getenv("SEG_C3X_REMAP")) : 1;      // XCD-aware box order (c3x_box_of_block)
     a.remap = remap;
+    // diagnostics only (tools/trace_gaps.py): SEG_C3X_TWICE=1 launches every conv twice without statistics first, so a kernel trace shows
+    // the same launch with cold and with warm operands
+    static const bool twice = getenv("SEG_C3X_TWICE") && atoi(getenv("SEG_C3X_TWICE"));
+    if (twice) {
+        Conv3xArgs w = a; w.stats = nullptr;
+        if (ndim == 3) { if (dtype == DT_F16) c3x::launch_3d<f16>(cfg, w, s); else c3x::launch_3d<bf16>(cfg, w, s); }
+        else { if (dtype == DT_F16) c3x::launch_2d<f16>(cfg, w, s); else c3x::launch_2d<bf16>(cfg, w, s); }
+    }
     if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d<f16>(cfg, a, s) : c3x::launch_3d<bf16>(cfg, a, s);
     return dtype == DT_F16 ? c3x::launch_2d<f16>(cfg, a, s) : c3x::launch_2d<bf16>(cfg, a, s);
 }

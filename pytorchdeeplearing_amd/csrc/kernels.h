@@ -216,6 +216,10 @@ void launch_pool3_bwd(const float* src, const float* dout, float* din, int plane
 size_t plane_dot_scratch_bytes(int planes, long long V);
 void launch_plane_dot(const float* a, const float* b, double* out, double* scratch, int planes, long long V, hipStream_t s);
 void launch_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long V, int accumulate, hipStream_t s);
+// binary soft-clDice, forward + backward to the logits in one call (cldice.hip)
+size_t cldice_binary_ws_bytes(int planes, long long V, int width);
+void launch_cldice_binary(const float* probs, const void* target, int label_type, int planes, int D, int H, int W, int nd, int width,
+                          float gscale, void* ws, float* out1, float* dlogits, hipStream_t s);
 
 // pre/post-processing around predict (prepost.hip): planar single-channel volumes [D][H][W]
 constexpr int RS_LINEAR = 0, RS_NEAREST = 1;

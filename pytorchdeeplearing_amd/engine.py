@@ -235,6 +235,30 @@ class SegEngine:
             "seg_loss_backward")
         return dlogits
 
+    def cldice_term(self, probs, target, weight=1.0, width=10, dlogits=None, grad_scale=None):
+        """Binary soft-clDice (model/lossescldice.py:37-59) on the head's probabilities as one library call (seg_cldice_binary): returns a
+        1-element device tensor with the loss; when `dlogits` is given, weight * loss scale * d loss / d logit is ADDED to it (call after
+        loss_backward of the companion loss).  The workspace is planned once per shape and kept."""
+        if probs.shape[1] != 1:
+            raise ValueError("cldice_term: the binary clDice term needs a one-channel head (numclass == 1)")
+        n = probs.shape[0]
+        sp = tuple(probs.shape[2:])
+        d, h, w = (sp if self.ndim == 3 else (1,) + sp)
+        key = (n, d, h, w, width)
+        if getattr(self, "_cld_key", None) != key:
+            nbytes = self.lib.seg_cldice_ws_bytes(n, d, h, w, self.ndim, width)
+            if nbytes < 0:
+                raise ValueError("cldice_term: bad extents")
+            self._cld_ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
+            self._cld_out = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._cld_key = key
+        target = target.contiguous()
+        gs = (self.loss_scale if grad_scale is None else grad_scale) * float(weight)
+        self.lib.check(self.lib.seg_cldice_binary(
+            _ptr(probs), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, d, h, w, self.ndim, int(width), float(gs),
+            _ptr(self._cld_ws), _ptr(self._cld_out), _ptr(dlogits) if dlogits is not None else None, self.stream()), "seg_cldice_binary")
+        return self._cld_out
+
     # ---- optimiser ------------------------------------------------------------------------------
     def init_optimizer(self):
         self.exp_avg = aligned_zeros_f32(self.numel, self.device)
@@ -272,14 +296,19 @@ class SegEngine:
     # ---- one optimisation step of the reference loop --------------------------------------------
     def train_step(self, x, target, loss_name="BinaryDiceLoss", lr=1e-3, weight_decay=0.01, decoupled=True,
                    focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, mask_mode=_capi.MASKS_RANDOM, masks=None,
-                   allreduce=None, logits=None, probs=None, loss_exchange=None):
+                   allreduce=None, logits=None, probs=None, loss_exchange=None, cldice_weight=0.0, cldice_width=10):
         """Returns out3 = device tensor [loss, dice metric, iou metric] (no host sync).
+        cldice_weight > 0 (binary heads): loss = loss_name + cldice_weight * soft-clDice(probabilities, target) — BASELINE configs[4];
+        out3[0] then holds the sum (the clDice part alone is `self.last_cldice`).
         loss_exchange (parallel.GlobalBatchLoss): exact loss of the global batch over all ranks; the parameter gradients
         of the ranks are then summed, not averaged (the 1/world factor is dropped)."""
         logits, probs = self.forward(x, mask_mode, masks, logits, probs)
         self._last_probs = probs
         out3 = self.loss_forward(logits, target, loss_name, focal_alpha, focal_gamma, class_alpha, exchange=loss_exchange)
         dl = self.loss_backward(logits, target, loss_name, focal_alpha, focal_gamma)
+        if cldice_weight:
+            self.last_cldice = self.cldice_term(probs, target, cldice_weight, cldice_width, dlogits=dl)
+            out3[0:1].add_(self.last_cldice, alpha=float(cldice_weight))
         world = getattr(allreduce, "world", 1) if allreduce is not None else 1
         grad_div = 1 if (loss_exchange is not None and loss_exchange.world > 1) else world
         if allreduce is not None and getattr(allreduce, "bucketed", False) and world > 1:

@@ -88,6 +88,58 @@ def test_cldice_vs_oracle_gpu(shape):
     np.testing.assert_allclose(p1.grad.cpu().numpy(), p0.grad.numpy(), rtol=5e-4, atol=3e-4 * float(p0.grad.abs().max()))
 
 
+def _first_class(pred, target, nd, dev, scale=1.0):
+    """seg_cldice_binary on (planes = n*c) probabilities: returns (loss, d loss / d logit) for logit = logit(pred)."""
+    from pytorchdeeplearing_amd import _capi
+    lib, st = _capi.lib_for(dev), _capi.stream_for(dev)
+    p = pred.detach().float().contiguous()
+    planes = p.shape[0] * p.shape[1]
+    sp = tuple(p.shape[2:])
+    d, h, w = sp if nd == 3 else (1,) + sp
+    t = target.to(torch.float32).contiguous()
+    ws = torch.empty(lib.seg_cldice_ws_bytes(planes, d, h, w, nd, 10) // 4 + 64, dtype=torch.float32, device=p.device)
+    out = torch.zeros(1, dtype=torch.float32, device=p.device)
+    dl = torch.full_like(p, 0.25)                       # the entry point ADDS to what the companion loss left there
+    lib.check(lib.seg_cldice_binary(p.data_ptr(), t.data_ptr(), _capi.LABEL_TYPES[str(t.dtype)], planes, d, h, w, nd, 10, float(scale),
+                                    ws.data_ptr(), out.data_ptr(), dl.data_ptr(), st), "seg_cldice_binary")
+    return float(out.cpu()), (dl - 0.25).cpu()
+
+
+@pytest.mark.parametrize("tag", ["b3", "b2"])
+def test_cldice_first_class_call_matches_reference_golden(dev, tag):
+    """the one-call loss of the engine (both skeletons, ratios, backward to the logits) against the repaired-reference golden values"""
+    pred, target = T(tag + "_pred", dev), T(tag + "_target", dev)
+    loss, dlogit = _first_class(pred, target, pred.dim() - 2, dev, scale=3.0)
+    assert abs(loss - float(G[tag + "_loss"])) < 2e-6
+    pr = T(tag + "_pred")
+    ref = 3.0 * torch.from_numpy(G[tag + "_dpred"]) * pr * (1.0 - pr)
+    np.testing.assert_allclose(dlogit.numpy(), ref.numpy(), rtol=3e-4, atol=3e-4 * float(ref.abs().max()))
+
+
+def test_engine_train_step_with_cldice_term(dev):
+    """SegEngine.train_step(cldice_weight=...) = Dice + clDice on the head's probabilities: loss value and d logits equal the sum of the
+    fused Dice path and the autograd clDice module on the same probabilities"""
+    from pytorchdeeplearing_amd import SegEngine
+    e = SegEngine("vnet", 3, 1, 1, dtype="f32", device=dev)
+    e.load_state_dict(seg.perturb_params(seg.init_params("vnet", 3, 1, 1, seed=0), seed=3))
+    x, y = seg.synthetic_batch(1, (16, 16, 16), 1, 1, seed=5)
+    x, y = x.to(dev), y.to(dev)
+    from pytorchdeeplearing_amd import _capi
+    logits, probs = e.forward(x, _capi.MASKS_EVAL)
+    out3 = e.loss_forward(logits, y, "BinaryDiceLoss").clone()
+    dl = e.loss_backward(logits, y, "BinaryDiceLoss").clone()
+    dl2 = dl.clone()
+    cld = e.cldice_term(probs, y, weight=0.5, dlogits=dl2).clone()
+    p = probs.detach().clone().requires_grad_(True)
+    ref = cl.Binary_Soft_cldice_loss()(p, y.reshape(p.shape).float())
+    ref.backward()
+    assert abs(float(cld) - float(ref.detach())) < 2e-6
+    want = dl + 0.5 * float(e.loss_scale) * p.grad * probs * (1 - probs)
+    np.testing.assert_allclose(dl2.cpu().numpy(), want.cpu().numpy(), rtol=3e-4, atol=3e-4 * float(want.abs().max()))
+    o = e.train_step(x, y, "BinaryDiceLoss", cldice_weight=0.5, mask_mode=_capi.MASKS_EVAL).cpu()
+    assert abs(float(o[0]) - (float(out3[0]) + 0.5 * float(cld))) < 5e-6
+
+
 def test_cldice_cpu_tensors_raise():
     from pytorchdeeplearing_amd import _capi
     if _capi._injected is not None:

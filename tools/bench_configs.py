@@ -68,3 +68,19 @@ for _ in range(10):
 torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
 print(json.dumps({"config": "C5 VNet3d 1x160^3 bf16 + Dice + soft-clDice (autograd path)", "ms_per_step": round(ms, 2),
                   "samples_per_s": round(1e3 / ms, 1), "loss_first": round(first, 5), "loss_after_13_steps": round(float(last), 5)}))
+
+# the same loss as ONE engine call behind SegEngine.train_step (seg_cldice_binary: planned workspace, no autograd, no torch elementwise ops)
+del net, eng
+torch.cuda.empty_cache()
+from pytorchdeeplearing_amd import SegEngine
+e = SegEngine("vnet", 3, 1, 1, dtype="bf16", device=dev)
+seg.init_engine(e, seed=0)
+first = float(e.train_step(x, y, "BinaryDiceLoss", cldice_weight=1.0)[0])
+for _ in range(2):
+    e.train_step(x, y, "BinaryDiceLoss", cldice_weight=1.0)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    out3 = e.train_step(x, y, "BinaryDiceLoss", cldice_weight=1.0)
+torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
+print(json.dumps({"config": "C5 VNet3d 1x160^3 bf16 + Dice + soft-clDice (engine call: train_step(cldice_weight=1))", "ms_per_step": round(ms, 2),
+                  "samples_per_s": round(1e3 / ms, 1), "loss_first": round(first, 5), "loss_after_13_steps": round(float(out3[0]), 5)}))

@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from pytorchdeeplearing_amd import ops
     dev = torch.device("cuda")
     res = {}
-    for (N, S, C, dt) in ((4, 48, 32, "f16"), (4, 24, 64, "f16"), (4, 12, 128, "f16"), (4, 6, 256, "f16"), (2, 64, 32, "f16"), (1, 80, 32, "bf16")):
+    for (N, S, C, dt) in ((4, 96, 16, "f16"), (4, 48, 32, "f16"), (4, 24, 64, "f16"), (4, 12, 128, "f16"), (4, 6, 256, "f16"), (2, 64, 32, "f16"), (1, 80, 32, "bf16")):
         x = ops.aligned_like(torch.randn(N, S, S, S, C, device=dev).to(ops.TORCH_DTYPE[dt]))
         dr = ops.aligned_like(torch.randn(N, S, S, S, C, device=dev).to(ops.TORCH_DTYPE[dt]))
         fn = lambda: ops.wgrad3(dr, x, dt, 3)

@@ -69,6 +69,7 @@ t0=step[0]['s']
 tl=[r for r in step if 'loss_reduce' in r['Kernel_Name']][0]['s']
 for name,sel in (("FORWARD (main)",lambda r:r['s']<tl and r['Queue_Id']=='1'),("BACKWARD main",lambda r:r['s']>=tl and r['Queue_Id']=='1'),("SIDE",lambda r:r['Queue_Id']!='1')):
     rs=[r for r in step if sel(r)]
+    if not rs: continue
     agg=collections.defaultdict(lambda:[0,0.0])
     for r in rs: a=agg[short(r['Kernel_Name'])]; a[0]+=1; a[1]+=(r['e']-r['s'])/1e3
     print("==",name,"%d kernels busy %.0f us span %.0f us"%(len(rs),sum(v[1] for v in agg.values()),(rs[-1]['e']-rs[0]['s'])/1e3))
