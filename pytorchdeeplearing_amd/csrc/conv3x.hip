@@ -127,12 +127,17 @@ int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres
 }
 
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep) {
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const Conv3xReduce* rq) {
     const Cfg* c = find_cfg(cfg);
     if (!c || !cfg_fits(*c, ndim, Cin, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
     Conv3xArgs a;
     a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.stat_rep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
+    a.rq_y = nullptr; a.rq_scale = nullptr; a.rq_shift = nullptr; a.rq_Q = nullptr; a.rq_rep = STAT_REP;
+    if (rq && rq->Q) {
+        a.rq_y = rq->y; a.rq_scale = rq->scale; a.rq_shift = rq->shift; a.rq_Q = rq->Q;
+        a.rq_rep = (rq->rep > 0 && rq->rep <= STAT_REP) ? rq->rep : STAT_REP;
+    }
     a.N = N; a.D = ndim == 3 ? D : 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     static const int remap = getenv("SEG_C3X_REMAP") ? atoi(getenv("SEG_C3X_REMAP")) : 1;      // XCD-aware box order (c3x_box_of_block)
     a.remap = remap;

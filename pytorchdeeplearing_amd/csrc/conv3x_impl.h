@@ -52,6 +52,12 @@ struct Conv3xArgs {
     const float* bias; void* out; double* stats; int stat_rep;   // stat_rep: replicas of `stats` the workgroups spread over (<= STAT_REP)
     int N, D, H, W, Cin, Cout;
     int remap;                                    // 1: XCD-aware box order (grid.x rounded up to a multiple of 8)
+    // data-gradient launches only: the GroupNorm-backward REDUCE pass of the unit that consumes this gradient, folded into the epilogue.
+    // The tensor written here is d loss / d activation of a [conv -> GroupNorm -> dropout -> ReLU] unit whose only gradient source it is;
+    // rq_y = that unit's raw conv output (same extent as `out`), rq_scale / rq_shift its forward coefficients [N][Cout].  The epilogue adds
+    // sum dz and sum dz*y (dz = dy where scale*y+shift > 0) per (sample, channel) into rq_Q [rep][N][Cout][2]: one read of y instead of the
+    // reduce kernel's reads of dy and y, and one launch less.
+    const void* rq_y; const float* rq_scale; const float* rq_shift; double* rq_Q; int rq_rep;
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md), each with its own L2.  With the
@@ -86,6 +92,52 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const 
     __syncthreads();
     constexpr int CPR = BN / 8;
     T* out = (T*)a.out;
+    if (a.rq_Q) {
+        // a thread keeps its 8-channel chunk (256 % CPR == 0): forward coefficients in registers, two partial sums per channel
+        const int c8 = tid % CPR;
+        const T* ry = (const T*)a.rq_y;
+        const vec<float, 8> sc = *(const vec<float, 8>*)(a.rq_scale + (long long)n * a.Cout + co0 + c8 * 8);
+        const vec<float, 8> sh = *(const vec<float, 8>*)(a.rq_shift + (long long)n * a.Cout + co0 + c8 * 8);
+        float q1[8], q2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
+        for (int i = tid; i < B::V * CPR; i += 256) {
+            const int v = i / CPR;
+            int vz, vy, vx;
+            B::vox(v, vz, vy, vx);
+            const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+            if (x < a.W && y < a.H && z < a.D) {
+                const long long o = ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8;
+                const vec<T, 8> dv = load8(&Os[v * OLD + c8 * 8]);
+                const vec<T, 8> yv = load8(ry + o);
+                store8(out + o, dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float yf = to_f(yv[j]);
+                    const float dz = (fmaf(sc[j], yf, sh[j]) > 0.f) ? to_f(dv[j]) : 0.f;
+                    q1[j] += dz;
+                    q2[j] = fmaf(dz, yf, q2[j]);
+                }
+            }
+        }
+        // lanes with equal lane % CPR hold the same channels: butterfly over the other lane bits, then the four waves through LDS
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            for (int o = CPR; o < 64; o <<= 1) { q1[j] += __shfl_xor(q1[j], o); q2[j] += __shfl_xor(q2[j], o); }
+        if (lane < CPR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[(wv * CPR + lane) * 16 + j] = q1[j]; red[(wv * CPR + lane) * 16 + 8 + j] = q2[j]; }
+        }
+        __syncthreads();
+        if (tid < CPR * 16) {
+            const int cc = tid / 16, jj = tid % 16;
+            const double sum = (double)red[(0 * CPR + cc) * 16 + jj] + (double)red[(1 * CPR + cc) * 16 + jj] + (double)red[(2 * CPR + cc) * 16 + jj] +
+                               (double)red[(3 * CPR + cc) * 16 + jj];
+            const int c = co0 + cc * 8 + (jj & 7), which = jj >> 3;
+            atomicAdd(a.rq_Q + (((long long)(blockIdx.x % a.rq_rep) * a.N + n) * a.Cout + c) * 2 + which, sum);
+        }
+        return;
+    }
     for (int i = tid; i < B::V * CPR; i += 256) {
         const int v = i / CPR, c8 = i % CPR;
         int vz, vy, vx;
@@ -125,7 +177,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     static_assert(WM * WN == 4 && WM * TM == B::NTILE, "wave grid must cover the box");
     static_assert(B::NTAP % (PF + 1) == 0, "register ring must divide the tap count");
     constexpr int BN = WN * TN * 16, OLD = BN + 8;
-    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 2048 / sizeof(T), XS_ELEMS = NRES * B::CHUNK_ELEMS;
+    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 4096 / sizeof(T), XS_ELEMS = NRES * B::CHUNK_ELEMS;
     // ONE LDS object: resident chunk images; the epilogue's output tile + reduction slots alias it
     __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS];
     constexpr int NI = (B::NINSTR + 3) / 4;               // copy instructions per wave and chunk
@@ -301,7 +353,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
     constexpr int NSTEP = (B::NTAP + 1) / 2;
     static_assert(NSTEP >= PF + 1, "ring deeper than the loop");
     constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
-    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 2048 / sizeof(T);
+    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 4096 / sizeof(T);
     __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS];
     constexpr int NI = (NINSTR + 3) / 4;
 
