@@ -3,6 +3,7 @@
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=${1:-step24}
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/gpu_tests_$TAG.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; tail -3 gpurun_out/smoke_$TAG.log
 timeout 300 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 rm -rf gpurun_out/prof gpurun_out/pmc
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o step -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --roofline-steps 0 > gpurun_out/prof_run.log 2>&1
