@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # see pytorchdeeplearing_amd/__init__.py (set before the HIP runtime starts)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
