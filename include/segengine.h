@@ -305,8 +305,11 @@ int seg_op_plane_axpb(const float* in, const float* a, const float* b, float* ou
  * companion loss (Dice) with grad_scale = weight * loss scale.  ws: seg_cldice_ws_bytes() bytes planned by the caller; no
  * allocation, no host synchronisation.  nd = 2 (d = 1) or 3. */
 long long seg_cldice_ws_bytes(int n, int d, int h, int w, int nd, int width);
+/* optional: the label-only part (float labels + the target skeleton) into ws ahead of time, e.g. on another stream while the forward pass
+ * runs; seg_cldice_binary(target_ready = 1) then skips it (the caller orders the two calls with an event). */
+int seg_cldice_target(const void* target, int label_type, int n, int d, int h, int w, int nd, int width, void* ws, void* stream);
 int seg_cldice_binary(const float* probs, const void* target, int label_type, int n, int d, int h, int w, int nd, int width,
-                      float grad_scale, void* ws, float* out1, float* dlogits, void* stream);
+                      float grad_scale, void* ws, float* out1, float* dlogits, int target_ready, void* stream);
 
 /* ---- measurement: HIP-event timing of kernel classes inside a running forward/backward.
  * seg_profile_enable(h, mask): from now on every launch whose class bit is set in `mask` is

@@ -79,7 +79,8 @@ SIGNATURES = {
     "seg_op_plane_dot": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _vp]),
     "seg_op_plane_axpb": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
     "seg_cldice_ws_bytes": (_ll, [_i, _i, _i, _i, _i, _i]),
-    "seg_cldice_binary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "seg_cldice_target": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "seg_cldice_binary": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "seg_op_resample3d": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _d, _d, _i, _vp]),
     "seg_op_normalize_ws_bytes": (_ll, []),
     "seg_op_normalize_meanstd": (_i, [_vp, _vp, _ll, _i, _f, _f, _vp, _vp]),

@@ -407,8 +407,21 @@ CldLayout cld_layout(int P, long long V, int width) {
 
 size_t cldice_binary_ws_bytes(int planes, long long V, int width) { return cld_layout(planes, V, width).total; }
 
+// the part that depends on the labels alone (float labels + their skeleton): may run on another stream next to the forward pass
+void launch_cldice_target(const void* target, int label_type, int planes, int D, int H, int W, int nd, int width, void* ws_, hipStream_t s) {
+    const long long V = (long long)D * H * W, n = (long long)planes * V;
+    const CldLayout L = cld_layout(planes, V, width);
+    char* ws = (char*)ws_;
+    const size_t vol = ((size_t)n * sizeof(float) + 255) / 256 * 256;
+    float* y = (float*)(ws + L.y);
+    float* t[3] = {(float*)(ws + L.tgt), (float*)(ws + L.tgt + vol), (float*)(ws + L.tgt + 2 * vol)};
+    hipLaunchKernelGGL(cld_labels_kernel, dim3(blocks_for(n)), dim3(256), 0, s, target, label_type, y, n);
+    const float* tc = y;
+    for (int it = 0; it < width; ++it) { float* nx = t[1 + (it & 1)]; launch_skel_iter(tc, t[0], nx, planes, D, H, W, nd, s); tc = nx; }
+}
+
 void launch_cldice_binary(const float* probs, const void* target, int label_type, int planes, int D, int H, int W, int nd, int width,
-                          float gscale, void* ws_, float* out1, float* dlogits, hipStream_t s) {
+                          float gscale, void* ws_, float* out1, float* dlogits, int target_ready, hipStream_t s) {
     const long long V = (long long)D * H * W, n = (long long)planes * V;
     const CldLayout L = cld_layout(planes, V, width);
     char* ws = (char*)ws_;
@@ -421,15 +434,13 @@ void launch_cldice_binary(const float* probs, const void* target, int label_type
     double* sums2 = sums1 + 2 * planes;
     double* scratch = (double*)(ws + L.scratch);
     float* coef = (float*)(ws + L.coef);
-    hipLaunchKernelGGL(cld_labels_kernel, dim3(blocks_for(n)), dim3(256), 0, s, target, label_type, y, n);
+    if (!target_ready) launch_cldice_target(target, label_type, planes, D, H, W, nd, width, ws_, s);
     // skeleton of the prediction: every iteration's input and eroded image stay for the backward pass
     const float* cur = probs;
     for (int it = 0; it < width; ++it) { launch_skel_iter(cur, work(it, 0), work(it, 1), planes, D, H, W, nd, s); cur = work(it, 1); }
     const float* cl_pred = cur;
-    // skeleton of the target: nothing is kept
-    const float* tc = y;
-    for (int it = 0; it < width; ++it) { float* nx = t[1 + (it & 1)]; launch_skel_iter(tc, t[0], nx, planes, D, H, W, nd, s); tc = nx; }
-    const float* cl_tgt = tc;
+    // skeleton of the target (launch_cldice_target): the last iterate sits in the ping-pong buffer of iteration width-1
+    const float* cl_tgt = width > 0 ? t[1 + ((width - 1) & 1)] : y;
     launch_plane_dot(cl_pred, y, sums1, scratch, planes, V, s);
     launch_plane_dot(cl_tgt, probs, sums2, scratch, planes, V, s);
     hipLaunchKernelGGL(cld_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)sums1, (const double*)sums2, planes, gscale, out1, coef);

@@ -1648,11 +1648,18 @@ long long seg_cldice_ws_bytes(int n, int d, int h, int w, int nd, int width) {
     if (n < 1 || h < 1 || w < 1 || width < 0 || (nd != 2 && nd != 3)) return -1;
     return (long long)cldice_binary_ws_bytes(n, (long long)(nd == 3 ? d : 1) * h * w, width);
 }
+int seg_cldice_target(const void* target, int label_type, int n, int d, int h, int w, int nd, int width, void* ws, void* stream) {
+    if (!target || !ws) return fail("seg_cldice_target: null pointer");
+    if (n < 1 || h < 1 || w < 1 || width < 0 || (nd != 2 && nd != 3)) return fail("seg_cldice_target: bad extents");
+    launch_cldice_target(target, label_type, n, nd == 3 ? d : 1, h, w, nd, width, ws, (hipStream_t)stream);
+    return SEG_OK("seg_cldice_target");
+}
 int seg_cldice_binary(const float* probs, const void* target, int label_type, int n, int d, int h, int w, int nd, int width,
-                      float grad_scale, void* ws, float* out1, float* dlogits, void* stream) {
+                      float grad_scale, void* ws, float* out1, float* dlogits, int target_ready, void* stream) {
     if (!probs || !target || !ws || !out1) return fail("seg_cldice_binary: null pointer");
     if (n < 1 || h < 1 || w < 1 || width < 0 || (nd != 2 && nd != 3)) return fail("seg_cldice_binary: bad extents");
-    launch_cldice_binary(probs, target, label_type, n, nd == 3 ? d : 1, h, w, nd, width, grad_scale, ws, out1, dlogits, (hipStream_t)stream);
+    launch_cldice_binary(probs, target, label_type, n, nd == 3 ? d : 1, h, w, nd, width, grad_scale, ws, out1, dlogits, target_ready,
+                         (hipStream_t)stream);
     return SEG_OK("seg_cldice_binary");
 }
 

@@ -220,8 +220,9 @@ void launch_plane_dot(const float* a, const float* b, double* out, double* scrat
 void launch_plane_axpb(const float* in, const float* a, const float* b, float* out, int planes, long long V, int accumulate, hipStream_t s);
 // binary soft-clDice, forward + backward to the logits in one call (cldice.hip)
 size_t cldice_binary_ws_bytes(int planes, long long V, int width);
+void launch_cldice_target(const void* target, int label_type, int planes, int D, int H, int W, int nd, int width, void* ws, hipStream_t s);
 void launch_cldice_binary(const float* probs, const void* target, int label_type, int planes, int D, int H, int W, int nd, int width,
-                          float gscale, void* ws, float* out1, float* dlogits, hipStream_t s);
+                          float gscale, void* ws, float* out1, float* dlogits, int target_ready, hipStream_t s);
 
 // pre/post-processing around predict (prepost.hip): planar single-channel volumes [D][H][W]
 constexpr int RS_LINEAR = 0, RS_NEAREST = 1;

@@ -235,15 +235,8 @@ class SegEngine:
             "seg_loss_backward")
         return dlogits
 
-    def cldice_term(self, probs, target, weight=1.0, width=10, dlogits=None, grad_scale=None):
-        """Binary soft-clDice (model/lossescldice.py:37-59) on the head's probabilities as one library call (seg_cldice_binary): returns a
-        1-element device tensor with the loss; when `dlogits` is given, weight * loss scale * d loss / d logit is ADDED to it (call after
-        loss_backward of the companion loss).  The workspace is planned once per shape and kept."""
-        if probs.shape[1] != 1:
-            raise ValueError("cldice_term: the binary clDice term needs a one-channel head (numclass == 1)")
-        n = probs.shape[0]
-        sp = tuple(probs.shape[2:])
-        d, h, w = (sp if self.ndim == 3 else (1,) + sp)
+    def _cldice_plan(self, n, sp, width):
+        d, h, w = (sp if self.ndim == 3 else (1,) + tuple(sp))
         key = (n, d, h, w, width)
         if getattr(self, "_cld_key", None) != key:
             nbytes = self.lib.seg_cldice_ws_bytes(n, d, h, w, self.ndim, width)
@@ -252,11 +245,42 @@ class SegEngine:
             self._cld_ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
             self._cld_out = torch.zeros(1, dtype=torch.float32, device=self.device)
             self._cld_key = key
+            self._cld_target_ready = False
+        return d, h, w
+
+    def cldice_prepare_target(self, target, n, sp, width=10):
+        """The label-only half of the clDice term (float labels + target skeleton) on a second stream, to be called BEFORE the forward
+        pass so the two overlap; cldice_term() then waits for it.  GPU only (the host checker has one stream)."""
+        d, h, w = self._cldice_plan(n, tuple(sp), width)
+        if self.device.type != "cuda":
+            return
+        if getattr(self, "_cld_stream", None) is None:
+            self._cld_stream = torch.cuda.Stream(device=self.device)
         target = target.contiguous()
+        cur = torch.cuda.current_stream(self.device)
+        self._cld_stream.wait_stream(cur)                  # labels (and the previous step's readers of the workspace) are done
+        self.lib.check(self.lib.seg_cldice_target(_ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, d, h, w, self.ndim, int(width),
+                                                  _ptr(self._cld_ws), self._cld_stream.cuda_stream), "seg_cldice_target")
+        target.record_stream(self._cld_stream)
+        self._cld_target_ready = True
+
+    def cldice_term(self, probs, target, weight=1.0, width=10, dlogits=None, grad_scale=None):
+        """Binary soft-clDice (model/lossescldice.py:37-59) on the head's probabilities as one library call (seg_cldice_binary): returns a
+        1-element device tensor with the loss; when `dlogits` is given, weight * loss scale * d loss / d logit is ADDED to it (call after
+        loss_backward of the companion loss).  The workspace is planned once per shape and kept."""
+        if probs.shape[1] != 1:
+            raise ValueError("cldice_term: the binary clDice term needs a one-channel head (numclass == 1)")
+        n = probs.shape[0]
+        d, h, w = self._cldice_plan(n, tuple(probs.shape[2:]), width)
+        target = target.contiguous()
+        ready = 1 if getattr(self, "_cld_target_ready", False) else 0
+        if ready:
+            torch.cuda.current_stream(self.device).wait_stream(self._cld_stream)
+            self._cld_target_ready = False
         gs = (self.loss_scale if grad_scale is None else grad_scale) * float(weight)
         self.lib.check(self.lib.seg_cldice_binary(
             _ptr(probs), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, d, h, w, self.ndim, int(width), float(gs),
-            _ptr(self._cld_ws), _ptr(self._cld_out), _ptr(dlogits) if dlogits is not None else None, self.stream()), "seg_cldice_binary")
+            _ptr(self._cld_ws), _ptr(self._cld_out), _ptr(dlogits) if dlogits is not None else None, ready, self.stream()), "seg_cldice_binary")
         return self._cld_out
 
     # ---- optimiser ------------------------------------------------------------------------------
@@ -302,6 +326,8 @@ class SegEngine:
         out3[0] then holds the sum (the clDice part alone is `self.last_cldice`).
         loss_exchange (parallel.GlobalBatchLoss): exact loss of the global batch over all ranks; the parameter gradients
         of the ranks are then summed, not averaged (the 1/world factor is dropped)."""
+        if cldice_weight:
+            self.cldice_prepare_target(target, x.shape[0], tuple(x.shape[2:]), cldice_width)     # overlaps the forward pass
         logits, probs = self.forward(x, mask_mode, masks, logits, probs)
         self._last_probs = probs
         out3 = self.loss_forward(logits, target, loss_name, focal_alpha, focal_gamma, class_alpha, exchange=loss_exchange)

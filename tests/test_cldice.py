@@ -101,7 +101,7 @@ def _first_class(pred, target, nd, dev, scale=1.0):
     out = torch.zeros(1, dtype=torch.float32, device=p.device)
     dl = torch.full_like(p, 0.25)                       # the entry point ADDS to what the companion loss left there
     lib.check(lib.seg_cldice_binary(p.data_ptr(), t.data_ptr(), _capi.LABEL_TYPES[str(t.dtype)], planes, d, h, w, nd, 10, float(scale),
-                                    ws.data_ptr(), out.data_ptr(), dl.data_ptr(), st), "seg_cldice_binary")
+                                    ws.data_ptr(), out.data_ptr(), dl.data_ptr(), 0, st), "seg_cldice_binary")
     return float(out.cpu()), (dl - 0.25).cpu()
 
 
