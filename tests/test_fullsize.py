@@ -15,6 +15,8 @@ And size-independent properties:
   * f16 / bf16 run dtypes stay within the Dice tolerance of the fp32 run on the same weights."""
 import os
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -275,3 +277,25 @@ def test_oracle_gradients_full_size_low_precision(tag, dtype, tol, med_tol, cos_
     assert rows[0][0] < tol, rows[0]
     assert med < med_tol, med
     assert min(c for _, _, _, c in rows) > cos_tol
+
+
+def test_c5_with_cldice_term_full_size():
+    """BASELINE configs[4] as worded — VNet3d 1x160^3 bf16 + clDice: the one-call clDice term at full size against the oracle's clDice on the
+    SAME probabilities (loss value; d loss / d logit through the sigmoid), then three train steps with it (finite, loss goes down)."""
+    kind, ndim, shape, ncls, _ = CONFIGS["C5_vnet3d"]
+    params, x, y, _, _ = oracle_eval("C5_vnet3d")
+    e = SegEngine(kind, ndim, shape[1], ncls, dtype="bf16", device=DEV)
+    e.load_state_dict(params)
+    xd, yd = x.to(DEV), y.to(DEV)
+    logits, probs = e.forward(xd)
+    dl = torch.zeros_like(logits)
+    cld = float(e.cldice_term(probs, yd, weight=1.0, dlogits=dl, grad_scale=1.0).cpu())
+    p = probs.detach().cpu().clone().requires_grad_(True)
+    ref = seg.binary_soft_cldice_loss(p, y.reshape(p.shape).float())
+    ref.backward()
+    assert abs(cld - float(ref.detach())) < 5e-6
+    want = (p.grad * p.detach() * (1 - p.detach())).reshape(dl.shape)
+    got = dl.cpu()
+    assert float((got - want).norm()) / float(want.norm()) < 2e-3
+    losses = [float(e.train_step(xd, yd, "BinaryDiceLoss", cldice_weight=1.0)[0]) for _ in range(3)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
