@@ -35,7 +35,8 @@ enum {
     SEG_LOSS_BINARY_ELDICE = 8,   /* model/losses.py:56-74   BinaryELDiceLoss */
     SEG_LOSS_BINARY_TVERSKY = 9,  /* model/losses.py:102-126 BinaryTverskyLoss (alpha 0.3, beta 0.7) */
     SEG_LOSS_MULTI_CE_DICE = 10,  /* model/losses.py:328-342 MutilCrossEntropyDiceLoss */
-    SEG_LOSS_MULTI_ELDICE = 11    /* model/losses.py:345-382 MutilELDiceLoss */
+    SEG_LOSS_MULTI_ELDICE = 11,   /* model/losses.py:345-382 MutilELDiceLoss */
+    SEG_LOSS_BINARY_SS = 12       /* model/losses.py:77-99   BinarySSLoss (sensitivity-specificity, r = 0.1) */
 };
 enum { SEG_MASKS_EVAL = 0, SEG_MASKS_GIVEN = 1, SEG_MASKS_RANDOM = 2 };
 

@@ -65,6 +65,7 @@ def make_losses_extra(losses):
             ("BinaryJaccardLoss", losses.BinaryJaccardLoss(), (z, y)),
             ("BinaryELDiceLoss", losses.BinaryELDiceLoss(), (z, y)),
             ("BinaryTverskyLoss", losses.BinaryTverskyLoss(), (z, y)),
+            ("BinarySSLoss", losses.BinarySSLoss(), (z, y)),
             ("MutilCrossEntropyDiceLoss", losses.MutilCrossEntropyDiceLoss(a), (z4, y4)),
             ("MutilELDiceLoss", losses.MutilELDiceLoss(a), (z4, y4))):
         zz = args[0].clone().requires_grad_(True)
@@ -278,12 +279,12 @@ def main():
         _nets, _losses, metric = ref_loader.load()
         make_metric_extra(metric)
         return
-    make_prepost()
-    if "--only-prepost" in sys.argv:
-        return
     if "--only-losses-extra" in sys.argv:
         _nets, losses, _metric = ref_loader.load()
         make_losses_extra(losses)
+        return
+    make_prepost()
+    if "--only-prepost" in sys.argv:
         return
     make_cldice()
     if "--only-cldice" in sys.argv:

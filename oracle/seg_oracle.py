@@ -373,6 +373,16 @@ def binary_tversky_loss(logits, y):
     return torch.clamp(1 - (tp + 1e-5) / (tp + 0.3 * fp + 0.7 * fn + 1e-5), 0, 2)
 
 
+def binary_ss_loss(logits, y):
+    """model/losses.py:77-99 BinarySSLoss: r * sum((p-y)^2 y) / (smooth + sum y) + (1-r) * sum((p-y)^2 (1-y)) / (smooth + sum (1-y)), r = 0.1"""
+    p = torch.sigmoid(logits).float().reshape(logits.shape[0], logits.shape[1], -1)
+    t = y.float().reshape(logits.shape[0], logits.shape[1], -1)
+    se = (p - t) ** 2
+    spec = (se * t).sum() / (1e-5 + t.sum())
+    sens = (se * (1 - t)).sum() / (1e-5 + (1 - t).sum())
+    return 0.1 * spec + 0.9 * sens
+
+
 def multi_ce_dice_loss(logits, y, alpha):
     """model/losses.py:337-342"""
     return multi_ce_loss(logits, y, alpha) + multi_dice_loss(logits, y, alpha)
@@ -395,6 +405,7 @@ LOSSES = {
     "BinaryJaccardLoss": binary_jaccard_loss,
     "BinaryELDiceLoss": binary_eldice_loss,
     "BinaryTverskyLoss": binary_tversky_loss,
+    "BinarySSLoss": binary_ss_loss,
     "MutilCrossEntropyDiceLoss": multi_ce_dice_loss,
     "MutilELDiceLoss": multi_eldice_loss,
     "BinaryDiceLoss": binary_dice_loss,

@@ -17,7 +17,7 @@ LABEL_TYPES = {"torch.uint8": 0, "torch.int32": 1, "torch.int64": 2, "torch.floa
 LOSS_KIND = {
     "BinaryDiceLoss": 0, "BinaryCrossEntropyLoss": 1, "BinaryFocalLoss": 2, "BinaryCrossEntropyDiceLoss": 3,
     "MutilCrossEntropyLoss": 4, "MutilFocalLoss": 5, "MutilDiceLoss": 6,
-    "BinaryJaccardLoss": 7, "BinaryELDiceLoss": 8, "BinaryTverskyLoss": 9, "MutilCrossEntropyDiceLoss": 10, "MutilELDiceLoss": 11,
+    "BinaryJaccardLoss": 7, "BinaryELDiceLoss": 8, "BinaryTverskyLoss": 9, "MutilCrossEntropyDiceLoss": 10, "MutilELDiceLoss": 11, "BinarySSLoss": 12,
 }
 MASKS_EVAL, MASKS_GIVEN, MASKS_RANDOM = 0, 1, 2
 KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head", "conv3_smallbox", "gn_group"]

@@ -1380,7 +1380,7 @@ static int fill_loss(LossArgs& a, const float* logits, const void* target, int l
     if (!logits || !target || !ws) return fail("loss: null pointer");
     if (c < 1 || c > 8) return fail("loss: classes must be 1..8");
     if (loss_kind < 0 || loss_kind >= L_KIND_COUNT) return fail("loss: unknown loss kind");
-    const bool binary_kind = loss_kind <= SEG_LOSS_BINARY_CE_DICE || (loss_kind >= L_BIN_JACCARD && loss_kind <= L_BIN_TVERSKY);
+    const bool binary_kind = loss_kind <= SEG_LOSS_BINARY_CE_DICE || (loss_kind >= L_BIN_JACCARD && loss_kind <= L_BIN_TVERSKY) || loss_kind == L_BIN_SS;
     if ((c == 1) != binary_kind) return fail("loss: binary losses need C == 1, multi-class losses C > 1");
     a.logits = logits; a.target = target; a.label_type = label_type; a.N = n; a.C = c; a.V = v; a.kind = loss_kind;
     a.focal_alpha = focal_alpha; a.focal_gamma = focal_gamma; a.class_alpha = nullptr; a.sums = (double*)ws;

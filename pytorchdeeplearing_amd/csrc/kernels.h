@@ -182,7 +182,7 @@ void launch_pack(const PackDesc* descs_dev, int ndesc, int max_rows, int dtype, 
 // Losses on planar fp32 logits [N][C][V]
 enum LossKind { L_BIN_DICE = 0, L_BIN_CE = 1, L_BIN_FOCAL = 2, L_BIN_CE_DICE = 3, L_MC_CE = 4, L_MC_FOCAL = 5, L_MC_DICE = 6,
                 // not selectable from the reference's wrappers: same reduction sums, different ratio
-                L_BIN_JACCARD = 7, L_BIN_ELDICE = 8, L_BIN_TVERSKY = 9, L_MC_CE_DICE = 10, L_MC_ELDICE = 11, L_KIND_COUNT = 12 };
+                L_BIN_JACCARD = 7, L_BIN_ELDICE = 8, L_BIN_TVERSKY = 9, L_MC_CE_DICE = 10, L_MC_ELDICE = 11, L_BIN_SS = 12, L_KIND_COUNT = 13 };
 struct LossArgs {
     const float* logits;
     const void* target; int label_type;

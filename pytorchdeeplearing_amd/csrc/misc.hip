@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
     if (C == 1) {
         const bool need_bce = a.kind == L_BIN_CE || a.kind == L_BIN_FOCAL || a.kind == L_BIN_CE_DICE;
         const bool need_focal = a.kind == L_BIN_FOCAL;
+        const bool need_ss = a.kind == L_BIN_SS;             // sensitivity-specificity: slots 3 / 4 carry sum p^2 and sum y*p^2 instead
         const long long base = (long long)n * a.V;
         for (long long v = v0 + tid; v < v1; v += 1024) {
             float z[4], y[4];
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
                 if (!ok[u]) continue;
                 const float p = 1.f / (1.f + expf(-z[u]));
                 g[0] += p * y[u]; g[1] += p; g[2] += y[u];
+                if (need_ss) { g[3] += p * p; g[4] += y[u] * p * p; }
                 if (need_bce) {
                     const float b = bce_with_logits(z[u], y[u]);
                     g[3] += b;
@@ -344,6 +346,13 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
             const double g = (v >= 0.0 && v <= 2.0) ? 0.3 * pow(t, -0.7) * (-1.0 / (dsc + smooth)) : 0.0;
             K[0] = g * 2.0 / D;
             K[1] = (P + Y + smooth < eps) ? 0.0 : -g * (2.0 * I + smooth) / (D * D);
+        } else if (a.kind == L_BIN_SS) {            // model/losses.py:77-99: r*sum((p-y)^2 y)/(smooth+Y) + (1-r)*sum((p-y)^2 (1-y))/(smooth+N-Y), r = 0.1
+            // y in {0,1}: sum (p-y)^2 y = sum y p^2 - 2 I + Y;  sum (p-y)^2 (1-y) = sum p^2 - sum y p^2
+            const double r = 0.1, P2 = S[3], YP2 = S[4];
+            const double ds = smooth + Y, db = smooth + (Ntot - Y);
+            loss = r * (YP2 - 2.0 * I + Y) / ds + (1.0 - r) * (P2 - YP2) / db;
+            K[0] = 2.0 * r / ds;                     // d loss / d p_i = K0 * y_i * (p_i - 1) + K1 * p_i * (1 - y_i)
+            K[1] = 2.0 * (1.0 - r) / db;
         } else if (a.kind == L_BIN_TVERSKY) {       // model/losses.py:102-126: alpha = 0.3 (false positives), beta = 0.7 (false negatives)
             const double al = 0.3, be = 0.7;
             const double den = I + al * (P - I) + be * (Y - I) + smooth;
@@ -429,7 +438,8 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
             const float y = (float)load_label(a.target, a.label_type, i);
             const float p = 1.f / (1.f + expf(-z));
             float dz = 0.f;
-            if (a.kind == L_BIN_DICE || a.kind == L_BIN_CE_DICE || a.kind >= L_BIN_JACCARD) dz += (k0 * y + k1) * p * (1.f - p);
+            if (a.kind == L_BIN_SS) dz += (k0 * y * (p - 1.f) + k1 * p * (1.f - y)) * p * (1.f - p);
+            else if (a.kind == L_BIN_DICE || a.kind == L_BIN_CE_DICE || a.kind >= L_BIN_JACCARD) dz += (k0 * y + k1) * p * (1.f - p);
             if (a.kind == L_BIN_CE || a.kind == L_BIN_CE_DICE) dz += (p - y) * kn;
             if (a.kind == L_BIN_FOCAL) {
                 const float b = bce_with_logits(z, y);

@@ -131,6 +131,11 @@ class BinaryTverskyLoss(_Loss):
     kind = "BinaryTverskyLoss"
 
 
+class BinarySSLoss(_Loss):
+    """model/losses.py:77-99 (sensitivity-specificity, r = 0.1)"""
+    kind = "BinarySSLoss"
+
+
 class MutilCrossEntropyDiceLoss(MutilDiceLoss):
     """model/losses.py:328-342: MutilDiceLoss(alpha) + MutilCrossEntropyLoss(alpha)"""
     kind = "MutilCrossEntropyDiceLoss"

@@ -50,7 +50,7 @@ def test_multiclass_iou_coeff_vs_reference_golden(dev, golden_dir):
     assert float(G["miou_a"]) > 0.05          # the fixture is not the trivial all-background case
 
 
-EXTRA_LOSSES = ["BinaryJaccardLoss", "BinaryELDiceLoss", "BinaryTverskyLoss", "MutilCrossEntropyDiceLoss", "MutilELDiceLoss"]
+EXTRA_LOSSES = ["BinaryJaccardLoss", "BinaryELDiceLoss", "BinaryTverskyLoss", "BinarySSLoss", "MutilCrossEntropyDiceLoss", "MutilELDiceLoss"]
 
 
 def test_oracle_extra_losses_equal_reference_golden(golden_dir):
