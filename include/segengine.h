@@ -90,6 +90,11 @@ int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* strea
 int seg_backward_ops(seg_handle h);
 int seg_backward_bucket(seg_handle h, double tail_fraction, int* op_split, long long* param_offset);
 int seg_backward_range(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, void* stream);
+/* the same with join = 0: the slice's weight gradients are released to the engine's side stream but `stream` does not wait for them;
+ * seg_side_wait(other_stream) makes ANOTHER stream (the one a collective is ordered after) wait for every weight gradient issued so far, so the
+ * backward pass itself never stalls at a bucket boundary.  The last slice of a pass must be run with join = 1 (or through seg_backward_range). */
+int seg_backward_slice(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, int join, void* stream);
+int seg_side_wait(seg_handle h, void* stream);
 
 int seg_set_loss_scale(seg_handle h, float scale);
 float seg_get_loss_scale(seg_handle h);

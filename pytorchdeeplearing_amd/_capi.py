@@ -42,6 +42,8 @@ SIGNATURES = {
     "seg_backward_ops": (_i, [_vp]),
     "seg_backward_bucket": (_i, [_vp, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "seg_backward_range": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "seg_backward_slice": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "seg_side_wait": (_i, [_vp, _vp]),
     "seg_set_loss_scale": (_i, [_vp, _f]),
     "seg_get_loss_scale": (_f, [_vp]),
     "seg_loss_ws_bytes": (_ll, [_i, _i]),

@@ -1325,7 +1325,23 @@ int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks,
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_forward: ") + hipGetErrorString(hipGetLastError()));
 }
 
+static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, int join, void* stream);
 int seg_backward_range(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, void* stream) {
+    return backward_slice(h, dlogits, zero_grads, op_begin, op_end, 1, stream);
+}
+int seg_backward_slice(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, int join, void* stream) {
+    return backward_slice(h, dlogits, zero_grads, op_begin, op_end, join, stream);
+}
+int seg_side_wait(seg_handle h, void* stream) {
+    if (check_handle(h)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->use_side && h->side) {
+        (void)hipEventRecord(h->side_done, h->side); (void)hipStreamWaitEvent(st, h->side_done, 0);
+        if (h->side2) { (void)hipEventRecord(h->side2_done, h->side2); (void)hipStreamWaitEvent(st, h->side2_done, 0); }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_side_wait: event error");
+}
+static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, int join, void* stream) {
     if (check_handle(h)) return -1;
     if (!h->ws || !h->g) return fail("seg_backward: gradients not bound");
     if (!dlogits) return fail("seg_backward: null dlogits");
@@ -1334,11 +1350,11 @@ int seg_backward_range(seg_handle h, const float* dlogits, int zero_grads, int o
     hipStream_t st = (hipStream_t)stream;
     if (zero_grads && op_begin == 0) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
-    h->ready_used = 0;
-    if (op_begin == 0) h->wgrad_seq = 0;
+    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; }
     if (h->pack_bwd_pending) { (void)hipStreamWaitEvent(st, h->pack_done, 0); h->pack_bwd_pending = false; }
     for (int i = op_begin; i < op_end; ++i) { h->bwd_ops[i](st); h->maybe_flush(st); }
-    h->join_side(st);
+    if (join) h->join_side(st);
+    else h->flush_side(st);          // the queued weight gradients of this slice are released; `stream` does not wait for them
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));
 }
 int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* stream) {

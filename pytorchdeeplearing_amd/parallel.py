@@ -26,7 +26,7 @@ class GradAllReduce:
 
 
 class BucketedGradAllReduce(GradAllReduce):
-    """Two buckets, overlapped with the backward pass.  Gradients finish in reverse registration order, so after the
+    """Buckets overlapped with the backward pass (two in round 1, up to four now).  Gradients finish in reverse registration order, so after the
     deepest level's backward ops a SUFFIX of the flat buffer (>= `tail_fraction` of the elements: the 256-/128-channel
     blocks and the whole decoder, ~80 % of VNet3d's 38 MB) is final: its all-reduce is issued asynchronously on the
     process group's own stream while the fine-level backward ops (the longest kernels of the step) still run; the head
@@ -34,9 +34,13 @@ class BucketedGradAllReduce(GradAllReduce):
     keep every link busy.  `SegEngine.train_step` drives it through seg_backward_bucket / seg_backward_range."""
     bucketed = True
 
-    def __init__(self, world_size=None, group=None, tail_fraction=0.5):
+    def __init__(self, world_size=None, group=None, tail_fraction=0.5, fractions=None):
         super().__init__(world_size, group)
         self.tail_fraction = tail_fraction
+        # bucket boundaries as finished fractions of the flat buffer.  Default: the deepest level + decoder (>= 50 %, in fact ~80 % of
+        # VNet3d), then the next encoder levels as they finish (97 %, 99.5 %), so that only a few hundred KB are left for the collective
+        # that nothing can hide any more (the one after the last backward op).  Boundaries that coincide are skipped.
+        self.fractions = tuple(fractions) if fractions is not None else (tail_fraction, 0.97, 0.995)
 
     def start(self, flat_slice: torch.Tensor):
         """asynchronous SUM all-reduce of one bucket (ordered after the work already queued on the current stream)."""
