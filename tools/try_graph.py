@@ -1,5 +1,8 @@
 """Experiment: whole train step captured in a HIP graph (torch.cuda.CUDAGraph around the C-ABI launches)."""
 import os, sys, time
+# a captured step must end with every forked stream joined: the backward-only weight layouts of the NEXT step are packed on the side stream at the
+# end of train_step and only joined by that step's backward pass, so the split is switched off for the capture
+os.environ.setdefault("SEG_PACK_SPLIT", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
