@@ -99,13 +99,17 @@ def cpu_model():
 def _quiet_stdout(fn, *args, **kw):
     """Run fn with file descriptor 1 pointed at stderr: MIOpen / composable_kernel print solver diagnostics with C-level printf
     while stock PyTorch searches its convolution kernels, and stdout of this script carries exactly ONE JSON line."""
+    import ctypes
+    libc = ctypes.CDLL(None)
     sys.stdout.flush()
+    libc.fflush(None)
     saved = os.dup(1)
     try:
         os.dup2(2, 1)
         return fn(*args, **kw)
     finally:
         sys.stdout.flush()
+        libc.fflush(None)          # the C library's own stdout buffer (printf from MIOpen / CK) must drain while fd 1 still points at stderr
         os.dup2(saved, 1)
         os.close(saved)
 
