@@ -214,6 +214,11 @@ def main(argv=None, checker_device=None):
     with the gloo backend, so the N > 1 path (barriers, bucketed exchange, MAX over ranks, the JSON line) is exercised on
     the GPU-less build box.  None = the real thing: one process per GPU, RCCL."""
     a = parse(argv)
+    # stdout carries exactly ONE JSON line: file descriptor 1 points at stderr for the whole run (RCCL prints a version banner, MIOpen / CK
+    # print solver diagnostics, all with C-level stdio) and comes back only for the final print
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -390,7 +395,12 @@ def main(argv=None, checker_device=None):
             line["cpu_baseline"], line["dice_vs_ref"], gt = cpu_baseline(S, sd, dev, a.dtype, batch=a.batch, gpu_leg=on_gpu)
             if gt is not None:
                 line["gpu_torch_baseline"] = gt
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_stdout_fd, 1)
         print(json.dumps(line))
+        sys.stdout.flush()
     if dist:
         dist.destroy_process_group()
 
