@@ -60,6 +60,11 @@ int seg_dropout_calls(seg_handle h);
 int seg_dropout_ld(seg_handle h);
 int seg_dropout_channels(seg_handle h, int call);
 
+/* SEG_MASKS_RANDOM forwards issued so far (the mask of draw k is a function of (seed, k)); a resumed run restores it so that the mask
+ * sequence continues instead of restarting (torch's generator state in the reference, model/modelVNet.py:570-596 under nn.Dropout3d). */
+long long seg_dropout_draws(seg_handle h);
+int seg_set_dropout_draws(seg_handle h, long long draws);
+
 /* Fix the batch shape (N, D, H, W; D ignored for ndim 2) and size the workspace. */
 int seg_plan(seg_handle h, int n, int d, int hgt, int wid);
 long long seg_workspace_bytes(seg_handle h);
@@ -115,7 +120,9 @@ int seg_loss_backward(const float* logits, const void* target, int label_type, i
  * count), so a rank-local loss is NOT the loss of the global batch.  seg_loss_forward == seg_loss_reduce followed by
  * seg_loss_finalize(n_global = n).  Across ranks: seg_loss_reduce, SUM-all-reduce the first seg_loss_shared_doubles()
  * doubles of `ws` (I, sum p, sum y, sum bce/nll, sum focal, per-class I_c / P_c / Y_c), seg_loss_finalize with
- * n_global = samples over all ranks, seg_loss_backward; parameter gradients are then SUMMED over ranks (not averaged).
+ * n_global = samples over all ranks (or 0: the count is read on the device - seg_loss_reduce leaves the local sample count in double
+ * [5] of `ws`, so the all-reduce of the shared doubles delivers the global count and unequal shards need no host read),
+ * seg_loss_backward; parameter gradients are then SUMMED over ranks (not averaged).
  * The metrics in out3[1..2] stay per-rank (they are per-sample means, model/metric.py:146-155). */
 int seg_loss_shared_doubles(void);
 int seg_loss_reduce(const float* logits, const void* target, int label_type, int n, int c, long long v,
@@ -160,6 +167,23 @@ int seg_metric(const float* probs, const void* target, int label_type, int n, in
 int seg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                   long long numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int decoupled, float inv_scale, int check_finite, int* state, void* stream);
+
+/* One whole optimisation step of the reference training loop (model/modelVNet.py:570-596: pred = model(x); loss = lossFunc(pred, y);
+ * opt.zero_grad(); loss.backward(); opt.step(), plus the accuracy line :587) enqueued by ONE call:
+ * [seg_pack_weights if !packed] -> seg_forward -> seg_loss_forward (out3 = {loss, dice, iou}) -> seg_loss_backward (times the loss
+ * scale) -> seg_backward(zero_grads = 1) -> seg_adam_step on the bound params / grads -> seg_pack_weights.  Same launches as the
+ * separate calls; the point is one FFI crossing per step.  The rank-local path only: gradient exchange, global-batch losses and the
+ * clDice term go through the separate entry points.  grad_div: extra gradient divisor (1 on a single rank). */
+typedef struct seg_train_args {
+    const float* x; const void* target; int label_type;
+    int loss_kind; float focal_alpha, focal_gamma; const float* class_alpha;
+    float* logits; float* probs; float* dlogits; void* loss_ws; float* out3;
+    int mask_mode; const float* masks; unsigned long long seed;
+    float* exp_avg; float* exp_avg_sq; int* opt_state;
+    float lr, beta1, beta2, eps, weight_decay; int decoupled; float grad_div; int check_finite;
+    int packed;      /* != 0: the run-dtype weight layouts are current (the previous seg_train_step left them so) */
+} seg_train_args;
+int seg_train_step(seg_handle h, const seg_train_args* a, void* stream);
 
 /* ---- operator-level entry points (what torch.nn.functional.conv3d / conv_transpose3d and their
  * autograd weight-gradients are to the reference: networks/VNet3d.py:8,28,29,49,65,70,88).  The
@@ -277,7 +301,7 @@ int seg_op_conv3x_num_cfgs(void);
 /* index in [0, num_cfgs): tiling id, ndim, box {d,h,w}, output channels per workgroup, resident 32-channel chunks, description */
 int seg_op_conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, char* name, int name_cap);
 int seg_op_conv3x_default_cfg(int ndim, int n, int d, int h, int wid, int cin, int cout, int dtype);
-/* sizeof of the structs above as compiled into the library: 0 conv, 1 wgrad, 2 pack, 3 stemx */
+/* sizeof of the structs of this header as compiled into the library: 0 conv, 1 wgrad, 2 pack, 3 stemx, 4 train */
 int seg_abi_sizeof(int which);
 
 /* ---- soft-clDice building blocks (model/lossescldice.py:5-59; corrected restatement).

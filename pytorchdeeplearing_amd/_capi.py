@@ -33,6 +33,8 @@ SIGNATURES = {
     "seg_dropout_calls": (_i, [_vp]),
     "seg_dropout_ld": (_i, [_vp]),
     "seg_dropout_channels": (_i, [_vp, _i]),
+    "seg_dropout_draws": (_ll, [_vp]),
+    "seg_set_dropout_draws": (_i, [_vp, _ll]),
     "seg_plan": (_i, [_vp, _i, _i, _i, _i]),
     "seg_workspace_bytes": (_ll, [_vp]),
     "seg_bind": (_i, [_vp, _vp, _vp, _vp]),
@@ -54,6 +56,7 @@ SIGNATURES = {
     "seg_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _f, _vp, _vp]),
     "seg_predict_mask": (_i, [_vp, _vp, _i, _i, _ll, C.c_float, _i, _vp]),
     "seg_metric": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp]),
+    "seg_train_step": (_i, [_vp, _vp, _vp]),
     "seg_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _i, _vp, _vp]),
     "seg_op_conv": (_i, [_vp, _i, _vp]),
     "seg_op_conv_kernel": (_i, [_vp]),
@@ -94,6 +97,17 @@ SIGNATURES = {
     "seg_last_error": (C.c_char_p, []),
     "seg_build_info": (C.c_char_p, []),
 }
+
+
+class TrainArgs(C.Structure):
+    """seg_train_args of include/segengine.h"""
+    _fields_ = [("x", _vp), ("target", _vp), ("label_type", _i),
+                ("loss_kind", _i), ("focal_alpha", _f), ("focal_gamma", _f), ("class_alpha", _vp),
+                ("logits", _vp), ("probs", _vp), ("dlogits", _vp), ("loss_ws", _vp), ("out3", _vp),
+                ("mask_mode", _i), ("masks", _vp), ("seed", C.c_ulonglong),
+                ("exp_avg", _vp), ("exp_avg_sq", _vp), ("opt_state", _vp),
+                ("lr", _f), ("beta1", _f), ("beta2", _f), ("eps", _f), ("weight_decay", _f), ("decoupled", _i), ("grad_div", _f),
+                ("check_finite", _i), ("packed", _i)]
 
 
 class SegLib:

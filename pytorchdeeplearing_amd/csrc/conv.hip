@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(StemArgs a) {
 // head: per-voxel dot products to numclass logits, planar fp32 outputs (the reference API returns
 // NC[D]HW float32 logits and probabilities).  One thread per voxel.
 // ------------------------------------------------------------------------------------------------
-constexpr int MAXCLS = 8;
+constexpr int MAXCLS = 16;      // class cap (misc.hip)
 
 template <class T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
@@ -544,15 +544,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
 
 // backward: din[m][ci] = sum_c dlogit[n][c][v] w[c][ci]; dw[c][ci] += sum_m dlogit*in; db[c] += sum dlogit.
 // grid = (slabs, N); thread = (voxel, 8-channel chunk), two voxels in flight; dw partials are reduced over the block in LDS.
-// NC = compile-time class count (0: runtime a.C <= MAXCLS, guarded full unroll so dw/db stay in registers); DIN = the data
+// NC = compile-time class count for 1..4 classes; NC = 8 / 16: runtime a.C <= NC (guarded full unroll so dw/db stay in registers); DIN = the data
 // gradient is materialised (the engine keeps it virtual: the consumer recomputes it from dlogits and the head weights).
 template <class T, int NC, bool DIN>
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
-    constexpr int CM = NC > 0 ? NC : MAXCLS;
+    constexpr int CM = NC;
     __shared__ float ws[MAXCLS * 64];
     __shared__ float red[256 * 9];
     const int tid = threadIdx.x, n = blockIdx.y;
-    const int C = NC > 0 ? NC : a.C;
+    const int C = NC <= 4 ? NC : a.C;
     for (int i = tid; i < C * a.Cin; i += 256) ws[i] = a.w[i];
     __syncthreads();
     const int CPR = a.Cin / 8;                 // chunks per voxel (power of two, <= 8)
@@ -663,7 +663,7 @@ static void head_bwd_dispatch(const HeadBwdArgs& a, dim3 grid, hipStream_t s) {
     if (a.din) hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<T, NC, true>), grid, dim3(256), 0, s, a);               \
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(head_bwd_kernel<T, NC, false>), grid, dim3(256), 0, s, a);
     if (a.C == 1) { SEG_HB(1) } else if (a.C == 2) { SEG_HB(2) } else if (a.C == 3) { SEG_HB(3) } else if (a.C == 4) { SEG_HB(4) }
-    else { SEG_HB(0) }
+    else if (a.C <= 8) { SEG_HB(8) } else { SEG_HB(16) }
 #undef SEG_HB
 }
 

@@ -1186,7 +1186,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (ndim != 2 && ndim != 3) return fail("seg_create: ndim must be 2 or 3");
     if (dtype < 0 || dtype > 2) return fail("seg_create: dtype must be SEG_F32/F16/BF16");
     if (init_features != 16) return fail("seg_create: init_features must be 16 (GroupNorm(8) tiles; the reference never overrides the default)");
-    if (num_class < 1 || num_class > 8) return fail("seg_create: num_class must be in 1..8");
+    if (num_class < 1 || num_class > 16) return fail("seg_create: num_class must be in 1..16");
     if (in_channels < 1 || in_channels > 3 || (ndim == 3 && in_channels > 1)) return fail("seg_create: in_channels must be 1 (3-D) or 1..3 (2-D)");
     seg_engine* e = new seg_engine();
     e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
@@ -1244,12 +1244,29 @@ int seg_dropout_channels(seg_handle h, int call) {
     return h->drop_ch[call];
 }
 
+long long seg_dropout_draws(seg_handle h) { return h ? (long long)h->draws : -1; }
+int seg_set_dropout_draws(seg_handle h, long long draws) {
+    if (check_handle(h)) return -1;
+    if (draws < 0 || draws > 0x7fffffffll) return fail("seg_set_dropout_draws: counter out of range");
+    h->draws = (int)draws;
+    if (h->ws) {          // bound: the device-side counter follows (seg_bind restores it from the host copy otherwise)
+        if (h->side) (void)hipStreamSynchronize(h->side);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h->ws + h->off_step, &h->draws, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            return fail("seg_set_dropout_draws: counter upload failed");
+    }
+    return 0;
+}
+
 int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
     if (check_handle(h)) return -1;
     if (n < 1) return fail("seg_plan: batch must be >= 1");
     if (h->ndim == 2) d = 1;
     if ((h->ndim == 3 && (d % 16 || d < 16)) || hgt % 16 || wid % 16 || hgt < 16 || wid < 16)
         return fail("seg_plan: spatial dims must be multiples of 16 (four 2x down-samplings)");
+    // a backward-only weight pack of the previous step may still be running on the (non-blocking) side stream into the workspace the
+    // caller is about to replace
+    if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }
+    if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->N = n; h->D = d; h->H = hgt; h->W = wid;
     g_err.clear();
     Planner pl(*h);
@@ -1265,6 +1282,8 @@ int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
     if (!h->planned) return fail("seg_bind: call seg_plan first");
     if (!params || !workspace) return fail("seg_bind: params/workspace must not be null");
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)workspace) & 255) return fail("seg_bind: buffers must be 256-byte aligned");
+    if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }     // see seg_plan
+    if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->p = params; h->g = grads; h->ws = (char*)workspace;
     // resolve and upload the weight re-layout descriptors; reset the device-side step counter
     std::vector<PackDesc> d = h->packdescs;
@@ -1394,7 +1413,7 @@ long long seg_loss_ws_bytes(int n, int c) { return (long long)align_up(loss_sums
 static int fill_loss(LossArgs& a, const float* logits, const void* target, int label_type, int n, int c, long long v,
                      int loss_kind, float focal_alpha, float focal_gamma, void* ws) {
     if (!logits || !target || !ws) return fail("loss: null pointer");
-    if (c < 1 || c > 8) return fail("loss: classes must be 1..8");
+    if (c < 1 || c > 16) return fail("loss: classes must be 1..16");
     if (loss_kind < 0 || loss_kind >= L_KIND_COUNT) return fail("loss: unknown loss kind");
     const bool binary_kind = loss_kind <= SEG_LOSS_BINARY_CE_DICE || (loss_kind >= L_BIN_JACCARD && loss_kind <= L_BIN_TVERSKY) || loss_kind == L_BIN_SS;
     if ((c == 1) != binary_kind) return fail("loss: binary losses need C == 1, multi-class losses C > 1");
@@ -1430,7 +1449,7 @@ int seg_loss_finalize(const float* logits, const void* target, int label_type, i
     LossArgs a;
     if (fill_loss(a, logits, target, label_type, n, c, v, loss_kind, focal_alpha, focal_gamma, ws)) return -1;
     if (!out3) return fail("seg_loss_finalize: out3 is null");
-    if (n_global < n) return fail("seg_loss_finalize: n_global must be >= the local sample count");
+    if (n_global != 0 && n_global < n) return fail("seg_loss_finalize: n_global must be >= the local sample count (or 0: the exchanged count)");
     a.class_alpha = class_alpha; a.out = out3; a.phase = 2; a.n_global = n_global;
     launch_loss_forward(a, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_loss_finalize: launch failed");
@@ -1502,7 +1521,7 @@ int seg_op_stitch_mask(const unsigned char* masks, const int* origins, int nb, i
 
 int seg_metric(const float* probs, const void* target, int label_type, int n, int c, long long v, void* ws, float* out2, void* stream) {
     if (!probs || !target || !ws || !out2) return fail("seg_metric: null pointer");
-    if (c < 1 || c > 8) return fail("seg_metric: classes must be 1..8");
+    if (c < 1 || c > 16) return fail("seg_metric: classes must be 1..16");
     launch_metric(probs, target, label_type, n, c, v, (double*)ws, out2, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_metric: launch failed");
 }
@@ -1519,6 +1538,29 @@ int seg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
     if (check_finite) launch_grad_check(grads, numel, state + 1, st);
     launch_adam(a, st);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_adam_step: launch failed");
+}
+
+// One optimisation step of the reference loop (model/modelVNet.py:570-596) enqueued by ONE call: the host side of a step is then a
+// single FFI crossing plus this function's launches (round 2: >= 6 crossings, each with Python argument marshalling and torch
+// stream look-ups, 0.7-4 ms of host time per 4.5 ms step depending on the box).
+int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
+    if (check_handle(h)) return -1;
+    if (!a) return fail("seg_train_step: args is null");
+    if (!h->ws || !h->g) return fail("seg_train_step: not bound");
+    if (!a->x || !a->target || !a->logits || !a->probs || !a->dlogits || !a->loss_ws || !a->out3)
+        return fail("seg_train_step: null tensor");
+    if (!a->exp_avg || !a->exp_avg_sq || !a->opt_state) return fail("seg_train_step: optimiser state is null");
+    if (!a->packed && seg_pack_weights(h, stream)) return -1;
+    if (seg_forward(h, a->x, a->mask_mode, a->masks, a->seed, a->logits, a->probs, stream)) return -1;
+    const long long v = h->vol(0);
+    if (seg_loss_forward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->class_alpha,
+                         a->loss_ws, a->out3, stream)) return -1;
+    if (seg_loss_backward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->loss_ws,
+                          h->loss_scale, a->dlogits, stream)) return -1;
+    if (seg_backward(h, a->dlogits, 1, stream)) return -1;
+    if (seg_adam_step(h->p, h->g, a->exp_avg, a->exp_avg_sq, h->nparam, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->decoupled,
+                      1.0f / (h->loss_scale * (a->grad_div > 0.f ? a->grad_div : 1.f)), a->check_finite, a->opt_state, stream)) return -1;
+    return seg_pack_weights(h, stream);
 }
 
 int seg_op_conv(const seg_conv_args* a, int dtype, void* stream) {
@@ -1612,7 +1654,7 @@ int seg_op_stemx(const seg_stemx_args* a, int mode, int ndim, int dtype, float* 
 }
 int seg_abi_sizeof(int which) {
     return which == 0 ? (int)sizeof(seg_conv_args) : which == 1 ? (int)sizeof(seg_wgrad_args) : which == 2 ? (int)sizeof(seg_pack_desc)
-                                                                                                           : (int)sizeof(seg_stemx_args);
+           : which == 3 ? (int)sizeof(seg_stemx_args) : (int)sizeof(seg_train_args);
 }
 
 #define SEG_OK(what) (hipGetLastError() == hipSuccess ? 0 : fail(what ": launch failed"))

@@ -168,8 +168,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolArgs a) {
 }
 
 // ---------------------------------------------------------------- losses + metrics
-constexpr int MAXCLS = 8;
-constexpr int S_GLOBAL = 0;                 // [0]=sum p*y [1]=sum p [2]=sum y [3]=sum bce|nll [4]=sum focal
+constexpr int MAXCLS = 16;                  // class cap (reference example.py:118,134,191 builds the multi-class wrappers with numclass=16);
+                                            // the kernels are instantiated with a register bound MC = 8 (C <= 8) or 16
+constexpr int S_GLOBAL = 0;                 // [0]=sum p*y [1]=sum p [2]=sum y [3]=sum bce|nll [4]=sum focal [5]=samples behind these sums
+constexpr int S_COUNT = 5;                  // written by the fold (phase 0/1), SUM-all-reduced with the rest: the global sample count on the device
 constexpr int S_CLASS = 8;                  // + 3*c : I_c, P_c, Y_c
 constexpr int S_METRIC = S_CLASS + 3 * MAXCLS;   // + ((n*C + c)*3) : inter, msum, ysum of thresholded masks
 inline __host__ __device__ int s_coef(int N, int C) { return S_METRIC + 3 * N * C; }   // + 4 + 2*MAXCLS coefficients
@@ -186,15 +188,16 @@ __device__ __forceinline__ float bce_with_logits(float z, float y) {
 // wave reduction, one LDS fold over the four waves and ONE set of fp64 atomics per block.
 constexpr int LOSS_VPB = 256 * 16;
 constexpr int LOSS_NVAL = 5 + 6 * MAXCLS;
+template <int MC>
 __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
     __shared__ float part[4][LOSS_NVAL];
     const int n = blockIdx.y, tid = threadIdx.x, C = a.C;
     const long long v0 = (long long)blockIdx.x * LOSS_VPB;
     const long long v1 = (v0 + LOSS_VPB < a.V) ? v0 + LOSS_VPB : a.V;
     float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    float cls[MAXCLS][3], met[MAXCLS][3];
+    float cls[MC][3], met[MC][3];
 #pragma unroll
-    for (int c = 0; c < MAXCLS; ++c)
+    for (int c = 0; c < MC; ++c)
 #pragma unroll
         for (int j = 0; j < 3; ++j) { cls[c][j] = 0.f; met[c][j] = 0.f; }
     if (C == 1) {
@@ -234,20 +237,20 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
         const bool need_focal = a.kind == L_MC_FOCAL;
         for (long long v = v0 + tid; v < v1; v += 256) {
             const int t = load_label(a.target, a.label_type, (long long)n * a.V + v);
-            float z[MAXCLS], mx = -3.0e38f;
+            float z[MC], mx = -3.0e38f;
 #pragma unroll
-            for (int c = 0; c < MAXCLS; ++c) {
+            for (int c = 0; c < MC; ++c) {
                 z[c] = (c < C) ? a.logits[((long long)n * C + c) * a.V + v] : -3.0e38f;
                 mx = fmaxf(mx, z[c]);
             }
-            float se = 0.f, e[MAXCLS];
+            float se = 0.f, e[MC];
 #pragma unroll
-            for (int c = 0; c < MAXCLS; ++c) { e[c] = (c < C) ? expf(z[c] - mx) : 0.f; se += e[c]; }
+            for (int c = 0; c < MC; ++c) { e[c] = (c < C) ? expf(z[c] - mx) : 0.f; se += e[c]; }
             const float inv = 1.f / se;
             const float lse = mx + logf(se);
             float zt = 0.f;
 #pragma unroll
-            for (int c = 0; c < MAXCLS; ++c) {
+            for (int c = 0; c < MC; ++c) {
                 if (c < C) {
                     const float p = e[c] * inv;
                     const float y = (c == t) ? 1.f : 0.f;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
         if (lane == 0) part[wv][j] = s;
     }
 #pragma unroll
-    for (int c = 0; c < MAXCLS; ++c)
+    for (int c = 0; c < MC; ++c)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (c < C) {
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
         for (int i = threadIdx.x; i < cnt_all; i += 64) {          // fold the replicas into copy 0
             double t = S[i];
             for (int rep = 1; rep < STAT_REP; ++rep) t += S[(long long)rep * loss_sums_count(N, C) + i];
-            S[i] = t;
+            S[i] = i == S_COUNT ? (double)N : t;
         }
         __syncthreads();
     }
@@ -315,7 +318,9 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
     if (threadIdx.x != 0 || a.phase == 1) return;
     double* K = S + s_coef(N, C);
     const double smooth = 1e-5, eps = 1e-7;
-    const double Ntot = (double)(a.n_global > 0 ? a.n_global : N) * (double)a.V;
+    // sample count behind the batch-global sums: the caller's n_global, or (phase 2 with n_global == 0) the count that was exchanged
+    // together with the sums - no host read on unequal shards
+    const double Ntot = (a.n_global > 0 ? (double)a.n_global : (a.phase == 2 ? S[S_COUNT] : (double)N)) * (double)a.V;
     double loss = 0.0;
     for (int i = 0; i < 4 + 2 * MAXCLS; ++i) K[i] = 0.0;
     if (C == 1) {
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
     a.out[2] = (float)(isum / nc);
 }
 
+template <int MC>
 __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
     const int C = a.C;
     const double* K = a.sums + s_coef(a.N, C);
@@ -454,17 +460,17 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
             const long long n = i / a.V, v = i % a.V;
             const int t = load_label(a.target, a.label_type, i);
-            float z[MAXCLS], p[MAXCLS], mx = -3.0e38f, se = 0.f;
+            float z[MC], p[MC], mx = -3.0e38f, se = 0.f;
             for (int c = 0; c < C; ++c) { z[c] = a.logits[(n * C + c) * a.V + v]; mx = fmaxf(mx, z[c]); }
             for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - mx); se += p[c]; }
             const float inv = 1.f / se;
             for (int c = 0; c < C; ++c) p[c] *= inv;
             const bool dice_like = a.kind == L_MC_DICE || a.kind == L_MC_CE_DICE || a.kind == L_MC_ELDICE;
             const bool ce_like = a.kind == L_MC_CE || a.kind == L_MC_FOCAL || a.kind == L_MC_CE_DICE;
-            float dz[MAXCLS];
+            float dz[MC];
             for (int c = 0; c < C; ++c) dz[c] = 0.f;
             if (dice_like) {
-                float gsum = 0.f, gc[MAXCLS];
+                float gsum = 0.f, gc[MC];
                 for (int c = 0; c < C; ++c) {
                     gc[c] = (float)K[4 + c] * ((c == t) ? 1.f : 0.f) + (float)K[4 + MAXCLS + c];
                     gsum += p[c] * gc[c];
@@ -671,11 +677,14 @@ void launch_loss_forward(const LossArgs& a, hipStream_t s) {
     }
     (void)hipMemsetAsync(a.sums, 0, loss_sums_count(a.N, a.C) * sizeof(double) * STAT_REP, s);
     dim3 grid(cdiv(a.V, LOSS_VPB), a.N);
-    hipLaunchKernelGGL(loss_reduce_kernel, grid, dim3(256), 0, s, a);
+    if (a.C <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(loss_reduce_kernel<8>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(loss_reduce_kernel<16>), grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, a);
 }
 void launch_loss_backward(const LossArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(loss_backward_kernel, dim3(ew_blocks((long long)a.N * a.V)), dim3(256), 0, s, a);
+    const dim3 grid(ew_blocks((long long)a.N * a.V));
+    if (a.C <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(loss_backward_kernel<8>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(loss_backward_kernel<16>), grid, dim3(256), 0, s, a);
 }
 
 void launch_metric(const float* probs, const void* target, int lt, int N, int C, long long V, double* sums, float* out2, hipStream_t s) {

@@ -62,15 +62,13 @@ class SegEngine:
         self._loss_ws = None
         self._out3 = None
         self._dlogits = None
-        # dropout stream: per-rank under data parallelism (sample n of rank 0 and of rank 1 must not share channel masks)
-        self.seed = 0x5EEDC0DE
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                self.seed ^= (dist.get_rank() * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-        except Exception:
-            pass
+        # dropout stream: per-rank under data parallelism (sample n of rank 0 and of rank 1 must not share channel masks).  The rank
+        # is resolved at the first engine-drawn forward (not here), so an engine built before init_process_group still gets its own
+        # stream; `seed` (constructor-independent base) and the draw counter travel with optimizer_state_dict().
+        self.base_seed = 0x5EEDC0DE
+        self._seed = None
         self.packed = False
+        self._targs = None
         # dynamic loss scaling for the f16 run dtype: the fused optimiser skips a step whose gradients overflow and tallies it on
         # the device; every `scale_check_every` steps the host reads the tally (one tiny sync) and halves the scale if anything
         # was skipped, doubles it again after `scale_growth_steps` clean steps (torch.cuda.amp.GradScaler's policy, coarse-grained)
@@ -87,6 +85,18 @@ class SegEngine:
                 self.h = None
         except Exception:
             pass
+
+    @property
+    def seed(self):
+        if self._seed is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            self._seed = self.base_seed ^ ((rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        return self._seed
+
+    @seed.setter
+    def seed(self, v):
+        self._seed = int(v) & 0xFFFFFFFFFFFFFFFF
 
     # ---- parameters -----------------------------------------------------------------------------
     def param_view(self, name, grad=False):
@@ -294,6 +304,25 @@ class SegEngine:
         self.exp_avg_sq = aligned_zeros_f32(self.numel, self.device)
         self.opt_state = torch.zeros(64, dtype=torch.int32, device=self.device)
 
+    def optimizer_state_dict(self):
+        """Everything a resumed run needs besides state_dict(): Adam moments and step, loss scale, dropout stream position."""
+        if self.exp_avg is None:
+            self.init_optimizer()
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": int(self.opt_state[0]),
+                "loss_scale": self.loss_scale, "dropout_seed": self.seed, "dropout_draws": int(self.lib.seg_dropout_draws(self.h))}
+
+    def load_optimizer_state_dict(self, sd):
+        if self.exp_avg is None:
+            self.init_optimizer()
+        with torch.no_grad():
+            self.exp_avg.copy_(sd["exp_avg"].to(self.device))
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"].to(self.device))
+            self.opt_state.zero_()
+            self.opt_state[0] = int(sd["step"])
+        self.loss_scale = float(sd["loss_scale"])
+        self.seed = int(sd["dropout_seed"])
+        self.lib.check(self.lib.seg_set_dropout_draws(self.h, int(sd["dropout_draws"])), "seg_set_dropout_draws")
+
     def adam_step(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decoupled=True, check_finite=None, grad_div=1.0):
         """grad_div: extra divisor of the gradient (world size after a SUM all-reduce), folded into the loss-scale factor."""
         if self.exp_avg is None:
@@ -331,6 +360,15 @@ class SegEngine:
         out3[0] then holds the sum (the clDice part alone is `self.last_cldice`).
         loss_exchange (parallel.GlobalBatchLoss): exact loss of the global batch over all ranks; the parameter gradients
         of the ranks are then summed, not averaged (the 1/world factor is dropped)."""
+        world = getattr(allreduce, "world", 1) if allreduce is not None else 1
+        xworld = loss_exchange.world if loss_exchange is not None else 1
+        if cldice_weight and xworld > 1:
+            # the clDice term is a rank-local ratio: under GlobalBatchLoss the summed (not averaged) gradients would carry it `world` times
+            raise NotImplementedError("train_step: cldice_weight together with a global-batch loss exchange is not supported; "
+                                      "use the per-rank (DDP) loss semantics for the clDice term")
+        if world == 1 and xworld == 1 and not cldice_weight:
+            return self._train_step_one_call(x, target, loss_name, lr, weight_decay, decoupled, focal_alpha, focal_gamma, class_alpha,
+                                             mask_mode, masks, logits, probs)
         if cldice_weight:
             self.cldice_prepare_target(target, x.shape[0], tuple(x.shape[2:]), cldice_width)     # overlaps the forward pass
         logits, probs = self.forward(x, mask_mode, masks, logits, probs)
@@ -340,8 +378,7 @@ class SegEngine:
         if cldice_weight:
             self.last_cldice = self.cldice_term(probs, target, cldice_weight, cldice_width, dlogits=dl)
             out3[0:1].add_(self.last_cldice, alpha=float(cldice_weight))
-        world = getattr(allreduce, "world", 1) if allreduce is not None else 1
-        grad_div = 1 if (loss_exchange is not None and loss_exchange.world > 1) else world
+        grad_div = 1 if xworld > 1 else world
         if allreduce is not None and getattr(allreduce, "bucketed", False) and world > 1:
             # buckets: every finished suffix of the flat gradient buffer is exchanged while the finer levels still run.  On the GPU the
             # collective is ordered after an auxiliary stream that waits for the main stream AND the weight-gradient stream, so the
@@ -377,22 +414,89 @@ class SegEngine:
                 allreduce(self.grads)
         self.adam_step(lr=lr, weight_decay=weight_decay, decoupled=decoupled, grad_div=grad_div)
         self.pack_weights()
-        self._steps_since_check += 1
-        if self.dtype in ("f16", "fp16", "float16") and self._steps_since_check >= self.scale_check_every:
-            self.update_loss_scale()
+        self._after_step()
         return out3
 
-    def update_loss_scale(self):
+    def _after_step(self):
+        self._steps_since_check += 1
+        if self.dtype in ("f16", "fp16", "float16") and self._steps_since_check >= self.scale_check_every:
+            self.update_loss_scale(blocking=False)
+
+    def _train_step_one_call(self, x, target, loss_name, lr, weight_decay, decoupled, focal_alpha, focal_gamma, class_alpha,
+                             mask_mode, masks, logits, probs):
+        """The rank-local step as ONE library call (seg_train_step): the argument block is filled once per (shape, buffers) and only
+        the pointers that change are rewritten, so the host side of a step is one FFI crossing."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.device.type == self.device.type
+        self.plan(x.shape[0], x.shape[2:])
+        if self.exp_avg is None:
+            self.init_optimizer()
+        oshape = (x.shape[0], self.numclass) + tuple(x.shape[2:])
+        if logits is None:
+            logits = torch.empty(oshape, dtype=torch.float32, device=self.device)
+        if probs is None:
+            probs = torch.empty(oshape, dtype=torch.float32, device=self.device)
+        target = target.contiguous()
+        mt = self.mask_table(masks) if mask_mode == _capi.MASKS_GIVEN else None
+        a = self._targs
+        if a is None:
+            a = self._targs = _capi.TrainArgs()
+            a.beta1, a.beta2, a.eps, a.grad_div = 0.9, 0.999, 1e-8, 1.0
+        a.x, a.target, a.label_type = x.data_ptr(), target.data_ptr(), _capi.LABEL_TYPES[str(target.dtype)]
+        a.loss_kind, a.focal_alpha, a.focal_gamma = _capi.LOSS_KIND[loss_name], float(focal_alpha), float(focal_gamma)
+        a.class_alpha = class_alpha.data_ptr() if class_alpha is not None else None
+        a.logits, a.probs, a.dlogits = logits.data_ptr(), probs.data_ptr(), self._dlogits.data_ptr()
+        a.loss_ws, a.out3 = self._loss_ws.data_ptr(), self._out3.data_ptr()
+        a.mask_mode, a.masks, a.seed = int(mask_mode), (mt.data_ptr() if mt is not None else None), self.seed
+        a.exp_avg, a.exp_avg_sq, a.opt_state = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.opt_state.data_ptr()
+        a.lr, a.weight_decay, a.decoupled = float(lr), float(weight_decay), 1 if decoupled else 0
+        a.check_finite = 1 if self.dtype in ("f16", "fp16", "float16") else 0
+        a.packed = 1 if self.packed else 0
+        self.lib.check(self.lib.seg_train_step(self.h, C.byref(a), self.stream()), "seg_train_step")
+        self.packed = True
+        self._keep = (x, mt)
+        self._keep_loss = (target, class_alpha)
+        self._last_probs = probs
+        self._after_step()
+        return self._out3
+
+    def update_loss_scale(self, blocking=True):
         """Read the device-side tally of skipped (overflowed) optimiser steps and adapt the loss scale; returns the number of
-        steps skipped since the last call.  A run whose gradients overflow persistently is reported instead of silently
-        training nothing."""
+        skipped steps applied by this call.  A run whose gradients overflow persistently is reported instead of silently
+        training nothing.  blocking=False (what train_step uses): the tally is snapshotted to pinned host memory asynchronously
+        (copy, then clear, in stream order) and applied at the NEXT check, so the step never waits for the device; the policy then
+        lags by one interval."""
         n = self._steps_since_check
         self._steps_since_check = 0
         if self.opt_state is None:
             return 0
-        skipped = int(self.opt_state[2].item())
+        pend = getattr(self, "_tally_pending", None)
+        if blocking or self.device.type != "cuda":
+            skipped = int(self.opt_state[2].item())
+            if skipped:
+                self.opt_state[2:3].zero_()
+            if pend is not None:
+                pend[1].synchronize()
+                skipped += int(pend[0][0])
+                n += pend[2]
+                self._tally_pending = None
+            return self._apply_tally(skipped, n)
+        applied = 0
+        if pend is not None:
+            if not pend[1].query():              # the previous snapshot has not landed yet: look again at the next step
+                self._steps_since_check = n
+                return 0
+            applied = self._apply_tally(int(pend[0][0]), pend[2])
+        if getattr(self, "_tally_host", None) is None:
+            self._tally_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._tally_host.copy_(self.opt_state[2:3], non_blocking=True)
+        self.opt_state[2:3].zero_()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._tally_pending = (self._tally_host, ev, n)
+        return applied
+
+    def _apply_tally(self, skipped, n):
         if skipped:
-            self.opt_state[2] = 0
             self.skipped_steps += skipped
             self._clean_steps = 0
             new = max(self.loss_scale * 0.5, 1.0)

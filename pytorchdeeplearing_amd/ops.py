@@ -56,6 +56,7 @@ def check_abi(lib):
     assert lib.dll.seg_abi_sizeof(0) == C.sizeof(ConvArgs), (lib.dll.seg_abi_sizeof(0), C.sizeof(ConvArgs))
     assert lib.dll.seg_abi_sizeof(1) == C.sizeof(WgradArgs)
     assert lib.dll.seg_abi_sizeof(2) == C.sizeof(PackDesc)
+    assert lib.dll.seg_abi_sizeof(4) == C.sizeof(_capi.TrainArgs), (lib.dll.seg_abi_sizeof(4), C.sizeof(_capi.TrainArgs))
 
 
 def make_taps(ndim, k, pad):

@@ -62,22 +62,18 @@ class GlobalBatchLoss:
     finalize kernel with the rank's batch-global sums (32 fp64 values, on the device); returns the global sample count.
     One tiny SUM all-reduce; the parameter gradients are then summed over ranks instead of averaged."""
 
-    def __init__(self, world_size=None, group=None, equal_shards=False):
+    def __init__(self, world_size=None, group=None, equal_shards=True):
         self.group = group
         self.world = world_size if world_size is not None else dist.get_world_size(group)
-        self.equal_shards = equal_shards     # True: every rank holds the same sample count (no count exchange, no host sync)
+        # True: every rank holds the same sample count, the global count is n_local * world.  False (a partial last batch): the
+        # count is taken from the exchanged sums ON THE DEVICE (seg_loss_reduce leaves the local sample count in the shared
+        # doubles, the all-reduce sums it, seg_loss_finalize(n_global = 0) reads it) - neither variant allocates or reads back
+        self.equal_shards = equal_shards
 
     def __call__(self, shared_sums: torch.Tensor, n_local: int):
-        if self.world > 1 and self.equal_shards:
-            dist.all_reduce(shared_sums, op=dist.ReduceOp.SUM, group=self.group)
-            return n_local * self.world
         if self.world > 1:
-            # the local sample count rides along (one extra double): shards may be unequal (partial last batch), and the
-            # 1/N of the CE / focal means (model/losses.py:259) must use the TRUE global count
-            buf = torch.cat([shared_sums, torch.tensor([float(n_local)], dtype=shared_sums.dtype, device=shared_sums.device)])
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            shared_sums.copy_(buf[:-1])
-            return int(round(float(buf[-1])))
+            dist.all_reduce(shared_sums, op=dist.ReduceOp.SUM, group=self.group)
+            return n_local * self.world if self.equal_shards else 0
         return n_local
 
 

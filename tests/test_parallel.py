@@ -103,7 +103,7 @@ def _worker_global(rank, world, port, q, ncls, loss, bucketed=False):
     e = SegEngine(kind, 2, 1, ncls, dtype="f32", device="cpu")
     e.load_state_dict(seg.perturb_params(seg.init_params(kind, 2, 1, ncls, seed=0), seed=7))
     x, y = seg.synthetic_batch(shape[0], shape[2:], 1, ncls, seed=100 + rank)
-    ar, ex = (BucketedGradAllReduce() if bucketed else GradAllReduce()), GlobalBatchLoss()
+    ar, ex = (BucketedGradAllReduce() if bucketed else GradAllReduce()), GlobalBatchLoss(equal_shards=False)   # count exchanged on the device
     losses = []
     for it in range(2):
         g = torch.Generator().manual_seed(10 * it + rank)
