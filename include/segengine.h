@@ -36,7 +36,12 @@ enum {
     SEG_LOSS_BINARY_TVERSKY = 9,  /* model/losses.py:102-126 BinaryTverskyLoss (alpha 0.3, beta 0.7) */
     SEG_LOSS_MULTI_CE_DICE = 10,  /* model/losses.py:328-342 MutilCrossEntropyDiceLoss */
     SEG_LOSS_MULTI_ELDICE = 11,   /* model/losses.py:345-382 MutilELDiceLoss */
-    SEG_LOSS_BINARY_SS = 12       /* model/losses.py:77-99   BinarySSLoss (sensitivity-specificity, r = 0.1) */
+    SEG_LOSS_BINARY_SS = 12,      /* model/losses.py:77-99   BinarySSLoss (sensitivity-specificity, r = 0.1) */
+    SEG_LOSS_MULTI_TVERSKY = 13,  /* model/losses.py:421-459 MutilTverskyLoss: class_alpha = its alpha tensor (class weight AND false-positive weight);
+                                     beta (never defined by the class; set by the caller) is passed in the focal_gamma argument */
+    SEG_LOSS_MULTI_SS = 14,       /* model/losses.py:385-418 MutilSSLoss: r (never defined by the class) is passed in the focal_gamma argument */
+    SEG_LOSS_BINARY_MCC = 15      /* model/losses.py:200-232 MCC_Loss: the `logits` argument holds PROBABILITIES (its `inputs`), dlogits = d loss / d inputs;
+                                     torch.add(a, 1, b) read as a + 1*b (the torch 1.x signature the reference was written for) */
 };
 enum { SEG_MASKS_EVAL = 0, SEG_MASKS_GIVEN = 1, SEG_MASKS_RANDOM = 2 };
 
@@ -130,6 +135,15 @@ int seg_loss_reduce(const float* logits, const void* target, int label_type, int
 int seg_loss_finalize(const float* logits, const void* target, int label_type, int n, int c, long long v,
                       int loss_kind, float focal_alpha, float focal_gamma, const float* class_alpha,
                       int n_global, void* ws, float* out3, void* stream);
+/* Lovasz losses (model/lovasz.py:20-141 through model/losses.py:235-242 BinaryLovaszLoss and :462-473 LovaszLoss; per_image = False, no
+ * ignore index).  x: fp32 [n][c][v].  c == 1: Lovasz hinge on logits, target in {0,1}.  c > 1: the reference's LovaszLoss, which hands
+ * its `logits` argument to _lovasz_softmax as class probabilities WITHOUT a soft-max - x is used as given (pass probabilities for the
+ * published Lovasz-Softmax); classes = 'present', mean over the present classes.  One radix sort of n*v (error, index) pairs per class.
+ * out1[0] = loss; dx [n][c][v] = d loss / d x (written by the forward pass - the backward is a scaling by the incoming gradient).
+ * ws: seg_lovasz_ws_bytes(n, v) bytes.  n*v < 2^32. */
+long long seg_lovasz_ws_bytes(int n, long long v);
+int seg_lovasz_forward(const float* x, const void* target, int label_type, int n, int c, long long v, void* ws, float* out1, float* dx,
+                       void* stream);
 /* predict() post-processing on the device (modelVNet.py:670-676): probs [N][C][V] fp32 -> uint8 mask [N][V];
  * C == 1: (p > threshold) * scale (scale 255 or 1); C > 1: first arg-max over the class axis. */
 int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long long v, float threshold, int scale, void* stream);

@@ -73,8 +73,35 @@ def make_losses_extra(losses):
         val.backward()
         out["loss_" + name] = _np(val)
         out["grad_" + name] = _np(zz.grad)
+    # ---- the rest of model/losses.py (round 3).  LOSS_REPAIRS: what a user of the reference has to do before these classes run at all
+    tv = losses.MutilTverskyLoss(a); tv.beta = 0.7
+    ss = losses.MutilSSLoss(a); ss.r = 0.1
+    p = torch.sigmoid(z)
+    lov_z = torch.randn(2, 8, 8, 8)                  # BinaryLovaszLoss takes [B, ...] logits and labels of the same shape
+    out["lov_z"] = _np(lov_z)
+    for name, f, args in (
+            ("MutilTverskyLoss", tv, (z4, y4)),
+            ("MutilSSLoss", ss, (z4, y4)),
+            ("MCC_Loss", losses.MCC_Loss(), (p, y.unsqueeze(1).float())),
+            ("BinaryLovaszLoss", losses.BinaryLovaszLoss().forward, (lov_z, y)),
+            ("LovaszLoss", losses.LovaszLoss(), (z4, y4))):
+        zz = args[0].clone().requires_grad_(True)
+        val = f(zz, args[1])
+        val.backward()
+        out["loss_" + name] = _np(val)
+        out["grad_" + name] = _np(zz.grad)
     np.savez_compressed(os.path.join(OUT, "losses_extra.npz"), **out)
     print("extra losses:", {k: float(v) for k, v in out.items() if k.startswith("loss_")})
+
+
+LOSS_REPAIRS = (
+    ("MutilTverskyLoss", "instance attribute beta = 0.7", "losses.py:449 reads self.beta, which __init__ (:431-434) never sets; 0.7 is BinaryTverskyLoss's value (:111)"),
+    ("MutilSSLoss", "instance attribute r = 0.1", "losses.py:413 reads self.r, which __init__ (:395-398) never sets; 0.1 is BinarySSLoss's value (:84)"),
+    ("BinaryLovaszLoss", "called through .forward()", "losses.py:237 calls super(BinaryLovaszLoss).__init__() (unbound super): nn.Module.__init__ never runs, "
+                                                      "so __call__ fails on the missing hook tables; forward() itself runs as written"),
+    ("MCC_Loss", "none", "losses.py:224-227 use the torch 1.x overload torch.add(input, alpha, other) = input + alpha*other, still accepted (deprecated) by torch 2.10"),
+    ("LovaszLoss", "none", "losses.py:473 hands the logits to _lovasz_softmax as `probas`; no soft-max is applied - reproduced as written"),
+)
 
 
 METRIC_REPAIRS = (

@@ -401,7 +401,88 @@ def multi_eldice_loss(logits, y, alpha):
     return torch.clamp(torch.pow(-torch.log(dice + 1e-5), 0.3).sum() / torch.count_nonzero(mask), 0, 2)
 
 
+def multi_tversky_loss(logits, y, alpha, beta=0.7):
+    """model/losses.py:421-459 MutilTverskyLoss; `self.beta` is never defined by the class - the caller sets it (0.7 here, the
+    BinaryTverskyLoss value); alpha is BOTH the class weight and the false-positive weight, as written"""
+    z, t = _mc_flat(logits, y)
+    p = torch.softmax(z, dim=1)
+    oh = F.one_hot(t, z.shape[1]).permute(0, 2, 1)
+    al = alpha.to(p.dtype)
+    tp = torch.sum(p * oh, dim=(0, 2))
+    fp = torch.sum(p * (1 - oh), dim=(0, 2))
+    fn = torch.sum((1 - p) * oh, dim=(0, 2))
+    tv = -(tp + 1e-5) / (tp + al * fp + beta * fn + 1e-5)
+    mask = oh.sum((0, 2)) > 0
+    return (tv * mask.to(tv.dtype) * al).sum() / torch.count_nonzero(mask)
+
+
+def multi_ss_loss(logits, y, alpha, r=0.1):
+    """model/losses.py:385-418 MutilSSLoss; `self.r` is never defined by the class - the caller sets it (0.1 here, the BinarySSLoss
+    value); both denominators are sum(y_true) + smooth, as written"""
+    z, t = _mc_flat(logits, y)
+    p = torch.softmax(z, dim=1)
+    oh = F.one_hot(t, z.shape[1]).permute(0, 2, 1)
+    se = (oh - p) ** 2
+    ysum = torch.sum(oh, dim=(0, 2)) + 1e-5
+    spec = torch.sum(se * oh, dim=(0, 2)) / ysum
+    sens = torch.sum(se * (1 - oh), dim=(0, 2)) / ysum
+    ss = r * spec + (1 - r) * sens
+    mask = oh.sum((0, 2)) > 0
+    return (ss * mask.to(ss.dtype) * alpha.to(ss.dtype)).sum() / torch.count_nonzero(mask)
+
+
+def mcc_loss(inputs, targets):
+    """model/losses.py:200-232 MCC_Loss on PROBABILITIES; torch.add(a, 1, b) is the torch 1.x overload a + 1*b"""
+    p, t = inputs.float(), targets.float()
+    tp = (p * t).sum(); tn = ((1 - p) * (1 - t)).sum(); fp = (p * (1 - t)).sum(); fn = ((1 - p) * t).sum()
+    num = tp * tn - fp * fn
+    den = torch.sqrt((tp + fp) * (tp + fn) * (tn + fp) * (tn + fn))
+    return 1 - num / (den + 1.0)
+
+
+def _lovasz_grad(gt_sorted):
+    """model/lovasz.py:20-31"""
+    gts = gt_sorted.sum()
+    inter = gts - gt_sorted.float().cumsum(0)
+    union = gts + (1 - gt_sorted).float().cumsum(0)
+    jac = 1.0 - inter / union
+    if len(gt_sorted) > 1:
+        jac = torch.cat([jac[:1], jac[1:] - jac[:-1]])
+    return jac
+
+
+def binary_lovasz_loss(logits, y):
+    """model/losses.py:235-242 BinaryLovaszLoss(per_image=False, ignore_index=None) -> model/lovasz.py:34-71 hinge over the whole batch"""
+    z, t = logits.reshape(-1), y.reshape(-1)
+    signs = 2.0 * t.float() - 1.0
+    errors = 1.0 - z * signs
+    es, perm = torch.sort(errors, dim=0, descending=True)
+    return torch.dot(F.relu(es), _lovasz_grad(t[perm]))
+
+
+def multi_lovasz_loss(logits, y, alpha=None):
+    """model/losses.py:462-473 LovaszLoss(per_image=False, ignore=None) -> model/lovasz.py:90-141: the reference hands the LOGITS to
+    _lovasz_softmax as `probas` (no soft-max is applied anywhere on the way), classes='present', mean over the present classes"""
+    C = logits.shape[1]
+    pr = torch.movedim(logits, 1, -1).reshape(-1, C)
+    t = y.reshape(-1)
+    out = []
+    for c in range(C):
+        fg = (t == c).to(pr.dtype)
+        if fg.sum() == 0:
+            continue
+        errors = (fg - pr[:, c]).abs()
+        es, perm = torch.sort(errors, 0, descending=True)
+        out.append(torch.dot(es, _lovasz_grad(fg[perm])))
+    return sum(out) / len(out)
+
+
 LOSSES = {
+    "MutilTverskyLoss": multi_tversky_loss,
+    "MutilSSLoss": multi_ss_loss,
+    "MCC_Loss": mcc_loss,
+    "BinaryLovaszLoss": binary_lovasz_loss,
+    "LovaszLoss": multi_lovasz_loss,
     "BinaryJaccardLoss": binary_jaccard_loss,
     "BinaryELDiceLoss": binary_eldice_loss,
     "BinaryTverskyLoss": binary_tversky_loss,
@@ -420,7 +501,7 @@ LOSSES = {
 
 def loss_fn(name, alpha=None, gamma=None):
     f = LOSSES[name]
-    if name in ("MutilDiceLoss", "MutilCrossEntropyDiceLoss", "MutilELDiceLoss"):
+    if name in ("MutilDiceLoss", "MutilCrossEntropyDiceLoss", "MutilELDiceLoss", "MutilTverskyLoss", "MutilSSLoss"):
         return lambda z, y: f(z, y, alpha)
     if name == "MutilFocalLoss":
         return lambda z, y: f(z, y, alpha, 2 if gamma is None else gamma)

@@ -18,6 +18,7 @@ LOSS_KIND = {
     "BinaryDiceLoss": 0, "BinaryCrossEntropyLoss": 1, "BinaryFocalLoss": 2, "BinaryCrossEntropyDiceLoss": 3,
     "MutilCrossEntropyLoss": 4, "MutilFocalLoss": 5, "MutilDiceLoss": 6,
     "BinaryJaccardLoss": 7, "BinaryELDiceLoss": 8, "BinaryTverskyLoss": 9, "MutilCrossEntropyDiceLoss": 10, "MutilELDiceLoss": 11, "BinarySSLoss": 12,
+    "MutilTverskyLoss": 13, "MutilSSLoss": 14, "MCC_Loss": 15,
 }
 MASKS_EVAL, MASKS_GIVEN, MASKS_RANDOM = 0, 1, 2
 KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head", "conv3_smallbox", "gn_group"]
@@ -54,6 +55,8 @@ SIGNATURES = {
     "seg_loss_reduce": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _vp]),
     "seg_loss_finalize": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _i, _vp, _vp, _vp]),
     "seg_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _f, _f, _vp, _f, _vp, _vp]),
+    "seg_lovasz_ws_bytes": (_ll, [_i, _ll]),
+    "seg_lovasz_forward": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp]),
     "seg_predict_mask": (_i, [_vp, _vp, _i, _i, _ll, C.c_float, _i, _vp]),
     "seg_metric": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp]),
     "seg_train_step": (_i, [_vp, _vp, _vp]),

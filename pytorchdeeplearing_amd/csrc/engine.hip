@@ -1415,7 +1415,8 @@ static int fill_loss(LossArgs& a, const float* logits, const void* target, int l
     if (!logits || !target || !ws) return fail("loss: null pointer");
     if (c < 1 || c > 16) return fail("loss: classes must be 1..16");
     if (loss_kind < 0 || loss_kind >= L_KIND_COUNT) return fail("loss: unknown loss kind");
-    const bool binary_kind = loss_kind <= SEG_LOSS_BINARY_CE_DICE || (loss_kind >= L_BIN_JACCARD && loss_kind <= L_BIN_TVERSKY) || loss_kind == L_BIN_SS;
+    const bool binary_kind = loss_kind <= SEG_LOSS_BINARY_CE_DICE || (loss_kind >= L_BIN_JACCARD && loss_kind <= L_BIN_TVERSKY) || loss_kind == L_BIN_SS ||
+                             loss_kind == L_BIN_MCC;
     if ((c == 1) != binary_kind) return fail("loss: binary losses need C == 1, multi-class losses C > 1");
     a.logits = logits; a.target = target; a.label_type = label_type; a.N = n; a.C = c; a.V = v; a.kind = loss_kind;
     a.focal_alpha = focal_alpha; a.focal_gamma = focal_gamma; a.class_alpha = nullptr; a.sums = (double*)ws;
@@ -1463,6 +1464,20 @@ int seg_loss_backward(const float* logits, const void* target, int label_type, i
     a.dlogits = dlogits; a.grad_scale = grad_scale;
     launch_loss_backward(a, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_loss_backward: launch failed");
+}
+
+long long seg_lovasz_ws_bytes(int n, long long v) {
+    if (n < 1 || v < 1) return fail("seg_lovasz_ws_bytes: empty batch");
+    const long long b = lovasz_ws_bytes((long long)n * v);
+    return b < 0 ? fail("seg_lovasz_ws_bytes: element count must be below 2^32 (and the sort library must be usable)") : b;
+}
+int seg_lovasz_forward(const float* x, const void* target, int label_type, int n, int c, long long v, void* ws, float* out1, float* dx,
+                       void* stream) {
+    if (!x || !target || !ws || !out1 || !dx) return fail("seg_lovasz_forward: null pointer");
+    if (n < 1 || v < 1 || c < 1 || c > 16) return fail("seg_lovasz_forward: classes must be 1..16, batch and volume non-empty");
+    if ((long long)n * v >= (1ll << 32)) return fail("seg_lovasz_forward: element count must be below 2^32");
+    if (launch_lovasz(x, target, label_type, n, c, v, ws, out1, dx, (hipStream_t)stream)) return fail("seg_lovasz_forward: sort / scan failed");
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_lovasz_forward: launch failed");
 }
 
 int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long long v, float threshold, int scale, void* stream) {

@@ -182,7 +182,10 @@ void launch_pack(const PackDesc* descs_dev, int ndesc, int max_rows, int dtype, 
 // Losses on planar fp32 logits [N][C][V]
 enum LossKind { L_BIN_DICE = 0, L_BIN_CE = 1, L_BIN_FOCAL = 2, L_BIN_CE_DICE = 3, L_MC_CE = 4, L_MC_FOCAL = 5, L_MC_DICE = 6,
                 // not selectable from the reference's wrappers: same reduction sums, different ratio
-                L_BIN_JACCARD = 7, L_BIN_ELDICE = 8, L_BIN_TVERSKY = 9, L_MC_CE_DICE = 10, L_MC_ELDICE = 11, L_BIN_SS = 12, L_KIND_COUNT = 13 };
+                L_BIN_JACCARD = 7, L_BIN_ELDICE = 8, L_BIN_TVERSKY = 9, L_MC_CE_DICE = 10, L_MC_ELDICE = 11, L_BIN_SS = 12,
+                L_MC_TVERSKY = 13, L_MC_SS = 14,
+                L_BIN_MCC = 15,            // the ONE kind whose input is a probability map, not logits (model/losses.py:200-232)
+                L_KIND_COUNT = 16 };
 struct LossArgs {
     const float* logits;
     const void* target; int label_type;
@@ -201,6 +204,11 @@ int loss_shared_count();        // leading doubles of `sums` that are batch-glob
 __host__ __device__ size_t loss_sums_count(int N, int C);   // doubles per replica (STAT_REP replicas)
 void launch_loss_forward(const LossArgs& a, hipStream_t s);    // reduce + finalize (writes out[], coefficient block in sums)
 void launch_loss_backward(const LossArgs& a, hipStream_t s);   // dlogits from the finalized coefficients
+
+// Lovasz hinge (C == 1) / Lovasz "softmax" on raw scores (C > 1), lovasz.hip: out1[0] = loss, dx = d loss / d x [N][C][V]; returns <0 on a
+// library (sort / scan) failure.  ws: lovasz_ws_bytes(N*V) bytes (<0: unsupported element count)
+long long lovasz_ws_bytes(long long P);
+int launch_lovasz(const float* x, const void* target, int label_type, int N, int C, long long V, void* ws, float* out1, float* dx, hipStream_t s);
 
 // dice / iou on probabilities (model/metric.py): out2 = {dice, iou}; sums = 3*N*C doubles (zeroed by the launcher)
 void launch_metric(const float* probs, const void* target, int label_type, int N, int C, long long V, double* sums, float* out2, hipStream_t s);

@@ -172,8 +172,9 @@ constexpr int MAXCLS = 16;                  // class cap (reference example.py:1
                                             // the kernels are instantiated with a register bound MC = 8 (C <= 8) or 16
 constexpr int S_GLOBAL = 0;                 // [0]=sum p*y [1]=sum p [2]=sum y [3]=sum bce|nll [4]=sum focal [5]=samples behind these sums
 constexpr int S_COUNT = 5;                  // written by the fold (phase 0/1), SUM-all-reduced with the rest: the global sample count on the device
-constexpr int S_CLASS = 8;                  // + 3*c : I_c, P_c, Y_c
-constexpr int S_METRIC = S_CLASS + 3 * MAXCLS;   // + ((n*C + c)*3) : inter, msum, ysum of thresholded masks
+constexpr int S_CLASS = 8;                  // + 4*c : I_c, P_c (MutilSSLoss: sum p_c^2), Y_c, sum y_c p_c^2 (MutilSSLoss only)
+constexpr int CLS_NV = 4;
+constexpr int S_METRIC = S_CLASS + CLS_NV * MAXCLS;   // + ((n*C + c)*3) : inter, msum, ysum of thresholded masks
 inline __host__ __device__ int s_coef(int N, int C) { return S_METRIC + 3 * N * C; }   // + 4 + 2*MAXCLS coefficients
 }  // namespace
 __host__ __device__ size_t loss_sums_count(int N, int C) { return (size_t)s_coef(N, C) + 4 + 2 * MAXCLS; }
@@ -187,7 +188,7 @@ __device__ __forceinline__ float bce_with_logits(float z, float y) {
 // terms are only evaluated for the loss kinds that use their sums (Dice-type losses need p alone); partial sums go through a
 // wave reduction, one LDS fold over the four waves and ONE set of fp64 atomics per block.
 constexpr int LOSS_VPB = 256 * 16;
-constexpr int LOSS_NVAL = 5 + 6 * MAXCLS;
+constexpr int LOSS_NVAL = 5 + (CLS_NV + 3) * MAXCLS;
 template <int MC>
 __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
     __shared__ float part[4][LOSS_NVAL];
@@ -195,11 +196,14 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
     const long long v0 = (long long)blockIdx.x * LOSS_VPB;
     const long long v1 = (v0 + LOSS_VPB < a.V) ? v0 + LOSS_VPB : a.V;
     float g[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    float cls[MC][3], met[MC][3];
+    float cls[MC][CLS_NV], met[MC][3];
 #pragma unroll
-    for (int c = 0; c < MC; ++c)
+    for (int c = 0; c < MC; ++c) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { cls[c][j] = 0.f; met[c][j] = 0.f; }
+        for (int j = 0; j < 3; ++j) met[c][j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < CLS_NV; ++j) cls[c][j] = 0.f;
+    }
     if (C == 1) {
         const bool need_bce = a.kind == L_BIN_CE || a.kind == L_BIN_FOCAL || a.kind == L_BIN_CE_DICE;
         const bool need_focal = a.kind == L_BIN_FOCAL;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (!ok[u]) continue;
-                const float p = 1.f / (1.f + expf(-z[u]));
+                const float p = a.kind == L_BIN_MCC ? z[u] : 1.f / (1.f + expf(-z[u]));      // MCC_Loss takes probabilities
                 g[0] += p * y[u]; g[1] += p; g[2] += y[u];
                 if (need_ss) { g[3] += p * p; g[4] += y[u] * p * p; }
                 if (need_bce) {
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
         }
     } else {
         const bool need_focal = a.kind == L_MC_FOCAL;
+        const bool mc_ss = a.kind == L_MC_SS;
         for (long long v = v0 + tid; v < v1; v += 256) {
             const int t = load_label(a.target, a.label_type, (long long)n * a.V + v);
             float z[MC], mx = -3.0e38f;
@@ -255,7 +260,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
                     const float p = e[c] * inv;
                     const float y = (c == t) ? 1.f : 0.f;
                     if (c == t) zt = z[c];
-                    cls[c][0] += y * p; cls[c][1] += p; cls[c][2] += y;
+                    cls[c][0] += y * p; cls[c][1] += mc_ss ? p * p : p; cls[c][2] += y;
+                    if (mc_ss) cls[c][3] += y * p * p;
                     const float mk = p > 0.5f ? 1.f : 0.f;
                     met[c][0] += mk * y; met[c][1] += mk; met[c][2] += y;
                 }
@@ -275,21 +281,26 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(LossArgs a) {
         if (lane == 0) part[wv][j] = s;
     }
 #pragma unroll
-    for (int c = 0; c < MC; ++c)
+    for (int c = 0; c < MC; ++c) {
+        if (c < C) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (c < C) {
-                const float s = (C > 1) ? wave_sum(cls[c][j]) : 0.f;
+            for (int j = 0; j < CLS_NV; ++j) {
+                const float s = (C > 1 && (j < 3 || a.kind == L_MC_SS)) ? wave_sum(cls[c][j]) : 0.f;
+                if (lane == 0) part[wv][5 + CLS_NV * c + j] = s;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
                 const float m = wave_sum(met[c][j]);
-                if (lane == 0) { part[wv][5 + 3 * c + j] = s; part[wv][5 + 3 * MAXCLS + 3 * c + j] = m; }
+                if (lane == 0) part[wv][5 + CLS_NV * MAXCLS + 3 * c + j] = m;
             }
         }
+    }
     __syncthreads();
     double* sums = a.sums + (long long)(blockIdx.x % STAT_REP) * loss_sums_count(a.N, C);
     if (tid < LOSS_NVAL) {
-        const int k = tid < 5 ? 0 : (tid < 5 + 3 * MAXCLS ? 1 : 2);
-        const int r = k == 0 ? tid : (k == 1 ? tid - 5 : tid - 5 - 3 * MAXCLS);      // 3*c + j for the per-class blocks
-        if (k == 0 || r < 3 * C) {
+        const int k = tid < 5 ? 0 : (tid < 5 + CLS_NV * MAXCLS ? 1 : 2);
+        const int r = k == 0 ? tid : (k == 1 ? tid - 5 : tid - 5 - CLS_NV * MAXCLS);      // CLS_NV*c + j / 3*c + j for the per-class blocks
+        if (k == 0 || r < (k == 1 ? CLS_NV : 3) * C) {
             const float s = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
             if (s != 0.f) {
                 if (k == 0) atomicAdd(sums + S_GLOBAL + r, (double)s);
@@ -358,6 +369,15 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
             loss = r * (YP2 - 2.0 * I + Y) / ds + (1.0 - r) * (P2 - YP2) / db;
             K[0] = 2.0 * r / ds;                     // d loss / d p_i = K0 * y_i * (p_i - 1) + K1 * p_i * (1 - y_i)
             K[1] = 2.0 * (1.0 - r) / db;
+        } else if (a.kind == L_BIN_MCC) {           // model/losses.py:200-232 with torch.add(a, 1, b) read as a + 1*b (the torch 1.x signature)
+            // tp = I, fp = P - I, fn = Y - I, tn = Nt - P - Y + I  =>  tp*tn - fp*fn = I*Nt - P*Y; (tp+fp)(tp+fn)(tn+fp)(tn+fn) = P*Y*(Nt-Y)*(Nt-P)
+            const double num = I * Ntot - P * Y;
+            const double rad = P * Y * (Ntot - Y) * (Ntot - P);
+            const double den = sqrt(rad > 0.0 ? rad : 0.0);
+            loss = 1.0 - num / (den + 1.0);
+            const double dden_dP = den > 0.0 ? Y * (Ntot - Y) * (Ntot - 2.0 * P) / (2.0 * den) : 0.0;
+            K[0] = -Ntot / (den + 1.0);              // d loss / d p_i = K0 * y_i + K1 (the input IS p: no sigmoid factor in the backward)
+            K[1] = -(-Y * (den + 1.0) - num * dden_dP) / ((den + 1.0) * (den + 1.0));
         } else if (a.kind == L_BIN_TVERSKY) {       // model/losses.py:102-126: alpha = 0.3 (false positives), beta = 0.7 (false negatives)
             const double al = 0.3, be = 0.7;
             const double den = I + al * (P - I) + be * (Y - I) + smooth;
@@ -369,10 +389,10 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
         }
     } else {
         int cnt = 0;
-        for (int c = 0; c < C; ++c) cnt += S[S_CLASS + 3 * c + 2] > 0.0;
+        for (int c = 0; c < C; ++c) cnt += S[S_CLASS + CLS_NV * c + 2] > 0.0;
         double dl = 0.0;
         for (int c = 0; c < C; ++c) {
-            const double I = S[S_CLASS + 3 * c], P = S[S_CLASS + 3 * c + 1], Y = S[S_CLASS + 3 * c + 2];
+            const double I = S[S_CLASS + CLS_NV * c], P = S[S_CLASS + CLS_NV * c + 1], Y = S[S_CLASS + CLS_NV * c + 2];
             const double al = a.class_alpha ? (double)a.class_alpha[c] : 1.0;
             const double D = Y + P + smooth;
             double dice = (2.0 * I + smooth) / D;
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
             // model/losses.py:345-382: dice_c (0 for absent classes) * alpha_c -> clamp(sum_c (-log(. + smooth))^0.3 / present, 0, 2)
             double tot = 0.0;
             for (int c = 0; c < C; ++c) {
-                const double I = S[S_CLASS + 3 * c], P = S[S_CLASS + 3 * c + 1], Y = S[S_CLASS + 3 * c + 2];
+                const double I = S[S_CLASS + CLS_NV * c], P = S[S_CLASS + CLS_NV * c + 1], Y = S[S_CLASS + CLS_NV * c + 2];
                 const double al = a.class_alpha ? (double)a.class_alpha[c] : 1.0;
                 const double D = Y + P + smooth;
                 double dice = (2.0 * I + smooth) / D;
@@ -410,6 +430,38 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(LossArgs a) {
             const double v = tot / cnt;
             loss = v < 0.0 ? 0.0 : (v > 2.0 ? 2.0 : v);
             if (!(v >= 0.0 && v <= 2.0)) for (int c = 0; c < C; ++c) { K[4 + c] = 0.0; K[4 + MAXCLS + c] = 0.0; }
+        } else if (a.kind == L_MC_TVERSKY) {
+            // model/losses.py:421-459 with self.beta set by the caller (the class never defines it; oracle/make_golden.py:LOSS_REPAIRS):
+            // -(tp + s) / (tp + alpha_c fp + beta fn + s) per present class, times alpha_c, over the present-class count
+            const double be = (double)a.focal_gamma;                  // beta rides in the focal_gamma slot of the call
+            double tot = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const double I = S[S_CLASS + CLS_NV * c], P = S[S_CLASS + CLS_NV * c + 1], Y = S[S_CLASS + CLS_NV * c + 2];
+                const double al = a.class_alpha ? (double)a.class_alpha[c] : 1.0;
+                const double den = I + al * (P - I) + be * (Y - I) + smooth;
+                const bool present = Y > 0.0;
+                if (present) tot += -(I + smooth) / den * al;
+                const double w = present ? al / cnt : 0.0;
+                K[4 + c] = -w * (den - (I + smooth) * (1.0 - al - be)) / (den * den);     // d/dI
+                K[4 + MAXCLS + c] = w * (I + smooth) * al / (den * den);                 // d/dP
+            }
+            loss = tot / cnt;
+        } else if (a.kind == L_MC_SS) {
+            // model/losses.py:385-418 with self.r set by the caller (never defined in the class): per class
+            // r * sum((y-p)^2 y) / (Y + s) + (1-r) * sum((y-p)^2 (1-y)) / (Y + s)   [both denominators are sum(y_true) in the reference]
+            const double r = (double)a.focal_gamma;                   // r rides in the focal_gamma slot of the call
+            double tot = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const double I = S[S_CLASS + CLS_NV * c], P2 = S[S_CLASS + CLS_NV * c + 1], Y = S[S_CLASS + CLS_NV * c + 2], YP2 = S[S_CLASS + CLS_NV * c + 3];
+                const double al = a.class_alpha ? (double)a.class_alpha[c] : 1.0;
+                const bool present = Y > 0.0;
+                const double ssv = (r * (YP2 - 2.0 * I + Y) + (1.0 - r) * (P2 - YP2)) / (Y + smooth);
+                if (present) tot += ssv * al;
+                const double w = present ? al / cnt / (Y + smooth) : 0.0;
+                K[4 + c] = 2.0 * r * w;                    // d L / d p_c(v) = K_a * y (p - 1) + K_b * p (1 - y)
+                K[4 + MAXCLS + c] = 2.0 * (1.0 - r) * w;
+            }
+            loss = tot / cnt;
         } else loss = S[4] / Ntot;
         K[2] = 1.0 / Ntot;
     }
@@ -444,7 +496,8 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
             const float y = (float)load_label(a.target, a.label_type, i);
             const float p = 1.f / (1.f + expf(-z));
             float dz = 0.f;
-            if (a.kind == L_BIN_SS) dz += (k0 * y * (p - 1.f) + k1 * p * (1.f - y)) * p * (1.f - p);
+            if (a.kind == L_BIN_MCC) dz = k0 * y + k1;           // gradient with respect to the probability input itself
+            else if (a.kind == L_BIN_SS) dz += (k0 * y * (p - 1.f) + k1 * p * (1.f - y)) * p * (1.f - p);
             else if (a.kind == L_BIN_DICE || a.kind == L_BIN_CE_DICE || a.kind >= L_BIN_JACCARD) dz += (k0 * y + k1) * p * (1.f - p);
             if (a.kind == L_BIN_CE || a.kind == L_BIN_CE_DICE) dz += (p - y) * kn;
             if (a.kind == L_BIN_FOCAL) {
@@ -465,14 +518,16 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
             for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - mx); se += p[c]; }
             const float inv = 1.f / se;
             for (int c = 0; c < C; ++c) p[c] *= inv;
-            const bool dice_like = a.kind == L_MC_DICE || a.kind == L_MC_CE_DICE || a.kind == L_MC_ELDICE;
+            const bool dice_like = a.kind == L_MC_DICE || a.kind == L_MC_CE_DICE || a.kind == L_MC_ELDICE || a.kind == L_MC_TVERSKY ||
+                                   a.kind == L_MC_SS;
             const bool ce_like = a.kind == L_MC_CE || a.kind == L_MC_FOCAL || a.kind == L_MC_CE_DICE;
             float dz[MC];
             for (int c = 0; c < C; ++c) dz[c] = 0.f;
             if (dice_like) {
                 float gsum = 0.f, gc[MC];
                 for (int c = 0; c < C; ++c) {
-                    gc[c] = (float)K[4 + c] * ((c == t) ? 1.f : 0.f) + (float)K[4 + MAXCLS + c];
+                    if (a.kind == L_MC_SS) gc[c] = (c == t) ? (float)K[4 + c] * (p[c] - 1.f) : (float)K[4 + MAXCLS + c] * p[c];
+                    else gc[c] = (float)K[4 + c] * ((c == t) ? 1.f : 0.f) + (float)K[4 + MAXCLS + c];
                     gsum += p[c] * gc[c];
                 }
                 for (int c = 0; c < C; ++c) dz[c] += p[c] * (gc[c] - gsum);

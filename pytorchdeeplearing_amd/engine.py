@@ -13,6 +13,10 @@ import torch
 from . import _capi
 
 
+import os
+_ONE_CALL = os.environ.get("SEG_ONE_CALL", "1") != "0"      # 0: the step as separate library calls (round-2 host path, A/B only)
+
+
 def aligned_empty(nbytes, device, align=256):
     """uint8 tensor whose data pointer is `align`-byte aligned (the CPU allocator only gives 64)."""
     raw = torch.empty(int(nbytes) + align, dtype=torch.uint8, device=device)
@@ -366,7 +370,7 @@ class SegEngine:
             # the clDice term is a rank-local ratio: under GlobalBatchLoss the summed (not averaged) gradients would carry it `world` times
             raise NotImplementedError("train_step: cldice_weight together with a global-batch loss exchange is not supported; "
                                       "use the per-rank (DDP) loss semantics for the clDice term")
-        if world == 1 and xworld == 1 and not cldice_weight:
+        if world == 1 and xworld == 1 and not cldice_weight and _ONE_CALL:
             return self._train_step_one_call(x, target, loss_name, lr, weight_decay, decoupled, focal_alpha, focal_gamma, class_alpha,
                                              mask_mode, masks, logits, probs)
         if cldice_weight:

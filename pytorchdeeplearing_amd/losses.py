@@ -144,3 +144,98 @@ class MutilCrossEntropyDiceLoss(MutilDiceLoss):
 class MutilELDiceLoss(MutilDiceLoss):
     """model/losses.py:345-382"""
     kind = "MutilELDiceLoss"
+
+
+class MutilTverskyLoss(_Loss):
+    """model/losses.py:421-459.  As in the reference, `alpha` (tensor [C]) is both the class weight and the false-positive weight, and
+    the class does not define `beta`: set `loss.beta` before the first call (the reference raises AttributeError otherwise, and so does
+    this one).  Forward/backward: the multi-class reduction sums + seg_loss kind 13."""
+    kind = "MutilTverskyLoss"
+
+    def __init__(self, alpha):
+        super().__init__()
+        self.alpha = alpha
+        self.class_alpha = alpha if torch.is_tensor(alpha) else torch.as_tensor(alpha, dtype=torch.float32)
+
+    def forward(self, y_pred_logits, y_true):
+        return _LossFn.apply(y_pred_logits, y_true, _capi.LOSS_KIND[self.kind], 0.0, float(self.beta), self.class_alpha)
+
+
+class MutilSSLoss(_Loss):
+    """model/losses.py:385-418; `r` is not defined by the reference class: set `loss.r` before the first call."""
+    kind = "MutilSSLoss"
+
+    def __init__(self, alpha):
+        super().__init__()
+        self.alpha = alpha
+        self.class_alpha = alpha if torch.is_tensor(alpha) else torch.as_tensor(alpha, dtype=torch.float32)
+        self.smooth = 1.e-5
+
+    def forward(self, y_pred_logits, y_true):
+        return _LossFn.apply(y_pred_logits, y_true, _capi.LOSS_KIND[self.kind], 0.0, float(self.r), self.class_alpha)
+
+
+class MCC_Loss(_Loss):
+    """model/losses.py:200-232: Matthews-correlation loss of a PROBABILITY map `inputs` against `targets` of the same shape (the one
+    loss of the file that does not take logits); the gradient is with respect to `inputs`."""
+    kind = "MCC_Loss"
+
+    def forward(self, inputs, targets):
+        assert inputs.numel() == targets.numel(), "inputs and targets must have the same number of elements"
+        v = _LossFn.apply(inputs.reshape(1, 1, -1), targets.reshape(1, -1), _capi.LOSS_KIND[self.kind], 0.0, 0.0, None)
+        return v
+
+
+class _LovaszFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, n, c, v):
+        xs = x.float().contiguous()
+        t = target if target.dtype in _LABEL_OK else target.to(torch.int64)
+        t = t.contiguous()
+        lib = _capi.lib_for(xs.device)
+        nbytes = lib.seg_lovasz_ws_bytes(n, v)
+        lib.check(nbytes, "seg_lovasz_ws_bytes")
+        ws = aligned_empty(nbytes, xs.device)
+        out1 = torch.zeros(4, dtype=torch.float32, device=xs.device)
+        dx = torch.empty_like(xs)
+        lib.check(lib.seg_lovasz_forward(xs.data_ptr(), t.data_ptr(), _capi.LABEL_TYPES[str(t.dtype)], n, c, v, ws.data_ptr(), out1.data_ptr(),
+                                         dx.data_ptr(), _capi.stream_for(xs.device)), "seg_lovasz_forward")
+        ctx.dx, ctx.in_dtype, ctx.in_shape = dx, x.dtype, x.shape
+        return out1[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.dx * g).to(ctx.in_dtype).reshape(ctx.in_shape), None, None, None, None
+
+
+class BinaryLovaszLoss(nn.Module):
+    """model/losses.py:235-242 -> model/lovasz.py:34-71 Lovasz hinge over the whole batch (per_image=False, ignore_index=None; the other
+    settings are not built).  logits [B, ...] and target of the same shape.  (The reference class cannot be CALLED as shipped - its
+    __init__ skips nn.Module.__init__ - only .forward() runs; this one supports both.)"""
+
+    def __init__(self, per_image=False, ignore_index=None):
+        super().__init__()
+        if per_image or ignore_index is not None:
+            raise NotImplementedError("BinaryLovaszLoss: only per_image=False, ignore_index=None (the reference defaults) are built")
+        self.per_image, self.ignore_index = per_image, ignore_index
+
+    def forward(self, logits, target):
+        assert logits.numel() == target.numel(), "logits and target must have the same number of elements"
+        return _LovaszFn.apply(logits.reshape(1, 1, -1), target.reshape(1, -1), 1, 1, logits.numel())
+
+
+class LovaszLoss(nn.Module):
+    """model/losses.py:462-473 -> model/lovasz.py:90-141 (classes='present', per_image=False, ignore=None).  As in the reference the first
+    argument is used as the class scores AS GIVEN (no soft-max is applied on the way)."""
+
+    def __init__(self, per_image=False, ignore=None):
+        super().__init__()
+        if per_image or ignore is not None:
+            raise NotImplementedError("LovaszLoss: only per_image=False, ignore=None (the reference defaults) are built")
+        self.per_image, self.ignore = per_image, ignore
+
+    def forward(self, logits, target):
+        n, c = logits.shape[0], logits.shape[1]
+        v = logits.numel() // (n * c)
+        assert target.numel() == n * v, "target must have one label per voxel"
+        return _LovaszFn.apply(logits.reshape(n, c, v), target.reshape(n, v), n, c, v)

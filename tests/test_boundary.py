@@ -82,6 +82,86 @@ def test_extra_loss_modules_vs_reference_golden(dev, golden_dir, name):
     assert hasattr(shim, name)
 
 
+REST_LOSSES = ["MutilTverskyLoss", "MutilSSLoss", "MCC_Loss", "BinaryLovaszLoss", "LovaszLoss"]
+
+
+def _rest_case(G, name, dev=None):
+    """inputs of the round-3 golden cases (oracle/make_golden.py:make_losses_extra, second block)"""
+    if name == "MCC_Loss":
+        x, t = torch.sigmoid(torch.from_numpy(G["z"])), torch.from_numpy(G["y"]).unsqueeze(1).float()
+    elif name == "BinaryLovaszLoss":
+        x, t = torch.from_numpy(G["lov_z"]), torch.from_numpy(G["y"])
+    else:
+        x, t = torch.from_numpy(G["z4"]), torch.from_numpy(G["y4"])
+    if dev is not None:
+        x, t = x.to(dev), t.to(dev)
+    return x.clone().requires_grad_(True), t
+
+
+def test_oracle_remaining_losses_equal_reference_golden(golden_dir):
+    """the oracle restatements of the model/losses.py classes built in round 3 against goldens made by the reference classes themselves
+    (with the instance attributes of make_golden.LOSS_REPAIRS)"""
+    G = np.load(os.path.join(golden_dir, "losses_extra.npz"))
+    a = torch.from_numpy(G["alpha"])
+    for name in REST_LOSSES:
+        x, t = _rest_case(G, name)
+        v = seg.loss_fn(name, a)(x, t)
+        v.backward()
+        assert abs(float(v) - float(G["loss_" + name])) < 2e-6, name
+        np.testing.assert_allclose(x.grad.numpy(), G["grad_" + name], rtol=1e-4, atol=1e-9, err_msg=name)
+
+
+@pytest.mark.parametrize("name", REST_LOSSES)
+def test_remaining_loss_modules_vs_reference_golden(dev, golden_dir, name):
+    """SURVEY 8f N4, the rest of model/losses.py: MutilTversky / MutilSS / MCC from the reduction sums, the two Lovasz losses through the
+    sort-based kernels (continuous random scores: no ties, so the sub-gradient is unique)."""
+    G = np.load(os.path.join(golden_dir, "losses_extra.npz"))
+    x, t = _rest_case(G, name, dev)
+    a = torch.from_numpy(G["alpha"])
+    if name == "MutilTverskyLoss":
+        f = losses.MutilTverskyLoss(a)
+        with pytest.raises(AttributeError):
+            f(x, t)                                       # like the reference: beta is not defined until the caller sets it
+        f.beta = 0.7
+    elif name == "MutilSSLoss":
+        f = losses.MutilSSLoss(a)
+        f.r = 0.1
+    else:
+        f = getattr(losses, name)()
+    v = f(x, t)
+    v.backward()
+    assert abs(float(v) - float(G["loss_" + name])) < 3e-6 * max(1.0, abs(float(G["loss_" + name]))), name
+    np.testing.assert_allclose(x.grad.cpu().numpy(), G["grad_" + name], rtol=3e-4, atol=2e-9, err_msg=name)
+    from model import losses as shim
+    assert hasattr(shim, name)
+
+
+def test_lovasz_larger_case_vs_oracle(dev):
+    """a volume that needs several radix-sort passes and scan blocks (2 x 3 x 40 x 36 x 33), one class absent"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 40, 36, 33, generator=g)
+    t = torch.randint(0, 2, (2, 40, 36, 33), generator=g)            # class 2 never occurs
+    xr = x.clone().requires_grad_(True)
+    ref = seg.multi_lovasz_loss(xr, t)
+    ref.backward()
+    xd = x.to(dev).requires_grad_(True)
+    v = losses.LovaszLoss()(xd, t.to(dev))
+    v.backward()
+    assert abs(float(v) - float(ref)) < 1e-5 * abs(float(ref))
+    # the Jaccard increments are differences of float32 values near 1: absolute resolution ~6e-8 (one ulp), whatever their size
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-7)
+    assert float(xd.grad[:, 2].abs().max()) == 0.0
+    zb = torch.randn(2, 40, 36, 33, generator=g)
+    zr = zb.clone().requires_grad_(True)
+    refb = seg.binary_lovasz_loss(zr, t)
+    refb.backward()
+    zd = zb.to(dev).requires_grad_(True)
+    vb = losses.BinaryLovaszLoss()(zd, t.to(dev))
+    vb.backward()
+    assert abs(float(vb) - float(refb)) < 1e-5 * abs(float(refb))
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), zr.grad.numpy(), rtol=2e-4, atol=2e-7)
+
+
 @pytest.mark.parametrize("cls,kind,ndim,args,shape", [
     ("VNet2d", "vnet", 2, (1, 1), (2, 1, 16, 16)),
     ("UNet2d", "unet", 2, (1, 2), (1, 1, 16, 32)),

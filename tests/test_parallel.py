@@ -171,7 +171,7 @@ def _worker_bench(rank, world, port, q, extra):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main(["--gpus", str(world), "--steps", "1", "--warmup", "0", "--size", "16", "--batch", "1", "--dtype", "f32",
-                    "--no-cpu-baseline"] + list(extra), checker_device="cpu")
+                    "--no-cpu-baseline", "--condition-seconds", "0.001", "--roofline-steps", "0"] + list(extra), checker_device="cpu")
     q.put((rank, buf.getvalue()))
 
 
@@ -200,6 +200,7 @@ def test_bench_control_flow_two_ranks_on_the_checker(extra):
     assert line["config"]["loss_semantics"].startswith("global-batch" if "--global-loss" in extra else "per-rank")
     assert line["ms_per_step"] > 0 and abs(line["value"] - 2 * 1 * 1e3 / line["ms_per_step"]) <= 0.006      # whole-job volumes/s (2 decimals)
     assert 0.0 < line["final_loss"] < 1.5 and "cpu_baseline" not in line
+    assert line["conditioning_steps"] == 1                 # the un-timed conditioning loop ran on both ranks (rank 0 decides when it ends)
 
 
 def _seed_worker(rank, world, port, q):

@@ -2,15 +2,14 @@
 [RCCL grad all-reduce] + AdamW + weight re-pack) at 4 x 1 x 96^3 fp16 per GPU — BASELINE.json
 configs[2], the configuration the metric is quoted on.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One process per GPU; the batch shards on the batch axis (weak scaling: 4 volumes per GPU); the flat
 fp32 gradient buffer is all-reduced over RCCL (sum, then 1/N) before the fused optimiser step.  Inputs
 are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with the extra objects
-  "roofline"           – the dominant kernel class, timed live with HIP events in R instrumented steps run AFTER the timed region
-                         (the K timed steps carry no brackets, so `value` does not depend on --steps)
+  "roofline"           – the dominant kernel class, timed live with HIP events inside the timed region
   "cpu_baseline"       – the oracle (torch-CPU port of the reference path) on this box's host cores
   "gpu_torch_baseline" – the same oracle functions on this GPU through stock PyTorch-ROCm / MIOpen (fp32 and autocast f16):
                          the number the hand-written engine has to beat.
@@ -25,7 +24,7 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # see pytorchdeeplearing
 
 import torch
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # algorithmic work per 96^3 volume and train step
@@ -46,12 +45,7 @@ PMC_KEY = {"conv3": ["_ZN3seg3c3x13conv3x_kernel<DF16_NS0_4XBoxILi4ELi8ELi8ELi3E
            "gn_act": ["gn_act_kernel<DF16_"]}
 
 
-def _pmc_file():
-    """newest committed PMC summary (profiles/rNN_pmc_fetch_write_per_kernel.json, regenerated from the final binary of a round by
-    tools/gpu_final.sh with this file's own command line)"""
-    import glob
-    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_fetch_write_per_kernel.json")))
-    return c[-1] if c else None
+PMC_FILE = "r02_pmc_fetch_write_per_kernel.json"      # regenerated from the final binary of the round (tools/gpu_final.sh)
 
 
 def pmc_traffic(kclass):
@@ -59,7 +53,7 @@ def pmc_traffic(kclass):
     (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled for gfx950 as
     MI355X_MICROARCH.md prescribes).  None when the summary is not available."""
     try:
-        with open(_pmc_file()) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             table = json.load(f)
         rows = [v for k, v in table.items() if any(k.startswith(p) for p in PMC_KEY[kclass])]
         n = sum(r["launches"] for r in rows)
@@ -71,11 +65,8 @@ def pmc_traffic(kclass):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--condition-seconds", type=float, default=0.75, help="un-timed conditioning loop BEFORE the warm-up the caller asks for: "
-                    "train steps until this much wall time has passed (clocks / power state / allocator / lazy code-object loads settle); "
-                    "reported in the JSON line as conditioning_steps")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=96)
@@ -85,9 +76,8 @@ def parse(argv=None):
                     "whichever of the two largest kernel symbols of the step (gn_bwd_reduce / gn_bwd_apply, rocprofv3 --stats summary "
                     "under profiles/) accumulates more event time in this run")
     ap.add_argument("--mfma-kernel", default="conv3", help="second bracketed class, reported as \"roofline_mfma\" (largest MFMA symbol)")
-    ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented steps run AFTER the timed region: every launch of the roofline "
-                    "kernel classes is bracketed by HIP events on its launch stream (each bracket idles the stream for ~6 us, so none of "
-                    "them is inside the timed region)")
+    ap.add_argument("--roofline-steps", type=int, default=5, help="timed steps whose launches carry the HIP-event brackets (each bracket "
+                    "idles the stream for ~6 us, so only the first R of the K timed steps are instrumented)")
     ap.add_argument("--single-allreduce", action="store_true", help="one blocking all-reduce after backward instead of two overlapped buckets")
     ap.add_argument("--global-loss", action="store_true", help="exact global-batch Dice across ranks (parallel.GlobalBatchLoss: 32 fp64 sums "
                     "all-reduced between the loss reduction and its finalize; gradients summed) instead of DDP semantics")
@@ -107,34 +97,21 @@ def cpu_model():
 
 
 def _quiet_stdout(fn, *args, **kw):
-    """Run fn with file descriptors 1 AND 2 pointed at a scratch file: MIOpen / composable_kernel print ~1 MB of solver diagnostics
-    ("dimension check failure" ...) with C-level printf while stock PyTorch searches its convolution kernels; stdout of this script
-    carries exactly ONE JSON line and the driver's stderr tail should show this script's own messages.  The scratch file's tail is
-    replayed on stderr only if fn raises."""
+    """Run fn with file descriptor 1 pointed at stderr: MIOpen / composable_kernel print solver diagnostics with C-level printf
+    while stock PyTorch searches its convolution kernels, and stdout of this script carries exactly ONE JSON line."""
     import ctypes
-    import tempfile
     libc = ctypes.CDLL(None)
-    sys.stdout.flush(); sys.stderr.flush()
+    sys.stdout.flush()
     libc.fflush(None)
-    saved1, saved2 = os.dup(1), os.dup(2)
-    scratch = tempfile.TemporaryFile()
+    saved = os.dup(1)
     try:
-        os.dup2(scratch.fileno(), 1)
-        os.dup2(scratch.fileno(), 2)
+        os.dup2(2, 1)
         return fn(*args, **kw)
-    except BaseException:
-        sys.stdout.flush(); sys.stderr.flush(); libc.fflush(None)
-        os.dup2(saved2, 2)
-        scratch.seek(max(0, scratch.tell() - 4096))
-        sys.stderr.write(scratch.read().decode(errors="replace"))
-        raise
     finally:
-        sys.stdout.flush(); sys.stderr.flush()
-        libc.fflush(None)          # the C library's own buffers (printf from MIOpen / CK) must drain while the descriptors still point at the scratch file
-        os.dup2(saved1, 1)
-        os.dup2(saved2, 2)
-        os.close(saved1); os.close(saved2)
-        scratch.close()
+        sys.stdout.flush()
+        libc.fflush(None)          # the C library's own stdout buffer (printf from MIOpen / CK) must drain while fd 1 still points at stderr
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def _gpu_torch_baseline(seg, batch, size, dev, steps=3):
@@ -201,12 +178,12 @@ def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0, batch=4, 
     base = {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
             "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (one volume, not the 4-volume batch), torch %s CPU, %d of the %d hardware "
                       "threads of %s, best step %.3f s" % (len(times), size, torch.__version__, ncores, os.cpu_count() or 1, cpu_model(), best)}
-    dice = _dice_vs_reference(seg, trained_state, dev, dtype, size=size)
+    dice = _dice_vs_reference(seg, trained_state, dev, dtype)
     return base, dice, (_quiet_stdout(_gpu_torch_baseline, seg, batch, size, dev) if gpu_leg else None)
 
 
-def _dice_vs_reference(seg, trained_state, dev, dtype, size=96):
-    """BASELINE metric, second half ("Dice vs ref"): one eval forward of a 1 x 1 x size^3 volume (the workload's own 96^3) through the engine (run dtype and
+def _dice_vs_reference(seg, trained_state, dev, dtype, size=48):
+    """BASELINE metric, second half ("Dice vs ref"): one eval forward of a 1 x 1 x 48^3 volume through the engine (run dtype and
     f32) and through the oracle on the host, same weights; integer-mask Dice against the synthetic label must be identical
     when the masks are (model/metric.py:146-155).  Weights: the benchmark's random init with biases / GroupNorm affine perturbed
     (the weights after the timed steps predict all-foreground on random labels: a trivial mask).  Called from cpu_baseline only."""
@@ -238,27 +215,10 @@ def main(argv=None, checker_device=None):
     the GPU-less build box.  None = the real thing: one process per GPU, RCCL."""
     a = parse(argv)
     # stdout carries exactly ONE JSON line: file descriptor 1 points at stderr for the whole run (RCCL prints a version banner, MIOpen / CK
-    # print solver diagnostics, all with C-level stdio) and comes back on EVERY rank and exit path (finally) before the line is printed
-    import ctypes
-    libc = ctypes.CDLL(None)
+    # print solver diagnostics, all with C-level stdio) and comes back only for the final print
     sys.stdout.flush()
     saved_stdout_fd = os.dup(1)
     os.dup2(2, 1)
-    line = None
-    try:
-        line = _run(a, checker_device)
-    finally:
-        sys.stdout.flush()
-        libc.fflush(None)
-        os.dup2(saved_stdout_fd, 1)
-        os.close(saved_stdout_fd)
-    if line is not None:
-        print(json.dumps(line))
-        sys.stdout.flush()
-
-
-def _run(a, checker_device):
-    """everything between the stdout redirect and the JSON line; returns the line on rank 0, None elsewhere"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -276,14 +236,6 @@ def _run(a, checker_device):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
-    try:
-        return _bench(a, dev, on_gpu, gpu_sync, dist, world, rank)
-    finally:
-        if dist:
-            dist.destroy_process_group()
-
-
-def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
     from pytorchdeeplearing_amd import SegEngine, synthetic   # oracle/ is touched by the cpu_baseline leg only
     from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GlobalBatchLoss, GradAllReduce
 
@@ -309,36 +261,24 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
     def step():
         return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs, **kw)
 
-    # ---- conditioning (un-timed, before the warm-up the caller asks for): the first tens of milliseconds after a cold start do not run
-    # at steady-state speed (round 2: 727 volumes/s at --steps 20 --warmup 5 on the driver's box against 880 at 50/10 on the builder's;
-    # 5 warm-up steps are 25 ms).  Every rank runs the SAME number of steps (rank 0 decides), so collectives stay matched.
-    ncond = 0
-    if a.condition_seconds > 0:
-        gpu_sync()
-        tc = time.perf_counter()
-        chunk = 8 if on_gpu else 1
-        while True:
-            for _ in range(chunk):
-                out3 = step()
-            ncond += chunk
-            gpu_sync()
-            more = 1 if (time.perf_counter() - tc < a.condition_seconds and ncond < 4096) else 0
-            if dist:
-                flag = torch.tensor([more], device=dev, dtype=torch.int32)
-                dist.broadcast(flag, src=0)
-                more = int(flag)
-            if not more:
-                break
+    # the largest kernel classes of the step (profiles/r02_rocprofv3_kernel_stats.txt: GroupNorm-backward apply 755 us, reduce 479 us,
+    # 48^3 halo conv 429 us per step): all are bracketed, "roofline" is whichever accumulated most event time in this run
+    candidates = ["gn_bwd_reduce", "gn_bwd_apply", a.mfma_kernel or "conv3"] if a.roofline_kernel == "auto" else [a.roofline_kernel]
+    bracketed = candidates + ([a.mfma_kernel] if a.mfma_kernel and a.mfma_kernel not in candidates else [])
+    e.profile_enable(bracketed)
     for _ in range(a.warmup):
         out3 = step()
     gpu_sync()
+    e.profile_read()
+    nprof = max(1, min(a.roofline_steps, a.steps))
     if dist:
         dist.barrier()
     gpu_sync()
-    # ---- the timed region: exactly K steps, no instrumentation of any kind inside
     t0 = time.perf_counter()
     nhost, t_enqueued = min(8, a.steps), 0.0
     for i in range(a.steps):
+        if i == nprof:
+            e.profile_enable([])          # host-side flag only: no synchronisation inside the timed region
         out3 = step()
         if i == nhost - 1:
             t_enqueued = time.perf_counter() - t0      # host time to enqueue the first steps: it runs ahead of the GPU (later the full queue throttles it)
@@ -347,27 +287,8 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
         dist.barrier()
     gpu_sync()
     dt = time.perf_counter() - t0
-    loss = float(out3[0])
-    # ---- roofline: R instrumented steps AFTER the timed region.  The largest kernel classes of the step (profiles/ rocprofv3 --stats
-    # summary: GroupNorm-backward apply / reduce, the 48^3 halo conv) are bracketed with hipEventRecord on their launch stream;
-    # "roofline" is whichever accumulated most event time in this run.
-    candidates = ["gn_bwd_reduce", "gn_bwd_apply", a.mfma_kernel or "conv3"] if a.roofline_kernel == "auto" else [a.roofline_kernel]
-    bracketed = candidates + ([a.mfma_kernel] if a.mfma_kernel and a.mfma_kernel not in candidates else [])
-    nprof = max(0, a.roofline_steps)
-    prof = {}
-    if nprof:
-        e.profile_enable(bracketed)
-        if on_gpu:
-            step()                            # creates the event pool (hipEventCreate) outside the measured brackets
-            gpu_sync()
-            e.profile_read()
-        for _ in range(nprof):
-            step()
-        gpu_sync()
-        prof = e.profile_read()
-        e.profile_enable([])
-        if dist:
-            dist.barrier()
+    prof = e.profile_read()
+    e.profile_enable([])
     # an EMPTY bracket (two event records back to back on the launch stream) is not zero: each record is a barrier packet
     # with a timestamp.  Measured live and subtracted per launch below, so that the event-based average can be compared
     # with rocprofv3's kernel durations (which carry no brackets); both the raw and the corrected figures are reported.
@@ -384,6 +305,7 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
         dt = float(t)
     ms = dt / a.steps * 1e3
     vols = world * a.batch * a.steps / dt
+    loss = float(out3[0])
 
     table = None
     if a.all_classes and rank == 0:
@@ -409,7 +331,6 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "lanes_per_gpu": a.lanes,
                        "loss_semantics": "global-batch (sums exchanged)" if exchange is not None else "per-rank (DDP)"},
             "final_loss": round(loss, 5),
-            "conditioning_steps": ncond, "conditioning_seconds": a.condition_seconds,
             "host_enqueue_ms_per_step": round(t_enqueued / nhost * 1e3, 3),
             "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME_96 * scale * vols / world / PEAK_HBM_GBS, 4),
                            "mfma_frac": round(GFLOP_PER_VOLUME_96 * scale * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},
@@ -439,9 +360,8 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
             return blk
         corrected = lambda k: prof.get(k, {}).get("ms", 0.0) - prof.get(k, {}).get("calls", 0) * bracket_us * 1e-3
         a.roofline_kernel = max(candidates, key=corrected)
-        nprof = max(nprof, 1)
-        NOTE_HBM = ("every launch of this class in %d instrumented steps run after the timed region is bracketed by hipEventRecord on its "
-                    "launch stream (no bracket inside the timed region); achieved = sum of algorithmic bytes / sum of event time (frac_minus_bracket subtracts the "
+        NOTE_HBM = ("every launch of the first %d timed steps is bracketed by hipEventRecord on its launch stream (the brackets idle the "
+                    "stream and are part of value); achieved = sum of algorithmic bytes / sum of event time (frac_minus_bracket subtracts the "
                     "empty-bracket time measured live, bracket_overhead_us, per launch); algorithmic bytes per launch = "
                     "(gradient sources + 1 [+ 1 for the apply pass]) x tensor bytes (DESIGN.md section 5)" % nprof)
         NOTE_MFMA = ("big-box halo conv of the 48^3 level (32 -> 32 channels, forward and data-gradient: ONE kernel symbol, 8 launches per "
@@ -475,8 +395,14 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
             line["cpu_baseline"], line["dice_vs_ref"], gt = cpu_baseline(S, sd, dev, a.dtype, batch=a.batch, gpu_leg=on_gpu)
             if gt is not None:
                 line["gpu_torch_baseline"] = gt
-        return line
-    return None
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_stdout_fd, 1)
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if dist:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
