@@ -38,6 +38,7 @@ SIGNATURES = {
     "seg_set_dropout_draws": (_i, [_vp, _ll]),
     "seg_plan": (_i, [_vp, _i, _i, _i, _i]),
     "seg_workspace_bytes": (_ll, [_vp]),
+    "seg_plan_count": (_i, [_vp, _i]),
     "seg_bind": (_i, [_vp, _vp, _vp, _vp]),
     "seg_pack_weights": (_i, [_vp, _vp]),
     "seg_forward": (_i, [_vp, _vp, _i, _vp, C.c_ulonglong, _vp, _vp, _vp]),

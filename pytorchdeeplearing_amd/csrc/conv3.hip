@@ -69,8 +69,18 @@ __device__ __forceinline__ int halo_swz(int row, int x) { return ((row & 1) << 1
 
 template <class T, class B, int CH, int LD, int PITCH = B::HW, bool SWZ = false>
 __device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, const BoxPos& p, int D, int H, int W,
-                                           const T* in1 = nullptr, int C0 = 0) {
+                                           const T* in1 = nullptr, int C0 = 0, const float* gsc = nullptr, const float* gsh = nullptr) {
     if (!in1) C0 = C;
+    // gsc / gsh ([N][C] scale / shift of the producer unit's GroupNorm + dropout + ReLU, published by the forward pass): `in` holds the
+    // producer's RAW conv output and the activation relu(scale * x + shift) is applied on the way into LDS (voxels outside the volume
+    // stay zero) - the weight gradient of a conv whose input tensor is never materialised (Conv3xArgs::fuse).  A thread keeps its
+    // channel piece over the whole copy (256 % (CH / 8) == 0), so the coefficients are loaded once per box.
+    vec<float, 8> gs, gh;
+    if (gsc) {
+        const int chq = c0 + (int)(threadIdx.x % (CH / 8)) * 8;
+        gs = *(const vec<float, 8>*)(gsc + (long long)p.n * C + chq);
+        gh = *(const vec<float, 8>*)(gsh + (long long)p.n * C + chq);
+    }
     // All global loads of a batch are issued before the first LDS store: a load->wait->store loop would
     // serialise ~9 HBM round trips per box (measured: the dominant cost of the first version).
     constexpr int CPV = CH / 8, TOTAL = B::HV * CPV, NIT = (TOTAL + 255) / 256;
@@ -89,6 +99,10 @@ __device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, co
                 const long long vox = (((long long)p.n * D + z) * H + y) * W + x;
                 const int ch = c0 + c8 * 8;
                 v[u] = ch < C0 ? load8(in + vox * C0 + ch) : load8(in1 + vox * (C - C0) + (ch - C0));
+                if (gsc) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[u][j] = from_f<T>(fmaxf(fmaf(gs[j], to_f(v[u][j]), gh[j]), 0.f));
+                }
             }
         }
 #pragma unroll
@@ -484,6 +498,7 @@ struct Wgrad3Args {
     const void* dr; const void* x; float* partial;
     int N, D, H, W, P, Q;       // channel counts of dr / x
     int nb;                     // workgroups per (p-tile, q-tile) combo
+    const float* xsc; const float* xsh;   // [N][Q] or null: x is a RAW conv output, activated while it is staged (stage_halo)
 };
 
 template <class T, int C> struct WLd { static constexpr int v = C == 32 ? 48 : 16; };   // 96 B / 32 B rows: conflict-free tr reads
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) void wgrad3_kernel(Wgrad3Args a) {
             const int i = u * 256 + tid;
             if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], dv[u]);
         }
-        stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W, (const T*)a.x1, a.C0);
+        stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W, (const T*)a.x1, a.C0, a.xsc, a.xsh);
         __syncthreads();
 #pragma unroll 1
         for (int ks = 0; ks < B::V / 32; ++ks) {
@@ -947,14 +962,14 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) 
 }
 
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1, int C0) {
+                   int dtype, hipStream_t s, const void* x1, int C0, const float* xscale, const float* xshift) {
     const int T = ndim == 3 ? 27 : 9;
     // 16-bit tensors, opt-in (SEG_WGRAD3X=1, read per call): double-buffered kernel (wgrad3x.hip), same partial-tile layout and
     // reduce.  Measured on MI355X (profiles/r02_wgrad3x_ab.log): op-level 67 vs 67 us at 32ch@48^3, 62 vs 52 us at 64ch@24^3, train
     // step 689 vs 712 volumes/s - one box in flight per CU is still latency-bound and its 112 KB / 512-thread workgroups crowd the
     // main stream's kernels out of the CU, so wgrad3_kernel (three 44 KB workgroups per CU) stays the default.
     const char* envx = getenv("SEG_WGRAD3X");
-    const bool use_x = envx && atoi(envx) != 0;
+    const bool use_x = envx && atoi(envx) != 0 && !xscale;      // the double-buffered variant copies x straight into LDS: no activation on the way
     if (use_x && wgrad3x_supported(dtype, N, ndim == 3 ? D : 1, H, W, P, Q, C0, x1 != nullptr)) {
         int CP, CQ;
         wgrad3x_tiles(P, Q, C0, x1 != nullptr, &CP, &CQ);
@@ -982,6 +997,7 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
     a.dr = dr; a.x = x; a.partial = partial;
     a.N = N; a.D = D; a.H = H; a.W = W; a.P = P; a.Q = Q;
     a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q);
+    a.xsc = xscale; a.xsh = xshift;
     if (dtype == DT_F32) wgrad3_dispatch<float>(a, ndim, dw, (long long)Q * T, T, s);
     else if (dtype == DT_F16) wgrad3_dispatch<f16>(a, ndim, dw, (long long)Q * T, T, s);
     else wgrad3_dispatch<bf16>(a, ndim, dw, (long long)Q * T, T, s);

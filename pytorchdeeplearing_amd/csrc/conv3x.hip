@@ -69,6 +69,9 @@ bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, 
     return true;
 }
 
+// the FUSE instantiations: one source tensor, 32-channel chunks, per-sample fold of <= 256 channels by 256 threads
+bool conv3x_gn_supported(int Cin, bool has_in1) { return !has_in1 && Cin % 32 == 0 && Cin <= 256 && 256 % Cin == 0; }
+
 // default tiling per problem.  Overrides: SEG_C3X_CFG=<id> (one tiling wherever it fits), SEG_C3X_MAP="cin:cout:w=id,..."
 // (per layer shape; tools/tune_conv3x.py prints the measured table).
 int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
@@ -127,10 +130,13 @@ int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres
 }
 
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const Conv3xReduce* rq) {
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const Conv3xReduce* rq, const GnFinArgs* gn) {
     const Cfg* c = find_cfg(cfg);
     if (!c || !cfg_fits(*c, ndim, Cin, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
+    if (gn && !conv3x_gn_supported(Cin, in1 != nullptr)) return false;
     Conv3xArgs a;
+    a.fuse = gn ? 1 : 0;
+    a.gn = gn ? *gn : GnFinArgs{};
     a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.stat_rep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
     a.rq_y = nullptr; a.rq_scale = nullptr; a.rq_shift = nullptr; a.rq_Q = nullptr; a.rq_rep = STAT_REP;
@@ -148,6 +154,10 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
         Conv3xArgs w = a; w.stats = nullptr;
         if (ndim == 3) { if (dtype == DT_F16) c3x::launch_3d<f16>(cfg, w, s); else c3x::launch_3d<bf16>(cfg, w, s); }
         else { if (dtype == DT_F16) c3x::launch_2d<f16>(cfg, w, s); else c3x::launch_2d<bf16>(cfg, w, s); }
+    }
+    if (a.fuse) {
+        if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d_gn<f16>(cfg, a, s) : c3x::launch_3d_gn<bf16>(cfg, a, s);
+        return dtype == DT_F16 ? c3x::launch_2d_gn<f16>(cfg, a, s) : c3x::launch_2d_gn<bf16>(cfg, a, s);
     }
     if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d<f16>(cfg, a, s) : c3x::launch_3d<bf16>(cfg, a, s);
     return dtype == DT_F16 ? c3x::launch_2d<f16>(cfg, a, s) : c3x::launch_2d<bf16>(cfg, a, s);

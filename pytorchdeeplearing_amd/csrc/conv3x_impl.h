@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "gn_fold.h"
 
 namespace seg {
 namespace c3x {
@@ -58,6 +59,12 @@ struct Conv3xArgs {
     // sum dz and sum dz*y (dz = dy where scale*y+shift > 0) per (sample, channel) into rq_Q [rep][N][Cout][2]: one read of y instead of the
     // reduce kernel's reads of dy and y, and one launch less.
     const void* rq_y; const float* rq_scale; const float* rq_shift; double* rq_Q; int rq_rep;
+    // forward launches only (FUSE instantiations): `in0` is the RAW output of the producer's convolution and the producer's GroupNorm +
+    // channel dropout + ReLU (reference op chain networks/VNet3d.py:13-15, networks/Unet3d.py:66-80) is applied while the halo sits in LDS:
+    // every workgroup folds the producer's statistics of its sample (gn_fold_block: scale / shift per channel), the first workgroup of a
+    // sample publishes them (plus mean / rstd) for the backward pass, and each lane rewrites the 16-B pieces it copied as
+    // relu(scale * x + shift); padding voxels stay zero.  The activated tensor is never written to HBM (the gn_act launch is gone).
+    int fuse; GnFinArgs gn;
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md), each with its own L2.  With the
@@ -171,9 +178,11 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const 
     }
 }
 
-template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC>
+template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC, bool FUSE>
 __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
+    __shared__ double gn_part[FUSE ? 256 : 1][2];
+    __shared__ __attribute__((aligned(16))) float gn_coef[2][FUSE ? 256 : 8];
     static_assert(WM * WN == 4 && WM * TM == B::NTILE, "wave grid must cover the box");
     static_assert(B::NTAP % (PF + 1) == 0, "register ring must divide the tap count");
     constexpr int BN = WN * TN * 16, OLD = BN + 8;
@@ -289,7 +298,31 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
         for (int s = 0; s < PF; ++s)
 #pragma unroll
             for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, wg + s * wstep);
+        if (FUSE && g0 == 0)      // the producer's statistics -> scale / shift of this sample, while the first copies are in flight
+            gn_fold_block(a.gn, n, x0 == 0 && y0 == 0 && z0 == 0 && blockIdx.y == 0, gn_part, gn_coef[0], gn_coef[1]);
         wait_vmem();
+        if (FUSE) {
+            // each lane activates the pieces it copied itself (lane-linear image: no other lane touches them before the barrier)
+#pragma unroll
+            for (int b = 0; b < NRES; ++b) {
+                if (b < nres) {
+#pragma unroll
+                    for (int u = 0; u < NI; ++u) {
+                        const int i = u * 4 + wv;
+                        if (i < B::NINSTR && src[u] >= 0) {
+                            T* pz = Xs + b * B::CHUNK_ELEMS + i * 512 + lane * 8;
+                            const int ch = (g0 + b) * 32 + (src[u] & 3) * 8;
+                            const vec<float, 8> sc = *(const vec<float, 8>*)&gn_coef[0][ch];
+                            const vec<float, 8> sh = *(const vec<float, 8>*)&gn_coef[1][ch];
+                            vec<T, 8> v = load8(pz);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = from_f<T>(fmaxf(fmaf(sc[j], to_f(v[j]), sh[j]), 0.f));
+                            store8(pz, v);
+                        }
+                    }
+                }
+            }
+        }
         __syncthreads();
         unsigned wo = wg + PF * wstep;                     // byte offset of the step being prefetched
         for (int b = 0; b < nres; ++b) {
@@ -328,12 +361,12 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
 }
 
 
-template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC>
+template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC, bool FUSE>
 void launch_cfg(const Conv3xArgs& a, hipStream_t s) {
     constexpr int BN = WN * TN * 16;
     const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
     dim3 grid(a.remap ? (unsigned)((nbox + 7) / 8 * 8) : (unsigned)nbox, a.Cout / BN);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x_kernel<T, B, TM, TN, WM, WN, NRES, PF, OCC>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x_kernel<T, B, TM, TN, WM, WN, NRES, PF, OCC, FUSE>), grid, dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,49 +491,54 @@ void launch_cfg16(const Conv3xArgs& a, hipStream_t s) {
 // one translation unit per (dtype, ndim): the tap loops are fully unrolled and each instantiation takes ~10 s to compile
 template <class T> bool launch_3d(int id, const Conv3xArgs& a, hipStream_t s);
 template <class T> bool launch_2d(int id, const Conv3xArgs& a, hipStream_t s);
+// the FUSE = true instantiations (conv3x_<dtype>_<nd>_gn.hip)
+template <class T> bool launch_3d_gn(int id, const Conv3xArgs& a, hipStream_t s);
+template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s);
 
-#define SEG_C3X_3D_BODY                                                                                       \
-    switch (id) {                                                                                             \
-        /*                       box (TD,TH,TW,KD,TX)      TM TN WM WN NRES PF OCC */                         \
-        case 0: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 2, 2>(a, s); return true;               \
-        case 1: launch_cfg<T, XBox<4, 8, 16, 3, 16>, 8, 2, 4, 1, 1, 2, 1>(a, s); return true;               \
-        case 2: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 8, 2, 2, 2, 2, 8, 1>(a, s); return true;               \
-        case 3: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 2, 8, 2>(a, s); return true;                 \
-        case 4: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 8, 2, 2, 2, 2, 8, 1>(a, s); return true;                 \
-        case 5: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 4, 4, 1, 2, 2, 1>(a, s); return true;                 \
-        case 6: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 4, 4, 1, 2, 2, 2>(a, s); return true;                 \
-        case 7: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 2, 2, 2, 4, 8, 1>(a, s); return true;                \
-        case 8: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 2, 2, 2, 4, 8, 1>(a, s); return true;                \
-        case 9: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 4, 2, 2, 4, 2, 1>(a, s); return true;                \
-        case 10: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 1, 4, 1, 1, 8, 2>(a, s); return true;              \
-        case 11: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 4, 8, 1>(a, s); return true;                \
-        case 12: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 4, 2, 2, 4, 2, 1>(a, s); return true;                \
-        case 13: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 2, 8, 2>(a, s); return true;                \
-        case 14: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 2>(a, s); return true;                \
-        case 15: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 2, 8, 1>(a, s); return true;              \
-        case 16: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;              \
-        case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;                \
-        /* Cin == 16:             box                    TM TN PF OCC */                                      \
-        case 24: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2, 4>(a, s); return true;                      \
-        case 25: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2, 3>(a, s); return true;                      \
-        case 26: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 2, 2, 3>(a, s); return true;                      \
-        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;                      \
-        default: return false;                                                                                \
-    }
-#define SEG_C3X_2D_BODY                                                                                       \
-    switch (id) {                                                                                             \
-        case 32: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;             \
-        case 33: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 8, 2, 2, 2, 2, 2, 2>(a, s); return true;             \
-        case 34: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 2, 8, 2>(a, s); return true;              \
-        case 35: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 4, 8, 2>(a, s); return true;              \
-        case 36: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 4, 2, 2, 4, 2, 2>(a, s); return true;              \
-        case 37: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 1, 4, 1, 1, 8, 3>(a, s); return true;             \
-        case 38: launch_cfg<T, XBox<1, 8, 8, 1, 8>, 2, 2, 2, 2, 4, 8, 2>(a, s); return true;                \
-        case 39: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 2, 2, 4, 1, 2, 8, 2>(a, s); return true;              \
-        case 56: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 1, 2, 4>(a, s); return true;                     \
-        case 57: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 2, 2, 4>(a, s); return true;                     \
-        default: return false;                                                                                \
-    }
+/* halo-conv tilings; FUSE (a constexpr bool in scope) selects the instantiation that applies the producer GroupNorm while staging */
+#define SEG_C3X_3D_CONV_CASES                                                                                         \
+        case 0: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 2, 2, FUSE>(a, s); return true;                   \
+        case 1: launch_cfg<T, XBox<4, 8, 16, 3, 16>, 8, 2, 4, 1, 1, 2, 1, FUSE>(a, s); return true;                   \
+        case 2: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 8, 2, 2, 2, 2, 8, 1, FUSE>(a, s); return true;                   \
+        case 3: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 2, 8, 2, FUSE>(a, s); return true;                     \
+        case 4: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 8, 2, 2, 2, 2, 8, 1, FUSE>(a, s); return true;                     \
+        case 5: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 4, 4, 1, 2, 2, 1, FUSE>(a, s); return true;                     \
+        case 6: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 4, 4, 1, 2, 2, 2, FUSE>(a, s); return true;                     \
+        case 7: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 2, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
+        case 8: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 2, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
+        case 9: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 4, 2, 2, 4, 2, 1, FUSE>(a, s); return true;                    \
+        case 10: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 1, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                  \
+        case 11: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
+        case 12: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 4, 2, 2, 4, 2, 1, FUSE>(a, s); return true;                    \
+        case 13: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 2, 8, 2, FUSE>(a, s); return true;                    \
+        case 14: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 2, FUSE>(a, s); return true;                    \
+        case 15: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 2, 8, 1, FUSE>(a, s); return true;                  \
+        case 16: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                  \
+        case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;
+#define SEG_C3X_3D_C16_CASES                                                                                          \
+        case 24: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2, 4>(a, s); return true;                               \
+        case 25: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2, 3>(a, s); return true;                               \
+        case 26: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 2, 2, 3>(a, s); return true;                               \
+        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;
+#define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_C16_CASES default: return false; }
+#define SEG_C3X_3D_GN_BODY switch (id) { SEG_C3X_3D_CONV_CASES default: return false; }
+
+/* halo-conv tilings; FUSE (a constexpr bool in scope) selects the instantiation that applies the producer GroupNorm while staging */
+#define SEG_C3X_2D_CONV_CASES                                                                                         \
+        case 32: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                 \
+        case 33: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 8, 2, 2, 2, 2, 2, 2, FUSE>(a, s); return true;                 \
+        case 34: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 2, 8, 2, FUSE>(a, s); return true;                  \
+        case 35: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 4, 8, 2, FUSE>(a, s); return true;                  \
+        case 36: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 4, 2, 2, 4, 2, 2, FUSE>(a, s); return true;                  \
+        case 37: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 1, 4, 1, 1, 8, 3, FUSE>(a, s); return true;                 \
+        case 38: launch_cfg<T, XBox<1, 8, 8, 1, 8>, 2, 2, 2, 2, 4, 8, 2, FUSE>(a, s); return true;                    \
+        case 39: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 2, 2, 4, 1, 2, 8, 2, FUSE>(a, s); return true;
+#define SEG_C3X_2D_C16_CASES                                                                                          \
+        case 56: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 1, 2, 4>(a, s); return true;                              \
+        case 57: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 2, 2, 4>(a, s); return true;
+#define SEG_C3X_2D_BODY switch (id) { SEG_C3X_2D_CONV_CASES SEG_C3X_2D_C16_CASES default: return false; }
+#define SEG_C3X_2D_GN_BODY switch (id) { SEG_C3X_2D_CONV_CASES default: return false; }
+
 
 }  // namespace c3x
 }  // namespace seg

@@ -53,6 +53,9 @@ struct Step {
     bool fold_fin = false;                    // statistics finalize folded into the consuming gn_act launch (no launch of its own)
     int x_fwd = -1, x_dg0 = -1, x_dg1 = -1;   // conv3x tiling of the forward / data-gradient launches (-1: conv3_kernel, row-major weights)
     int draw = -1;           // gradient wrt raw
+    int vact_prod = -1;      // UNIT (3^d conv on conv3x): its input tensor is VIRTUAL - the launch reads the raw output of unit `vact_prod` and
+                             // applies that unit's GroupNorm + dropout + ReLU while staging (forward conv and weight gradient alike)
+    bool vact = false;       // ACT: the activated tensor is never written (its single consumer is a vact_prod conv)
     // ACT
     int ua = -1, ub = -1, res = -1, out = -1;
     // POOL / HEAD
@@ -100,6 +103,7 @@ struct seg_engine {
     int npack_fwd = 0;
     bool pack_split = true, pack_bwd_pending = false;      // SEG_PACK_SPLIT=0: one launch on the caller's stream
     hipEvent_t pack_fork = nullptr, pack_done = nullptr;
+    bool use_vact = true;       // SEG_GN_VACT=0: every GroupNorm + dropout + ReLU is its own elementwise launch (round-2 path)
     bool use_rfuse = true;      // SEG_GN_RFUSE=0: every GroupNorm-backward reduce is its own launch
     bool use_fold = true;       // SEG_GN_FOLD=0: finalize kernels between the GroupNorm passes (round-1 path)
     bool use_vhead = true;      // SEG_VHEAD=0: head_bwd writes its data-gradient tensor (round-1 path)
@@ -132,6 +136,20 @@ struct seg_engine {
         // path.  At equal priority the command processor kept serving the side queue's back-to-back launches while the main
         // queue's next dispatch waited 30-125 us (profiles/r01_stream_gaps_step25.txt)
         hipStream_t st = nullptr;
+#ifndef SEG_EMU
+        // experiment knob (A/B only): confine the weight-gradient stream to a subset of the CUs so that its long, low-occupancy kernels
+        // cannot sit on every CU the main stream's kernels need.  SEG_SIDE_CUS=n: n of the CUs; SEG_SIDE_CU_STRIDE=k: every k-th mask bit
+        // (default 1 = the first n bits).  A masked stream has the default priority.
+        if (getenv("SEG_SIDE_CUS") && atoi(getenv("SEG_SIDE_CUS")) > 0) {
+            const int n = atoi(getenv("SEG_SIDE_CUS")), k = getenv("SEG_SIDE_CU_STRIDE") ? atoi(getenv("SEG_SIDE_CU_STRIDE")) : 1;
+            uint32_t mask[16] = {0};
+            int set = 0;
+            for (int off = 0; off < (k > 0 ? k : 1) && set < n; ++off)
+                for (int b = off; b < 256 && set < n; b += (k > 0 ? k : 1)) { mask[b >> 5] |= 1u << (b & 31); ++set; }
+            if (hipExtStreamCreateWithCUMask(&st, 16, mask) == hipSuccess && st) return st;
+            st = nullptr;
+        }
+#endif
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (side_prio && lo != hi) (void)hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo);
@@ -515,7 +533,10 @@ struct Planner {
         E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_is_bwd.clear(); E.pack_max = 0; E.n_deferred = 0;
         // drop gradient tensors of a previous plan
         size_t nfw = 0;
-        for (auto& s : E.steps) { nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1); s.draw = -1; s.rq_unit[0] = s.rq_unit[1] = -1; s.rfused = false; }
+        for (auto& s : E.steps) {
+            nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1);
+            s.draw = -1; s.rq_unit[0] = s.rq_unit[1] = -1; s.rfused = false; s.vact = false; s.vact_prod = -1;
+        }
         E.tens.resize(std::max<size_t>(nfw, (size_t)E.image_ten + 1));
         for (auto& t : E.tens) t.grads.clear();
 
@@ -614,6 +635,29 @@ struct Planner {
                     break;
             }
         }
+        // ---- virtual activations: an ACT (one branch, no residual) whose output feeds exactly ONE 3^d conv that runs on conv3x is
+        // never written: the consumer applies relu(scale * raw + shift) while it stages its halo, and so does the consumer's weight
+        // gradient (LUConv chains of networks/VNet3d.py:5-23, the two convs of networks/Unet3d.py:64-86 _block)
+        if (E.use_vact && dt != DT_F32 && !(getenv("SEG_WGRAD3X") && atoi(getenv("SEG_WGRAD3X")) != 0))
+            for (size_t ai = 0; ai < E.steps.size(); ++ai) {
+                Step& act = E.steps[ai];
+                if (act.type != ST_ACT || act.ub >= 0 || act.res >= 0) continue;
+                const Step& prod = E.steps[act.ua];
+                if (prod.fused_stem || prod.gn_w < 0 || prod.Cout > 256) continue;
+                int users = 0, cons = -1;
+                for (size_t ci = 0; ci < E.steps.size(); ++ci) {
+                    const Step& c = E.steps[ci];
+                    if (c.type == ST_UNIT && (c.in0 == act.out || c.in1 == act.out)) { ++users; cons = (int)ci; }
+                    if (c.type == ST_ACT && c.res == act.out) ++users;
+                    if ((c.type == ST_POOL || c.type == ST_HEAD) && c.in == act.out) ++users;
+                }
+                if (users != 1 || cons < 0) continue;
+                Step& c = E.steps[cons];
+                if (c.ck != CK_K3 || c.in0 != act.out || c.in1 >= 0 || c.x_fwd < 0 || !conv3x_gn_supported(c.Cin, false)) continue;
+                act.vact = true;
+                c.vact_prod = act.ua;
+                E.steps[act.ua].fold_fin = true;       // no finalize launch either: the consumer folds the statistics itself
+            }
         {   // forward layouts first, backward-only layouts behind them: the second range is packed on the weight-gradient stream
             std::vector<PackDesc> fw, bw;
             for (size_t i = 0; i < E.packdescs.size(); ++i) (E.pack_is_bwd[i] ? bw : fw).push_back(E.packdescs[i]);
@@ -675,7 +719,19 @@ struct Planner {
                                                     2.0 * E.N * E.vol(l) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout);
                         // replicas this producer spreads the statistics over (read back by the folded finalize of the consumers)
                         E.steps[si].stat_rep = (s.x_fwd >= 0 && E.use_fold) ? stat_rep_for(E.vol(l)) : STAT_REP;
-                        if (s.x_fwd >= 0)
+                        if (s.x_fwd >= 0 && s.vact_prod >= 0) {
+                            const Step& u = E.steps[s.vact_prod];        // the producer: its raw output is this launch's input
+                            GnFinArgs f{};
+                            f.stats = (double*)(E.ws + u.stats); f.gamma = E.p + E.params[u.gn_w].off; f.beta = E.p + E.params[u.gn_b].off;
+                            f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
+                                     : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                            f.mask_ld = E.ld_mask();
+                            f.scale = (float*)(E.ws + u.scale); f.shift = (float*)(E.ws + u.shift);
+                            f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
+                            f.N = E.N; f.C = u.Cout; f.V = E.vol(E.tens[u.raw].lvl); f.eps = 1e-5f; f.rep = u.stat_rep;
+                            launch_conv3x(s.x_fwd, E.ws + E.tens[u.raw].off, nullptr, i0.C, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N,
+                                          E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st, s.stat_rep, nullptr, &f);
+                        } else if (s.x_fwd >= 0)
                             launch_conv3x(s.x_fwd, E.ws + i0.off, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, E.ws + s.wp_fwd, bias,
                                           E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st,
                                           s.stat_rep);
@@ -733,6 +789,7 @@ struct Planner {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
                     const Step& ua = E.steps[s.ua];
+                    if (s.vact) return;                    // applied by the consuming conv while it stages its halo (Step::vact_prod)
                     if (ua.fused_stem) {
                         // fused input block: statistics of both branches from the image, finalize, then recompute + normalise + add
                         seg_stemx_args x = stemx_args(E, s);
@@ -1058,6 +1115,12 @@ struct Planner {
                             const Step& s = E.steps[si];
                             const Ten& i0 = E.tens[s.in0];
                             const int pi = E.prof_begin(ws_, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), fl);
+                            if (s.vact_prod >= 0) {     // the input tensor was never written: raw producer output + its published scale / shift
+                                const Step& u = E.steps[s.vact_prod];
+                                launch_wgrad3(E.ws + E.tens[draw].off, E.ws + E.tens[u.raw].off, (float*)(E.ws + E.cur_partial),
+                                              E.g + E.params[s.w].off, E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
+                                              nullptr, i0.C, (const float*)(E.ws + u.scale), (const float*)(E.ws + u.shift));
+                            } else
                             launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.cur_partial), E.g + E.params[s.w].off,
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
                                           s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
@@ -1196,6 +1259,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (getenv("SEG_STEMX")) e->use_stemx = atoi(getenv("SEG_STEMX")) != 0;
     if (getenv("SEG_PACK_SPLIT")) e->pack_split = atoi(getenv("SEG_PACK_SPLIT")) != 0;
     if (getenv("SEG_GN_RFUSE")) e->use_rfuse = atoi(getenv("SEG_GN_RFUSE")) != 0;
+    if (getenv("SEG_GN_VACT")) e->use_vact = atoi(getenv("SEG_GN_VACT")) != 0;
     if (getenv("SEG_GN_FOLD")) e->use_fold = atoi(getenv("SEG_GN_FOLD")) != 0;
     if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
     if (getenv("SEG_TAIL_WGRADS")) e->tail_wgrads = atoi(getenv("SEG_TAIL_WGRADS"));
@@ -1274,6 +1338,17 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
     if (!g_err.empty()) return -1;
     h->p = nullptr; h->g = nullptr; h->ws = nullptr;
     return 0;
+}
+int seg_plan_count(seg_handle h, int what) {
+    if (!h || !h->planned) return -1;
+    int n = 0;
+    for (auto& s : h->steps) {
+        if (what == 0) n += s.type == ST_ACT && s.vact;                                   // activations applied by their consumer (never written)
+        else if (what == 1) n += s.type == ST_UNIT;                                       // convolution units
+        else if (what == 2) n += s.type == ST_UNIT && s.rfused;                           // GroupNorm-backward reduces done by a data-gradient epilogue
+        else return -1;
+    }
+    return n;
 }
 long long seg_workspace_bytes(seg_handle h) { return (h && h->planned) ? (long long)h->ws_bytes : -1; }
 

@@ -23,8 +23,13 @@ int conv3x_num_cfgs();
 int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name);
 // GroupNorm-backward reduce of the consuming unit folded into a data-gradient launch (Conv3xArgs::rq_*, conv3x_impl.h)
 struct Conv3xReduce { const void* y; const float* scale; const float* shift; double* Q; int rep; };
+struct GnFinArgs;
+// gn != null: in0 is the RAW conv output of the producer unit; its GroupNorm + dropout + ReLU is applied while the halo is staged
+// (Conv3xArgs::fuse, conv3x_impl.h).  conv3x_gn_supported: which inputs that variant takes.
+bool conv3x_gn_supported(int Cin, bool has_in1);
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep = STAT_REP, const Conv3xReduce* rq = nullptr);
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep = STAT_REP, const Conv3xReduce* rq = nullptr,
+                   const GnFinArgs* gn = nullptr);
 // replicas a statistics producer spreads its atomics over, by voxels per sample: enough to keep same-address fp64 atomics apart,
 // few enough that the consumer-side fold (gn_fold_block) reads ~8 KB
 inline int stat_rep_for(long long V) { return V >= 262144 ? 32 : V >= 65536 ? 16 : V >= 8192 ? 8 : 4; }
@@ -40,7 +45,7 @@ bool launch_wgrad3x(const void* dr, const void* x0, const void* x1, int C0, floa
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q);
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0);
+                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, const float* xscale = nullptr, const float* xshift = nullptr);
 
 // MFMA image stem (K = taps*Cimg <= 32): forward and weight gradient on box tiles (conv3.hip)
 void launch_stem_fwd(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cimg,

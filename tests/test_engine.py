@@ -336,3 +336,29 @@ def check_conv3x_path(dev, monkeypatch, tag, dtype):
         # GroupNorm-parameter gradients are cancelling sums: two equally valid 16-bit roundings of the activations move some
         # of them by several percent at these tiny volumes (the same noise the oracle comparison of smoke() shows)
         assert float((a - b).norm()) / float(b.norm()) < (0.2 if dtype == "f16" else 0.6), k
+
+
+@pytest.mark.parametrize("tag,dtype", [("vnet3d", "f16"), ("unet3d", "bf16"), ("vnet2d", "f16")])
+def test_virtual_activation_equals_materialised(dev, tag, dtype, monkeypatch):
+    """The activation of a [conv -> GroupNorm -> dropout -> ReLU] unit whose only consumer is a halo conv is applied by that consumer
+    while it stages its input (and by the consumer's weight gradient) instead of being written by an elementwise launch
+    (Step::vact_prod, conv3x FUSE instantiations; reference chain networks/VNet3d.py:13-15).  Same arithmetic on the same values:
+    logits, loss and every gradient must equal the materialised path (SEG_GN_VACT=0) - bit for bit on the sequential host checker, to
+    rounding on the GPU (the statistics are accumulated with fp64 atomics whose order varies from launch to launch)."""
+    res = []
+    for vact in ("0", "1"):
+        monkeypatch.setenv("SEG_GN_VACT", vact)
+        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
+        res.append(run_engine(e, x, y, masks, alpha, loss, dev))
+        nv = e.lib.seg_plan_count(e.h, 0)
+        assert nv == (0 if vact == "0" else {"vnet3d": 12, "unet3d": 7, "vnet2d": 12}[tag]), nv      # LUConv chains / second conv of a _block
+        del e
+    (l0, p0, o0, g0), (l1, p1, o1, g1) = res
+    exact = dev.type == "cpu"
+    tol = 0.0 if exact else 2e-3
+    assert float((l0 - l1).abs().max()) <= tol * max(1.0, float(l0.abs().max()))
+    assert abs(float(o0[0]) - float(o1[0])) <= (0.0 if exact else 1e-5)
+    for k in g0:
+        d = float((g0[k] - g1[k]).norm())
+        # fp32 atomics of the weight-gradient reduce order differently from run to run on the GPU
+        assert d <= (0.0 if exact else 2e-3 * float(g0[k].norm()) + 1e-12), k
