@@ -20,7 +20,10 @@ typedef struct seg_engine* seg_handle;
 
 enum { SEG_NET_VNET = 0, SEG_NET_UNET = 1 };
 enum { SEG_F32 = 0, SEG_F16 = 1, SEG_BF16 = 2 };
-enum { SEG_LABEL_U8 = 0, SEG_LABEL_I32 = 1, SEG_LABEL_I64 = 2, SEG_LABEL_F32 = 3 };
+enum { SEG_LABEL_U8 = 0, SEG_LABEL_I32 = 1, SEG_LABEL_I64 = 2, SEG_LABEL_F32 = 3,
+       /* flag, or-ed into a label type: every kernel reads the label as (value != 0): `y[y != 0] = 1` of the binary training loops
+        * (model/modelVNet.py:576) on the device, so e.g. 0/255 mask images go to the loss / metric / clDice kernels as stored */
+       SEG_LABEL_BINARIZE = 16 };
 /* loss_name strings of model/modelVNet.py:68-76,513-521,750-756 */
 enum {
     SEG_LOSS_BINARY_DICE = 0,     /* model/losses.py:33-53   BinaryDiceLoss */

@@ -160,14 +160,18 @@ template <class T> __device__ __forceinline__ void dma16_async(i32x4 rsrc, T* ld
 __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // labels arrive as u8 / i32 / i64 / f32 class ids (the reference's datasets hand out int64)
-enum LabelType { LT_U8 = 0, LT_I32 = 1, LT_I64 = 2, LT_F32 = 3 };
+// LT_BINARIZE (flag, or-ed into the type): the label is read as (value != 0) - the `y[y != 0] = 1` of the reference's binary
+// training loops (model/modelVNet.py:576, modelUnet.py:576) done by the consumer kernels instead of a host pass over the labels
+enum LabelType { LT_U8 = 0, LT_I32 = 1, LT_I64 = 2, LT_F32 = 3, LT_BINARIZE = 16 };
 __device__ __forceinline__ int load_label(const void* p, int lt, long long i) {
-    switch (lt) {
-        case LT_U8: return (int)((const uint8_t*)p)[i];
-        case LT_I32: return ((const int*)p)[i];
-        case LT_I64: return (int)((const long long*)p)[i];
-        default: return (int)((const float*)p)[i];
+    int v;
+    switch (lt & 15) {
+        case LT_U8: v = (int)((const uint8_t*)p)[i]; break;
+        case LT_I32: v = ((const int*)p)[i]; break;
+        case LT_I64: v = (int)((const long long*)p)[i]; break;
+        default: v = (int)((const float*)p)[i]; break;
     }
+    return (lt & LT_BINARIZE) ? (v != 0) : v;
 }
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

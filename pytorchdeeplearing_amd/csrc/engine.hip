@@ -103,7 +103,10 @@ struct seg_engine {
     int npack_fwd = 0;
     bool pack_split = true, pack_bwd_pending = false;      // SEG_PACK_SPLIT=0: one launch on the caller's stream
     hipEvent_t pack_fork = nullptr, pack_done = nullptr;
-    bool use_vact = true;       // SEG_GN_VACT=0: every GroupNorm + dropout + ReLU is its own elementwise launch (round-2 path)
+    bool use_vact = false;      // SEG_GN_VACT=1: GroupNorm + dropout + ReLU of the LUConv chains applied by the consuming halo conv and its weight
+                                // gradient (12 launches and 12 activated tensors less in VNet3d).  Bit-identical, but measured 2.3 % SLOWER
+                                // (863 vs 883 volumes/s, profiles/r03_vact_cumask_ab.log): the per-workgroup statistics fold costs the two L2
+                                // round trips the 4.8 us launch cost, and the FUSE kernels spill scalars into the tap loop.  Opt-in.
     bool use_rfuse = true;      // SEG_GN_RFUSE=0: every GroupNorm-backward reduce is its own launch
     bool use_fold = true;       // SEG_GN_FOLD=0: finalize kernels between the GroupNorm passes (round-1 path)
     bool use_vhead = true;      // SEG_VHEAD=0: head_bwd writes its data-gradient tensor (round-1 path)
@@ -136,20 +139,8 @@ struct seg_engine {
         // path.  At equal priority the command processor kept serving the side queue's back-to-back launches while the main
         // queue's next dispatch waited 30-125 us (profiles/r01_stream_gaps_step25.txt)
         hipStream_t st = nullptr;
-#ifndef SEG_EMU
-        // experiment knob (A/B only): confine the weight-gradient stream to a subset of the CUs so that its long, low-occupancy kernels
-        // cannot sit on every CU the main stream's kernels need.  SEG_SIDE_CUS=n: n of the CUs; SEG_SIDE_CU_STRIDE=k: every k-th mask bit
-        // (default 1 = the first n bits).  A masked stream has the default priority.
-        if (getenv("SEG_SIDE_CUS") && atoi(getenv("SEG_SIDE_CUS")) > 0) {
-            const int n = atoi(getenv("SEG_SIDE_CUS")), k = getenv("SEG_SIDE_CU_STRIDE") ? atoi(getenv("SEG_SIDE_CU_STRIDE")) : 1;
-            uint32_t mask[16] = {0};
-            int set = 0;
-            for (int off = 0; off < (k > 0 ? k : 1) && set < n; ++off)
-                for (int b = off; b < 256 && set < n; b += (k > 0 ? k : 1)) { mask[b >> 5] |= 1u << (b & 31); ++set; }
-            if (hipExtStreamCreateWithCUMask(&st, 16, mask) == hipSuccess && st) return st;
-            st = nullptr;
-        }
-#endif
+        // (hipExtStreamCreateWithCUMask was tried for this stream in round 3: ANY mask - 64 ... 192 CUs, contiguous or strided - halves the
+        // step throughput, profiles/r03_vact_cumask_ab.log; not kept)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (side_prio && lo != hi) (void)hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo);

@@ -73,6 +73,9 @@ class SegEngine:
         self._seed = None
         self.packed = False
         self._targs = None
+        # True: every kernel that reads the target (losses, metrics, clDice) takes (label != 0) - the `y[y != 0] = 1` of the reference's
+        # binary training loops (model/modelVNet.py:576) without a host pass; the script-facing binary wrappers switch it on
+        self.binarize_labels = False
         # dynamic loss scaling for the f16 run dtype: the fused optimiser skips a step whose gradients overflow and tallies it on
         # the device; every `scale_check_every` steps the host reads the tally (one tiny sync) and halves the scale if anything
         # was skipped, doubles it again after `scale_growth_steps` clean steps (torch.cuda.amp.GradScaler's policy, coarse-grained)
@@ -227,7 +230,7 @@ class SegEngine:
         out3 = self._out3 if out3 is None else out3
         target = target.contiguous()
         if exchange is not None and exchange.world > 1:
-            args = (_ptr(logits), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, c, self.V, _capi.LOSS_KIND[loss_name],
+            args = (_ptr(logits), _ptr(target), _capi.label_type(target, self.binarize_labels), n, c, self.V, _capi.LOSS_KIND[loss_name],
                     float(focal_alpha), float(focal_gamma))
             self.lib.check(self.lib.seg_loss_reduce(*args, _ptr(self._loss_ws), self.stream()), "seg_loss_reduce")
             shared = self._loss_ws[:8 * self.lib.seg_loss_shared_doubles()].view(torch.float64)
@@ -237,7 +240,7 @@ class SegEngine:
             self._keep_loss = (target, class_alpha)
             return out3
         self.lib.check(self.lib.seg_loss_forward(
-            _ptr(logits), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, c, self.V, _capi.LOSS_KIND[loss_name],
+            _ptr(logits), _ptr(target), _capi.label_type(target, self.binarize_labels), n, c, self.V, _capi.LOSS_KIND[loss_name],
             float(focal_alpha), float(focal_gamma), _ptr(class_alpha), _ptr(self._loss_ws), _ptr(out3), self.stream()),
             "seg_loss_forward")
         self._keep_loss = (target, class_alpha)
@@ -249,7 +252,7 @@ class SegEngine:
         target = target.contiguous()
         gs = self.loss_scale if grad_scale is None else grad_scale
         self.lib.check(self.lib.seg_loss_backward(
-            _ptr(logits), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, c, self.V, _capi.LOSS_KIND[loss_name],
+            _ptr(logits), _ptr(target), _capi.label_type(target, self.binarize_labels), n, c, self.V, _capi.LOSS_KIND[loss_name],
             float(focal_alpha), float(focal_gamma), _ptr(self._loss_ws), float(gs), _ptr(dlogits), self.stream()),
             "seg_loss_backward")
         return dlogits
@@ -278,7 +281,7 @@ class SegEngine:
         target = target.contiguous()
         cur = torch.cuda.current_stream(self.device)
         self._cld_stream.wait_stream(cur)                  # labels (and the previous step's readers of the workspace) are done
-        self.lib.check(self.lib.seg_cldice_target(_ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, d, h, w, self.ndim, int(width),
+        self.lib.check(self.lib.seg_cldice_target(_ptr(target), _capi.label_type(target, self.binarize_labels), n, d, h, w, self.ndim, int(width),
                                                   _ptr(self._cld_ws), self._cld_stream.cuda_stream), "seg_cldice_target")
         target.record_stream(self._cld_stream)
         self._cld_target_ready = True
@@ -298,7 +301,7 @@ class SegEngine:
             self._cld_target_ready = False
         gs = (self.loss_scale if grad_scale is None else grad_scale) * float(weight)
         self.lib.check(self.lib.seg_cldice_binary(
-            _ptr(probs), _ptr(target), _capi.LABEL_TYPES[str(target.dtype)], n, d, h, w, self.ndim, int(width), float(gs),
+            _ptr(probs), _ptr(target), _capi.label_type(target, self.binarize_labels), n, d, h, w, self.ndim, int(width), float(gs),
             _ptr(self._cld_ws), _ptr(self._cld_out), _ptr(dlogits) if dlogits is not None else None, ready, self.stream()), "seg_cldice_binary")
         return self._cld_out
 
@@ -445,7 +448,7 @@ class SegEngine:
         if a is None:
             a = self._targs = _capi.TrainArgs()
             a.beta1, a.beta2, a.eps, a.grad_div = 0.9, 0.999, 1e-8, 1.0
-        a.x, a.target, a.label_type = x.data_ptr(), target.data_ptr(), _capi.LABEL_TYPES[str(target.dtype)]
+        a.x, a.target, a.label_type = x.data_ptr(), target.data_ptr(), _capi.label_type(target, self.binarize_labels)
         a.loss_kind, a.focal_alpha, a.focal_gamma = _capi.LOSS_KIND[loss_name], float(focal_alpha), float(focal_gamma)
         a.class_alpha = class_alpha.data_ptr() if class_alpha is not None else None
         a.logits, a.probs, a.dlogits = logits.data_ptr(), probs.data_ptr(), self._dlogits.data_ptr()

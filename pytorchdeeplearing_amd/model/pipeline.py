@@ -1,17 +1,23 @@
 """Input pipeline for `trainprocess`.  The reference loop reads one batch synchronously
 (`num_workers=0`, modelVNet.py:508-510), binarises the int64 label on the host (`y[y != 0] = 1`, :576) and copies both
-tensors with a blocking `.to(device)` (:577-578) before every step.  At >600 volumes/s that serial chain starves the GPU,
+tensors with a blocking `.to(device)` (:577-578) before every step.  At ~900 volumes/s that serial chain starves the GPU,
 so here:
 
-  * a reader thread walks the DataLoader ahead of the consumer (np.load / image decode overlap the train step);
-  * labels are binarised and narrowed to uint8 on the host (class ids < 256): one byte per voxel crosses PCIe instead of
-    eight (the loss kernels read u8 / i32 / i64 / f32 labels alike, common.h:load_label);
+  * `workers` reader threads (default 2, SEGENGINE_READER_THREADS) fetch and collate whole batches ahead of the consumer, in
+    DataLoader order (np.load / image decode release the GIL; a DataLoader that brings its own worker PROCESSES is simply
+    iterated by one thread);
+  * the binarisation happens on the DEVICE: the consumer kernels read labels as (value != 0) (SEG_LABEL_BINARIZE,
+    `SegEngine.binarize_labels`): uint8 / bool label batches (0/255 masks as stored) go to the GPU untouched.  int64 labels
+    (what the reference datasets hand out) are narrowed to one byte per voxel before PCIe in ONE host pass (`ne(0)` viewed as
+    uint8 for the binary nets - 8x less traffic; multi-class ids keep int64 if one does not fit a byte);
   * batches are staged in pinned memory and copied on a dedicated HIP stream; the consumer's stream waits on the copy's
     event, never the host (no `hipDeviceSynchronize` in the loop).
 
 Yields (x float32 (N,C,...) contiguous, y uint8/int64 (N,...) contiguous) on `device`, in DataLoader order."""
+import os
 import queue
 import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -19,31 +25,60 @@ _END = object()
 
 
 class DevicePrefetcher:
-    def __init__(self, loader, device, binary, depth=2):
+    def __init__(self, loader, device, binary, depth=2, workers=None):
         self.loader, self.device, self.binary, self.depth = loader, torch.device(device), binary, max(1, int(depth))
         self.cuda = self.device.type == "cuda"
         self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        if workers is None:
+            workers = int(os.environ.get("SEGENGINE_READER_THREADS", "2"))
+        self.workers = max(1, int(workers))
 
     def __len__(self):
         return len(self.loader)
 
     def _prepare(self, batch):
         x, y = batch["image"], batch["label"]
-        if self.binary:
-            y = (y != 0)                                   # == `y[y != 0] = 1` for the non-negative class ids of the datasets
-        if y.dtype == torch.bool or (y.numel() and int(y.min()) >= 0 and int(y.max()) < 256):
-            y = y.to(torch.uint8)
+        if y.dtype == torch.bool:
+            y = y.view(torch.uint8)
+        elif y.dtype != torch.uint8:
+            if self.binary:
+                y = y.ne(0).view(torch.uint8)              # the ONE narrowing pass (8 -> 1 byte per voxel) keeps "non-zero" exactly
+            elif y.numel() and int(y.min()) >= 0 and int(y.max()) < 256:
+                y = y.to(torch.uint8)
         x, y = x.float().contiguous(), y.contiguous()
         if self.cuda:
             x, y = x.pin_memory(), y.pin_memory()
         return x, y
 
+    def _batches(self):
+        """iterator over prepared (pinned) batches in loader order; several reader threads when the loader allows it"""
+        ld = self.loader
+        threaded = (self.workers > 1 and getattr(ld, "num_workers", 1) == 0 and getattr(ld, "batch_sampler", None) is not None and
+                    hasattr(ld, "dataset") and hasattr(ld, "collate_fn"))
+        if not threaded:
+            for batch in ld:
+                yield self._prepare(batch)
+            return
+        ds, collate = ld.dataset, ld.collate_fn
+
+        def fetch(indices):
+            return self._prepare(collate([ds[i] for i in indices]))
+
+        with ThreadPoolExecutor(max_workers=self.workers) as pool:
+            window = []
+            for indices in ld.batch_sampler:                 # the sampler is walked once, in order: shuffling stays the loader's
+                window.append(pool.submit(fetch, list(indices)))
+                if len(window) > self.workers:
+                    yield window.pop(0).result()
+            while window:
+                yield window.pop(0).result()
+
     def _reader(self, q, stop):
         try:
-            for batch in self.loader:
+            for item in self._batches():
                 if stop.is_set():
                     return
-                q.put(self._prepare(batch))
+                q.put(item)
             q.put(_END)
         except BaseException as ex:                        # surface loader errors in the consumer
             q.put(ex)

@@ -108,6 +108,7 @@ class _SegModel(object):
         self.model.apply(networks.initialize_weights)          # always re-initialises (modelVNet.py:546)
         eng = self.model.engine
         eng.init_optimizer()
+        eng.binarize_labels = bool(self._binary)               # `label[label != 0] = 1` (modelVNet.py:576) is done by the kernels that read the labels
         train_loader = self._dataloder(trainimage, trainmask, True)
         val_loader = self._dataloder(validationimage, validationmask, True)
         H = {"train_loss": [], "train_accuracy": [], "valdation_loss": [], "valdation_accuracy": []}

@@ -242,3 +242,95 @@ def test_device_prefetcher_order_labels_and_early_exit(dev, tmp_path, binary):
             raise OSError("unreadable volume")
     with pytest.raises(OSError):
         list(DevicePrefetcher(DataLoader(Broken(), batch_size=1), dev, binary))
+
+
+def test_reader_threads_keep_order_and_device_side_binarise(dev):
+    """several reader threads (items finish out of order) still deliver the sampler's order, one batch per
+    sampler entry; uint8 0/255 masks reach the device as stored and the kernels read them as (label != 0) (SEG_LABEL_BINARIZE):
+    loss, metric and gradient equal those of the host-binarised labels."""
+    import time
+    from torch.utils.data import DataLoader
+    from pytorchdeeplearing_amd import SegEngine, synthetic
+    from pytorchdeeplearing_amd.model.pipeline import DevicePrefetcher
+
+    class Slow(torch.utils.data.Dataset):
+        def __len__(self):
+            return 12
+
+        def __getitem__(self, i):
+            time.sleep(0.02 if i % 3 == 0 else 0.001)             # every third item is slow: later batches finish first
+            lab = torch.zeros((4, 4), dtype=torch.uint8)
+            lab[i % 4, :] = 255                                    # a 0/255 mask image, as stored
+            return {"image": torch.full((1, 4, 4), float(i)), "label": lab}
+    loader = DataLoader(Slow(), batch_size=2, shuffle=False, num_workers=0)
+    got = list(DevicePrefetcher(loader, dev, True, workers=4))
+    assert [float(x[0, 0, 0, 0]) for x, _ in got] == [0.0, 2.0, 4.0, 6.0, 8.0, 10.0]
+    assert all(y.dtype == torch.uint8 and int(y.max()) == 255 for _, y in got)             # untouched on the host
+    # the engine's kernels binarise: same numbers as with labels binarised beforehand
+    e = SegEngine("vnet", 2, 1, 1, dtype="f32", device=dev)
+    synthetic.init_engine(e, seed=0)
+    x, y = synthetic.synthetic_batch(2, (16, 16), 1, 1, seed=3)
+    x = x.to(dev)
+    y255 = (y * 255).to(torch.uint8).to(dev)
+    logits, probs = e.forward(x)
+    ref = e.loss_forward(logits, y.to(dev), "BinaryCrossEntropyDiceLoss").clone()
+    dref = e.loss_backward(logits, y.to(dev), "BinaryCrossEntropyDiceLoss").clone()
+    wrong = e.loss_forward(logits, y255, "BinaryCrossEntropyDiceLoss").clone()
+    e.binarize_labels = True
+    out = e.loss_forward(logits, y255, "BinaryCrossEntropyDiceLoss").clone()
+    dout = e.loss_backward(logits, y255, "BinaryCrossEntropyDiceLoss").clone()
+    assert torch.equal(out.cpu(), ref.cpu()) and torch.equal(dout.cpu(), dref.cpu())
+    assert abs(float(wrong[0]) - float(ref[0])) > 1e-3              # without the flag a 255 is a 255
+
+
+def _script_like_reference(tmp, cls, dims, numclass, loss, logdir, epochs, csv_rows, showwind):
+    """the body of the reference's train.py:13-37 / example.py:108-137 as a script text: CSV with image / mask paths read by pandas,
+    `from model import *`, keyword constructor, trainprocess.  Executed with exec() so `from model import *` resolves like in the scripts."""
+    import pandas as pd
+    tr, va = os.path.join(tmp, "traindata.csv"), os.path.join(tmp, "validata.csv")
+    pd.DataFrame(csv_rows[0], columns=["image", "mask"]).to_csv(tr, index=False)
+    pd.DataFrame(csv_rows[1], columns=["image", "mask"]).to_csv(va, index=False)
+    return """
+import pandas as pd
+import numpy as np
+from model import *
+csvdata = pd.read_csv(r'%s')
+maskdata = csvdata.iloc[:, 1].values
+imagedata = csvdata.iloc[:, 0].values
+perm = np.arange(len(imagedata))
+np.random.shuffle(perm)
+trainimages = imagedata[perm]
+trainlabels = maskdata[perm]
+csv_data2 = pd.read_csv(r'%s')
+valimages = csv_data2.iloc[:, 0].values
+vallabels = csv_data2.iloc[:, 1].values
+net = %s(image_depth=%d, image_height=%d, image_width=%d, image_channel=1, numclass=%d,
+         batch_size=1, loss_name='%s')
+net.trainprocess(trainimages, trainlabels, valimages, vallabels, model_dir=r'%s', epochs=%d, showwind=%s)
+""" % (tr, va, cls, dims[0], dims[1], dims[2], numclass, loss, logdir, epochs, showwind)
+
+
+@pytest.mark.parametrize("cls,numclass,loss,dims_gpu", [
+    ("MutilUNet3dModel", 5, "MutilDiceLoss", (128, 112, 112)),            # train.py:34-37 as shipped
+    ("MutilVNet3dModel", 16, "MutilCrossEntropyLoss", (80, 112, 176)),    # example.py:118-121: sixteen classes
+])
+def test_reference_entry_script_runs_unchanged(dev, tmp_path, monkeypatch, cls, numclass, loss, dims_gpu):
+    """the reference's own entry-script text (CSV of paths -> pandas -> `from model import *` -> keyword
+    constructor -> trainprocess) executes against this repo's `model` package at the script's own volume size, including the sixteen-class
+    wrappers of example.py."""
+    if dev.type != "cuda":
+        pytest.skip("the script text constructs its wrapper with the reference default use_cuda=True; covered by the -m gpu run")
+    monkeypatch.setenv("SEGENGINE_DTYPE", "f16")
+    tmp = str(tmp_path)
+    dims = dims_gpu
+    tr_i, tr_l = _make_npy(tmp, 2, dims, numclass, 11)
+    va_i, va_l = _make_npy(tmp, 1, dims, numclass, 12)
+    log = os.path.join(tmp, "log", cls)
+    text = _script_like_reference(tmp, cls, dims, numclass, loss, log, 1, (list(zip(tr_i, tr_l)), list(zip(va_i, va_l))), [4, 4])
+    ns = {}
+    exec(compile(text, "train_like_reference.py", "exec"), ns)
+    net = ns["net"]
+    assert len(net.history["train_loss"]) == 1 and np.isfinite(net.history["train_loss"]).all()
+    assert net.model.numclass == numclass
+    out = net.predict(np.load(tr_i[0]).reshape((1,) + dims))
+    assert out.shape == dims and out.dtype == np.uint8 and int(out.max()) < numclass
