@@ -6,7 +6,8 @@ namespace seg {
 namespace {
 using c3x::Conv3xArgs;
 
-struct Cfg { int id, ndim, td, th, tw, bn, nres; const char* name; int cin16 = 0; };   // cin16: the Cin == 16 kernel (two taps per MFMA step)
+struct Cfg { int id, ndim, td, th, tw, bn, nres; const char* name; int cin16 = 0; int cin32 = 0; };   // cin16: the Cin == 16 kernel (two taps per
+                                                                                                        // MFMA step); cin32: the persistent Cin == 32 kernel
 
 // id, ndim, box, BN, resident chunks — kept in sync with SEG_C3X_3D_BODY / SEG_C3X_2D_BODY (conv3x_impl.h)
 const Cfg kCfgs[] = {
@@ -29,10 +30,14 @@ const Cfg kCfgs[] = {
     {15, 3, 2, 8, 16, 32, 2, "2x8x16 t16 4x1 waves 4x2 tiles, 2 resident chunks"},
     {16, 3, 2, 8, 16, 32, 1, "2x8x16 t16 4x1 waves 4x2 tiles, deep B ring, 2 workgroups/CU"},
     {17, 3, 4, 8, 8, 32, 1, "4x8x8 t8 4x1 waves 4x2 tiles, deep B ring, 2 workgroups/CU"},
+    {18, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
+    {19, 3, 2, 8, 8, 32, 1, "Cin32 persistent: 2x8x8 t8 4x1 waves 2x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {24, 3, 2, 8, 16, 16, 1, "Cin16: 2x8x16 t16 4x1 waves 4x1 tiles", 1},
     {25, 3, 4, 8, 16, 16, 1, "Cin16: 4x8x16 t16 4x1 waves 8x1 tiles", 1},
     {26, 3, 2, 8, 16, 32, 1, "Cin16: 2x8x16 t16 4x1 waves 4x2 tiles", 1},
     {27, 3, 4, 8, 16, 32, 1, "Cin16: 4x8x16 t16 4x1 waves 8x2 tiles", 1},
+    {28, 3, 2, 8, 16, 16, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x1 tiles, weights in LDS, double-buffered halo", 1},
+    {29, 3, 2, 8, 16, 32, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 1},
     // 2-D
     {32, 2, 1, 16, 16, 32, 1, "16x16 t16 4x1 waves 4x2 tiles"},
     {33, 2, 1, 16, 16, 64, 2, "16x16 t16 2x2 waves 8x2 tiles"},
@@ -42,8 +47,10 @@ const Cfg kCfgs[] = {
     {37, 2, 1, 16, 16, 16, 1, "16x16 t16 4x1 waves 4x1 tiles"},
     {38, 2, 1, 8, 8, 64, 4, "8x8 t8 2x2 waves 2x2 tiles, 4 resident chunks"},
     {39, 2, 1, 8, 16, 32, 2, "8x16 t16 4x1 waves 2x2 tiles, 2 resident chunks"},
+    {40, 2, 1, 16, 16, 32, 1, "Cin32 persistent: 16x16 t16 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {56, 2, 1, 16, 16, 16, 1, "Cin16: 16x16 t16 4x1 waves 4x1 tiles", 1},
     {57, 2, 1, 16, 16, 32, 1, "Cin16: 16x16 t16 4x1 waves 4x2 tiles", 1},
+    {58, 2, 1, 16, 16, 16, 1, "Cin16 persistent: 16x16 t16 4x1 waves 4x1 tiles, weights in LDS, double-buffered halo", 1},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -53,7 +60,9 @@ const Cfg* find_cfg(int id) {
     return nullptr;
 }
 
-bool cfg_fits(const Cfg& c, int ndim, int Cin, int Cout) { return c.ndim == ndim && Cout % c.bn == 0 && (c.cin16 != 0) == (Cin == 16); }
+bool cfg_fits(const Cfg& c, int ndim, int Cin, int Cout) {
+    return c.ndim == ndim && Cout % c.bn == 0 && (c.cin16 != 0) == (Cin == 16) && (!c.cin32 || Cin == 32);
+}
 
 }  // namespace
 
@@ -74,11 +83,11 @@ bool conv3x_gn_supported(int Cin, bool has_in1) { return !has_in1 && Cin % 32 ==
 
 // default tiling per problem.  Overrides: SEG_C3X_CFG=<id> (one tiling wherever it fits), SEG_C3X_MAP="cin:cout:w=id,..."
 // (per layer shape; tools/tune_conv3x.py prints the measured table).
-int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
+int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool has_in1) {
     static const int force = getenv("SEG_C3X_CFG") ? atoi(getenv("SEG_C3X_CFG")) : -1;
     if (force >= 0) {
         const Cfg* c = find_cfg(force);
-        if (c && cfg_fits(*c, ndim, Cin, Cout)) return force;
+        if (c && cfg_fits(*c, ndim, Cin, Cout) && !(c->cin32 && has_in1)) return force;
     }
     static const char* map = getenv("SEG_C3X_MAP");
     if (map) {
@@ -86,7 +95,7 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
             int ci = 0, co = 0, w = 0, id = -1;
             if (sscanf(p, "%d:%d:%d=%d", &ci, &co, &w, &id) == 4 && ci == Cin && co == Cout && w == W) {
                 const Cfg* c = find_cfg(id);
-                if (c && cfg_fits(*c, ndim, Cin, Cout)) return id;
+                if (c && cfg_fits(*c, ndim, Cin, Cout) && !(c->cin32 && has_in1)) return id;
             }
             while (*p && *p != ',') ++p;
             if (*p == ',') ++p;
@@ -98,10 +107,18 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
     // more than operand reuse; for 32 output channels a 256-voxel box and 4 x 2 register tiles.
     const long long vox = (long long)N * D * H * W;
     int id;
-    if (Cin == 16) id = ndim == 3 ? (Cout % 32 ? 24 : 26) : (Cout % 32 ? 56 : 57);
+    if (Cin == 16) {
+        id = ndim == 3 ? (Cout % 32 ? 24 : 26) : (Cout % 32 ? 56 : 57);
+        // volumes with at least four boxes per resident workgroup (512): the persistent double-buffered tilings
+        if (ndim == 3 && vox >= 512ll * 4 * 256) id = Cout % 32 ? 28 : 29;
+    }
     else if (ndim == 3) {
         if (Cout % 32) id = 10;
-        else if (Cout % 64) id = Cin <= 32 ? 14 : (Cin == 64 ? (W >= 48 ? 17 : 15) : 14);
+        else if (Cout % 64) {
+            id = Cin <= 32 ? 14 : (Cin == 64 ? (W >= 48 ? 17 : 15) : 14);
+            // 32 -> 32 channels on a volume with at least two boxes per CU: persistent workgroups, LDS-resident weights, double-buffered halo
+            if (Cin == 32 && !has_in1 && vox >= 256ll * 2 * 256) id = 18;
+        }
         else if (vox <= 16384) id = Cout >= 2 * Cin ? 13 : 7;
         else id = Cin >= 128 ? 5 : 3;
     } else {
@@ -112,7 +129,7 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout) {
     const Cfg* c = find_cfg(id);
     if (c && cfg_fits(*c, ndim, Cin, Cout)) return id;
     for (int i = 0; i < kNumCfgs; ++i)
-        if (cfg_fits(kCfgs[i], ndim, Cin, Cout)) return kCfgs[i].id;
+        if (cfg_fits(kCfgs[i], ndim, Cin, Cout) && !kCfgs[i].cin32) return kCfgs[i].id;
     return -1;
 }
 
@@ -133,7 +150,8 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
                    int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const Conv3xReduce* rq, const GnFinArgs* gn) {
     const Cfg* c = find_cfg(cfg);
     if (!c || !cfg_fits(*c, ndim, Cin, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
-    if (gn && !conv3x_gn_supported(Cin, in1 != nullptr)) return false;
+    if (gn && (!conv3x_gn_supported(Cin, in1 != nullptr) || c->cin32)) return false;
+    if (c->cin32 && in1) return false;
     Conv3xArgs a;
     a.fuse = gn ? 1 : 0;
     a.gn = gn ? *gn : GnFinArgs{};

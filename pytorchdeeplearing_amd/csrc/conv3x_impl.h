@@ -370,6 +370,145 @@ void launch_cfg(const Conv3xArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cin == 32, 32 output channels per workgroup: PERSISTENT workgroups with LDS-RESIDENT weights and a DOUBLE-BUFFERED halo
+// (the 48^3 x 32-channel LUConv level of VNet3d, networks/VNet3d.py:117-125 down_tr32 / up_tr64: 8 launches per train step).
+// conv3x_kernel spends 3-5 us of a box's ~8 us staging its halo and streams 54 KB of B fragments per wave and box from L2 (the
+// round-2 roofline_mfma kernel: 0.16 of MFMA peak).  Here a workgroup
+//   * copies the [27][2][64 lanes][8] fragment-major weight slab (54 KB) into LDS ONCE and reads its B fragments from there:
+//     the tap loop issues no vector-memory instruction at all, so
+//   * the halo of the NEXT box travels global -> LDS (dma16_async: untracked buffer_load ... lds) while the MFMAs of the current
+//     box run out of the other buffer; one s_waitcnt vmcnt(0) + barrier per box publishes it;
+//   * walks the boxes of ONE XCD's contiguous range (block b -> XCD b % 8), stride = workgroups per XCD.
+// One workgroup per CU (2 x 45 KB halo + 54 KB weights); the epilogue (shared with conv3x_kernel) aliases the consumed buffer.
+// ------------------------------------------------------------------------------------------------
+template <class T, class B, int TM, int TN>
+__global__ __launch_bounds__(256, 1) void conv3p_kernel(Conv3xArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
+    static_assert(4 * TM == B::NTILE, "four waves cover the box");
+    constexpr int WM = 4, WN = 1, BN = TN * 16, OLD = BN + 8;
+    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 4096 / sizeof(T);
+    constexpr int BUF = B::CHUNK_ELEMS > OS_ELEMS + RED_ELEMS ? B::CHUNK_ELEMS : OS_ELEMS + RED_ELEMS;
+    constexpr int NW = B::NTAP * TN;                       // 1 KB weight fragments resident in LDS
+    __shared__ __attribute__((aligned(16))) T Ws[NW * 512];
+    __shared__ __attribute__((aligned(16))) T Xs[2][BUF];
+    constexpr int NI = (B::NINSTR + 3) / 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
+    const int nbox = a.N * nbz * nby * nbx;
+    // this workgroup's boxes: XCD k = blockIdx.x % 8 owns [k * per, (k + 1) * per), its workgroups stride through it
+    const int per = (nbox + 7) >> 3, xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    const int b_end = (xcd + 1) * per < nbox ? (xcd + 1) * per : nbox;
+    int box = xcd * per + (int)(blockIdx.x >> 3);
+    if (box >= b_end) return;
+    const int co0 = blockIdx.y * BN;
+    const int NT_total = a.Cout >> 4;
+    const long long vol = (long long)a.D * a.H * a.W;
+
+    // ---- weights -> LDS (tracked copies; waited for together with the first halo)
+    {
+        const i32x4 wr = make_rsrc(a.w, (unsigned)B::NTAP * (unsigned)NT_total * 1024u);
+        for (int i = wv; i < NW; i += 4) {
+            const int tap = i / TN, j = i % TN;
+            dma16(wr, Ws + i * 512, ((unsigned)(tap * NT_total + blockIdx.y * TN + j) * 64u + lane) * 16u);
+        }
+    }
+    struct Pos { int x0, y0, z0, n; };
+    auto pos_of = [&](int b) {
+        Pos p;
+        p.x0 = (b % nbx) * B::TW; b /= nbx;
+        p.y0 = (b % nby) * B::TH; b /= nby;
+        p.z0 = (b % nbz) * B::TD;
+        p.n = b / nbz;
+        return p;
+    };
+    auto issue_box = [&](const Pos& p, int buf) {
+        const i32x4 rs = make_rsrc((const T*)a.in0 + (long long)p.n * vol * 32, (unsigned)(vol * 64));
+        T* dst = Xs[buf];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = u * 4 + wv;                      // instruction index inside the chunk image (wave-uniform)
+            if (i < B::NINSTR) {
+                const int g = i * 64 + lane;
+                const int row = g / (B::HWP * 4), rem = g % (B::HWP * 4);
+                const int hx = rem >> 2, slot = rem & 3;
+                const int hz = row / B::HH, hy = row % B::HH;
+                const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
+                const bool ok = row < B::ROWS && hx < B::HW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
+                                (unsigned)x < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)((z * a.H + y) * a.W + x) * 64u + (unsigned)(slot ^ halo_swz_x(row, hx)) * 16u : DMA_OOB;
+                dma16_async(rs, dst + i * 512, off);
+            }
+        }
+    };
+    // ---- A-fragment addressing (as conv3x_kernel)
+    int ab[TM][3];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        int vz, vy, vx;
+        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
+        const int row = vz * B::HH + vy;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) ab[m][kw] = (row * B::HWP + vx) * 32 + ((q ^ halo_swz_x(row, vx + kw)) << 3);
+    }
+    Pos p = pos_of(box);
+    issue_box(p, 0);
+    int cur = 0;
+    for (; box < b_end; box += stride) {
+        wait_vmem();                                       // this wave's copies into Xs[cur] (and, the first time, the weights) have landed
+        __syncthreads();                                   // ... everybody's; the other buffer's epilogue scratch is free
+        const int nxt = box + stride;
+        Pos pn = p;
+        if (nxt < b_end) { pn = pos_of(nxt); issue_box(pn, cur ^ 1); }
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* Xc = Xs[cur];
+        typename Mma<T>::frag af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xc[ab[m][0]]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = load8(&Ws[j * 512 + lane * 8]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int t = 0; t < B::NTAP; ++t) {
+            if (t + 1 < B::NTAP) {
+                const int t1 = t + 1, kw = t1 % 3, srow = (t1 / 9) * B::HH + (t1 / 3) % 3;
+                const int toff = (srow * B::HWP + kw) * 32, flip = (srow & 1) << 4;
+#pragma unroll
+                for (int m = 0; m < TM; ++m) af[t1 & 1][m] = load8(&Xc[toff + (ab[m][kw] ^ flip)]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[t1 & 1][j] = load8(&Ws[(t1 * TN + j) * 512 + lane * 8]);
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(af[t & 1][m], bf[t & 1][j], acc[m][j]);
+            if (t + 1 < B::NTAP) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS reads of tap t + 1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                        // ... ahead of the MFMAs of tap t
+        }
+        __syncthreads();                                   // every wave is done reading Xs[cur]: the epilogue may alias it
+        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs[cur], a, p.n, p.x0, p.y0, p.z0, co0);
+        p = pn;
+        cur ^= 1;
+    }
+}
+
+template <class T, class B, int TM, int TN>
+void launch_cfgp(const Conv3xArgs& a, hipStream_t s) {
+    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
+    // one workgroup per CU of the 256; fewer when there are fewer boxes (grid.x a multiple of 8: workgroups per XCD x 8 XCDs)
+    static const int wgs = getenv("SEG_C3P_WGS") ? atoi(getenv("SEG_C3P_WGS")) : 256;
+    long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
+    const long long per = (nbox + 7) / 8;
+    if (per_xcd > per) per_xcd = per;
+    dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3p_kernel<T, B, TM, TN>), grid, dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cin == 16 (the full-resolution LUConv / _block layers: networks/VNet3d.py:117-125 up_tr32.ops, networks/Unet3d.py enc1 / dec1).
 // One 16x16x32 MFMA step multiplies TWO taps: lanes q = 0, 1 hold the 16 channels of tap 2s, lanes q = 2, 3 those of tap 2s + 1
 // (K order of the weights is (tap, ci) flat; seg_pack_desc.frag = 2).  Halo rows are 32 B; 16 consecutive voxels of an x row
@@ -481,6 +620,140 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
     c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs, a, n, x0, y0, z0, co0);
 }
 
+// The same persistent scheme for Cin == 16 (conv3x16_kernel's two-taps-per-step arithmetic): the [14 steps][TN][64][8] weight slab (14 / 28 KB)
+// lives in LDS, the 25 KB halo is double-buffered, two workgroups per CU.  These launches are HBM-bound (226 MB at 4 x 96^3):
+// what the double buffer buys is that the copy of box i + 1 streams while box i is multiplied and written back.
+template <class T, class B, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv3p16_kernel(Conv3xArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
+    static_assert(B::TX == 16, "x rows of 16 voxels");
+    static_assert(4 * TM == B::NTILE, "four waves cover the box");
+    constexpr int WM = 4, WN = 1, BN = TN * 16, OLD = BN + 8;
+    constexpr int NSTEP = (B::NTAP + 1) / 2;
+    constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
+    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 4096 / sizeof(T);
+    constexpr int BUF = XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS;
+    constexpr int NW = NSTEP * TN;
+    __shared__ __attribute__((aligned(16))) T Ws[NW * 512];
+    __shared__ __attribute__((aligned(16))) T Xs[2][BUF];
+    constexpr int NI = (NINSTR + 3) / 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
+    const int nbox = a.N * nbz * nby * nbx;
+    const int per = (nbox + 7) >> 3, xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    const int b_end = (xcd + 1) * per < nbox ? (xcd + 1) * per : nbox;
+    int box = xcd * per + (int)(blockIdx.x >> 3);
+    if (box >= b_end) return;
+    const int co0 = blockIdx.y * BN;
+    const long long vol = (long long)a.D * a.H * a.W;
+    {
+        const unsigned wstep = (unsigned)(a.Cout >> 4) * 1024u;
+        const i32x4 wr = make_rsrc(a.w, (unsigned)NSTEP * wstep);
+        for (int i = wv; i < NW; i += 4) {
+            const int st = i / TN, j = i % TN;
+            dma16(wr, Ws + i * 512, (unsigned)st * wstep + ((unsigned)(blockIdx.y * TN + j) * 64u + lane) * 16u);
+        }
+    }
+    struct Pos { int x0, y0, z0, n; };
+    auto pos_of = [&](int b) {
+        Pos p;
+        p.x0 = (b % nbx) * B::TW; b /= nbx;
+        p.y0 = (b % nby) * B::TH; b /= nby;
+        p.z0 = (b % nbz) * B::TD;
+        p.n = b / nbz;
+        return p;
+    };
+    auto issue_box = [&](const Pos& p, int buf) {
+        const i32x4 rs = make_rsrc((const T*)a.in0 + (long long)p.n * vol * 16, (unsigned)(vol * 32));
+        T* dst = Xs[buf];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = u * 4 + wv;
+            if (i < NINSTR) {
+                const int g = i * 64 + lane;
+                const int row = g / (B::HWP * 2), rem = g % (B::HWP * 2);
+                const int hx = rem >> 1, piece = rem & 1;
+                const int hz = row / B::HH, hy = row % B::HH;
+                const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
+                const bool ok = row < B::ROWS && hx < B::HW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                dma16_async(rs, dst + i * 512, ok ? (unsigned)(((z * a.H + y) * a.W + x) * 32 + piece * 16) : DMA_OOB);
+            }
+        }
+    };
+    // ---- A addressing (conv3x16_kernel): lanes q < 2 read tap 2s, lanes q >= 2 tap 2s + 1
+    constexpr int D_KW = 16, D_KH = (B::HWP - 2) * 16, D_KD = ((B::HH - 2) * B::HWP - 2) * 16;    // elements
+    const int hi = q >> 1, piece = q & 1;
+    int ab[TM][3];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        int vz, vy, vx;
+        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
+        const int base = ((vz * B::HH + vy) * B::HWP + vx) * 16 + piece * 8;
+        ab[m][0] = base + (hi ? D_KW : 0);
+        ab[m][1] = base + (hi ? D_KH : 0);
+        ab[m][2] = base + (hi ? D_KD : 0);
+    }
+    auto tap_off = [](int t) { return ((t / 9) * B::HH + (t / 3) % 3) * B::HWP + t % 3; };       // halo voxels
+    Pos p = pos_of(box);
+    issue_box(p, 0);
+    int cur = 0;
+    for (; box < b_end; box += stride) {
+        wait_vmem();
+        __syncthreads();
+        const int nxt = box + stride;
+        Pos pn = p;
+        if (nxt < b_end) { pn = pos_of(nxt); issue_box(pn, cur ^ 1); }
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* Xc = Xs[cur];
+        typename Mma<T>::frag af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xc[ab[m][0] + tap_off(0) * 16]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = load8(&Ws[j * 512 + lane * 8]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) {
+                const int t0 = 2 * (s + 1), t1 = t0 + 1;
+                const int d = t1 >= B::NTAP ? -1 : (tap_off(t1) - tap_off(t0) == 1 ? 0 : (t1 % 9 == 0 ? 2 : 1));
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const int basev = d < 0 ? ab[m][0] - (hi ? D_KW : 0) : ab[m][d];
+                    af[(s + 1) & 1][m] = load8(&Xc[basev + tap_off(t0) * 16]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(s + 1) & 1][j] = load8(&Ws[((s + 1) * TN + j) * 512 + lane * 8]);
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(af[s & 1][m], bf[s & 1][j], acc[m][j]);
+            if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        __syncthreads();
+        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs[cur], a, p.n, p.x0, p.y0, p.z0, co0);
+        p = pn;
+        cur ^= 1;
+    }
+}
+
+template <class T, class B, int TM, int TN>
+void launch_cfgp16(const Conv3xArgs& a, hipStream_t s) {
+    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
+    static const int wgs = getenv("SEG_C3P16_WGS") ? atoi(getenv("SEG_C3P16_WGS")) : 512;      // two workgroups per CU
+    long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
+    const long long per = (nbox + 7) / 8;
+    if (per_xcd > per) per_xcd = per;
+    dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3p16_kernel<T, B, TM, TN>), grid, dim3(256), 0, s, a);
+}
+
 template <class T, class B, int TM, int TN, int PF, int OCC>
 void launch_cfg16(const Conv3xArgs& a, hipStream_t s) {
     const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
@@ -515,12 +788,18 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 15: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 2, 8, 1, FUSE>(a, s); return true;                  \
         case 16: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                  \
         case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;
+/* Cin == 32 persistent tilings (conv3p_kernel):   box                  TM TN */
+#define SEG_C3X_3D_P_CASES                                                                                            \
+        case 18: launch_cfgp<T, XBox<4, 8, 8, 3, 8>, 4, 2>(a, s); return true;                                       \
+        case 19: launch_cfgp<T, XBox<2, 8, 8, 3, 8>, 2, 2>(a, s); return true;
 #define SEG_C3X_3D_C16_CASES                                                                                          \
         case 24: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2, 4>(a, s); return true;                               \
         case 25: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2, 3>(a, s); return true;                               \
         case 26: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 2, 2, 3>(a, s); return true;                               \
-        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;
-#define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_C16_CASES default: return false; }
+        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;                               \
+        case 28: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 1>(a, s); return true;                                    \
+        case 29: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 2>(a, s); return true;
+#define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_P_CASES SEG_C3X_3D_C16_CASES default: return false; }
 #define SEG_C3X_3D_GN_BODY switch (id) { SEG_C3X_3D_CONV_CASES default: return false; }
 
 /* halo-conv tilings; FUSE (a constexpr bool in scope) selects the instantiation that applies the producer GroupNorm while staging */
@@ -533,10 +812,13 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 37: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 1, 4, 1, 1, 8, 3, FUSE>(a, s); return true;                 \
         case 38: launch_cfg<T, XBox<1, 8, 8, 1, 8>, 2, 2, 2, 2, 4, 8, 2, FUSE>(a, s); return true;                    \
         case 39: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 2, 2, 4, 1, 2, 8, 2, FUSE>(a, s); return true;
+#define SEG_C3X_2D_P_CASES                                                                                            \
+        case 40: launch_cfgp<T, XBox<1, 16, 16, 1, 16>, 4, 2>(a, s); return true;
 #define SEG_C3X_2D_C16_CASES                                                                                          \
         case 56: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 1, 2, 4>(a, s); return true;                              \
-        case 57: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 2, 2, 4>(a, s); return true;
-#define SEG_C3X_2D_BODY switch (id) { SEG_C3X_2D_CONV_CASES SEG_C3X_2D_C16_CASES default: return false; }
+        case 57: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 2, 2, 4>(a, s); return true;                              \
+        case 58: launch_cfgp16<T, XBox<1, 16, 16, 1, 16>, 4, 1>(a, s); return true;
+#define SEG_C3X_2D_BODY switch (id) { SEG_C3X_2D_CONV_CASES SEG_C3X_2D_P_CASES SEG_C3X_2D_C16_CASES default: return false; }
 #define SEG_C3X_2D_GN_BODY switch (id) { SEG_C3X_2D_CONV_CASES default: return false; }
 
 

@@ -585,7 +585,7 @@ struct Planner {
                     if (s.ck == CK_K3 && E.use_conv3x) {
                         // register-blocked halo kernel (conv3x.hip) wherever the shape allows: fragment-major weights
                         const int l = E.tens[s.raw].lvl, d_ = E.dim_d(l), h_ = E.dim_h(l), w_ = E.dim_w(l);
-                        if (conv3x_supported(dt, E.ndim, N, d_, h_, w_, Ci, Co, C0, C1 > 0)) s.x_fwd = conv3x_pick(E.ndim, N, d_, h_, w_, Ci, Co);
+                        if (conv3x_supported(dt, E.ndim, N, d_, h_, w_, Ci, Co, C0, C1 > 0)) s.x_fwd = conv3x_pick(E.ndim, N, d_, h_, w_, Ci, Co, C1 > 0);
                         if (!E.tens[s.in0].image && conv3x_supported(dt, E.ndim, N, d_, h_, w_, Co, C0, 0, false))
                             s.x_dg0 = conv3x_pick(E.ndim, N, d_, h_, w_, Co, C0);
                         if (C1 && conv3x_supported(dt, E.ndim, N, d_, h_, w_, Co, C1, 0, false)) s.x_dg1 = conv3x_pick(E.ndim, N, d_, h_, w_, Co, C1);

@@ -18,7 +18,7 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
                   int Cout, int ndim, int dtype, hipStream_t s, const void* in1 = nullptr, int C0 = 0);   // in1: second concat source
 // register-blocked variant for 16-bit tensors, Cin % 32 == 0 (conv3x.hip); weights fragment-major (PackDesc.frag = 1)
 bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, int Cout, int C0, bool has_in1);
-int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout);    // tiling id for the shape, -1: none
+int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool has_in1 = false);    // tiling id for the shape, -1: none
 int conv3x_num_cfgs();
 int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name);
 // GroupNorm-backward reduce of the consuming unit folded into a data-gradient launch (Conv3xArgs::rq_*, conv3x_impl.h)

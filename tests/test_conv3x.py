@@ -1,6 +1,8 @@
 """Register-blocked halo conv (csrc/conv3x.hip) against torch.nn.functional on integer-valued data: every tiling of the
 kernel, forward (+ bias + GroupNorm partial sums), data-gradient (flipped fragment-major weights), virtual concat inputs
 (aligned and straddling a 32-channel chunk), partial boxes, several chunk groups.  Bit-exact for f16 and bf16."""
+import os
+
 import pytest
 
 import conftest
@@ -11,6 +13,10 @@ from pytorchdeeplearing_amd import ops
 from test_ops import cl, ncdhw, ints, to_dev
 
 # ndim, N, spatial, Cin (list = concat sources), Cout, tiling ids to run (None: the default pick)
+# the persistent Cin == 32 kernel launches one workgroup per CU; 16 workgroups make every workgroup of these small volumes walk several boxes
+os.environ.setdefault("SEG_C3P_WGS", "16")
+os.environ.setdefault("SEG_C3P16_WGS", "16")
+
 CASES = [
     (3, 1, (3, 9, 18), [32], 32, [0, 1, 13, 14]),          # partial boxes in every direction
     (3, 2, (2, 8, 16), [64], 64, [2, 15]),
@@ -23,11 +29,16 @@ CASES = [
     (3, 1, (2, 4, 8), [64, 64], 64, [None]),
     (3, 1, (3, 9, 18), [16], 16, [24, 25]),                 # Cin == 16: two taps per MFMA step, flat-K weights
     (3, 2, (2, 8, 32), [16], 32, [26, 27]),
+    (3, 2, (5, 17, 34), [16], 16, [28]),                    # Cin == 16 persistent tilings, several boxes per workgroup (SEG_C3P16_WGS)
+    (3, 1, (4, 16, 48), [16], 32, [29]),
+    (2, 2, (33, 40), [16], 16, [58]),
     (2, 1, (19, 24), [16], 16, [56]),
     (2, 2, (16, 16), [16], 32, [57, None]),
     (2, 2, (17, 20), [32], 32, [32, 39]),
     (2, 1, (16, 32), [64], 64, [33, 34, 35, 38]),
     (2, 1, (9, 16), [128], 128, [36]),
+    (3, 2, (9, 17, 18), [32], 32, [18, 19]),               # Cin == 32 persistent tilings: several boxes per workgroup (SEG_C3P_WGS below), both halo buffers
+    (2, 2, (33, 40), [32], 32, [40]),
     (2, 1, (8, 16), [32], 16, [37]),
     (2, 1, (12, 24), [16, 16], 64, [38]),
 ]

@@ -15,6 +15,7 @@ from pytorchdeeplearing_amd import ops  # noqa: E402
 
 # (ndim, N, spatial, Cin, Cout): forward shapes; data-gradient shapes are (Cout -> Cin parts) and are listed explicitly
 SETS = {
+    "top": ("f16", [(3, 4, 96, 16, 16), (3, 4, 48, 32, 32)]),
     "c3": ("f16", [(3, 4, 48, 32, 32), (3, 4, 24, 64, 64), (3, 4, 12, 128, 128), (3, 4, 6, 256, 256)]),
     "c5": ("bf16", [(3, 1, 80, 32, 32), (3, 1, 40, 64, 64), (3, 1, 20, 128, 128), (3, 1, 10, 256, 256)]),
     "c4": ("f16", [(3, 2, 64, 32, 32), (3, 2, 64, 32, 16), (3, 2, 64, 64, 32), (3, 2, 32, 32, 64), (3, 2, 32, 64, 64), (3, 2, 32, 64, 32),
