@@ -88,6 +88,10 @@ def parse(argv=None):
     ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented steps run AFTER the timed region: every launch of the roofline "
                     "kernel classes is bracketed by HIP events on its launch stream (each bracket idles the stream for ~6 us, so none of "
                     "them is inside the timed region)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "stream", "graph"], help="how the single-rank step reaches the GPU: stream = ~250 "
+                    "launches enqueued per step by one library call; graph = the step captured once as a HIP graph, one hipGraphLaunch per step; "
+                    "auto = both are timed for a few steps inside the un-timed conditioning phase and the faster one runs the warm-up and the "
+                    "timed steps (a host that cannot keep up with the GPU is the case for the graph: BENCH_r02 lost 17 %% that way)")
     ap.add_argument("--single-allreduce", action="store_true", help="one blocking all-reduce after backward instead of two overlapped buckets")
     ap.add_argument("--global-loss", action="store_true", help="exact global-batch Dice across ranks (parallel.GlobalBatchLoss: 32 fp64 sums "
                     "all-reduced between the loss reduction and its finalize; gradients summed) instead of DDP semantics")
@@ -306,8 +310,39 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
     exchange = GlobalBatchLoss(world, equal_shards=True) if (a.global_loss and world > 1 and a.lanes == 1) else None
     kw = {"loss_exchange": exchange} if exchange is not None else {}
 
+    can_graph = on_gpu and world == 1 and a.lanes == 1
+    launch = {"mode": a.launch if (can_graph and a.launch != "auto") else "stream"}
+    if a.lanes == 1:
+        kw["launch"] = "stream"
+
     def step():
+        if a.lanes == 1:
+            kw["launch"] = launch["mode"]
         return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs, **kw)
+
+    probe = None
+    if can_graph and a.launch == "auto":
+        # un-timed: 8 steps to settle, then the same number of steps through each launch path; the faster one is used from here on
+        def timed_steps(mode, n):
+            launch["mode"] = mode
+            for _ in range(3):
+                step()
+            gpu_sync()
+            t = time.perf_counter()
+            for _ in range(n):
+                step()
+            gpu_sync()
+            return (time.perf_counter() - t) / n * 1e3
+        for _ in range(8):
+            step()
+        probe = {"stream": round(timed_steps("stream", 24), 3)}
+        try:
+            probe["graph"] = round(timed_steps("graph", 24), 3)
+            if getattr(e, "_graph_key", None) is None:
+                probe["graph"] = None                     # the capture was refused: the steps above ran through the stream path
+        except RuntimeError as ex:
+            probe["graph"], probe["graph_error"] = None, str(ex)[:160]
+        launch["mode"] = "graph" if (probe["graph"] is not None and probe["graph"] < 0.985 * probe["stream"]) else "stream"
 
     # ---- conditioning (un-timed, before the warm-up the caller asks for): the first tens of milliseconds after a cold start do not run
     # at steady-state speed (round 2: 727 volumes/s at --steps 20 --warmup 5 on the driver's box against 880 at 50/10 on the builder's;
@@ -410,6 +445,7 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
                        "loss_semantics": "global-batch (sums exchanged)" if exchange is not None else "per-rank (DDP)"},
             "final_loss": round(loss, 5),
             "conditioning_steps": ncond, "conditioning_seconds": a.condition_seconds,
+            "launch_mode": launch["mode"], "launch_probe_ms_per_step": probe,
             "host_enqueue_ms_per_step": round(t_enqueued / nhost * 1e3, 3),
             "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME_96 * scale * vols / world / PEAK_HBM_GBS, 4),
                            "mfma_frac": round(GFLOP_PER_VOLUME_96 * scale * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},

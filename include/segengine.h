@@ -205,6 +205,14 @@ typedef struct seg_train_args {
     int packed;      /* != 0: the run-dtype weight layouts are current (the previous seg_train_step left them so) */
 } seg_train_args;
 int seg_train_step(seg_handle h, const seg_train_args* a, void* stream);
+/* The same step captured ONCE as a HIP graph (hipStreamBeginCapture around seg_train_step on `stream`, the weight-gradient stream forked and
+ * joined inside) and replayed with one hipGraphLaunch per step: for hosts that cannot enqueue ~250 launches per step as fast as the GPU runs
+ * them.  Every pointer / scalar of `a` and the current loss scale are baked into the graph (re-capture to change them; seg_plan, seg_bind and
+ * seg_set_loss_scale drop the graph); the device-side dropout-draw and Adam step counters keep advancing, so replays are successive steps.
+ * a->packed must be 1 (run one ordinary step first).  seg_train_graph_ready: 1 while a captured step exists. */
+int seg_train_graph_capture(seg_handle h, const seg_train_args* a, void* stream);
+int seg_train_graph_launch(seg_handle h, void* stream);
+int seg_train_graph_ready(seg_handle h);
 
 /* ---- operator-level entry points (what torch.nn.functional.conv3d / conv_transpose3d and their
  * autograd weight-gradients are to the reference: networks/VNet3d.py:8,28,29,49,65,70,88).  The

@@ -67,6 +67,9 @@ SIGNATURES = {
     "seg_predict_mask": (_i, [_vp, _vp, _i, _i, _ll, C.c_float, _i, _vp]),
     "seg_metric": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp]),
     "seg_train_step": (_i, [_vp, _vp, _vp]),
+    "seg_train_graph_capture": (_i, [_vp, _vp, _vp]),
+    "seg_train_graph_launch": (_i, [_vp, _vp]),
+    "seg_train_graph_ready": (_i, [_vp]),
     "seg_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _i, _vp, _vp]),
     "seg_op_conv": (_i, [_vp, _i, _vp]),
     "seg_op_conv_kernel": (_i, [_vp]),

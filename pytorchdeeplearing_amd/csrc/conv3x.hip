@@ -109,15 +109,16 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool ha
     int id;
     if (Cin == 16) {
         id = ndim == 3 ? (Cout % 32 ? 24 : 26) : (Cout % 32 ? 56 : 57);
-        // volumes with at least four boxes per resident workgroup (512): the persistent double-buffered tilings
-        if (ndim == 3 && vox >= 512ll * 4 * 256) id = Cout % 32 ? 28 : 29;
+        // (the persistent double-buffered tilings 28 / 29 lose: 106 us against 73.7 us at 4 x 96^3 standalone, same log)
     }
     else if (ndim == 3) {
         if (Cout % 32) id = 10;
         else if (Cout % 64) {
             id = Cin <= 32 ? 14 : (Cin == 64 ? (W >= 48 ? 17 : 15) : 14);
-            // 32 -> 32 channels on a volume with at least two boxes per CU: persistent workgroups, LDS-resident weights, double-buffered halo
-            if (Cin == 32 && !has_in1 && vox >= 256ll * 2 * 256) id = 18;
+            // (tilings 18 / 19, persistent workgroups with LDS-resident weights and a double-buffered halo, are NOT the default: measured on
+            // MI355X at 4 x 48^3 they run 37.4 us standalone against 35.0 / 37.8 us of tilings 17 / 14 and 70 against 61 us inside the train
+            // step - one 144 KB workgroup per CU hides less than two 46 KB ones; profiles/r03_persistent_conv_ab.log)
+            (void)has_in1;
         }
         else if (vox <= 16384) id = Cout >= 2 * Cin ? 13 : 7;
         else id = Cin >= 128 ? 5 : 3;
@@ -162,6 +163,9 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
         a.rq_y = rq->y; a.rq_scale = rq->scale; a.rq_shift = rq->shift; a.rq_Q = rq->Q;
         a.rq_rep = (rq->rep > 0 && rq->rep <= STAT_REP) ? rq->rep : STAT_REP;
     }
+    // diagnostics only (WRONG results): SEG_DIAG_NOSTATS=1 drops the GroupNorm statistics epilogue, to time what it costs inside a step
+    static const bool nostats = getenv("SEG_DIAG_NOSTATS") && atoi(getenv("SEG_DIAG_NOSTATS"));
+    if (nostats) a.stats = nullptr;
     a.N = N; a.D = ndim == 3 ? D : 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     static const int remap = getenv("SEG_C3X_REMAP") ? atoi(getenv("SEG_C3X_REMAP")) : 1;      // XCD-aware box order (c3x_box_of_block)
     a.remap = remap;

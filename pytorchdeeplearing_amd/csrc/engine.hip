@@ -200,6 +200,15 @@ struct seg_engine {
         }
         ready_used = 0;
     }
+    // one optimisation step captured as a HIP graph (seg_train_graph_*): the host side of a replay is ONE hipGraphLaunch
+    hipGraph_t tgraph = nullptr;
+    hipGraphExec_t tgraph_exec = nullptr;
+    bool capturing = false;
+    int tgraph_mask_mode = 0;
+    void drop_graph() {
+        if (tgraph_exec) { (void)hipGraphExecDestroy(tgraph_exec); tgraph_exec = nullptr; }
+        if (tgraph) { (void)hipGraphDestroy(tgraph); tgraph = nullptr; }
+    }
     // measurement (seg_profile_*)
     struct ProfRec { hipEvent_t a, b; int cls; double bytes, flops; };
     unsigned prof_mask = 0;
@@ -1269,6 +1278,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
 
 void seg_destroy(seg_handle h) {
     if (!h) return;
+    h->drop_graph();
     for (auto& r : h->prof_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->ready_ev) (void)hipEventDestroy(e);
     if (h->pack_fork) (void)hipEventDestroy(h->pack_fork);
@@ -1322,6 +1332,7 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
     // caller is about to replace
     if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }
     if (h->side2) (void)hipStreamSynchronize(h->side2);
+    h->drop_graph();
     h->N = n; h->D = d; h->H = hgt; h->W = wid;
     g_err.clear();
     Planner pl(*h);
@@ -1350,6 +1361,7 @@ int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)workspace) & 255) return fail("seg_bind: buffers must be 256-byte aligned");
     if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }     // see seg_plan
     if (h->side2) (void)hipStreamSynchronize(h->side2);
+    h->drop_graph();
     h->p = params; h->g = grads; h->ws = (char*)workspace;
     // resolve and upload the weight re-layout descriptors; reset the device-side step counter
     std::vector<PackDesc> d = h->packdescs;
@@ -1371,7 +1383,7 @@ int seg_pack_weights(seg_handle h, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const PackDesc* descs = (const PackDesc*)(h->ws + h->off_packdesc);
     const int nall = (int)h->packdescs.size(), nbwd = nall - h->npack_fwd;
-    if (h->use_side && h->pack_split && nbwd > 0 && h->npack_fwd > 0) {
+    if (h->use_side && h->pack_split && !h->capturing && nbwd > 0 && h->npack_fwd > 0) {
         h->ensure_side();
         if (!h->pack_fork) {
             (void)hipEventCreateWithFlags(&h->pack_fork, hipEventDisableTiming);
@@ -1469,6 +1481,7 @@ int seg_backward_bucket(seg_handle h, double tail_fraction, int* op_split, long 
 int seg_set_loss_scale(seg_handle h, float scale) {
     if (check_handle(h)) return -1;
     if (!(scale > 0.f)) return fail("seg_set_loss_scale: scale must be positive");
+    if (scale != h->loss_scale) h->drop_graph();          // the scale is baked into the captured launches
     h->loss_scale = scale;
     return 0;
 }
@@ -1643,6 +1656,54 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
                       1.0f / (h->loss_scale * (a->grad_div > 0.f ? a->grad_div : 1.f)), a->check_finite, a->opt_state, stream)) return -1;
     return seg_pack_weights(h, stream);
 }
+
+// The same step captured once as a HIP graph and replayed: ~250 launches + ~60 event operations become one hipGraphLaunch on the host.  For
+// hosts that cannot enqueue a step as fast as the GPU runs it (BENCH_r02: 4.2 ms of host time per 5.5 ms step on the driver's box against
+// 0.9 ms on the builder's); on a fast host the stream launches are as fast or faster (the graph orders the weight-gradient branch less
+// favourably), so the caller measures both and picks (SegEngine.train_step(launch="auto"), bench.py --launch auto).
+// Every pointer and scalar of `a` (and the loss scale) is baked in; the device-side dropout / Adam step counters keep advancing.
+int seg_train_graph_capture(seg_handle h, const seg_train_args* a, void* stream) {
+    if (check_handle(h)) return -1;
+    if (!a) return fail("seg_train_graph_capture: args is null");
+    if (!a->packed) return fail("seg_train_graph_capture: run one ordinary step first (the captured step starts from packed weights)");
+    if (h->prof_mask) return fail("seg_train_graph_capture: switch seg_profile_enable off first");
+    hipStream_t st = (hipStream_t)stream;
+    h->drop_graph();
+    // nothing un-captured may be pending on the streams the capture forks to
+    (void)hipStreamSynchronize(st);
+    if (h->side) (void)hipStreamSynchronize(h->side);
+    if (h->side2) (void)hipStreamSynchronize(h->side2);
+    h->pack_bwd_pending = false;
+    h->ensure_side();
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return fail("seg_train_graph_capture: hipStreamBeginCapture failed"); }
+    h->capturing = true;
+    const int draws0 = h->draws;
+    const int rc = seg_train_step(h, a, stream);
+    h->capturing = false;
+    h->draws = draws0;                                   // the capture itself executes nothing
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(st, &g);
+    if (rc || ec != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return rc ? -1 : fail(std::string("seg_train_graph_capture: hipStreamEndCapture failed: ") + hipGetErrorString(ec));
+    }
+    hipGraphExec_t ge = nullptr;
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess || !ge) {
+        (void)hipGraphDestroy(g); (void)hipGetLastError();
+        return fail("seg_train_graph_capture: hipGraphInstantiate failed");
+    }
+    h->tgraph = g; h->tgraph_exec = ge; h->tgraph_mask_mode = a->mask_mode;
+    return 0;
+}
+int seg_train_graph_launch(seg_handle h, void* stream) {
+    if (check_handle(h)) return -1;
+    if (!h->tgraph_exec) return fail("seg_train_graph_launch: no captured step (seg_train_graph_capture; a re-plan, re-bind or loss-scale change drops it)");
+    if (hipGraphLaunch(h->tgraph_exec, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return fail("seg_train_graph_launch: hipGraphLaunch failed"); }
+    if (h->tgraph_mask_mode == SEG_MASKS_RANDOM) ++h->draws;
+    return 0;
+}
+int seg_train_graph_ready(seg_handle h) { return (h && h->tgraph_exec) ? 1 : 0; }
 
 int seg_op_conv(const seg_conv_args* a, int dtype, void* stream) {
     if (!a || !a->in0 || !a->w || !a->out) return fail("seg_op_conv: null pointer");

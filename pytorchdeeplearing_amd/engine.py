@@ -361,12 +361,16 @@ class SegEngine:
     # ---- one optimisation step of the reference loop --------------------------------------------
     def train_step(self, x, target, loss_name="BinaryDiceLoss", lr=1e-3, weight_decay=0.01, decoupled=True,
                    focal_alpha=0.25, focal_gamma=2.0, class_alpha=None, mask_mode=_capi.MASKS_RANDOM, masks=None,
-                   allreduce=None, logits=None, probs=None, loss_exchange=None, cldice_weight=0.0, cldice_width=10):
+                   allreduce=None, logits=None, probs=None, loss_exchange=None, cldice_weight=0.0, cldice_width=10, launch="stream"):
         """Returns out3 = device tensor [loss, dice metric, iou metric] (no host sync).
         cldice_weight > 0 (binary heads): loss = loss_name + cldice_weight * soft-clDice(probabilities, target) — BASELINE configs[4];
         out3[0] then holds the sum (the clDice part alone is `self.last_cldice`).
         loss_exchange (parallel.GlobalBatchLoss): exact loss of the global batch over all ranks; the parameter gradients
-        of the ranks are then summed, not averaged (the 1/world factor is dropped)."""
+        of the ranks are then summed, not averaged (the 1/world factor is dropped).
+        launch (single-rank path): "stream" = the step's launches are enqueued one by one (one library call); "graph" = the step is captured
+        once per (buffers, hyper-parameters) as a HIP graph and replayed - for hosts that cannot enqueue ~250 launches per step as fast as
+        the GPU runs them (the tensors must then stay at the same addresses from step to step); falls back to "stream" where a capture is
+        not possible."""
         world = getattr(allreduce, "world", 1) if allreduce is not None else 1
         xworld = loss_exchange.world if loss_exchange is not None else 1
         if cldice_weight and xworld > 1:
@@ -375,7 +379,7 @@ class SegEngine:
                                       "use the per-rank (DDP) loss semantics for the clDice term")
         if world == 1 and xworld == 1 and not cldice_weight and _ONE_CALL:
             return self._train_step_one_call(x, target, loss_name, lr, weight_decay, decoupled, focal_alpha, focal_gamma, class_alpha,
-                                             mask_mode, masks, logits, probs)
+                                             mask_mode, masks, logits, probs, launch)
         if cldice_weight:
             self.cldice_prepare_target(target, x.shape[0], tuple(x.shape[2:]), cldice_width)     # overlaps the forward pass
         logits, probs = self.forward(x, mask_mode, masks, logits, probs)
@@ -430,7 +434,7 @@ class SegEngine:
             self.update_loss_scale(blocking=False)
 
     def _train_step_one_call(self, x, target, loss_name, lr, weight_decay, decoupled, focal_alpha, focal_gamma, class_alpha,
-                             mask_mode, masks, logits, probs):
+                             mask_mode, masks, logits, probs, launch="stream"):
         """The rank-local step as ONE library call (seg_train_step): the argument block is filled once per (shape, buffers) and only
         the pointers that change are rewritten, so the host side of a step is one FFI crossing."""
         assert x.dtype == torch.float32 and x.is_contiguous() and x.device.type == self.device.type
@@ -458,6 +462,18 @@ class SegEngine:
         a.lr, a.weight_decay, a.decoupled = float(lr), float(weight_decay), 1 if decoupled else 0
         a.check_finite = 1 if self.dtype in ("f16", "fp16", "float16") else 0
         a.packed = 1 if self.packed else 0
+        if launch == "graph" and self.packed and self.device.type == "cuda" and mask_mode != _capi.MASKS_GIVEN:
+            # the argument block as bytes is the identity of the captured step (pointers, scalars; the loss scale is tracked by the library)
+            key = bytes(a)
+            if getattr(self, "_graph_key", None) != key or not self.lib.seg_train_graph_ready(self.h):
+                self._graph_key = key if self.lib.seg_train_graph_capture(self.h, C.byref(a), self.stream()) == 0 else None
+            if self._graph_key is not None:
+                self.lib.check(self.lib.seg_train_graph_launch(self.h, self.stream()), "seg_train_graph_launch")
+                self._keep = (x, mt)
+                self._keep_loss = (target, class_alpha)
+                self._last_probs = probs
+                self._after_step()
+                return self._out3
         self.lib.check(self.lib.seg_train_step(self.h, C.byref(a), self.stream()), "seg_train_step")
         self.packed = True
         self._keep = (x, mt)

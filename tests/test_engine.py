@@ -362,3 +362,36 @@ def test_virtual_activation_equals_materialised(dev, tag, dtype, monkeypatch):
         d = float((g0[k] - g1[k]).norm())
         # fp32 atomics of the weight-gradient reduce order differently from run to run on the GPU
         assert d <= (0.0 if exact else 2e-3 * float(g0[k].norm()) + 1e-12), k
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_stream_launches():
+    """seg_train_graph_capture / _launch: the train step captured as a HIP graph (weight-gradient stream forked and joined inside the
+    capture) and replayed is the same sequence of launches as the stream path: five steps with engine-drawn dropout from the same
+    weights give the same loss curve and the same parameters up to the run-to-run noise of the fp32 / fp64 atomics (Adam turns a
+    rounding-level gradient difference into at most one lr-sized step per weight)."""
+    dev = torch.device("cuda:0")
+    _capi.product_library()
+    kind, ndim, shape, ncls, loss = CASES["vnet3d"]
+    x, y = seg.synthetic_batch(shape[0], (32, 32, 32), shape[1], ncls, seed=1)
+    xd, yd = x.to(dev), y.to(dev)
+    runs = {}
+    for mode in ("stream", "graph"):
+        e = SegEngine(kind, ndim, shape[1], ncls, dtype="f16", device=dev)
+        e.load_state_dict(seg.perturb_params(seg.init_params(kind, ndim, shape[1], ncls, seed=0), seed=7))
+        logits = torch.empty((shape[0], ncls, 32, 32, 32), dtype=torch.float32, device=dev)
+        probs = torch.empty_like(logits)
+        curve = [float(e.train_step(xd, yd, loss, lr=1e-3, logits=logits, probs=probs, launch=mode)[0]) for _ in range(5)]
+        torch.cuda.synchronize()
+        assert e.lib.seg_train_graph_ready(e.h) == (1 if mode == "graph" else 0)
+        assert int(e.opt_state[0]) == 5 and int(e.lib.seg_dropout_draws(e.h)) == 5
+        runs[mode] = (curve, e.params.detach().cpu().clone())
+        # a re-plan drops the captured step; the next graph step captures again
+        if mode == "graph":
+            e.plan(1, (32, 32, 32))
+            assert e.lib.seg_train_graph_ready(e.h) == 0
+        del e
+    (c0, p0), (c1, p1) = runs["stream"], runs["graph"]
+    assert max(abs(a - b) for a, b in zip(c0, c1)) < 2e-3, (c0, c1)
+    d = (p0 - p1).abs()
+    assert float(d.max()) <= 5 * 1e-3 + 1e-6 and float((d > 1e-4).float().mean()) < 0.02

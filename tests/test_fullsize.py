@@ -299,3 +299,36 @@ def test_c5_with_cldice_term_full_size():
     assert float((got - want).norm()) / float(want.norm()) < 2e-3
     losses = [float(e.train_step(xd, yd, "BinaryDiceLoss", cldice_weight=1.0)[0]) for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-3), ("f16", 3e-2), ("bf16", 6e-2)])
+def test_thirty_step_loss_curve_follows_the_fp32_oracle(dtype, tol):
+    """16-bit TRAINING fidelity, not just one gradient: thirty AdamW steps of VNet3d on 1 x 48^3 (BinaryCrossEntropyDice,
+    dropout on with the SAME masks on both sides) against thirty steps of the fp32 torch-CPU oracle from the same initial weights.  The loss
+    curve of the engine must stay within `tol` (absolute, on a loss that starts near 1.5) of the oracle's at EVERY step and must fall like
+    it does.  The measured deviations are printed (and kept under profiles/ by tools/gpu_final.sh through SEG_FULLSIZE_REPORT)."""
+    kind, ndim, ncls, loss, steps = "vnet", 3, 1, "BinaryCrossEntropyDiceLoss", 30
+    params = seg.perturb_params(seg.init_params(kind, ndim, 1, ncls, seed=0), seed=7)
+    x, y = seg.synthetic_batch(1, (48, 48, 48), 1, ncls, seed=21)
+    g = torch.Generator().manual_seed(3)
+    all_masks = [seg.draw_masks(kind, 1, generator=g) for _ in range(steps)]
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    cur, st, ref_curve = {k: v.clone() for k, v in params.items()}, {}, []
+    for it in range(steps):
+        r = seg.forward_backward(kind, cur, x, y, loss, masks=all_masks[it])
+        ref_curve.append(float(r["loss"]))
+        cur = seg.adamw_step(cur, r["grads"], st)
+    e = SegEngine(kind, ndim, 1, ncls, dtype=dtype, device=DEV)
+    e.load_state_dict(params)
+    xd, yd = x.to(DEV), y.to(DEV)
+    curve = [float(e.train_step(xd, yd, loss, lr=1e-3, mask_mode=_capi.MASKS_GIVEN, masks=all_masks[it])[0]) for it in range(steps)]
+    dev = [abs(a - b) for a, b in zip(curve, ref_curve)]
+    line = "loss curve %s: oracle %.4f -> %.4f, engine %.4f -> %.4f, max |diff| %.2e at step %d, mean |diff| %.2e, skipped steps %d" % (
+        dtype, ref_curve[0], ref_curve[-1], curve[0], curve[-1], max(dev), dev.index(max(dev)), sum(dev) / len(dev), e.skipped_steps)
+    print(line)
+    if os.environ.get("SEG_FULLSIZE_REPORT"):
+        with open(os.environ["SEG_FULLSIZE_REPORT"], "a") as f:
+            f.write(line + "\n")
+    assert all(np.isfinite(curve))
+    assert max(dev) < tol, line
+    assert curve[-1] < curve[0] - 0.5 * (ref_curve[0] - ref_curve[-1]), line          # it trains: at least half the oracle's descent
