@@ -151,6 +151,16 @@ int seg_loss_finalize(const float* logits, const void* target, int label_type, i
 long long seg_lovasz_ws_bytes(int n, long long v);
 int seg_lovasz_forward(const float* x, const void* target, int label_type, int n, int c, long long v, void* ws, float* out1, float* dx,
                        void* stream);
+/* SSIM / SSIM3D (model/lossesSSIM.py:47-99, 102-167): img1, img2 fp32 [n][c][d][h][w] (nd = 2: d = 1), Gaussian window `window` (11 in the
+ * reference, sigma 1.5), zero padding, the same window for every channel.  out[0] = mean of the SSIM map (size_average=True),
+ * out[1 .. n] = the per-sample means.  seg_ssim_forward leaves the derivative maps in ws (seg_ssim_ws_bytes(n, c, d*h*w) bytes) for
+ * seg_ssim_backward: dimg = gscale * d(sum of the map)/d img, gscale[0] (per_sample = 0) or gscale[sample] (per_sample = 1) carrying the
+ * incoming gradient times 1/count; dimg1 or dimg2 may be NULL.  The backward pass consumes ws (one backward per forward). */
+long long seg_ssim_ws_bytes(int n, int c, long long v);
+int seg_ssim_forward(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, float* out,
+                     void* stream);
+int seg_ssim_backward(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, const float* gscale,
+                      int per_sample, float* dimg1, float* dimg2, void* stream);
 /* predict() post-processing on the device (modelVNet.py:670-676): probs [N][C][V] fp32 -> uint8 mask [N][V];
  * C == 1: (p > threshold) * scale (scale 255 or 1); C > 1: first arg-max over the class axis. */
 int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long long v, float threshold, int scale, void* stream);

@@ -111,6 +111,32 @@ METRIC_REPAIRS = (
 )
 
 
+def make_ssim():
+    """model/lossesSSIM.py run as shipped: SSIM (2-D, size_average True / False) and SSIM3D on small volumes, values and gradients
+    with respect to both images."""
+    import sys as _sys
+    ref_loader.load()
+    S = _sys.modules["ref_model.lossesSSIM"]
+    torch.manual_seed(3)
+    a2, b2 = torch.rand(2, 3, 20, 24), torch.rand(2, 3, 20, 24)
+    a3 = torch.rand(2, 1, 12, 14, 16)
+    b3 = (a3 + 0.2 * torch.randn(2, 1, 12, 14, 16)).clamp(0, 1)
+    out = dict(a2=_np(a2), b2=_np(b2), a3=_np(a3), b3=_np(b3))
+    for tag, f, (x, y) in (("ssim2d", S.SSIM(window_size=11, size_average=True), (a2, b2)),
+                           ("ssim2d_w7", lambda p, q: S.ssim(p, q, window_size=7), (a2, b2)),
+                           ("ssim3d", S.SSIM3D(window_size=11), (a3, b3))):
+        xx, yy = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        v = f(xx, yy)
+        v.backward()
+        out["val_" + tag], out["g1_" + tag], out["g2_" + tag] = _np(v), _np(xx.grad), _np(yy.grad)
+    xx = a2.clone().requires_grad_(True)
+    v = S.SSIM(window_size=11, size_average=False)(xx, b2)
+    (v * torch.tensor([1.0, -2.0])).sum().backward()
+    out["val_ssim2d_persample"], out["g1_ssim2d_persample"] = _np(v), _np(xx.grad)
+    np.savez_compressed(os.path.join(OUT, "ssim.npz"), **out)
+    print("ssim:", {k: np.asarray(v).tolist() for k, v in out.items() if k.startswith("val_")})
+
+
 def make_metric_extra(metric):
     """M4 multiclass_iou_coeff (model/metric.py:204-215): the reference's own function text with METRIC_REPAIRS applied in
     memory, on the section-8(c) recipe inputs (+ a case with an absent class)."""
@@ -306,6 +332,9 @@ def main():
         _nets, _losses, metric = ref_loader.load()
         make_metric_extra(metric)
         return
+    if "--only-ssim" in sys.argv:
+        make_ssim()
+        return
     if "--only-losses-extra" in sys.argv:
         _nets, losses, _metric = ref_loader.load()
         make_losses_extra(losses)
@@ -321,6 +350,7 @@ def main():
     make_losses(nets, losses, metric)
     make_losses_extra(losses)
     make_metric_extra(metric)
+    make_ssim()
     from . import seg_oracle as seg
     a4 = torch.ones(4)
     make_net(nets, losses, seg, "vnet3d_bin_16", "vnet", 3, lambda: nets.VNet3d(1, 1), (2, 1, 16, 16, 16), 1,

@@ -58,6 +58,7 @@ def load():
         return mod
 
     leaf("lovasz")
+    leaf("lossesSSIM")
     losses = leaf("losses")
     metric = leaf("metric")
     _cache["v"] = (nets, losses, metric)

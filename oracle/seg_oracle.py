@@ -16,6 +16,8 @@ Never imported by the product package (pytorchdeeplearing_amd, model, networks).
 """
 from collections import OrderedDict
 
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -475,6 +477,31 @@ def multi_lovasz_loss(logits, y, alpha=None):
         es, perm = torch.sort(errors, 0, descending=True)
         out.append(torch.dot(es, _lovasz_grad(fg[perm])))
     return sum(out) / len(out)
+
+
+def ssim_oracle(img1, img2, window_size=11, size_average=True):
+    """model/lossesSSIM.py:30-99: Gaussian window (sigma 1.5) as the outer product of the normalised 1-D window, depth-wise conv with zero
+    padding, SSIM map, mean.  4-D inputs -> _ssim (2-D windows), 5-D inputs -> _ssim_3D."""
+    nd = img1.dim() - 2
+    ch = img1.shape[1]
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(window_size)], dtype=torch.float32)
+    g = (g / g.sum()).unsqueeze(1)
+    w2 = g.mm(g.t())
+    if nd == 2:
+        win = w2.float().unsqueeze(0).unsqueeze(0).expand(ch, 1, window_size, window_size).contiguous()
+        conv = lambda t: F.conv2d(t, win, padding=window_size // 2, groups=ch)
+    else:
+        w3 = g.mm(w2.reshape(1, -1)).reshape(window_size, window_size, window_size).float().unsqueeze(0).unsqueeze(0)
+        win = w3.expand(ch, 1, window_size, window_size, window_size).contiguous()
+        conv = lambda t: F.conv3d(t, win, padding=window_size // 2, groups=ch)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = conv(img1 * img1) - mu1_sq
+    s2 = conv(img2 * img2) - mu2_sq
+    s12 = conv(img1 * img2) - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return m.mean() if size_average else m.mean(1).mean(1).mean(1)
 
 
 LOSSES = {

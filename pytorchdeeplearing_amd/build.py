@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsegengine.so")
-SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "cldice.hip", "prepost.hip", "engine.hip"]
+SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "ssim.hip", "cldice.hip", "prepost.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
 

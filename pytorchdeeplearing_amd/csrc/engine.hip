@@ -1559,6 +1559,28 @@ int seg_lovasz_forward(const float* x, const void* target, int label_type, int n
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_lovasz_forward: launch failed");
 }
 
+static int ssim_check(const char* what, const void* a, const void* b, const void* ws, int n, int c, int d, int h, int w, int nd, int window) {
+    if (!a || !b || !ws) return fail(std::string(what) + ": null pointer");
+    if (n < 1 || n > 64 || c < 1 || h < 1 || w < 1 || (nd != 2 && nd != 3) || (nd == 3 && d < 1)) return fail(std::string(what) + ": bad extents (batch 1..64)");
+    if (window < 1 || window > 15 || !(window & 1)) return fail(std::string(what) + ": window_size must be odd and <= 15");
+    return 0;
+}
+long long seg_ssim_ws_bytes(int n, int c, long long v) { return (n < 1 || c < 1 || v < 1) ? -1 : ssim_ws_bytes(n * c, v); }
+int seg_ssim_forward(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, float* out,
+                     void* stream) {
+    if (ssim_check("seg_ssim_forward", img1, img2, ws, n, c, d, h, w, nd, window) || !out) return out ? -1 : fail("seg_ssim_forward: out is null");
+    if (launch_ssim_forward(img1, img2, n, c, nd == 3 ? d : 1, h, w, nd, window, ws, out, (hipStream_t)stream)) return fail("seg_ssim_forward: bad arguments");
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_ssim_forward: launch failed");
+}
+int seg_ssim_backward(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, const float* gscale,
+                      int per_sample, float* dimg1, float* dimg2, void* stream) {
+    if (ssim_check("seg_ssim_backward", img1, img2, ws, n, c, d, h, w, nd, window)) return -1;
+    if (!gscale || (!dimg1 && !dimg2)) return fail("seg_ssim_backward: null pointer");
+    if (launch_ssim_backward(img1, img2, n, c, nd == 3 ? d : 1, h, w, nd, window, ws, gscale, per_sample, dimg1, dimg2, (hipStream_t)stream))
+        return fail("seg_ssim_backward: bad arguments");
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_ssim_backward: launch failed");
+}
+
 int seg_predict_mask(const float* probs, unsigned char* mask, int n, int c, long long v, float threshold, int scale, void* stream) {
     if (!probs || !mask) return fail("seg_predict_mask: null pointer");
     if (c < 1 || n < 1 || v < 1 || scale < 0 || scale > 255) return fail("seg_predict_mask: bad arguments");

@@ -215,6 +215,12 @@ void launch_loss_backward(const LossArgs& a, hipStream_t s);   // dlogits from t
 long long lovasz_ws_bytes(long long P);
 int launch_lovasz(const float* x, const void* target, int label_type, int N, int C, long long V, void* ws, float* out1, float* dx, hipStream_t s);
 
+// SSIM / SSIM3D (ssim.hip; model/lossesSSIM.py): planar fp32 [N][C][D][H][W]; out = {mean, per-sample means[N]}; ws keeps the derivative maps
+long long ssim_ws_bytes(int planes, long long v);
+int launch_ssim_forward(const float* x1, const float* x2, int N, int C, int D, int H, int W, int nd, int window, void* ws, float* out, hipStream_t s);
+int launch_ssim_backward(const float* x1, const float* x2, int N, int C, int D, int H, int W, int nd, int window, void* ws, const float* gscale,
+                         int per_sample_scale, float* dx1, float* dx2, hipStream_t s);
+
 // dice / iou on probabilities (model/metric.py): out2 = {dice, iou}; sums = 3*N*C doubles (zeroed by the launcher)
 void launch_metric(const float* probs, const void* target, int label_type, int N, int C, long long V, double* sums, float* out2, hipStream_t s);
 // out[c] += sum_m x[m][c]   (bias gradient of a conv without GroupNorm)

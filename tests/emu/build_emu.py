@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pytorchdeeplearing_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libsegengine_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "cldice.hip", "prepost.hip", "engine.hip"]
+SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "ssim.hip", "cldice.hip", "prepost.hip", "engine.hip"]
 
 
 def build(force=False):

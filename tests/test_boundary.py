@@ -285,3 +285,41 @@ def test_bench_and_product_do_not_touch_the_oracle_outside_the_cpu_baseline_leg(
         if isinstance(node, (ast.Import, ast.ImportFrom)):
             mod = node.module if isinstance(node, ast.ImportFrom) else node.names[0].name
             assert not (mod and mod.split(".")[0] == "oracle")
+
+
+def test_oracle_ssim_equals_reference_golden(golden_dir):
+    G = np.load(os.path.join(golden_dir, "ssim.npz"))
+    for tag, ka, kb, win in (("ssim2d", "a2", "b2", 11), ("ssim2d_w7", "a2", "b2", 7), ("ssim3d", "a3", "b3", 11)):
+        a, b = torch.from_numpy(G[ka]).requires_grad_(True), torch.from_numpy(G[kb]).requires_grad_(True)
+        v = seg.ssim_oracle(a, b, win)
+        v.backward()
+        assert abs(float(v) - float(G["val_" + tag])) < 1e-6, tag
+        np.testing.assert_allclose(a.grad.numpy(), G["g1_" + tag], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(b.grad.numpy(), G["g2_" + tag], rtol=1e-4, atol=1e-9)
+
+
+def test_ssim_modules_vs_reference_golden(dev, golden_dir):
+    """model/lossesSSIM.py (SSIM, SSIM3D, ssim with another window, size_average=False) on the device against goldens written by the reference
+    module itself: values 1e-5, gradients with respect to BOTH images (separable windows: rounding order differs from the 11^d window)."""
+    from pytorchdeeplearing_amd import lossesSSIM as S
+    from model import lossesSSIM as shim
+    assert shim.SSIM3D is S.SSIM3D and shim.ssim is S.ssim
+    G = np.load(os.path.join(golden_dir, "ssim.npz"))
+    for tag, f, ka, kb in (("ssim2d", S.SSIM(window_size=11, size_average=True), "a2", "b2"),
+                           ("ssim2d_w7", lambda p, q: S.ssim(p, q, window_size=7), "a2", "b2"),
+                           ("ssim3d", S.SSIM3D(window_size=11), "a3", "b3")):
+        a, b = torch.from_numpy(G[ka]).to(dev).requires_grad_(True), torch.from_numpy(G[kb]).to(dev).requires_grad_(True)
+        v = f(a, b)
+        v.backward()
+        assert abs(float(v) - float(G["val_" + tag])) < 1e-5, (tag, float(v), float(G["val_" + tag]))
+        for got, want in ((a.grad, G["g1_" + tag]), (b.grad, G["g2_" + tag])):
+            err = np.abs(got.cpu().numpy() - want).max()
+            assert err < 2e-3 * np.abs(want).max() + 1e-9, (tag, err, np.abs(want).max())
+    a = torch.from_numpy(G["a2"]).to(dev).requires_grad_(True)
+    v = S.SSIM(window_size=11, size_average=False)(a, torch.from_numpy(G["b2"]).to(dev))
+    np.testing.assert_allclose(v.detach().cpu().numpy(), G["val_ssim2d_persample"], rtol=0, atol=1e-5)
+    (v * torch.tensor([1.0, -2.0], device=dev)).sum().backward()
+    want = G["g1_ssim2d_persample"]
+    assert np.abs(a.grad.cpu().numpy() - want).max() < 2e-3 * np.abs(want).max()
+    with pytest.raises(NotImplementedError):
+        S.ssim3D(torch.zeros(1, 1, 4, 4, 4, device=dev), torch.zeros(1, 1, 4, 4, 4, device=dev), size_average=False)
