@@ -340,6 +340,7 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
             probe["graph"] = round(timed_steps("graph", 24), 3)
             if getattr(e, "_graph_key", None) is None:
                 probe["graph"] = None                     # the capture was refused: the steps above ran through the stream path
+                probe["graph_error"] = getattr(e, "graph_error", None)
         except RuntimeError as ex:
             probe["graph"], probe["graph_error"] = None, str(ex)[:160]
         launch["mode"] = "graph" if (probe["graph"] is not None and probe["graph"] < 0.985 * probe["stream"]) else "stream"

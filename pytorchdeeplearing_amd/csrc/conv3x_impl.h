@@ -87,16 +87,49 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const 
     const int wm = wv % WM, wn = wv / WM;
     T* Os = Xs;
     float* red = (float*)(Xs + OS_ELEMS);
+    // GroupNorm statistics straight from the accumulators (the values as stored: rounded to T), voxels outside the volume excluded.
+    // Round 2 re-read the whole output tile from LDS for them behind one more barrier: 3.7 % of the train step (SEG_DIAG_NOSTATS,
+    // profiles/r03_graph_stats_ab.log).  A lane holds TM x 4 rows of TN columns: per-lane sums, a butterfly over the four 16-lane groups
+    // (same column), then the WM waves of a column meet in LDS.
+    bool okr[TM][4];
+    if (a.stats) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int vz, vy, vx;
+                B::vox((wm * TM + m) * 16 + q * 4 + r, vz, vy, vx);
+                okr[m][r] = x0 + vx < a.W && y0 + vy < a.H && z0 + vz < a.D;
+            }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = (wn * TN + j) * 16 + l15;
         const float bsv = a.bias ? a.bias[co0 + col] : 0.f;
+        float cs = 0.f, css = 0.f;
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Os[((wm * TM + m) * 16 + q * 4 + r) * OLD + col] = from_f<T>(acc[m][j][r] + bsv);
+            for (int r = 0; r < 4; ++r) {
+                const T tv = from_f<T>(acc[m][j][r] + bsv);
+                Os[((wm * TM + m) * 16 + q * 4 + r) * OLD + col] = tv;
+                if (a.stats && okr[m][r]) { const float f = to_f(tv); cs += f; css = fmaf(f, f, css); }
+            }
+        if (a.stats) {
+            cs += __shfl_xor(cs, 16); css += __shfl_xor(css, 16);
+            cs += __shfl_xor(cs, 32); css += __shfl_xor(css, 32);
+            if (q == 0) { red[(wm * BN + col) * 2] = cs; red[(wm * BN + col) * 2 + 1] = css; }
+        }
     }
     __syncthreads();
+    if (a.stats && tid < BN) {
+        double ts = 0.0, tss = 0.0;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) { ts += (double)red[(k * BN + tid) * 2]; tss += (double)red[(k * BN + tid) * 2 + 1]; }
+        double* dst = a.stats + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + tid) * 2;
+        atomicAdd(dst, ts);
+        atomicAdd(dst + 1, tss);
+    }
     constexpr int CPR = BN / 8;
     T* out = (T*)a.out;
     if (a.rq_Q) {
@@ -152,29 +185,6 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const 
         const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
         if (x < a.W && y < a.H && z < a.D)
             store8(out + ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8, load8(&Os[v * OLD + c8 * 8]));
-    }
-    if (a.stats) {
-        constexpr int G = 256 / BN;
-        const int col = tid % BN, g = tid / BN;
-        float s = 0.f, ss = 0.f;
-        for (int v = g; v < B::V; v += G) {
-            int vz, vy, vx;
-            B::vox(v, vz, vy, vx);
-            if (x0 + vx < a.W && y0 + vy < a.H && z0 + vz < a.D) {
-                const float f = to_f(Os[v * OLD + col]);
-                s += f; ss += f * f;
-            }
-        }
-        red[(g * BN + col) * 2] = s;
-        red[(g * BN + col) * 2 + 1] = ss;
-        __syncthreads();
-        if (tid < BN) {
-            double ts = 0.0, tss = 0.0;
-            for (int k = 0; k < G; ++k) { ts += red[(k * BN + col) * 2]; tss += red[(k * BN + col) * 2 + 1]; }
-            double* dst = a.stats + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + col) * 2;
-            atomicAdd(dst, ts);
-            atomicAdd(dst + 1, tss);
-        }
     }
 }
 

@@ -462,13 +462,28 @@ class SegEngine:
         a.lr, a.weight_decay, a.decoupled = float(lr), float(weight_decay), 1 if decoupled else 0
         a.check_finite = 1 if self.dtype in ("f16", "fp16", "float16") else 0
         a.packed = 1 if self.packed else 0
-        if launch == "graph" and self.packed and self.device.type == "cuda" and mask_mode != _capi.MASKS_GIVEN:
+        if (launch == "graph" and self.packed and self.device.type == "cuda" and mask_mode != _capi.MASKS_GIVEN and
+                not getattr(self, "_graph_refused", False)):
             # the argument block as bytes is the identity of the captured step (pointers, scalars; the loss scale is tracked by the library)
             key = bytes(a)
+            # the legacy default stream cannot be captured: graph steps run on a stream of their own, ordered after / before the caller's
+            cur = torch.cuda.current_stream(self.device)
+            if getattr(self, "_graph_stream", None) is None:
+                self._graph_stream = torch.cuda.Stream(device=self.device)
+            gs = self._graph_stream if cur.cuda_stream == 0 else cur
+            gsp = C.c_void_p(gs.cuda_stream)
+            if gs is not cur:
+                gs.wait_stream(cur)
             if getattr(self, "_graph_key", None) != key or not self.lib.seg_train_graph_ready(self.h):
-                self._graph_key = key if self.lib.seg_train_graph_capture(self.h, C.byref(a), self.stream()) == 0 else None
+                if self.lib.seg_train_graph_capture(self.h, C.byref(a), gsp) == 0:
+                    self._graph_key = key
+                else:                         # not retried step after step: a failed capture costs milliseconds
+                    self._graph_key, self._graph_refused = None, True
+                    self.graph_error = self.lib.seg_last_error().decode()
             if self._graph_key is not None:
-                self.lib.check(self.lib.seg_train_graph_launch(self.h, self.stream()), "seg_train_graph_launch")
+                self.lib.check(self.lib.seg_train_graph_launch(self.h, gsp), "seg_train_graph_launch")
+                if gs is not cur:
+                    cur.wait_stream(gs)
                 self._keep = (x, mt)
                 self._keep_loss = (target, class_alpha)
                 self._last_probs = probs

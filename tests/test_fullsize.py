@@ -301,7 +301,7 @@ def test_c5_with_cldice_term_full_size():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-3), ("f16", 3e-2), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 4e-3), ("f16", 4e-3), ("bf16", 8e-3)])      # measured on MI355X: 1.4e-3 / 7.3e-4 / 2.5e-3
 def test_thirty_step_loss_curve_follows_the_fp32_oracle(dtype, tol):
     """16-bit TRAINING fidelity, not just one gradient: thirty AdamW steps of VNet3d on 1 x 48^3 (BinaryCrossEntropyDice,
     dropout on with the SAME masks on both sides) against thirty steps of the fp32 torch-CPU oracle from the same initial weights.  The loss

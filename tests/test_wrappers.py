@@ -331,6 +331,6 @@ def test_reference_entry_script_runs_unchanged(dev, tmp_path, monkeypatch, cls, 
     exec(compile(text, "train_like_reference.py", "exec"), ns)
     net = ns["net"]
     assert len(net.history["train_loss"]) == 1 and np.isfinite(net.history["train_loss"]).all()
-    assert net.model.numclass == numclass
+    assert net.numclass == numclass
     out = net.predict(np.load(tr_i[0]).reshape((1,) + dims))
     assert out.shape == dims and out.dtype == np.uint8 and int(out.max()) < numclass
