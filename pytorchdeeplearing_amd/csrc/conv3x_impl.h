@@ -87,6 +87,26 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const 
     const int wm = wv % WM, wn = wv / WM;
     T* Os = Xs;
     float* red = (float*)(Xs + OS_ELEMS);
+    // data-gradient launches with the GroupNorm-backward reduce folded in: the consumer unit's raw outputs come from HBM - up to 8 independent
+    // 16-B loads per thread are issued right after the accumulators have gone to LDS, in front of the barrier, so the round trip overlaps
+    // the tile exchange (round 2 loaded one tile row per loop trip: a dependent global round trip per trip inside every such epilogue)
+    constexpr int RQ_CPR = BN / 8, RQ_NIT = (B::V * RQ_CPR + 255) / 256, RQ_UB = RQ_NIT < 8 ? RQ_NIT : 8;
+    vec<T, 8> rq_yv[RQ_UB];
+    long long rq_oo[RQ_UB];
+    auto rq_issue = [&](int i0) {
+        const int c8 = tid % RQ_CPR;
+        const T* ry = (const T*)a.rq_y;
+#pragma unroll
+        for (int u = 0; u < RQ_UB; ++u) {
+            const int i = (i0 + u) * 256 + tid, v = i / RQ_CPR;
+            int vz, vy, vx;
+            B::vox(v < B::V ? v : 0, vz, vy, vx);
+            const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+            const bool ok = i0 + u < RQ_NIT && i < B::V * RQ_CPR && x < a.W && y < a.H && z < a.D;
+            rq_oo[u] = ok ? ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8 : -1;
+            rq_yv[u] = ok ? load8(ry + rq_oo[u]) : zero8<T>();
+        }
+    };
     // GroupNorm statistics straight from the accumulators (the values as stored: rounded to T), voxels outside the volume excluded.
     // Round 2 re-read the whole output tile from LDS for them behind one more barrier: 3.7 % of the train step (SEG_DIAG_NOSTATS,
     // profiles/r03_graph_stats_ab.log).  A lane holds TM x 4 rows of TN columns: per-lane sums, a butterfly over the four 16-lane groups
@@ -121,6 +141,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const 
             if (q == 0) { red[(wm * BN + col) * 2] = cs; red[(wm * BN + col) * 2 + 1] = css; }
         }
     }
+    if (a.rq_Q) rq_issue(0);                               // the accumulators are dead from here on: their registers take the loads
     __syncthreads();
     if (a.stats && tid < BN) {
         double ts = 0.0, tss = 0.0;
@@ -135,28 +156,27 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const 
     if (a.rq_Q) {
         // a thread keeps its 8-channel chunk (256 % CPR == 0): forward coefficients in registers, two partial sums per channel
         const int c8 = tid % CPR;
-        const T* ry = (const T*)a.rq_y;
         const vec<float, 8> sc = *(const vec<float, 8>*)(a.rq_scale + (long long)n * a.Cout + co0 + c8 * 8);
         const vec<float, 8> sh = *(const vec<float, 8>*)(a.rq_shift + (long long)n * a.Cout + co0 + c8 * 8);
         float q1[8], q2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
-        for (int i = tid; i < B::V * CPR; i += 256) {
-            const int v = i / CPR;
-            int vz, vy, vx;
-            B::vox(v, vz, vy, vx);
-            const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
-            if (x < a.W && y < a.H && z < a.D) {
-                const long long o = ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8;
-                const vec<T, 8> dv = load8(&Os[v * OLD + c8 * 8]);
-                const vec<T, 8> yv = load8(ry + o);
-                store8(out + o, dv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float yf = to_f(yv[j]);
-                    const float dz = (fmaf(sc[j], yf, sh[j]) > 0.f) ? to_f(dv[j]) : 0.f;
-                    q1[j] += dz;
-                    q2[j] = fmaf(dz, yf, q2[j]);
+        for (int i0 = 0; i0 < RQ_NIT; i0 += RQ_UB) {
+            if (i0) rq_issue(i0);                          // (tilings with more than 8 rows per thread: the next batch)
+#pragma unroll
+            for (int u = 0; u < RQ_UB; ++u) {
+                if (rq_oo[u] >= 0) {
+                    const int v = ((i0 + u) * 256 + tid) / CPR;
+                    const vec<T, 8> dv = load8(&Os[v * OLD + c8 * 8]);
+                    store8(out + rq_oo[u], dv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float yf = to_f(rq_yv[u][j]);
+                        const float dz = (fmaf(sc[j], yf, sh[j]) > 0.f) ? to_f(dv[j]) : 0.f;
+                        q1[j] += dz;
+                        q2[j] = fmaf(dz, yf, q2[j]);
+                    }
                 }
             }
         }

@@ -14,6 +14,13 @@ __device__ __forceinline__ void gn_fold_block(const GnFinArgs& f, int n, bool pu
     const int S = 256 / C;                              // replica slices folded side by side (C <= 256)
     const int c = tid % C, sl = tid / C;
     const int nrep = f.rep > 0 ? f.rep : STAT_REP;
+    // the per-channel parameters do not depend on the statistics: their loads travel together with the first replica loads instead of
+    // forming a second L2 round trip behind the barrier (every workgroup of every elementwise launch runs this prologue)
+    float mk = 1.f, ga = 0.f, be = 0.f;
+    if (tid < C) {
+        mk = f.mask ? f.mask[(long long)n * f.mask_ld + tid] : 1.f;
+        ga = f.gamma[tid]; be = f.beta[tid];
+    }
     double s = 0.0, ss = 0.0;
     for (int r0 = sl; r0 < nrep; r0 += 4 * S) {         // four independent 16-B loads per trip
         double v0[4], v1[4];
@@ -39,8 +46,6 @@ __device__ __forceinline__ void gn_fold_block(const GnFinArgs& f, int n, bool pu
         double var = ss / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
-        const float mk = f.mask ? f.mask[(long long)n * f.mask_ld + c] : 1.f;
-        const float ga = f.gamma[c], be = f.beta[c];
         const float sc = mk * ga * rstd, sh = mk * (be - ga * (float)mean * rstd);
         sc_s[c] = sc; sh_s[c] = sh;
         if (publish) {

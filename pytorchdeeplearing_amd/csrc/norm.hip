@@ -290,6 +290,13 @@ __device__ __forceinline__ void gn_bwd_fold_block(const GnBwdFinArgs& f, int n, 
     const int c = tid % C, sl = tid / C;
     const int nq = f.rep_q > 0 ? f.rep_q : STAT_REP, ns = f.rep_s > 0 ? f.rep_s : STAT_REP;
     const int nrep = nq > ns ? nq : ns;
+    // loads that do not depend on the folded sums are issued up front (one L2 round trip for the prologue, not two)
+    double mu = 0.0, rs = 0.0, mk = 1.0, ga = 0.0;
+    if (tid < C) {
+        mu = f.mean[n * GN_GROUPS + tid / cpg]; rs = f.rstd[n * GN_GROUPS + tid / cpg];
+        mk = f.mask ? (double)f.mask[(long long)n * f.mask_ld + tid] : 1.0;
+        ga = f.gamma[tid];
+    }
     double f1 = 0.0, f2 = 0.0, f3 = 0.0;
     for (int r0 = sl; r0 < nrep; r0 += 4 * S) {
         double v1[4], v2[4], v3[4];
@@ -305,12 +312,9 @@ __device__ __forceinline__ void gn_bwd_fold_block(const GnBwdFinArgs& f, int n, 
     }
     part[tid][0] = f1; part[tid][1] = f2; part[tid][2] = f3;
     __syncthreads();
-    double Q1 = 0.0, Q2 = 0.0, R1 = 0.0, mu = 0.0, rs = 0.0, mk = 1.0, ga = 0.0, q1 = 0.0, qx = 0.0;
+    double Q1 = 0.0, Q2 = 0.0, R1 = 0.0, q1 = 0.0, qx = 0.0;
     if (tid < C) {
         for (int k = 0; k < S; ++k) { Q1 += part[tid + k * C][0]; Q2 += part[tid + k * C][1]; R1 += part[tid + k * C][2]; }
-        mu = f.mean[n * GN_GROUPS + c / cpg]; rs = f.rstd[n * GN_GROUPS + c / cpg];
-        mk = f.mask ? (double)f.mask[(long long)n * f.mask_ld + c] : 1.0;
-        ga = f.gamma[c];
         q1 = mk * Q1;                                    // sum dz
         qx = (mk * Q2 - mu * q1) * rs;                   // sum dz * xhat
         if (publish) {
