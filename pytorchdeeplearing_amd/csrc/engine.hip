@@ -107,7 +107,9 @@ struct seg_engine {
                                 // gradient (12 launches and 12 activated tensors less in VNet3d).  Bit-identical, but measured 2.3 % SLOWER
                                 // (863 vs 883 volumes/s, profiles/r03_vact_cumask_ab.log): the per-workgroup statistics fold costs the two L2
                                 // round trips the 4.8 us launch cost, and the FUSE kernels spill scalars into the tap loop.  Opt-in.
-    bool use_rfuse = true;      // SEG_GN_RFUSE=0: every GroupNorm-backward reduce is its own launch
+    bool use_rfuse = false;     // SEG_GN_RFUSE=1: the GroupNorm-backward reduce of a unit rides in the epilogue of the data-gradient conv that produces
+                                // its only gradient (10 launches less).  Neutral in round 2, 0.4 % slower in round 3 even with its loads batched
+                                // (907 vs 903 volumes/s twice, profiles/r03_epilogue_ab.log): the epilogue sits on the conv's critical path.  Opt-in.
     bool use_fold = true;       // SEG_GN_FOLD=0: finalize kernels between the GroupNorm passes (round-1 path)
     bool use_vhead = true;      // SEG_VHEAD=0: head_bwd writes its data-gradient tensor (round-1 path)
     bool head_din_needed = false;   // planning: some reader of the head's data-gradient cannot evaluate it on the fly

@@ -1,19 +1,26 @@
-# Round-end measurement set on one MI355X: GPU parity tests, the contract bench line, rocprofv3 kernel stats of the same
-# command, the two PMC passes (separate runs, kernel-trace only), the other BASELINE configs.  Outputs under gpurun_out/.
+# Round-end measurement set on one MI355X (everything from the FINAL binary, the bench lines with the DRIVER'S command): GPU parity tests,
+# smoke, three fresh-process bench lines, rocprofv3 kernel stats + kernel trace timeline of the same command, the two PMC passes (separate
+# runs, kernel-trace only), the other BASELINE configs, pre/post-processing, full-size fidelity report.  Outputs under gpurun_out/<tag>/.
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-TAG=${1:-step24}
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/gpu_tests_$TAG.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; tail -3 gpurun_out/smoke_$TAG.log
-timeout 300 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
-rm -rf gpurun_out/prof gpurun_out/pmc
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o step -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --roofline-steps 0 > gpurun_out/prof_run.log 2>&1
-DB=$(find gpurun_out/prof -name "*.db" | head -1)
-if [ -n "$DB" ]; then python profiles/summarize_rocpd.py $DB 45 > gpurun_out/kernel_stats_$TAG.txt 2>&1; fi
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc -o $c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --roofline-steps 0 > gpurun_out/pmc_$c.log 2>&1
+TAG=${1:-final}; O=gpurun_out/$TAG; mkdir -p $O
+SEG_FULLSIZE_REPORT=$O/fullsize_report.txt timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $O/gpu_tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log
+DRV="python bench.py --gpus 1 --steps 20 --warmup 5"
+for i in 1 2 3; do
+  timeout 400 $DRV $( [ $i -gt 1 ] && echo --no-cpu-baseline ) > $O/bench_driver_cmd_$i.json 2> $O/bench_driver_cmd_$i.err
 done
-python profiles/summarize_pmc.py gpurun_out/pmc gpurun_out/pmc_fetch_write_$TAG.json > gpurun_out/pmc_summary.log 2>&1
-timeout 300 python tools/bench_configs.py > gpurun_out/configs_$TAG.jsonl 2> gpurun_out/configs.err
-timeout 300 python tools/bench_prepost.py > gpurun_out/prepost_$TAG.jsonl 2> gpurun_out/prepost.err
-find gpurun_out/pmc -name "*.csv" -size +5M -delete; rm -rf gpurun_out/prof
-cat gpurun_out/gpu_tests_$TAG.log; cut -c1-300 gpurun_out/bench_$TAG.json; head -12 gpurun_out/kernel_stats_$TAG.txt; tail -3 gpurun_out/pmc_summary.log; cat gpurun_out/configs_$TAG.jsonl | cut -c1-120
+rm -rf gpurun_out/prof gpurun_out/pmc gpurun_out/trace
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o step -- $DRV --no-cpu-baseline --roofline-steps 0 --launch stream > $O/prof_run.log 2>&1
+DB=$(find gpurun_out/prof -name "*.db" | head -1)
+if [ -n "$DB" ]; then python profiles/summarize_rocpd.py $DB 50 > $O/rocprofv3_kernel_stats.txt 2>&1; fi
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -o t -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --roofline-steps 0 --condition-seconds 0.2 --launch stream > $O/trace_run.log 2>&1
+CSV=$(find gpurun_out/trace -name "*kernel_trace.csv" | head -1)
+if [ -n "$CSV" ]; then python tools/trace_gaps.py $CSV > $O/trace_timeline.txt 2>&1; fi
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc -o $c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --roofline-steps 0 --condition-seconds 0 --launch stream > $O/pmc_$c.log 2>&1
+done
+python profiles/summarize_pmc.py gpurun_out/pmc $O/pmc_fetch_write_per_kernel.json > $O/pmc_summary.log 2>&1
+timeout 300 python tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err
+timeout 300 python tools/bench_prepost.py > $O/prepost.jsonl 2> $O/prepost.err
+rm -rf gpurun_out/prof gpurun_out/pmc gpurun_out/trace
+cat $O/gpu_tests.log; for i in 1 2 3; do cut -c1-260 $O/bench_driver_cmd_$i.json; done; head -14 $O/rocprofv3_kernel_stats.txt; tail -3 $O/pmc_summary.log; cut -c1-140 $O/configs.jsonl; head -12 $O/trace_timeline.txt
