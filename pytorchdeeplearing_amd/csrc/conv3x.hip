@@ -30,6 +30,10 @@ const Cfg kCfgs[] = {
     {15, 3, 2, 8, 16, 32, 2, "2x8x16 t16 4x1 waves 4x2 tiles, 2 resident chunks"},
     {16, 3, 2, 8, 16, 32, 1, "2x8x16 t16 4x1 waves 4x2 tiles, deep B ring, 2 workgroups/CU"},
     {17, 3, 4, 8, 8, 32, 1, "4x8x8 t8 4x1 waves 4x2 tiles, deep B ring, 2 workgroups/CU"},
+    {20, 3, 4, 8, 8, 32, 1, "4x8x8 t8 4x1 waves 4x2 tiles, 3 workgroups/CU"},
+    {21, 3, 2, 8, 8, 32, 1, "2x8x8 t8 4x1 waves 2x2 tiles, 1 resident chunk, 4 workgroups/CU"},
+    {22, 3, 2, 8, 8, 32, 1, "2x8x8 t8 4x1 waves 2x2 tiles, 1 resident chunk, deep B ring, 3 workgroups/CU"},
+    {23, 3, 4, 8, 8, 32, 1, "4x8x8 t8 4x1 waves 4x2 tiles, deep B ring, 3 workgroups/CU"},
     {18, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {19, 3, 2, 8, 8, 32, 1, "Cin32 persistent: 2x8x8 t8 4x1 waves 2x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {24, 3, 2, 8, 16, 16, 1, "Cin16: 2x8x16 t16 4x1 waves 4x1 tiles", 1},
@@ -108,13 +112,15 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool ha
     const long long vox = (long long)N * D * H * W;
     int id;
     if (Cin == 16) {
-        id = ndim == 3 ? (Cout % 32 ? 24 : 26) : (Cout % 32 ? 56 : 57);
+        id = ndim == 3 ? (Cout % 32 ? (vox >= (1ll << 21) ? 25 : 24) : 26) : (Cout % 32 ? 56 : 57);      // 25: 4x8x16 boxes, 67.6 vs 72.2 us at 4 x 96^3
         // (the persistent double-buffered tilings 28 / 29 lose: 106 us against 73.7 us at 4 x 96^3 standalone, same log)
     }
     else if (ndim == 3) {
         if (Cout % 32) id = 10;
         else if (Cout % 64) {
-            id = Cin <= 32 ? 14 : (Cin == 64 ? (W >= 48 ? 17 : 15) : 14);
+            // 32 -> 32: tiling 17 (deep B ring) since the epilogue stores from the accumulators: 912 vs 903 volumes/s against tiling 14 inside the
+            // step, 33.4 vs 36.4 us standalone at 4 x 48^3 (profiles/r03_tiling_ab.log; round 2 had measured 14 ahead)
+            id = Cin <= 32 ? 17 : (Cin == 64 ? (W >= 48 ? 17 : 15) : 14);
             // (tilings 18 / 19, persistent workgroups with LDS-resident weights and a double-buffered halo, are NOT the default: measured on
             // MI355X at 4 x 48^3 they run 37.4 us standalone against 35.0 / 37.8 us of tilings 17 / 14 and 70 against 61 us inside the train
             // step - one 144 KB workgroup per CU hides less than two 46 KB ones; profiles/r03_persistent_conv_ab.log)
@@ -148,7 +154,7 @@ int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres
 }
 
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const Conv3xReduce* rq, const GnFinArgs* gn) {
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const GnFinArgs* gn) {
     const Cfg* c = find_cfg(cfg);
     if (!c || !cfg_fits(*c, ndim, Cin, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
     if (gn && (!conv3x_gn_supported(Cin, in1 != nullptr) || c->cin32)) return false;
@@ -158,11 +164,6 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
     a.gn = gn ? *gn : GnFinArgs{};
     a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.stat_rep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
-    a.rq_y = nullptr; a.rq_scale = nullptr; a.rq_shift = nullptr; a.rq_Q = nullptr; a.rq_rep = STAT_REP;
-    if (rq && rq->Q) {
-        a.rq_y = rq->y; a.rq_scale = rq->scale; a.rq_shift = rq->shift; a.rq_Q = rq->Q;
-        a.rq_rep = (rq->rep > 0 && rq->rep <= STAT_REP) ? rq->rep : STAT_REP;
-    }
     // diagnostics only (WRONG results): SEG_DIAG_NOSTATS=1 drops the GroupNorm statistics epilogue, to time what it costs inside a step
     static const bool nostats = getenv("SEG_DIAG_NOSTATS") && atoi(getenv("SEG_DIAG_NOSTATS"));
     if (nostats) a.stats = nullptr;

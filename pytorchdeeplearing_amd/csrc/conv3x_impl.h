@@ -53,12 +53,6 @@ struct Conv3xArgs {
     const float* bias; void* out; double* stats; int stat_rep;   // stat_rep: replicas of `stats` the workgroups spread over (<= STAT_REP)
     int N, D, H, W, Cin, Cout;
     int remap;                                    // 1: XCD-aware box order (grid.x rounded up to a multiple of 8)
-    // data-gradient launches only: the GroupNorm-backward REDUCE pass of the unit that consumes this gradient, folded into the epilogue.
-    // The tensor written here is d loss / d activation of a [conv -> GroupNorm -> dropout -> ReLU] unit whose only gradient source it is;
-    // rq_y = that unit's raw conv output (same extent as `out`), rq_scale / rq_shift its forward coefficients [N][Cout].  The epilogue adds
-    // sum dz and sum dz*y (dz = dy where scale*y+shift > 0) per (sample, channel) into rq_Q [rep][N][Cout][2]: one read of y instead of the
-    // reduce kernel's reads of dy and y, and one launch less.
-    const void* rq_y; const float* rq_scale; const float* rq_shift; double* rq_Q; int rq_rep;
     // forward launches only (FUSE instantiations): `in0` is the RAW output of the producer's convolution and the producer's GroupNorm +
     // channel dropout + ReLU (reference op chain networks/VNet3d.py:13-15, networks/Unet3d.py:66-80) is applied while the halo sits in LDS:
     // every workgroup folds the producer's statistics of its sample (gn_fold_block: scale / shift per channel), the first workgroup of a
@@ -78,133 +72,85 @@ __device__ __forceinline__ int c3x_box_of_block(int b, int nbox, int remap) {
     return ((b >> 3) < per && box < nbox) ? box : -1;
 }
 
-// shared epilogue of the conv3x kernels: bias -> LDS tile [voxel][co] (aliases the halo buffer; the caller has passed the barrier that
-// ends the tap loops) -> coalesced channels-last stores + per-channel sum / sum-of-squares into this workgroup's statistics replica
+// Shared epilogue of the conv3x kernels.  The tap loops multiply with SWAPPED operands (D^T = W x X^T: the weight fragment is the MFMA's A
+// operand, the halo fragment its B operand - the two have the same per-lane layout), so
+//     acc[m][j][r] = out[voxel (wm*TM + m)*16 + l15][channel (wn*TN + j)*16 + 4q + r]:
+// a lane holds FOUR CONSECUTIVE CHANNELS of one voxel.  Lanes q / q^1 exchange one 4-channel piece (tiles in pairs) and every lane stores
+// 16 B: a wave instruction covers whole 64-B voxel rows of 16 voxels.  No LDS transpose, no barrier in front of the stores (rounds 1-2 wrote the
+// tile to LDS with 2-byte stores, synchronised and read it back; every barrier in this epilogue is worth ~1-2 us per workgroup round,
+// profiles/r03_graph_stats_ab.log).  GroupNorm statistics: per-lane sums over the TM voxels of its 4 x TN channels (values as stored), a
+// butterfly over the 16 voxel lanes, one LDS slot per wave (`red`: WM * BN * 2 floats, its own array), one barrier, fp64 atomics.
 template <class T, class B, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], T* Xs, const Conv3xArgs& a, int n, int x0, int y0, int z0, int co0) {
-    constexpr int BN = WN * TN * 16, OLD = BN + 8, OS_ELEMS = B::V * OLD;
+__device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, const Conv3xArgs& a, int n, int x0, int y0, int z0, int co0) {
+    constexpr int BN = WN * TN * 16;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int wm = wv % WM, wn = wv / WM;
-    T* Os = Xs;
-    float* red = (float*)(Xs + OS_ELEMS);
-    // data-gradient launches with the GroupNorm-backward reduce folded in: the consumer unit's raw outputs come from HBM - up to 8 independent
-    // 16-B loads per thread are issued right after the accumulators have gone to LDS, in front of the barrier, so the round trip overlaps
-    // the tile exchange (round 2 loaded one tile row per loop trip: a dependent global round trip per trip inside every such epilogue)
-    constexpr int RQ_CPR = BN / 8, RQ_NIT = (B::V * RQ_CPR + 255) / 256, RQ_UB = RQ_NIT < 8 ? RQ_NIT : 8;
-    vec<T, 8> rq_yv[RQ_UB];
-    long long rq_oo[RQ_UB];
-    auto rq_issue = [&](int i0) {
-        const int c8 = tid % RQ_CPR;
-        const T* ry = (const T*)a.rq_y;
+    T* out = (T*)a.out;
+    float bs[TN][4], cs[TN][4], css[TN][4];
 #pragma unroll
-        for (int u = 0; u < RQ_UB; ++u) {
-            const int i = (i0 + u) * 256 + tid, v = i / RQ_CPR;
-            int vz, vy, vx;
-            B::vox(v < B::V ? v : 0, vz, vy, vx);
-            const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
-            const bool ok = i0 + u < RQ_NIT && i < B::V * RQ_CPR && x < a.W && y < a.H && z < a.D;
-            rq_oo[u] = ok ? ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8 : -1;
-            rq_yv[u] = ok ? load8(ry + rq_oo[u]) : zero8<T>();
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bs[j][r] = a.bias ? a.bias[co0 + (wn * TN + j) * 16 + 4 * q + r] : 0.f;
+            cs[j][r] = 0.f; css[j][r] = 0.f;
         }
-    };
-    // GroupNorm statistics straight from the accumulators (the values as stored: rounded to T), voxels outside the volume excluded.
-    // Round 2 re-read the whole output tile from LDS for them behind one more barrier: 3.7 % of the train step (SEG_DIAG_NOSTATS,
-    // profiles/r03_graph_stats_ab.log).  A lane holds TM x 4 rows of TN columns: per-lane sums, a butterfly over the four 16-lane groups
-    // (same column), then the WM waves of a column meet in LDS.
-    bool okr[TM][4];
+    const bool odd = q & 1;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        int vz, vy, vx;
+        B::vox((wm * TM + m) * 16 + l15, vz, vy, vx);
+        const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+        const bool ok = x < a.W && y < a.H && z < a.D;
+        T* row = out + ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + wn * TN * 16;
+        vec<T, 4> o4[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const T tv = from_f<T>(acc[m][j][r] + bs[j][r]);
+                o4[j][r] = tv;
+                if (a.stats && ok) { const float f = to_f(tv); cs[j][r] += f; css[j][r] = fmaf(f, f, css[j][r]); }
+            }
+        if (TN % 2 == 0) {
+#pragma unroll
+            for (int jp = 0; jp < TN / 2; ++jp) {
+                // even q keeps tile A = 2jp (its channels 4q .. 4q+3) and receives A's next four from q + 1; odd q keeps tile B likewise
+                const vec<T, 4> mine = odd ? o4[2 * jp + 1] : o4[2 * jp], send = odd ? o4[2 * jp] : o4[2 * jp + 1];
+                int sw[2], rw[2];
+                __builtin_memcpy(sw, &send, 8);
+                rw[0] = __shfl_xor(sw[0], 16); rw[1] = __shfl_xor(sw[1], 16);
+                vec<T, 4> recv;
+                __builtin_memcpy(&recv, rw, 8);
+                vec<T, 8> w8;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { w8[r] = odd ? recv[r] : mine[r]; w8[4 + r] = odd ? mine[r] : recv[r]; }
+                if (ok) store8(row + (odd ? 2 * jp + 1 : 2 * jp) * 16 + (q >> 1) * 8, w8);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (ok) *(vec<T, 4>*)(row + j * 16 + 4 * q) = o4[j];
+        }
+    }
     if (a.stats) {
 #pragma unroll
-        for (int m = 0; m < TM; ++m)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int vz, vy, vx;
-                B::vox((wm * TM + m) * 16 + q * 4 + r, vz, vy, vx);
-                okr[m][r] = x0 + vx < a.W && y0 + vy < a.H && z0 + vz < a.D;
+                float u = cs[j][r], v = css[j][r];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) { u += __shfl_xor(u, msk); v += __shfl_xor(v, msk); }
+                if (l15 == 0) { const int col = (wn * TN + j) * 16 + 4 * q + r; red[(wm * BN + col) * 2] = u; red[(wm * BN + col) * 2 + 1] = v; }
             }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 16 + l15;
-        const float bsv = a.bias ? a.bias[co0 + col] : 0.f;
-        float cs = 0.f, css = 0.f;
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const T tv = from_f<T>(acc[m][j][r] + bsv);
-                Os[((wm * TM + m) * 16 + q * 4 + r) * OLD + col] = tv;
-                if (a.stats && okr[m][r]) { const float f = to_f(tv); cs += f; css = fmaf(f, f, css); }
-            }
-        if (a.stats) {
-            cs += __shfl_xor(cs, 16); css += __shfl_xor(css, 16);
-            cs += __shfl_xor(cs, 32); css += __shfl_xor(css, 32);
-            if (q == 0) { red[(wm * BN + col) * 2] = cs; red[(wm * BN + col) * 2 + 1] = css; }
-        }
-    }
-    if (a.rq_Q) rq_issue(0);                               // the accumulators are dead from here on: their registers take the loads
-    __syncthreads();
-    if (a.stats && tid < BN) {
-        double ts = 0.0, tss = 0.0;
-#pragma unroll
-        for (int k = 0; k < WM; ++k) { ts += (double)red[(k * BN + tid) * 2]; tss += (double)red[(k * BN + tid) * 2 + 1]; }
-        double* dst = a.stats + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + tid) * 2;
-        atomicAdd(dst, ts);
-        atomicAdd(dst + 1, tss);
-    }
-    constexpr int CPR = BN / 8;
-    T* out = (T*)a.out;
-    if (a.rq_Q) {
-        // a thread keeps its 8-channel chunk (256 % CPR == 0): forward coefficients in registers, two partial sums per channel
-        const int c8 = tid % CPR;
-        const vec<float, 8> sc = *(const vec<float, 8>*)(a.rq_scale + (long long)n * a.Cout + co0 + c8 * 8);
-        const vec<float, 8> sh = *(const vec<float, 8>*)(a.rq_shift + (long long)n * a.Cout + co0 + c8 * 8);
-        float q1[8], q2[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
-#pragma unroll
-        for (int i0 = 0; i0 < RQ_NIT; i0 += RQ_UB) {
-            if (i0) rq_issue(i0);                          // (tilings with more than 8 rows per thread: the next batch)
-#pragma unroll
-            for (int u = 0; u < RQ_UB; ++u) {
-                if (rq_oo[u] >= 0) {
-                    const int v = ((i0 + u) * 256 + tid) / CPR;
-                    const vec<T, 8> dv = load8(&Os[v * OLD + c8 * 8]);
-                    store8(out + rq_oo[u], dv);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float yf = to_f(rq_yv[u][j]);
-                        const float dz = (fmaf(sc[j], yf, sh[j]) > 0.f) ? to_f(dv[j]) : 0.f;
-                        q1[j] += dz;
-                        q2[j] = fmaf(dz, yf, q2[j]);
-                    }
-                }
-            }
-        }
-        // lanes with equal lane % CPR hold the same channels: butterfly over the other lane bits, then the four waves through LDS
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            for (int o = CPR; o < 64; o <<= 1) { q1[j] += __shfl_xor(q1[j], o); q2[j] += __shfl_xor(q2[j], o); }
-        if (lane < CPR) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { red[(wv * CPR + lane) * 16 + j] = q1[j]; red[(wv * CPR + lane) * 16 + 8 + j] = q2[j]; }
-        }
         __syncthreads();
-        if (tid < CPR * 16) {
-            const int cc = tid / 16, jj = tid % 16;
-            const double sum = (double)red[(0 * CPR + cc) * 16 + jj] + (double)red[(1 * CPR + cc) * 16 + jj] + (double)red[(2 * CPR + cc) * 16 + jj] +
-                               (double)red[(3 * CPR + cc) * 16 + jj];
-            const int c = co0 + cc * 8 + (jj & 7), which = jj >> 3;
-            atomicAdd(a.rq_Q + (((long long)(blockIdx.x % a.rq_rep) * a.N + n) * a.Cout + c) * 2 + which, sum);
+        if (tid < BN) {
+            double ts = 0.0, tss = 0.0;
+#pragma unroll
+            for (int k = 0; k < WM; ++k) { ts += (double)red[(k * BN + tid) * 2]; tss += (double)red[(k * BN + tid) * 2 + 1]; }
+            double* dst = a.stats + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + tid) * 2;
+            atomicAdd(dst, ts);
+            atomicAdd(dst + 1, tss);
         }
-        return;
-    }
-    for (int i = tid; i < B::V * CPR; i += 256) {
-        const int v = i / CPR, c8 = i % CPR;
-        int vz, vy, vx;
-        B::vox(v, vz, vy, vx);
-        const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
-        if (x < a.W && y < a.H && z < a.D)
-            store8(out + ((((long long)n * a.D + z) * a.H + y) * a.W + x) * a.Cout + co0 + c8 * 8, load8(&Os[v * OLD + c8 * 8]));
     }
 }
 
@@ -215,10 +161,11 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     __shared__ __attribute__((aligned(16))) float gn_coef[2][FUSE ? 256 : 8];
     static_assert(WM * WN == 4 && WM * TM == B::NTILE, "wave grid must cover the box");
     static_assert(B::NTAP % (PF + 1) == 0, "register ring must divide the tap count");
-    constexpr int BN = WN * TN * 16, OLD = BN + 8;
-    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 4096 / sizeof(T), XS_ELEMS = NRES * B::CHUNK_ELEMS;
-    // ONE LDS object: resident chunk images; the epilogue's output tile + reduction slots alias it
-    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS];
+    constexpr int BN = WN * TN * 16;
+    constexpr int XS_ELEMS = NRES * B::CHUNK_ELEMS;
+    // resident chunk images; the epilogue stores straight from the accumulators and only needs the small statistics exchange array
+    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
+    __shared__ float red_s[WM * BN * 2];
     constexpr int NI = (B::NINSTR + 3) / 4;               // copy instructions per wave and chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -378,16 +325,14 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(af[t & 1][m], bq[t % (PF + 1)][j], acc[m][j]);
+                    for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bq[t % (PF + 1)][j], af[t & 1][m], acc[m][j]);
                 __builtin_amdgcn_sched_group_barrier(0x020, TN, 0);           // VMEM reads: B fragments of step t + PF
                 if (t + 1 < B::NTAP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);   // DS reads: A fragments of tap t + 1
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);      // the MFMAs of tap t
             }
         }
     }
-    __syncthreads();
-
-    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs, a, n, x0, y0, z0, co0);
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0);      // no barrier: nothing of the halo buffer is reused
 }
 
 
@@ -415,10 +360,10 @@ template <class T, class B, int TM, int TN>
 __global__ __launch_bounds__(256, 1) void conv3p_kernel(Conv3xArgs a) {
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     static_assert(4 * TM == B::NTILE, "four waves cover the box");
-    constexpr int WM = 4, WN = 1, BN = TN * 16, OLD = BN + 8;
-    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 4096 / sizeof(T);
-    constexpr int BUF = B::CHUNK_ELEMS > OS_ELEMS + RED_ELEMS ? B::CHUNK_ELEMS : OS_ELEMS + RED_ELEMS;
+    constexpr int WM = 4, WN = 1, BN = TN * 16;
+    constexpr int BUF = B::CHUNK_ELEMS;
     constexpr int NW = B::NTAP * TN;                       // 1 KB weight fragments resident in LDS
+    __shared__ float red_s[WM * BN * 2];
     __shared__ __attribute__((aligned(16))) T Ws[NW * 512];
     __shared__ __attribute__((aligned(16))) T Xs[2][BUF];
     constexpr int NI = (B::NINSTR + 3) / 4;
@@ -515,12 +460,11 @@ __global__ __launch_bounds__(256, 1) void conv3p_kernel(Conv3xArgs a) {
 #pragma unroll
             for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(af[t & 1][m], bf[t & 1][j], acc[m][j]);
+                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bf[t & 1][j], af[t & 1][m], acc[m][j]);
             if (t + 1 < B::NTAP) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS reads of tap t + 1 ...
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                        // ... ahead of the MFMAs of tap t
         }
-        __syncthreads();                                   // every wave is done reading Xs[cur]: the epilogue may alias it
-        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs[cur], a, p.n, p.x0, p.y0, p.z0, co0);
+        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0);
         p = pn;
         cur ^= 1;
     }
@@ -551,12 +495,12 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     static_assert(B::TX == 16, "x rows of 16 voxels");
     static_assert(4 * TM == B::NTILE, "four waves cover the box");
-    constexpr int WM = 4, WN = 1, BN = TN * 16, OLD = BN + 8;
+    constexpr int WM = 4, WN = 1, BN = TN * 16;
     constexpr int NSTEP = (B::NTAP + 1) / 2;
     static_assert(NSTEP >= PF + 1, "ring deeper than the loop");
     constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
-    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 4096 / sizeof(T);
-    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS];
+    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
+    __shared__ float red_s[WM * BN * 2];
     constexpr int NI = (NINSTR + 3) / 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -641,13 +585,12 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(af[s & 1][m], bq[s % (PF + 1)][j], acc[m][j]);
+            for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bq[s % (PF + 1)][j], af[s & 1][m], acc[m][j]);
         __builtin_amdgcn_sched_group_barrier(0x020, TN, 0);
         if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
-    __syncthreads();
-    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs, a, n, x0, y0, z0, co0);
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0);
 }
 
 // The same persistent scheme for Cin == 16 (conv3x16_kernel's two-taps-per-step arithmetic): the [14 steps][TN][64][8] weight slab (14 / 28 KB)
@@ -658,11 +601,11 @@ __global__ __launch_bounds__(256, 2) void conv3p16_kernel(Conv3xArgs a) {
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     static_assert(B::TX == 16, "x rows of 16 voxels");
     static_assert(4 * TM == B::NTILE, "four waves cover the box");
-    constexpr int WM = 4, WN = 1, BN = TN * 16, OLD = BN + 8;
+    constexpr int WM = 4, WN = 1, BN = TN * 16;
     constexpr int NSTEP = (B::NTAP + 1) / 2;
     constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
-    constexpr int OS_ELEMS = B::V * OLD, RED_ELEMS = 4096 / sizeof(T);
-    constexpr int BUF = XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS;
+    constexpr int BUF = XS_ELEMS;
+    __shared__ float red_s[WM * BN * 2];
     constexpr int NW = NSTEP * TN;
     __shared__ __attribute__((aligned(16))) T Ws[NW * 512];
     __shared__ __attribute__((aligned(16))) T Xs[2][BUF];
@@ -762,12 +705,11 @@ __global__ __launch_bounds__(256, 2) void conv3p16_kernel(Conv3xArgs a) {
 #pragma unroll
             for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(af[s & 1][m], bf[s & 1][j], acc[m][j]);
+                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bf[s & 1][j], af[s & 1][m], acc[m][j]);
             if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        __syncthreads();
-        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, Xs[cur], a, p.n, p.x0, p.y0, p.z0, co0);
+        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0);
         p = pn;
         cur ^= 1;
     }
@@ -817,7 +759,11 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 14: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 2, FUSE>(a, s); return true;                    \
         case 15: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 2, 8, 1, FUSE>(a, s); return true;                  \
         case 16: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                  \
-        case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;
+        case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                    \
+        case 20: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 3, FUSE>(a, s); return true;                    \
+        case 21: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 1, 2, 4, FUSE>(a, s); return true;                    \
+        case 22: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 1, 8, 3, FUSE>(a, s); return true;                    \
+        case 23: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 3, FUSE>(a, s); return true;
 /* Cin == 32 persistent tilings (conv3p_kernel):   box                  TM TN */
 #define SEG_C3X_3D_P_CASES                                                                                            \
         case 18: launch_cfgp<T, XBox<4, 8, 8, 3, 8>, 4, 2>(a, s); return true;                                       \

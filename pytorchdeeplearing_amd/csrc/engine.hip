@@ -35,7 +35,6 @@ struct Ten {
     bool image = false;
     bool virt = false;       // gradient of the head's input kept virtual (evaluated from dlogits and the head weights by its readers)
     std::vector<int> grads;  // gradient contribution tensors (ids)
-    int prod_step = -1, prod_which = 0;   // gradient tensors: the UNIT step whose conv3x data-gradient launch (in0 / in1 part) writes it
 };
 
 struct Step {
@@ -47,8 +46,6 @@ struct Step {
     size_t stats = 0, scale = 0, shift = 0, mean = 0, rstd = 0, Q = 0, coef = 0;
     size_t wp_fwd = 0, wp_dg0 = 0, wp_dg1 = 0;
     bool fused_stem = false;                  // image stem evaluated inside the fused input block of its ACT step (stemx.hip)
-    int rq_unit[2] = {-1, -1};                // UNIT: its data-gradient launch (in0 / in1 part) also runs the GroupNorm-backward reduce of this unit
-    bool rfused = false;                      // UNIT: its GroupNorm-backward reduce is done by the epilogue of the conv that produces its gradient
     int stat_rep = 0;                         // replicas of the statistics buffers this unit's producers use (0 = STAT_REP)
     bool fold_fin = false;                    // statistics finalize folded into the consuming gn_act launch (no launch of its own)
     int x_fwd = -1, x_dg0 = -1, x_dg1 = -1;   // conv3x tiling of the forward / data-gradient launches (-1: conv3_kernel, row-major weights)
@@ -107,9 +104,9 @@ struct seg_engine {
                                 // gradient (12 launches and 12 activated tensors less in VNet3d).  Bit-identical, but measured 2.3 % SLOWER
                                 // (863 vs 883 volumes/s, profiles/r03_vact_cumask_ab.log): the per-workgroup statistics fold costs the two L2
                                 // round trips the 4.8 us launch cost, and the FUSE kernels spill scalars into the tap loop.  Opt-in.
-    bool use_rfuse = false;     // SEG_GN_RFUSE=1: the GroupNorm-backward reduce of a unit rides in the epilogue of the data-gradient conv that produces
-                                // its only gradient (10 launches less).  Neutral in round 2, 0.4 % slower in round 3 even with its loads batched
-                                // (907 vs 903 volumes/s twice, profiles/r03_epilogue_ab.log): the epilogue sits on the conv's critical path.  Opt-in.
+    // (rounds 2-3 could fold the GroupNorm-backward reduce of a unit into the epilogue of the data-gradient conv producing its only gradient;
+    // neutral in round 2, 0.4 % slower in round 3 - profiles/r03_epilogue_ab.log - and gone since the conv epilogue stores straight from the
+    // accumulators)
     bool use_fold = true;       // SEG_GN_FOLD=0: finalize kernels between the GroupNorm passes (round-1 path)
     bool use_vhead = true;      // SEG_VHEAD=0: head_bwd writes its data-gradient tensor (round-1 path)
     bool head_din_needed = false;   // planning: some reader of the head's data-gradient cannot evaluate it on the fly
@@ -229,17 +226,6 @@ struct seg_engine {
         return (int)prof_used++;
     }
     void prof_end(hipStream_t st, int idx) { if (idx >= 0) (void)hipEventRecord(prof_pool[idx].b, st); }
-    // arguments of a GroupNorm-backward reduce folded into a data-gradient launch (unit index, or -1: none)
-    Conv3xReduce reduce_args(int ui) const {
-        Conv3xReduce r{nullptr, nullptr, nullptr, nullptr, STAT_REP};
-        if (ui < 0) return r;
-        const Step& u = steps[ui];
-        r.y = ws + tens[u.raw].off;
-        r.scale = (const float*)(ws + u.scale); r.shift = (const float*)(ws + u.shift);
-        r.Q = (double*)(ws + u.Q);
-        r.rep = use_fold ? stat_rep_for(vol(tens[u.raw].lvl)) : STAT_REP;
-        return r;
-    }
     double tbytes(int ten) const { return (double)N * vol(tens[ten].lvl) * tens[ten].C * esz(); }
     size_t esz() const { return dtype == DT_F32 ? 4 : 2; }
     int ld_mask() const { return 16 * feat; }
@@ -537,7 +523,7 @@ struct Planner {
         size_t nfw = 0;
         for (auto& s : E.steps) {
             nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1);
-            s.draw = -1; s.rq_unit[0] = s.rq_unit[1] = -1; s.rfused = false; s.vact = false; s.vact_prod = -1;
+            s.draw = -1; s.vact = false; s.vact_prod = -1;
         }
         E.tens.resize(std::max<size_t>(nfw, (size_t)E.image_ten + 1));
         for (auto& t : E.tens) t.grads.clear();
@@ -732,7 +718,7 @@ struct Planner {
                             f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
                             f.N = E.N; f.C = u.Cout; f.V = E.vol(E.tens[u.raw].lvl); f.eps = 1e-5f; f.rep = u.stat_rep;
                             launch_conv3x(s.x_fwd, E.ws + E.tens[u.raw].off, nullptr, i0.C, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N,
-                                          E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st, s.stat_rep, nullptr, &f);
+                                          E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st, s.stat_rep, &f);
                         } else if (s.x_fwd >= 0)
                             launch_conv3x(s.x_fwd, E.ws + i0.off, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, E.ws + s.wp_fwd, bias,
                                           E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st,
@@ -1044,12 +1030,6 @@ struct Planner {
                     if (ui < 0) continue;
                     Step& u = E.steps[ui];
                     u.draw = new_grad(u.raw);
-                    // the reduce pass rides on the conv that produces this unit's only gradient (c3x_epilogue)
-                    if (E.use_rfuse && s.ub < 0 && gl.size() == 1 && E.tens[gl[0]].prod_step >= 0 && !E.tens[gl[0]].virt &&
-                        !gn_bwd_group_eligible(E.tens[u.raw].C, E.vol(E.tens[u.raw].lvl), (int)E.esz())) {
-                        u.rfused = true;
-                        E.steps[E.tens[gl[0]].prod_step].rq_unit[E.tens[gl[0]].prod_which] = ui;
-                    }
                     E.bwd_writes.push_back({u.gn_w, u.gn_b, u.b});      // gamma/beta and (analytically) the conv bias
                     E.bwd_ops.push_back([this_ = &E, ui, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
@@ -1064,12 +1044,9 @@ struct Planner {
                             E.prof_end(st, pg);
                             return;
                         }
-                        int pi = -1;
-                        if (!u.rfused) {
-                            pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
-                            launch_gn_bwd_reduce(a, E.dtype, st);
-                            E.prof_end(st, pi);
-                        }
+                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
+                        launch_gn_bwd_reduce(a, E.dtype, st);
+                        E.prof_end(st, pi);
                         const bool fold = E.use_fold && a.C <= 256;
                         if (!fold) launch_gn_bwd_finalize(f, st);
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
@@ -1092,10 +1069,6 @@ struct Planner {
                 int g0 = -1, g1 = -1;
                 if (need_dg0) { g0 = new_grad(s.in0); E.tens[s.in0].grads.push_back(g0); }
                 if (s.in1 >= 0) { g1 = new_grad(s.in1); E.tens[s.in1].grads.push_back(g1); }
-                if (s.ck == CK_K3) {
-                    if (g0 >= 0 && s.x_dg0 >= 0) { E.tens[g0].prod_step = si; E.tens[g0].prod_which = 0; }
-                    if (g1 >= 0 && s.x_dg1 >= 0) { E.tens[g1].prod_step = si; E.tens[g1].prod_which = 1; }
-                }
                 E.bwd_writes.push_back({s.w, s.gn_w < 0 ? s.b : -1});
                 if (s.ck != CK_STEM3 && s.ck != CK_STEM1) ++E.n_deferred;
                 E.bwd_ops.push_back([this_ = &E, si, draw, g0, g1](hipStream_t st) {
@@ -1131,11 +1104,9 @@ struct Planner {
                         int pi;
                         if (g0 >= 0) {
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
-                            if (s.x_dg0 >= 0) {
-                                Conv3xReduce rq = E.reduce_args(s.rq_unit[0]);
+                            if (s.x_dg0 >= 0)
                                 launch_conv3x(s.x_dg0, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr,
-                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st, STAT_REP, &rq);
-                            }
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st, STAT_REP);
                             else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
@@ -1144,11 +1115,9 @@ struct Planner {
                         if (g1 >= 0) {
                             const int C1 = E.tens[s.in1].C;
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g1), fl * C1 / s.Cin);
-                            if (s.x_dg1 >= 0) {
-                                Conv3xReduce rq = E.reduce_args(s.rq_unit[1]);
+                            if (s.x_dg1 >= 0)
                                 launch_conv3x(s.x_dg1, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr,
-                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st, STAT_REP, &rq);
-                            }
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st, STAT_REP);
                             else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);
@@ -1260,7 +1229,6 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;
     if (getenv("SEG_STEMX")) e->use_stemx = atoi(getenv("SEG_STEMX")) != 0;
     if (getenv("SEG_PACK_SPLIT")) e->pack_split = atoi(getenv("SEG_PACK_SPLIT")) != 0;
-    if (getenv("SEG_GN_RFUSE")) e->use_rfuse = atoi(getenv("SEG_GN_RFUSE")) != 0;
     if (getenv("SEG_GN_VACT")) e->use_vact = atoi(getenv("SEG_GN_VACT")) != 0;
     if (getenv("SEG_GN_FOLD")) e->use_fold = atoi(getenv("SEG_GN_FOLD")) != 0;
     if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
@@ -1349,7 +1317,6 @@ int seg_plan_count(seg_handle h, int what) {
     for (auto& s : h->steps) {
         if (what == 0) n += s.type == ST_ACT && s.vact;                                   // activations applied by their consumer (never written)
         else if (what == 1) n += s.type == ST_UNIT;                                       // convolution units
-        else if (what == 2) n += s.type == ST_UNIT && s.rfused;                           // GroupNorm-backward reduces done by a data-gradient epilogue
         else return -1;
     }
     return n;

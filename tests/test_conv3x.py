@@ -18,7 +18,7 @@ os.environ.setdefault("SEG_C3P_WGS", "16")
 os.environ.setdefault("SEG_C3P16_WGS", "16")
 
 CASES = [
-    (3, 1, (3, 9, 18), [32], 32, [0, 1, 13, 14]),          # partial boxes in every direction
+    (3, 1, (3, 9, 18), [32], 32, [0, 1, 13, 14, 20, 21, 22, 23]),          # partial boxes in every direction
     (3, 2, (2, 8, 16), [64], 64, [2, 15]),
     (3, 1, (4, 8, 10), [64], 64, [3, 4, 5, 6, 11]),
     (3, 1, (3, 5, 12), [128], 128, [7, 8, 9, 12]),
