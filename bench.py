@@ -36,11 +36,11 @@ PEAK_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA
 # kernel classes whose launches are ONE kernel symbol each (so rocprofv3's per-kernel average is comparable)
 KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel<f16, DUAL=0|1>", "gn_bwd_apply": "gn_bwd_apply_kernel<f16, DUAL=0|1, FOLD=1>",
                  "gn_act": "gn_act_kernel<f16, FOLD=1>",
-                 "conv3": "c3x::conv3x_kernel<f16, XBox<4,8,8>, TM=4, TN=2, 4x1 waves> (48^3 level, 32 -> 32 channels)"}
+                 "conv3": "c3x::conv3x_kernel<f16, XBox<4,8,8>, TM=4, TN=2, 4x1 waves, PF=8> (tiling 17; 48^3 level, 32 -> 32 channels)"}
 MFMA_BOUND = {"conv3_smallbox", "conv3", "wgrad3"}
 # PMC summary keys (profiles/summarize_pmc.py), matched by prefix: the GroupNorm-backward classes have a single- and a dual-branch
 # instantiation of the same template: the traffic figure is the launch-weighted mean over both
-PMC_KEY = {"conv3": ["_ZN3seg3c3x13conv3x_kernel<DF16_NS0_4XBoxILi4ELi8ELi8ELi3ELi8EEELi4ELi2ELi4ELi1ELi1ELi2ELi2E>"],
+PMC_KEY = {"conv3": ["_ZN3seg3c3x13conv3x_kernel<DF16_NS0_4XBoxILi4ELi8ELi8ELi3ELi8EEELi4ELi2ELi4ELi1ELi1E"],      # the 4x8x8-box TM4 TN2 tilings (14 / 17)
            "gn_bwd_reduce": ["gn_bwd_reduce_kernel<DF16_"],
            "gn_bwd_apply": ["gn_bwd_apply_kernel<DF16_"],
            "gn_act": ["gn_act_kernel<DF16_"]}
