@@ -155,9 +155,25 @@ struct seg_engine {
     int n_deferred = 0, wgrad_seq = 0, tail_wgrads = 0;       // SEG_TAIL_WGRADS
     size_t off_partial_main = 0;
     std::vector<std::function<void(hipStream_t)>> tail_pending;
-    void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> f, double bytes = 0.0) {
+    // SEG_HOLD_HEAVY_LVL=L (experiment, default off = -1): the weight gradients over >= hold_bytes tensors of the DECODER's top levels are
+    // not released while the main stream still works on those bandwidth-bound levels; they are held until the backward pass reaches level L
+    // (24^3 for L = 2), where the main stream's kernels are small and latency-bound and leave the HBM to the weight gradients
+    int hold_lvl = -1;
+    double hold_bytes = 64e6;                       // SEG_HOLD_HEAVY_MB
+    bool hold_open = false;                         // the release level has been reached in this backward pass
+    std::vector<std::function<void(hipStream_t)>> held;
+    void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> f, double bytes = 0.0, int lvl = 0) {
         if (!use_side) { cur_partial = off_partial; f(main); return; }
         if (wgrad_seq++ >= n_deferred - tail_wgrads) { tail_pending.push_back(std::move(f)); return; }
+        if (hold_lvl >= 0) {
+            if (!hold_open && lvl >= hold_lvl) {
+                hold_open = true;
+                for (auto& h : held) pending.push_back(std::move(h));
+                held.clear();
+                flush_due = true;
+            }
+            if (!hold_open && bytes >= hold_bytes) { held.push_back(std::move(f)); return; }
+        }
         pending.push_back(std::move(f));
         // a full batch is released AFTER the op that queued it has enqueued its own main-stream kernels (maybe_flush): the dozen
         // launches + events of a batch take the host ~45 us, during which the main queue used to run dry (r02 trace: 138 us idle)
@@ -190,6 +206,8 @@ struct seg_engine {
         pending.clear();
     }
     void join_side(hipStream_t main) {
+        for (auto& h : held) pending.push_back(std::move(h));      // (a network without deep levels never reached the release level)
+        held.clear();
         flush_side(main);
         for (auto& f : tail_pending) { cur_partial = off_partial_main; f(main); }
         tail_pending.clear();
@@ -1100,7 +1118,7 @@ struct Planner {
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
                                           s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
                             E.prof_end(ws_, pi);
-                        }, E.tbytes(draw));
+                        }, E.tbytes(draw), lo);
                         int pi;
                         if (g0 >= 0) {
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
@@ -1155,7 +1173,7 @@ struct Planner {
                                                     E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
                         launch_wgrad(w, (float*)(E.ws + E.cur_partial), E.dtype, ws_);
                         E.prof_end(ws_, pi);
-                    }, E.tbytes(draw));
+                    }, E.tbytes(draw), lo < li ? lo : li);
                     // ---- data gradient(s)
                     if (g0 < 0 && g1 < 0) return;
                     ConvArgs a{};
@@ -1235,6 +1253,8 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (getenv("SEG_TAIL_WGRADS")) e->tail_wgrads = atoi(getenv("SEG_TAIL_WGRADS"));
     if (getenv("SEG_FORK_HEAVY_MB")) e->fork_heavy_bytes = atof(getenv("SEG_FORK_HEAVY_MB")) * 1e6;
     if (getenv("SEG_FLUSH_LATE")) e->flush_late = atoi(getenv("SEG_FLUSH_LATE")) != 0;
+    if (getenv("SEG_HOLD_HEAVY_LVL")) e->hold_lvl = atoi(getenv("SEG_HOLD_HEAVY_LVL"));
+    if (getenv("SEG_HOLD_HEAVY_MB")) e->hold_bytes = atof(getenv("SEG_HOLD_HEAVY_MB")) * 1e6;
     if (getenv("SEG_DUAL_GN")) e->dual_gn_bwd = atoi(getenv("SEG_DUAL_GN")) != 0;
     if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
     if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
@@ -1416,7 +1436,7 @@ static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, in
     hipStream_t st = (hipStream_t)stream;
     if (zero_grads && op_begin == 0) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
-    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; }
+    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; }
     if (h->pack_bwd_pending) { (void)hipStreamWaitEvent(st, h->pack_done, 0); h->pack_bwd_pending = false; }
     for (int i = op_begin; i < op_end; ++i) { h->bwd_ops[i](st); h->maybe_flush(st); }
     if (join) h->join_side(st);

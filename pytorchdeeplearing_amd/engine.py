@@ -113,7 +113,15 @@ class SegEngine:
             n *= s
         return (self.grads if grad else self.params)[off:off + n].view(shape)
 
+    def _wait_side(self):
+        """the backward-only weight layouts of the last step are packed on the engine's side stream, which nothing orders against the
+        caller's stream until the next backward pass: whoever overwrites the parameters before that waits for it here"""
+        if self.ws is not None and self.device.type == "cuda" and getattr(self, "_pack_pending", False):
+            self.lib.check(self.lib.seg_side_wait(self.h, self.stream()), "seg_side_wait")
+            self._pack_pending = False
+
     def load_state_dict(self, sd):
+        self._wait_side()
         with torch.no_grad():
             for k in self.table:
                 self.param_view(k).copy_(sd[k].to(device=self.device, dtype=torch.float32))
@@ -167,6 +175,7 @@ class SegEngine:
     def pack_weights(self):
         self.lib.check(self.lib.seg_pack_weights(self.h, self.stream()), "seg_pack_weights")
         self.packed = True
+        self._pack_pending = True          # part of the pack may run on the side stream until the next backward pass joins it
 
     # ---- forward / backward ---------------------------------------------------------------------
     def forward(self, x, mask_mode=_capi.MASKS_EVAL, masks=None, logits=None, probs=None):
@@ -205,6 +214,7 @@ class SegEngine:
         op_range = (begin, end): only that slice of the backward op list (bucketed gradient exchange); join=False leaves the slice's
         weight gradients running on the engine's side stream without making the current stream wait (see side_wait)."""
         assert dlogits.dtype == torch.float32 and dlogits.is_contiguous()
+        self._pack_pending = False         # the backward pass waits for the side-stream pack itself
         if op_range is None:
             self.lib.check(self.lib.seg_backward(self.h, _ptr(dlogits), 1 if zero_grads else 0, self.stream()), "seg_backward")
         else:
@@ -336,6 +346,7 @@ class SegEngine:
             self.init_optimizer()
         if check_finite is None:
             check_finite = self.dtype in ("f16", "fp16", "float16")
+        self._wait_side()
         self.lib.check(self.lib.seg_adam_step(
             _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), self.numel,
             float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), 1 if decoupled else 0,
@@ -484,6 +495,7 @@ class SegEngine:
                 self.lib.check(self.lib.seg_train_graph_launch(self.h, gsp), "seg_train_graph_launch")
                 if gs is not cur:
                     cur.wait_stream(gs)
+                self._pack_pending = False          # the captured step packs on one stream
                 self._keep = (x, mt)
                 self._keep_loss = (target, class_alpha)
                 self._last_probs = probs
@@ -491,6 +503,7 @@ class SegEngine:
                 return self._out3
         self.lib.check(self.lib.seg_train_step(self.h, C.byref(a), self.stream()), "seg_train_step")
         self.packed = True
+        self._pack_pending = True
         self._keep = (x, mt)
         self._keep_loss = (target, class_alpha)
         self._last_probs = probs
