@@ -139,6 +139,8 @@ __global__ __launch_bounds__(256) void plane_axpb_kernel(const float* in, const 
 // backward pass needs e).  A workgroup owns a TZ x TY x TX output tile: x with a 2-voxel halo sits in LDS (+inf outside the
 // volume), e is formed on the 1-voxel halo (-inf outside), then the update reads only LDS.  Pure min / max / sub / relu in
 // fp32: bit-identical to the two-kernel form (pool3_kernel + skel_update_kernel), which read every input 27 times from L2.
+// (Round 3 tried SEPARABLE pools - min over x, then y, then z; likewise max: 38 k instead of 83 k LDS reads per tile, same bits - and
+// lost: six more barriers and 46 KB instead of 22 KB of LDS per workgroup; C5 + clDice 7.67 vs 7.38 ms per step.  Not kept.)
 template <int TZ, int TY, int TX, bool ND3>
 __global__ __launch_bounds__(256) void skel_iter_kernel(const float* x, float* e_out, float* x_out, Vol v) {
     constexpr int HZ = ND3 ? 2 : 0;
