@@ -1,5 +1,5 @@
 # round 3, session a: is the 20/5 vs 50/10 gap of round 2 reproducible on ONE box, and what does the new bench / one-call step give?
-cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+cd /root/repo; mkdir -p gpurun_out  # (run as: gpurun -- bash tools/sessions_r03/<this file>); export TMPDIR=/tmp
 O=gpurun_out/r3a; mkdir -p $O
 timeout 600 python -m pytest tests/test_engine.py tests/test_boundary.py -m gpu -x -q 2>&1 | tail -4 > $O/tests.log; cat $O/tests.log
 # legacy bench (round-2 file, same library): driver's command vs builder's command, twice each, fresh processes
