@@ -154,7 +154,8 @@ int seg_lovasz_forward(const float* x, const void* target, int label_type, int n
  * reference, sigma 1.5), zero padding, the same window for every channel.  out[0] = mean of the SSIM map (size_average=True),
  * out[1 .. n] = the per-sample means.  seg_ssim_forward leaves the derivative maps in ws (seg_ssim_ws_bytes(n, c, d*h*w) bytes) for
  * seg_ssim_backward: dimg = gscale * d(sum of the map)/d img, gscale[0] (per_sample = 0) or gscale[sample] (per_sample = 1) carrying the
- * incoming gradient times 1/count; dimg1 or dimg2 may be NULL.  The backward pass consumes ws (one backward per forward). */
+ * incoming gradient times 1/count; dimg1 or dimg2 may be NULL.  The backward pass consumes ws (one backward per forward).
+ * Limits: n <= 64, window odd and <= 15. */
 long long seg_ssim_ws_bytes(int n, int c, long long v);
 int seg_ssim_forward(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, float* out,
                      void* stream);

@@ -289,8 +289,10 @@ def test_oracle_gradients_full_size_f32(tag):
     print("%s f32: worst gradient tensors (relative L2 vs the fp32 oracle): %s" % (tag, ", ".join("%s %.2e" % (k, v) for v, k, _ in rows[:4])))
     # the fp32 torch-CPU oracle is itself up to 2e-2 from its fp64 twin at these sizes (ReLU gates at ~0, tests/test_engine.py);
     # the gate is the same relative-L2 bound as the small-size network tests
+    # measured on MI355X: 7.9e-3 (C3) / 3.4e-3 (C4) worst tensor; against the float64 oracle the engine (3.9e-3) is closer than the fp32 oracle
+    # itself (7.5e-3): test_f32_gradients_full_size_against_the_fp64_oracle
     for err, k, _ in rows:
-        assert err < 3e-2, (k, err)
+        assert err < 1.5e-2, (k, err)
 
 
 @pytest.mark.parametrize("tag", list(GRAD_CASES))
