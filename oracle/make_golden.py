@@ -73,6 +73,18 @@ def make_losses_extra(losses):
         val.backward()
         out["loss_" + name] = _np(val)
         out["grad_" + name] = _np(zz.grad)
+    # ---- multi-label use of the binary classes: [N, C > 1, ...] logits with a same-shaped 0/1 target (model/losses.py:43-53 `view(bs, num_classes, -1)`)
+    zml = torch.randn(2, 3, 6, 6, 6)
+    yml = (torch.rand(2, 3, 6, 6, 6) > 0.6).float()
+    out["zml"], out["yml"] = _np(zml), _np(yml)
+    for name, f in (("BinaryDiceLoss", losses.BinaryDiceLoss()), ("BinaryCrossEntropyDiceLoss", losses.BinaryCrossEntropyDiceLoss()),
+                    ("BinaryFocalLoss", losses.BinaryFocalLoss()), ("BinaryTverskyLoss", losses.BinaryTverskyLoss()),
+                    ("BinarySSLoss", losses.BinarySSLoss()), ("BinaryJaccardLoss", losses.BinaryJaccardLoss())):
+        zz = zml.clone().requires_grad_(True)
+        val = f(zz, yml)
+        val.backward()
+        out["mlloss_" + name] = _np(val)
+        out["mlgrad_" + name] = _np(zz.grad)
     # ---- the rest of model/losses.py (round 3).  LOSS_REPAIRS: what a user of the reference has to do before these classes run at all
     tv = losses.MutilTverskyLoss(a); tv.beta = 0.7
     ss = losses.MutilSSLoss(a); ss.r = 0.1

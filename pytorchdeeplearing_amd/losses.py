@@ -13,7 +13,12 @@ from .engine import aligned_empty
 _LABEL_OK = (torch.uint8, torch.int32, torch.int64, torch.float32)
 
 
-def _prep(logits, target):
+# loss kinds whose reference classes apply a sigmoid and sum over EVERY element of a same-shaped target (model/losses.py:19-30, 43-53, 66-74,
+# 87-99, 113-126, 141-147, 160-181, 192-197): a multi-label [N, C > 1, ...] prediction is C*N independent planes to them
+_BINARY_KINDS = (0, 1, 2, 3, 7, 8, 9, 12)
+
+
+def _prep(logits, target, kind=None):
     lg = logits.float().contiguous()
     t = target
     if t.dtype not in _LABEL_OK:
@@ -21,6 +26,11 @@ def _prep(logits, target):
     t = t.contiguous()
     n, c = lg.shape[0], lg.shape[1]
     v = lg.numel() // (n * c)
+    if kind in _BINARY_KINDS and c > 1:
+        # multi-label head: the reference views both tensors as (bs, num_classes, -1) and reduces with plain .sum() / .mean(), i.e. over all
+        # N*C planes alike - the same numbers as a one-channel batch of N*C planes
+        assert t.numel() == n * c * v, "a multi-label binary loss needs a target of the prediction's shape"
+        n, c = n * c, 1
     assert t.numel() == n * v, "target must have one label per voxel"
     return lg, t, n, c, v
 
@@ -28,7 +38,7 @@ def _prep(logits, target):
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, kind, falpha, fgamma, class_alpha):
-        lg, t, n, c, v = _prep(logits, target)
+        lg, t, n, c, v = _prep(logits, target, kind)
         lib = _capi.lib_for(lg.device)
         ws = aligned_empty(lib.seg_loss_ws_bytes(n, c), lg.device)
         out3 = torch.zeros(4, dtype=torch.float32, device=lg.device)

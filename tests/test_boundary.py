@@ -323,3 +323,17 @@ def test_ssim_modules_vs_reference_golden(dev, golden_dir):
     assert np.abs(a.grad.cpu().numpy() - want).max() < 2e-3 * np.abs(want).max()
     with pytest.raises(NotImplementedError):
         S.ssim3D(torch.zeros(1, 1, 4, 4, 4, device=dev), torch.zeros(1, 1, 4, 4, 4, device=dev), size_average=False)
+
+
+@pytest.mark.parametrize("name", ["BinaryDiceLoss", "BinaryCrossEntropyDiceLoss", "BinaryFocalLoss", "BinaryTverskyLoss", "BinarySSLoss", "BinaryJaccardLoss"])
+def test_binary_losses_accept_multi_label_heads(dev, golden_dir, name):
+    """the reference's Binary* classes accept a multi-label [N, C > 1, ...] prediction with a same-shaped target
+    (`view(bs, num_classes, -1)`, model/losses.py:43-53) and reduce over every element; so do the modules here (goldens from the reference classes)."""
+    G = np.load(os.path.join(golden_dir, "losses_extra.npz"))
+    z = torch.from_numpy(G["zml"]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(G["yml"]).to(dev)
+    v = getattr(losses, name)()(z, t)
+    v.backward()
+    assert abs(float(v) - float(G["mlloss_" + name])) < 2e-6, name
+    np.testing.assert_allclose(z.grad.cpu().numpy(), G["mlgrad_" + name], rtol=3e-4, atol=1e-9, err_msg=name)
+    assert z.grad.shape == z.shape
