@@ -50,7 +50,8 @@ enum { SEG_MASKS_EVAL = 0, SEG_MASKS_GIVEN = 1, SEG_MASKS_RANDOM = 2 };
 
 /* networks/VNet3d.py:109 VNet3d(image_channel, numclass, init_features=16), networks/VNet2d.py:109,
  * networks/Unet3d.py:11 UNet3d(in_channels, out_channels, init_features=16), networks/Unet2d.py:11.
- * ndim = 2 or 3. */
+ * ndim = 2 or 3.  in_channels 1..16 (1 in 3-D / 1..3 in 2-D take the fused image stem; more channels are zero-padded to a 16-channel image tensor
+ * and run through the ordinary 16-channel convs), num_class 1..16, init_features 16. */
 int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_features, int dtype,
                seg_handle* out);
 void seg_destroy(seg_handle h);
@@ -287,6 +288,8 @@ typedef struct seg_pack_desc {
     int Kpad;
     long long s1, s2, sT, sC;
     int flipT;
+    int csrc;   /* channels the SOURCE holds per tap (0: Cc).  csrc < Cc: channels csrc .. Cc-1 of the packed layout are zeros - the image convs of a
+                   multi-channel 3-D input, whose image tensor is zero-padded to 16 channels so that they run as ordinary 16-channel halo convs */
     int frag;   /* 0: rows [R1*R2][Kpad]; 1: MFMA-fragment-major [Cc/32][T][rows/16][64 lanes][8] (Cc % 32 == 0, rows % 16 == 0):
                    lane = 16*((c%32)/8) + row%16 holds k = c%8 .. — one 16x32 B fragment is one contiguous 1 KB line;
                    2: the same over the flat k = t*Cc + c axis, [Kpad/32][rows/16][64 lanes][8] (Cc == 16: two taps per step) */

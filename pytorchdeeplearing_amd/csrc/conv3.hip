@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) void wgrad3_kernel(Wgrad3Args a) {
 // dw[p][q][tap] += sum_b partial[combo][b][p'][tap][q']   (one thread per dw element: coalesced read-modify-write of
 // the master gradient, partial tiles gathered through L1/L2)
 __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial, float* dw, int P, int Q, int CP, int CQ, int ntap, int nb,
-                                                            long long sP, long long sQ) {
+                                                            long long sP, long long sQ, int qreal) {
     // grid.y slices the partial list (32 partial tiles per slice); slices meet in dw through one atomic each
     const long long total = (long long)P * Q * ntap;
     const int tile = CP * ntap * CQ, nqt = Q / CQ;
@@ -649,13 +649,14 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial
         for (; b < b1; ++b) s0 += src[(long long)b * tile];
         const float tot = (s0 + s1) + (s2 + s3);
         const int p = (combo / nqt) * CP + pp, qc = (combo % nqt) * CQ + qq;
+        if (qc >= qreal) continue;                      // zero-padded input channels (multi-channel image tensor): no such weight
         if (gridDim.y == 1) dw[p * sP + qc * sQ + tap] += tot;
         else atomicAdd(&dw[p * sP + qc * sQ + tap], tot);
     }
 }
 
 template <class T, int TD, int TH, int TW, int KD>
-void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s) {
+void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
     Wgrad3Args a = a0;
     const int CP = a.P >= 32 ? 32 : 16, CQ = a.Q >= 32 ? 32 : 16;
     const int combos = (a.P / CP) * (a.Q / CQ);
@@ -670,17 +671,17 @@ void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long lon
     const long long total = (long long)a.P * a.Q * ntap;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, a.nb, sP, sQ);
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, a.nb, sP, sQ, qreal);
 }
 
 template <class T>
-void wgrad3_dispatch(const Wgrad3Args& a, int ndim, float* dw, long long sP, long long sQ, hipStream_t s) {
+void wgrad3_dispatch(const Wgrad3Args& a, int ndim, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
     if (ndim == 3) {
-        if (wide_box(a.W)) wgrad3_launch_shape<T, 3, 4, 16, 3>(a, dw, sP, sQ, s);
-        else wgrad3_launch_shape<T, 3, 8, 8, 3>(a, dw, sP, sQ, s);
+        if (wide_box(a.W)) wgrad3_launch_shape<T, 3, 4, 16, 3>(a, dw, sP, sQ, s, qreal);
+        else wgrad3_launch_shape<T, 3, 8, 8, 3>(a, dw, sP, sQ, s, qreal);
     } else {
-        if (wide_box(a.W)) wgrad3_launch_shape<T, 1, 8, 16, 1>(a, dw, sP, sQ, s);
-        else wgrad3_launch_shape<T, 1, 8, 8, 1>(a, dw, sP, sQ, s);
+        if (wide_box(a.W)) wgrad3_launch_shape<T, 1, 8, 16, 1>(a, dw, sP, sQ, s, qreal);
+        else wgrad3_launch_shape<T, 1, 8, 8, 1>(a, dw, sP, sQ, s, qreal);
     }
 }
 
@@ -962,14 +963,15 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) 
 }
 
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1, int C0, const float* xscale, const float* xshift) {
+                   int dtype, hipStream_t s, const void* x1, int C0, const float* xscale, const float* xshift, int qreal) {
     const int T = ndim == 3 ? 27 : 9;
+    if (qreal <= 0 || qreal > Q) qreal = Q;
     // 16-bit tensors, opt-in (SEG_WGRAD3X=1, read per call): double-buffered kernel (wgrad3x.hip), same partial-tile layout and
     // reduce.  Measured on MI355X (profiles/r02_wgrad3x_ab.log): op-level 67 vs 67 us at 32ch@48^3, 62 vs 52 us at 64ch@24^3, train
     // step 689 vs 712 volumes/s - one box in flight per CU is still latency-bound and its 112 KB / 512-thread workgroups crowd the
     // main stream's kernels out of the CU, so wgrad3_kernel (three 44 KB workgroups per CU) stays the default.
     const char* envx = getenv("SEG_WGRAD3X");
-    const bool use_x = envx && atoi(envx) != 0 && !xscale;      // the double-buffered variant copies x straight into LDS: no activation on the way
+    const bool use_x = envx && atoi(envx) != 0 && !xscale && qreal == Q;      // the double-buffered variant copies x straight into LDS: no activation on the way
     if (use_x && wgrad3x_supported(dtype, N, ndim == 3 ? D : 1, H, W, P, Q, C0, x1 != nullptr)) {
         int CP, CQ;
         wgrad3x_tiles(P, Q, C0, x1 != nullptr, &CP, &CQ);
@@ -989,7 +991,7 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
         int blocks = (int)((tot + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, ((int)nb + 31) / 32), dim3(256), 0, s, (const float*)partial, dw, P, Q, CP, CQ, T, (int)nb,
-                           (long long)Q * T, (long long)T);
+                           (long long)Q * T, (long long)T, Q);
         return;
     }
     Wgrad3Args a;
@@ -998,9 +1000,9 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
     a.N = N; a.D = D; a.H = H; a.W = W; a.P = P; a.Q = Q;
     a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q);
     a.xsc = xscale; a.xsh = xshift;
-    if (dtype == DT_F32) wgrad3_dispatch<float>(a, ndim, dw, (long long)Q * T, T, s);
-    else if (dtype == DT_F16) wgrad3_dispatch<f16>(a, ndim, dw, (long long)Q * T, T, s);
-    else wgrad3_dispatch<bf16>(a, ndim, dw, (long long)Q * T, T, s);
+    if (dtype == DT_F32) wgrad3_dispatch<float>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
+    else if (dtype == DT_F16) wgrad3_dispatch<f16>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
+    else wgrad3_dispatch<bf16>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
 }
 
 }  // namespace seg

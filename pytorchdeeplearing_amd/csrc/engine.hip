@@ -42,6 +42,7 @@ struct Step {
     // UNIT
     int ck = 0, in0 = -1, in1 = -1, raw = -1, Cin = 0, Cout = 0;
     int w = -1, b = -1, gn_w = -1, gn_b = -1;   // param indices (-1: absent)
+    int cin_par = 0;                          // input channels of the weight PARAMETER when the conv reads a zero-padded image tensor (0: Cin)
     int mask_slot = -1;
     size_t stats = 0, scale = 0, shift = 0, mean = 0, rstd = 0, Q = 0, coef = 0;
     size_t wp_fwd = 0, wp_dg0 = 0, wp_dg1 = 0;
@@ -74,6 +75,8 @@ struct seg_engine {
     std::vector<Step> steps;
     std::vector<int> drop_ch;    // channels per dropout call
     int image_ten = -1;
+    bool pad_img = false;        // the image tensor is zero-padded to 16 channels: 3-D inputs with > 1 channel (2-D: > 3) cannot take the fused image stem
+                                 // (one MFMA K step holds taps x channels <= 32) and run through the ordinary 16-channel convs instead
     // plan
     int N = 0, D = 0, H = 0, W = 0;
     size_t ws_bytes = 0;
@@ -287,8 +290,10 @@ struct Builder {
         Step s; s.type = ST_UNIT; s.ck = ck; s.in0 = in0; s.in1 = in1;
         s.Cin = e.tens[in0].C + (in1 >= 0 ? e.tens[in1].C : 0);
         s.Cout = Cout;
+        if (e.tens[in0].image && e.pad_img) s.cin_par = e.in_ch;        // the parameter keeps the reference's shape [Cout][image channels][k^d]
+        const int cpar = s.cin_par ? s.cin_par : s.Cin;
         const int k = (ck == CK_K3 || ck == CK_STEM3) ? 3 : (ck == CK_K2S2 || ck == CK_KT) ? 2 : 1;
-        s.w = param(cname + ".weight", ck == CK_KT ? kshape(s.Cin, Cout, k) : kshape(Cout, s.Cin, k));
+        s.w = param(cname + ".weight", ck == CK_KT ? kshape(s.Cin, Cout, k) : kshape(Cout, cpar, k));
         if (bias) s.b = param(cname + ".bias", {Cout});
         if (has_gn) {
             if (gw == -2) { gw = param(gname + ".weight", {Cout}); gb = param(gname + ".bias", {Cout}); }
@@ -322,11 +327,11 @@ struct Builder {
 
     void build_vnet() {   // networks/VNet3d.py:102-158
         const int F = e.feat;
-        const int x = tensor(e.in_ch, 0, true);
+        const int x = tensor(e.pad_img ? 16 : e.in_ch, 0, true);
         e.image_ten = x;
         // InputTransition (VNet3d.py:25-43): parameter order conv1, conv2, bn1; ONE GroupNorm for both branches
-        const int ua = unit(CK_STEM3, "in_tr.conv1", true, x, -1, F, 0, "", -1, -1, false);
-        const int ub = unit(CK_STEM1, "in_tr.conv2", true, x, -1, F, 0, "", -1, -1, false);
+        const int ua = unit(e.pad_img ? CK_K3 : CK_STEM3, "in_tr.conv1", true, x, -1, F, 0, "", -1, -1, false);
+        const int ub = unit(e.pad_img ? CK_K1 : CK_STEM1, "in_tr.conv2", true, x, -1, F, 0, "", -1, -1, false);
         const int gw = param("in_tr.bn1.weight", {F}), gb = param("in_tr.bn1.bias", {F});
         for (int u : {ua, ub}) {
             e.steps[u].gn_w = gw; e.steps[u].gn_b = gb;
@@ -395,14 +400,14 @@ struct Builder {
 
     int unet_block(const std::string& mod, const std::string& name, int in0, int in1, int C, int lvl, bool first) {
         // Unet3d.py:64-86: conv3(no bias) GN drop relu, twice
-        const int u1 = unit(first ? CK_STEM3 : CK_K3, mod + "." + name + "conv1", false, in0, in1, C, lvl, mod + "." + name + "norm1");
+        const int u1 = unit((first && !e.pad_img) ? CK_STEM3 : CK_K3, mod + "." + name + "conv1", false, in0, in1, C, lvl, mod + "." + name + "norm1");
         const int a1 = act(u1, -1, -1);
         const int u2 = unit(CK_K3, mod + "." + name + "conv2", false, a1, -1, C, lvl, mod + "." + name + "norm2");
         return act(u2, -1, -1);
     }
     void build_unet() {   // networks/Unet3d.py:6-62
         const int F = e.feat;
-        const int x = tensor(e.in_ch, 0, true);
+        const int x = tensor(e.pad_img ? 16 : e.in_ch, 0, true);
         e.image_ten = x;
         int t = x;
         std::vector<int> enc;
@@ -469,7 +474,7 @@ WgradArgs make_wgrad_args(const seg_engine& E, const Step& s, int draw) {
         const int str = s.ck == CK_K2S2 ? 2 : 1;
         w.sd = E.ndim == 3 ? str : 1; w.sh = str; w.sw = str;
         w.taps = make_taps(E.ndim, k, k == 3 ? 1 : 0);
-        w.sP = (long long)s.Cin * T;
+        w.sP = (long long)(s.cin_par ? s.cin_par : s.Cin) * T;
         if (s.ck == CK_STEM3 || s.ck == CK_STEM1) { w.stem = 1; w.Q = T * s.Cin; }
     }
     return w;
@@ -518,9 +523,10 @@ struct Planner {
     }
     bool pack_bwd = false;     // the descriptors added while set feed the backward pass only (data-gradient layouts)
     void add_pack(size_t dst, long long src_off, int R1, int R2, int T, int Cc, long long s1, long long s2, long long sT, long long sC, int flip,
-                  int frag = 0) {
+                  int frag = 0, int csrc = 0) {
         PackDesc d;
         d.frag = frag;
+        d.csrc = csrc;
         d.src = (const float*)(uintptr_t)src_off;   // offsets; resolved in seg_bind
         d.dst = (void*)(uintptr_t)dst;
         d.R1 = R1; d.R2 = R2; d.T = T; d.Cc = Cc;
@@ -606,7 +612,8 @@ struct Planner {
                         if (C1 && conv3x_supported(dt, E.ndim, N, d_, h_, w_, Co, C1, 0, false)) s.x_dg1 = conv3x_pick(E.ndim, N, d_, h_, w_, Co, C1);
                     }
                     s.wp_fwd = alloc_pack(Co, T * Ci);
-                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)Ci * T, 0, 1, T, 0, s.x_fwd >= 0 ? (Ci == 16 ? 2 : 1) : 0);
+                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)(s.cin_par ? s.cin_par : Ci) * T, 0, 1, T, 0, s.x_fwd >= 0 ? (Ci == 16 ? 2 : 1) : 0,
+                             s.cin_par);                         // image convs on a zero-padded image tensor: the parameter has cin_par channels
                     if (s.ck == CK_K2S2) {       // data-gradient = scatter GEMM, rows (a, ci), K = Cout
                         s.wp_dg0 = alloc_pack(T * Ci, Co);
                         pack_bwd = true;
@@ -700,7 +707,7 @@ struct Planner {
             seg_engine& E = *this_;
             (void)hipMemsetAsync(E.ws + E.off_stats, 0, E.stats_bytes, st);
             const Ten& x = E.tens[E.image_ten];
-            launch_ingest(E.cur_x, E.ws + x.off, E.N, x.C, E.vol(0), E.dtype, st);
+            launch_ingest(E.cur_x, E.ws + x.off, E.N, x.C, E.vol(0), E.dtype, st, E.in_ch);
         });
         for (size_t si = 0; si < E.steps.size(); ++si) {
             Step& s = E.steps[si];
@@ -1116,7 +1123,7 @@ struct Planner {
                             } else
                             launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.cur_partial), E.g + E.params[s.w].off,
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
-                                          s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
+                                          s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, nullptr, nullptr, s.cin_par);
                             E.prof_end(ws_, pi);
                         }, E.tbytes(draw), lo);
                         int pi;
@@ -1171,7 +1178,7 @@ struct Planner {
                         WgradArgs w = make_wgrad_args(E, s, draw);
                         const int pi = E.prof_begin(ws_, SEG_K_WGRAD_GENERIC,
                                                     E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
-                        launch_wgrad(w, (float*)(E.ws + E.cur_partial), E.dtype, ws_);
+                        launch_wgrad(w, (float*)(E.ws + E.cur_partial), E.dtype, ws_, s.cin_par);
                         E.prof_end(ws_, pi);
                     }, E.tbytes(draw), lo < li ? lo : li);
                     // ---- data gradient(s)
@@ -1239,9 +1246,10 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (dtype < 0 || dtype > 2) return fail("seg_create: dtype must be SEG_F32/F16/BF16");
     if (init_features != 16) return fail("seg_create: init_features must be 16 (GroupNorm(8) tiles; the reference never overrides the default)");
     if (num_class < 1 || num_class > 16) return fail("seg_create: num_class must be in 1..16");
-    if (in_channels < 1 || in_channels > 3 || (ndim == 3 && in_channels > 1)) return fail("seg_create: in_channels must be 1 (3-D) or 1..3 (2-D)");
+    if (in_channels < 1 || in_channels > 16) return fail("seg_create: in_channels must be in 1..16");
     seg_engine* e = new seg_engine();
     e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
+    e->pad_img = in_channels > 3 || (ndim == 3 && in_channels > 1);
     e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
     e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
     if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;

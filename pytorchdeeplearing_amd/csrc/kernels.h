@@ -42,7 +42,8 @@ bool launch_wgrad3x(const void* dr, const void* x0, const void* x1, int C0, floa
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q);
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, const float* xscale = nullptr, const float* xshift = nullptr);
+                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, const float* xscale = nullptr, const float* xshift = nullptr,
+                   int qreal = 0);      // qreal in (0, Q): x carries zero-padded channels, dw is [P][qreal][taps] (the channels beyond qreal are not written)
 
 // MFMA image stem (K = taps*Cimg <= 32): forward and weight gradient on box tiles (conv3.hip)
 void launch_stem_fwd(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cimg,
@@ -163,7 +164,7 @@ void launch_gn_bwd_group(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, h
 // Weight gradient: see seg_wgrad_args in include/segengine.h
 typedef seg_wgrad_args WgradArgs;
 size_t wgrad_partial_bytes(const WgradArgs& a);   // scratch for the per-slice partial tiles
-void launch_wgrad(const WgradArgs& a, float* partial, int dtype, hipStream_t s);
+void launch_wgrad(const WgradArgs& a, float* partial, int dtype, hipStream_t s, int qreal = 0);   // qreal in (0, Q): zero-padded input channels, see launch_wgrad3
 
 struct PoolArgs {
     const void* in; void* out;       // fwd: in fine, out coarse
@@ -175,7 +176,7 @@ void launch_maxpool_fwd(const PoolArgs& a, int dtype, hipStream_t s);
 void launch_maxpool_bwd(const PoolArgs& a, int dtype, hipStream_t s);
 
 // fp32 NC[D]HW image -> channels-last T
-void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s);
+void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s, int Csrc = 0);      // Csrc < C: zero-padded channels
 
 // Generic weight re-layout: see seg_pack_desc in include/segengine.h
 typedef seg_pack_desc PackDesc;

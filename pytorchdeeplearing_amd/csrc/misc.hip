@@ -14,13 +14,14 @@ inline int ew_blocks(long long total_threads, int cap = 16384) {
 
 // ---------------------------------------------------------------- ingest: fp32 NC[D]HW -> T N[D]HWC
 template <class T>
-__global__ __launch_bounds__(256) void ingest_kernel(const float* x, T* out, int N, int C, long long V) {
+__global__ __launch_bounds__(256) void ingest_kernel(const float* x, T* out, int N, int C, long long V, int Csrc) {
+    // Csrc < C: the image tensor is zero-padded to C channels (multi-channel 3-D inputs run through the 16-channel halo convs)
     const long long total = (long long)N * V * C;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C);
         const long long nv = i / C;
         const long long n = nv / V, v = nv % V;
-        out[i] = from_f<T>(x[(n * C + c) * V + v]);
+        out[i] = from_f<T>(c < Csrc ? x[(n * Csrc + c) * V + v] : 0.f);
     }
 }
 
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs) {
     const PackDesc d = descs[blockIdx.y];
     const long long rows = (long long)d.R1 * d.R2;
     const int K = d.T * d.Cc;
+    const int Cs = (d.csrc > 0 && d.csrc < d.Cc) ? d.csrc : d.Cc;          // channels the source holds; the rest of the layout is zero
     T* dst = (T*)d.dst;
     const bool t_fast = d.sT == 1 || d.sC != 1;         // which source index is contiguous
     if (K > PACK_MAXK - 32) {                            // rows too long for the LDS row buffer: destination-order walk
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs) {
             if (k < K) {
                 const int t = k / d.Cc, c = k % d.Cc;
                 const int tt = d.flipT ? (d.T - 1 - t) : t;
-                v = d.src[(row / d.R2) * d.s1 + (row % d.R2) * d.s2 + tt * d.sT + c * d.sC];
+                if (c < Cs) v = d.src[(row / d.R2) * d.s1 + (row % d.R2) * d.s2 + tt * d.sT + c * d.sC];
             }
             dst[i] = from_f<T>(v);
         }
@@ -56,8 +58,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs) {
     for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
         const long long r1 = row / d.R2, r2 = row % d.R2;
         const float* src = d.src + r1 * d.s1 + r2 * d.s2;
-        for (int j = threadIdx.x; j < K; j += 256) {
-            const int t = t_fast ? j % d.T : j / d.Cc, c = t_fast ? j / d.T : j % d.Cc;
+        if (Cs < d.Cc) {
+            for (int j = threadIdx.x; j < K; j += 256) row_s[j] = 0.f;
+            __syncthreads();
+        }
+        for (int j = threadIdx.x; j < d.T * Cs; j += 256) {
+            const int t = t_fast ? j % d.T : j / Cs, c = t_fast ? j / d.T : j % Cs;
             const int tt = d.flipT ? (d.T - 1 - t) : t;
             row_s[t * d.Cc + c] = src[tt * d.sT + c * d.sC];
         }
@@ -666,11 +672,12 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* masks, long lo
 
 }  // namespace
 
-void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s) {
+void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s, int Csrc) {
+    if (Csrc <= 0 || Csrc > C) Csrc = C;
     dim3 grid(ew_blocks((long long)N * V * C));
-    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<float>), grid, dim3(256), 0, s, x, (float*)out, N, C, V);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<f16>), grid, dim3(256), 0, s, x, (f16*)out, N, C, V);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<bf16>), grid, dim3(256), 0, s, x, (bf16*)out, N, C, V);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<float>), grid, dim3(256), 0, s, x, (float*)out, N, C, V, Csrc);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<f16>), grid, dim3(256), 0, s, x, (f16*)out, N, C, V, Csrc);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<bf16>), grid, dim3(256), 0, s, x, (bf16*)out, N, C, V, Csrc);
 }
 
 // predict() post-processing on the device (modelVNet.py:670-676, modelUnet.py:672-680): probs planar fp32 [N][C][V] ->

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, floa
 
 // dw[p*sP + q*sQ + tap*sT] += sum_slices partial[slice][p][tap][q]    (stem: column q = (tap, ci))
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, int P, int Tn, int Qc, int parts, long long sP,
-                                                           long long sQ, long long sT, int stem_cimg) {
+                                                           long long sQ, long long sT, int stem_cimg, int qreal) {
     // grid.y slices the partial list (32 per slice); slices meet in dw through one atomic each
     const long long total = (long long)P * Tn * Qc;
     const int b0 = blockIdx.y * 32, b1 = (b0 + 32 < parts) ? b0 + 32 : parts;
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial,
         }
         for (; b < b1; ++b) s0 += partial[(long long)b * total + i];
         const int qq = (int)(i % Qc), tap = (int)((i / Qc) % Tn), p = (int)(i / ((long long)Qc * Tn));
+        if (!stem_cimg && qq >= qreal) continue;        // zero-padded input channels: no such weight
         long long o;
         if (stem_cimg) o = p * sP + (qq % stem_cimg) * sQ + (qq / stem_cimg) * sT;
         else o = p * sP + qq * sQ + tap * sT;
@@ -269,7 +270,7 @@ WgPlan make_plan(const WgradArgs& a) {
 }
 
 template <class T>
-void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s) {
+void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s, int qreal) {
     const WgPlan pl = make_plan(a);
     dim3 grid(pl.ntg * pl.ntile, pl.parts);
     if (a.stem) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, true, 1>), grid, dim3(256), 0, s, a, pl, partial);
@@ -280,7 +281,7 @@ void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s) {
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks, (pl.parts + 31) / 32), dim3(256), 0, s, (const float*)partial, a.dw, a.P, Tn, a.Q, pl.parts, a.sP, a.sQ,
-                       a.sT, a.stem ? a.C0 : 0);
+                       a.sT, a.stem ? a.C0 : 0, (qreal > 0 && qreal < a.Q) ? qreal : a.Q);
 }
 
 }  // namespace
@@ -290,10 +291,10 @@ size_t wgrad_partial_bytes(const WgradArgs& a) {
     return (size_t)pl.parts * a.P * (a.stem ? 1 : a.taps.n) * a.Q * sizeof(float);
 }
 
-void launch_wgrad(const WgradArgs& a, float* partial, int dtype, hipStream_t s) {
-    if (dtype == DT_F32) wgrad_dispatch<float>(a, partial, s);
-    else if (dtype == DT_F16) wgrad_dispatch<f16>(a, partial, s);
-    else wgrad_dispatch<bf16>(a, partial, s);
+void launch_wgrad(const WgradArgs& a, float* partial, int dtype, hipStream_t s, int qreal) {
+    if (dtype == DT_F32) wgrad_dispatch<float>(a, partial, s, qreal);
+    else if (dtype == DT_F16) wgrad_dispatch<f16>(a, partial, s, qreal);
+    else wgrad_dispatch<bf16>(a, partial, s, qreal);
 }
 
 }  // namespace seg

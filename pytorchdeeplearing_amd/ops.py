@@ -39,7 +39,7 @@ class WgradArgs(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R1", C.c_int), ("R2", C.c_int), ("T", C.c_int),
                 ("Cc", C.c_int), ("Kpad", C.c_int), ("s1", C.c_longlong), ("s2", C.c_longlong),
-                ("sT", C.c_longlong), ("sC", C.c_longlong), ("flipT", C.c_int), ("frag", C.c_int)]
+                ("sT", C.c_longlong), ("sC", C.c_longlong), ("flipT", C.c_int), ("csrc", C.c_int), ("frag", C.c_int)]
 
 
 class StemxArgs(C.Structure):

@@ -20,6 +20,11 @@ CASES = {
     "unet2d": ("unet", 2, (2, 1, 32, 32), 1, "BinaryCrossEntropyDiceLoss"),
     "vnet2d_s": ("vnet", 2, (2, 1, 16, 16), 1, "BinaryFocalLoss"),
     "unet2d_s": ("unet", 2, (1, 3, 16, 32), 3, "MutilFocalLoss"),
+    # multi-channel images: 3-D inputs with more than one channel (multi-modal MRI; 2-D: more than three) run on a zero-padded 16-channel image tensor
+    # (data seed 3: with seed 1 one ReLU input of up_tr32 sits 4.9e-8 from zero in the fp64 oracle and the gate opens differently in fp32)
+    "vnet3d_c4": ("vnet", 3, (1, 4, 16, 16, 16), 1, "BinaryCrossEntropyDiceLoss", 3),
+    "unet3d_c2": ("unet", 3, (2, 2, 16, 16, 16), 3, "MutilDiceLoss"),
+    "vnet2d_c5": ("vnet", 2, (2, 5, 16, 32), 2, "MutilCrossEntropyLoss"),
     "vnet3d_48": ("vnet", 3, (2, 1, 48, 48, 48), 1, "BinaryDiceLoss"),
     "unet3d_32": ("unet", 3, (2, 1, 32, 32, 32), 4, "MutilDiceLoss"),
     "vnet2d_128": ("vnet", 2, (3, 1, 128, 128), 2, "MutilCrossEntropyLoss"),
@@ -27,12 +32,13 @@ CASES = {
 
 
 def build(tag, dtype, dev, train):
-    kind, ndim, shape, ncls, loss = CASES[tag]
+    kind, ndim, shape, ncls, loss = CASES[tag][:5]
+    data_seed = CASES[tag][5] if len(CASES[tag]) > 5 else 1
     e = SegEngine(kind, ndim, shape[1], ncls, dtype=dtype, device=dev)
     params = seg.perturb_params(seg.init_params(kind, ndim, shape[1], ncls, seed=0), seed=7)
     assert list(params.keys()) == list(e.table.keys())
     e.load_state_dict(params)
-    x, y = seg.synthetic_batch(shape[0], shape[2:], shape[1], ncls, seed=1)
+    x, y = seg.synthetic_batch(shape[0], shape[2:], shape[1], ncls, seed=data_seed)
     masks = None
     if train:
         g = torch.Generator().manual_seed(5)
@@ -98,6 +104,24 @@ def test_parity_f32_small(dev, tag, train):
                                        ("vnet3d_48", True), ("unet3d_32", True), ("vnet2d_128", False)])
 def test_parity_f32_gpu(tag, train):
     check_f32(tag, torch.device("cuda:0"), train)
+
+
+@pytest.mark.parametrize("tag,train", [("vnet2d_c5", True), pytest.param("vnet3d_c4", True, marks=pytest.mark.gpu),
+                                       pytest.param("unet3d_c2", True, marks=pytest.mark.gpu)])
+def test_parity_f32_multi_channel_images(dev, tag, train):
+    """networks.VNet3d(image_channel=4, ...) / UNet3d(in_channels=2, ...) (networks/VNet3d.py:109, Unet3d.py:11 take any channel count): the image
+    tensor is zero-padded to 16 channels, the image convs run as ordinary 16-channel halo / 1^d convs with zero-padded weight layouts, and their
+    weight gradients are written for the parameter's real channels only; parameter shapes stay the reference's."""
+    e, params, x, y, masks, alpha, loss = build(tag, "f32", dev, train)
+    assert tuple(e.table[list(e.table)[0]][0])[1] == CASES[tag][2][1]          # first conv weight: [16][image channels][k^d]
+    del e
+    check_f32(tag, dev, train)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["vnet3d_c4", "unet3d_c2"])
+def test_parity_f16_multi_channel_images(tag):
+    check_lowp(tag, "f16", torch.device("cuda:0"), True, 3e-2, 2e-3)
 
 
 def check_lowp(tag, dtype, dev, train, logit_tol, flip_frac):
