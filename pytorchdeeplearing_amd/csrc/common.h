@@ -158,6 +158,14 @@ template <class T> __device__ __forceinline__ void dma16_async(i32x4 rsrc, T* ld
 #endif
 // all of this wave's outstanding global loads / LDS copies have landed (s_waitcnt vmcnt(0); expcnt / lgkmcnt untouched)
 __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// "this loaded value has arrived": an empty asm statement that reads v makes hipcc place the value's s_waitcnt HERE (in front of a
+// loop) instead of in front of its first use inside the loop, where - vmcnt retiring in order - the wait also drains every younger
+// load of the loop body and the "loads in flight" run one after the other
+#ifndef SEG_EMU
+__device__ __forceinline__ void settle(int& v) { asm volatile("" : "+v"(v)); }
+#else
+__device__ __forceinline__ void settle(int&) {}
+#endif
 
 // labels arrive as u8 / i32 / i64 / f32 class ids (the reference's datasets hand out int64)
 // LT_BINARIZE (flag, or-ed into the type): the label is read as (value != 0) - the `y[y != 0] = 1` of the reference's binary

@@ -287,11 +287,25 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+    // scatter form: the output tap of every 16-channel tile, read ONCE (inside the loop each store sat behind three serial
+    // tap-table loads, every one with its own s_waitcnt vmcnt(0))
+    int od[NTL], oh[NTL], ow[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+        const int tap = SCATTER ? (j * 16) / a.Cout : 0;
+        od[j] = SCATTER ? a.taps.d[tap] : 0; oh[j] = SCATTER ? a.taps.h[tap] : 0; ow[j] = SCATTER ? a.taps.w[tap] : 0;
+        if (SCATTER) { settle(od[j]); settle(oh[j]); settle(ow[j]); }
+    }
 
     const int ntile = (int)(Vrow / 16);
     // U tiles per iteration: all their loads are issued before the first MFMA (>= 4 x 16 B in flight per lane)
     constexpr int U = KS >= 4 ? 1 : 4 / KS;
     const int step = gridDim.x * 4;
+    // the tap-table entries above are vector-memory loads (dynamic index into the argument segment): make them land HERE.  Left
+    // pending at the loop entry they made hipcc put s_waitcnt vmcnt(2) / (1) / (0) in front of every tile's address arithmetic, which
+    // (vmcnt retires in order) also waited for the previous tile's load: the U loads "in flight" ran one after the other
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { settle(td[ks]); settle(th[ks]); settle(tw[ks]); settle(ci[ks]); }
     for (int t0 = blockIdx.x * 4 + wv; t0 < ntile; t0 += step * U) {
         typename Mma<T>::frag xf[U][KS];
         int d_[U], h_[U], w_[U];
@@ -336,11 +350,9 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
                     s2[j][r] = fmaf(f, f, s2[j][r]);
                 }
             // address of the 16-channel group of tile j for this lane's voxel
-            auto tile_ptr = [&](int j) -> T* {
+            auto tile_ptr = [&](int j) -> T* {          // j: a compile-time constant at every call site
                 if (SCATTER) {
-                    const int tap = (j * 16) / a.Cout;
-                    const long long orow = (((long long)n * a.FD + d_[u] * a.sd + a.taps.d[tap]) * a.FH + h_[u] * a.sh + a.taps.h[tap]) * a.FW +
-                                           w_[u] * a.sw + a.taps.w[tap];
+                    const long long orow = (((long long)n * a.FD + d_[u] * a.sd + od[j]) * a.FH + h_[u] * a.sh + oh[j]) * a.FW + w_[u] * a.sw + ow[j];
                     return out + orow * a.Cout + (j * 16) % a.Cout;
                 }
                 return out + ((long long)n * Vrow + t * 16 + l15) * a.Cout + j * 16;
@@ -363,7 +375,9 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
                     vec<T, 8> w8;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { w8[r] = odd ? recv[r] : mine[r]; w8[4 + r] = odd ? mine[r] : recv[r]; }
-                    store8(tile_ptr(odd ? 2 * jp + 1 : 2 * jp) + (q >> 1) * 8, w8);
+                    T* const pa = tile_ptr(2 * jp);
+                    T* const pb = tile_ptr(2 * jp + 1);
+                    store8((odd ? pb : pa) + (q >> 1) * 8, w8);
                 }
             } else {
 #pragma unroll

@@ -551,28 +551,8 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) void wgrad3_kernel(Wgrad3Args a) {
 #pragma unroll
             for (int j = 0; j < QT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (long long b = blockIdx.x; b < nbox; b += gridDim.x) {
-        const BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
-        __syncthreads();                                  // previous box fully consumed
-        // dR tile [voxel][CP] (zero rows outside the volume)
-        constexpr int CPV = CP / 8, DN = (B::V * CPV + 255) / 256;
-        vec<T, 8> dv[DN];
-#pragma unroll
-        for (int u = 0; u < DN; ++u) {
-            const int i = u * 256 + tid;
-            const int v = i / CPV, c8 = i % CPV;
-            const int xx = bp.x0 + v % TW, yy = bp.y0 + (v / TW) % TH, zz = bp.z0 + v / (TW * TH);
-            dv[u] = zero8<T>();
-            if (i < B::V * CPV && xx < a.W && yy < a.H && zz < a.D)
-                dv[u] = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.P + p0 + c8 * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < DN; ++u) {
-            const int i = u * 256 + tid;
-            if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], dv[u]);
-        }
-        stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W, (const T*)a.x1, a.C0, a.xsc, a.xsh);
-        __syncthreads();
+    // one K sweep over the box whose tiles sit in LDS
+    auto sweep = [&]() {
 #pragma unroll 1
         for (int ks = 0; ks < B::V / 32; ++ks) {
             int drow[NR], xrow[NR];
@@ -600,6 +580,86 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) void wgrad3_kernel(Wgrad3Args a) {
                     }
                 }
             }
+        }
+    };
+    constexpr int CPV = CP / 8, DN = (B::V * CPV + 255) / 256;
+    constexpr int CQV = CQ / 8, XN = (B::HV * CQV + 255) / 256;
+    // 16-bit tensors whose x is a stored (activated) tensor: the NEXT box's dR tile and x halo are loaded into registers right after the
+    // barrier that publishes the current box and land while its MFMAs run (one HBM round trip per box, hidden); the plain loop below
+    // spent two exposed round trips per box (dR tile -> wait -> LDS, then the halo -> wait -> LDS) - the kernel is latency-bound, not
+    // bandwidth-bound, so that was most of its time.  Costs (DN + XN) x 4 VGPRs (48 at 32 x 32 channels).
+    const bool prefetch = sizeof(T) == 2 && !a.xsc;
+    if (prefetch) {
+        const T* x1 = (const T*)a.x1;
+        const int C0 = x1 ? a.C0 : a.Q;
+        vec<T, 8> dv[DN], xv[XN];
+        auto issue = [&](long long b) {
+            const BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
+#pragma unroll
+            for (int u = 0; u < DN; ++u) {
+                const int i = u * 256 + tid;
+                const int v = i / CPV, c8 = i % CPV;
+                const int xx = bp.x0 + v % TW, yy = bp.y0 + (v / TW) % TH, zz = bp.z0 + v / (TW * TH);
+                dv[u] = zero8<T>();
+                if (i < B::V * CPV && xx < a.W && yy < a.H && zz < a.D)
+                    dv[u] = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.P + p0 + c8 * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < XN; ++u) {
+                const int i = u * 256 + tid;
+                const int hv = i / CQV, c8 = i % CQV;
+                const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
+                const int z = bp.z0 + hz - B::PD, y = bp.y0 + hy - 1, xx = bp.x0 + hx - 1;
+                xv[u] = zero8<T>();
+                if (i < B::HV * CQV && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
+                    const long long vox = (((long long)bp.n * a.D + z) * a.H + y) * a.W + xx;
+                    const int ch = q0 + c8 * 8;
+                    const T* src = ch < C0 ? x + vox * C0 + ch : x1 + vox * (a.Q - C0) + (ch - C0);     // one load, pointer select
+                    xv[u] = load8(src);
+                }
+            }
+        };
+        long long b = blockIdx.x;
+        if (b < nbox) issue(b);
+        for (; b < nbox; b += gridDim.x) {
+            __syncthreads();                              // previous box fully consumed
+#pragma unroll
+            for (int u = 0; u < DN; ++u) {
+                const int i = u * 256 + tid;
+                if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], dv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < XN; ++u) {
+                const int i = u * 256 + tid;
+                if (i < B::HV * CQV) store8(&Xs[(i / CQV) * XLD + (i % CQV) * 8], xv[u]);
+            }
+            __syncthreads();
+            if (b + gridDim.x < nbox) issue(b + gridDim.x);
+            sweep();
+        }
+    } else {
+        for (long long b = blockIdx.x; b < nbox; b += gridDim.x) {
+            const BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
+            __syncthreads();                                  // previous box fully consumed
+            // dR tile [voxel][CP] (zero rows outside the volume)
+            vec<T, 8> dv[DN];
+#pragma unroll
+            for (int u = 0; u < DN; ++u) {
+                const int i = u * 256 + tid;
+                const int v = i / CPV, c8 = i % CPV;
+                const int xx = bp.x0 + v % TW, yy = bp.y0 + (v / TW) % TH, zz = bp.z0 + v / (TW * TH);
+                dv[u] = zero8<T>();
+                if (i < B::V * CPV && xx < a.W && yy < a.H && zz < a.D)
+                    dv[u] = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.P + p0 + c8 * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < DN; ++u) {
+                const int i = u * 256 + tid;
+                if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], dv[u]);
+            }
+            stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W, (const T*)a.x1, a.C0, a.xsc, a.xsh);
+            __syncthreads();
+            sweep();
         }
     }
     // partial tile [p][tap][q] of this workgroup

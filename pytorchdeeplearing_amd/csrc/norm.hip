@@ -58,7 +58,11 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinArgs a) {
 
 // elementwise; one thread = one 8-channel chunk.  FOLD: the statistics finalize runs as a per-workgroup prologue
 // (gn_fold_block) instead of a launch of its own - a kernel boundary costs 4-5 us on this part, the fold 1-2.
-template <class T, bool FOLD>
+// R2 / RES: which optional sources exist, as template flags: the loop body has no branches between its loads, so a thread issues the
+// loads of UNR chunks back to back and waits ONCE (with runtime `if (r2)` tests the compiler emitted load -> s_waitcnt vmcnt(0) ->
+// load -> ... : up to three serial HBM round trips per 16 bytes, memory-level parallelism left to occupancy alone - and next to the
+// weight-gradient stream's register-heavy workgroups a streaming kernel gets few waves per SIMD).
+template <class T, bool FOLD, bool R2, bool RES>
 __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
     __shared__ double part[FOLD ? 256 : 1][2];
     __shared__ float coef_s[FOLD ? 4 : 1][256];
@@ -75,38 +79,54 @@ __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
     vec<float, 8> sc, sh, sc2, sh2;
     if (FOLD) {
         gn_fold_block(a.fin1, n, blockIdx.x == 0, part, coef_s[0], coef_s[1]);
-        if (r2) gn_fold_block(a.fin2, n, blockIdx.x == 0, part, coef_s[2], coef_s[3]);
+        if (R2) gn_fold_block(a.fin2, n, blockIdx.x == 0, part, coef_s[2], coef_s[3]);
         sc = *(const vec<float, 8>*)&coef_s[0][c0];
         sh = *(const vec<float, 8>*)&coef_s[1][c0];
-        if (r2) { sc2 = *(const vec<float, 8>*)&coef_s[2][c0]; sh2 = *(const vec<float, 8>*)&coef_s[3][c0]; }
+        if (R2) { sc2 = *(const vec<float, 8>*)&coef_s[2][c0]; sh2 = *(const vec<float, 8>*)&coef_s[3][c0]; }
     } else {
         sc = *(const vec<float, 8>*)(a.scale1 + (long long)n * a.C + c0);
         sh = *(const vec<float, 8>*)(a.shift1 + (long long)n * a.C + c0);
-        if (r2) {
+        if (R2) {
             sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + c0);
             sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
         }
     }
-    for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += gridDim.x * 256) {
-        const long long i = base + ii;
-        const vec<T, 8> x = load8(r1 + i * 8);
-        float y[8];
+    constexpr int UNR = (R2 || RES) ? 2 : 4;
+    const int stride = gridDim.x * 256;
+    for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += stride * UNR) {
+        long long iu[UNR];
+        bool ok[UNR];
+        vec<T, 8> x[UNR], x2[UNR], rr[UNR];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = fmaxf(fmaf(sc[j], to_f(x[j]), sh[j]), 0.f);
-        if (r2) {
-            const vec<T, 8> x2 = load8(r2 + i * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] += fmaxf(fmaf(sc2[j], to_f(x2[j]), sh2[j]), 0.f);
+        for (int u = 0; u < UNR; ++u) {                 // out-of-range slots re-read slot 0 (no branch around a load) and store nothing
+            const int t = ii + u * stride;
+            ok[u] = t < per_n;
+            iu[u] = base + (ok[u] ? t : ii);
         }
-        if (res) {
-            const vec<T, 8> rr = load8(res + i * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] += to_f(rr[j]);
+        for (int u = 0; u < UNR; ++u) {
+            x[u] = load8(r1 + iu[u] * 8);
+            if (R2) x2[u] = load8(r2 + iu[u] * 8);
+            if (RES) rr[u] = load8(res + iu[u] * 8);
         }
-        vec<T, 8> o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = from_f<T>(y[j]);
-        store8(out + i * 8, o);
+        for (int u = 0; u < UNR; ++u) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = fmaxf(fmaf(sc[j], to_f(x[u][j]), sh[j]), 0.f);
+            if (R2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] += fmaxf(fmaf(sc2[j], to_f(x2[u][j]), sh2[j]), 0.f);
+            }
+            if (RES) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] += to_f(rr[u][j]);
+            }
+            vec<T, 8> o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = from_f<T>(y[j]);
+            if (ok[u]) store8(out + iu[u] * 8, o);
+        }
     }
 }
 
@@ -140,9 +160,30 @@ __device__ __forceinline__ void load_dy_sum(const GnBwdArgs& a, long long i, flo
     }
 }
 
+// NDY = 1..3: exactly that many stored gradient sources and no virtual one - issue() is branch-free, so callers can put the loads of
+// several chunks in flight before the first use; NDY = 0: anything else (the unit below the head), through load_dy_sum.
+template <class T, int NDY> struct DySrc {
+    vec<T, 8> d[NDY > 0 ? NDY : 1];
+    float g0[8];
+    __device__ __forceinline__ void issue(const GnBwdArgs& a, long long i, int n, long long v, int c0) {
+        if (NDY == 0) { load_dy_sum<T>(a, i, g0, n, v, c0); return; }
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) d[k] = load8((const T*)a.dy[k] + i * 8);
+    }
+    __device__ __forceinline__ void sum(float* g) const {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = NDY == 0 ? g0[j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NDY; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += to_f(d[k][j]);          // same order as load_dy_sum: ((0 + d0) + d1) + d2
+    }
+};
+__host__ inline int dy_variant(const GnBwdArgs& a) { return (!a.vdl && a.ndy >= 1 && a.ndy <= 3) ? a.ndy : 0; }
+
 // pass 1.  grid = (slabs, N); a block reduces `rows_per_block` voxels of one sample over all channels.
 // thread = (chunk column cc, row group g); LDS tree over row groups; fp64 atomics per (n,c).
-template <class T, bool DUAL>
+template <class T, bool DUAL, int NDY>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB_ROWS) {
     __shared__ float red[256 * 16];
     const int tid = threadIdx.x, n = blockIdx.y;
@@ -163,50 +204,42 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
     float q1[8], q2[8], p1[8], p2[8];          // p*: second branch
 #pragma unroll
     for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; p1[j] = 0.f; p2[j] = 0.f; }
-    // two rows in flight per thread: the loop is pure streaming (2-4 x 16 B loads per row)
+    // RW rows in flight per thread, every load issued before the first use (pure streaming: 2-4 x 16 B loads per row)
+    constexpr int RW = (NDY == 0) ? 1 : ((DUAL || NDY > 1) ? 2 : 4);
     long long v = v0 + g;
-    for (; v + G < v1; v += 2 * G) {
-        const long long i0 = ((long long)n * a.V + v) * CPR + cc, i1 = i0 + (long long)G * CPR;
-        float dy0[8], dy1[8];
-        load_dy_sum<T>(a, i0, dy0, n, v, cc * 8);
-        load_dy_sum<T>(a, i1, dy1, n, v + G, cc * 8);
-        const vec<T, 8> x0 = load8(r + i0 * 8), x1 = load8(r + i1 * 8);
-        vec<T, 8> z0 = x0, z1 = x1;
-        if (DUAL) { z0 = load8(r2 + i0 * 8); z1 = load8(r2 + i1 * 8); }
+    for (; v < v1; v += (long long)RW * G) {
+        long long iu[RW];
+        bool ok[RW];
+        DySrc<T, NDY> src[RW];
+        vec<T, 8> x[RW], z[RW];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xa = to_f(x0[j]), xb = to_f(x1[j]);
-            const float da = (fmaf(sc[j], xa, sh[j]) > 0.f) ? dy0[j] : 0.f;
-            const float db = (fmaf(sc[j], xb, sh[j]) > 0.f) ? dy1[j] : 0.f;
-            q1[j] += da + db;
-            q2[j] = fmaf(da, xa, fmaf(db, xb, q2[j]));
-            if (DUAL) {
-                const float za = to_f(z0[j]), zb = to_f(z1[j]);
-                const float ea = (fmaf(sc2[j], za, sh2[j]) > 0.f) ? dy0[j] : 0.f;
-                const float eb = (fmaf(sc2[j], zb, sh2[j]) > 0.f) ? dy1[j] : 0.f;
-                p1[j] += ea + eb;
-                p2[j] = fmaf(ea, za, fmaf(eb, zb, p2[j]));
-            }
+        for (int u = 0; u < RW; ++u) {                  // rows past the slab re-read row 0 and contribute nothing
+            const long long vv = v + (long long)u * G;
+            ok[u] = vv < v1;
+            iu[u] = ((long long)n * a.V + (ok[u] ? vv : v)) * CPR + cc;
         }
-    }
-    for (; v < v1; v += G) {
-        const long long i = ((long long)n * a.V + v) * CPR + cc;
-        float dy[8];
-        load_dy_sum<T>(a, i, dy, n, v, cc * 8);
-        const vec<T, 8> x = load8(r + i * 8);
-        vec<T, 8> z = x;
-        if (DUAL) z = load8(r2 + i * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xv = to_f(x[j]);
-            const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
-            q1[j] += d;
-            q2[j] = fmaf(d, xv, q2[j]);
-            if (DUAL) {
-                const float zv = to_f(z[j]);
-                const float e = (fmaf(sc2[j], zv, sh2[j]) > 0.f) ? dy[j] : 0.f;
-                p1[j] += e;
-                p2[j] = fmaf(e, zv, p2[j]);
+        for (int u = 0; u < RW; ++u) {
+            src[u].issue(a, iu[u], n, ok[u] ? v + (long long)u * G : v, cc * 8);
+            x[u] = load8(r + iu[u] * 8);
+            if (DUAL) z[u] = load8(r2 + iu[u] * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            float dy[8];
+            src[u].sum(dy);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = to_f(x[u][j]);
+                const float d = (ok[u] && fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
+                q1[j] += d;
+                q2[j] = fmaf(d, xv, q2[j]);
+                if (DUAL) {
+                    const float zv = to_f(z[u][j]);
+                    const float e = (ok[u] && fmaf(sc2[j], zv, sh2[j]) > 0.f) ? dy[j] : 0.f;
+                    p1[j] += e;
+                    p2[j] = fmaf(e, zv, p2[j]);
+                }
             }
         }
     }
@@ -340,7 +373,7 @@ __device__ __forceinline__ void gn_bwd_fold_block(const GnBwdFinArgs& f, int n, 
 }
 
 // FOLD: the backward finalize runs as a per-workgroup prologue (gn_bwd_fold_block); fa / fb are the finalize arguments of the branches
-template <class T, bool DUAL, bool FOLD>
+template <class T, bool DUAL, bool FOLD, int NDY>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a, GnBwdFinArgs fa, GnBwdFinArgs fb) {
     __shared__ double part[FOLD ? 256 : 1][3];
     __shared__ float coef_s[FOLD ? (DUAL ? 6 : 3) : 1][256];
@@ -380,28 +413,49 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a, GnBwdFin
         sc2 = *(const vec<float, 8>*)(a.scale2 + (long long)n * a.C + c0);
         sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
     }
-    for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += gridDim.x * 256) {
-        const long long i = base + ii;
-        float dy[8];
-        load_dy_sum<T>(a, i, dy, n, ii >> lc, c0);
-        const vec<T, 8> x = load8(r + i * 8);
-        vec<T, 8> o;
+    // UNR chunks per trip, all loads in front (see gn_act_kernel)
+    constexpr int UNR = (NDY == 0) ? 1 : ((DUAL || NDY > 1) ? 2 : 4);
+    const int stride = gridDim.x * 256;
+    for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += stride * UNR) {
+        long long iu[UNR];
+        int tu[UNR];
+        bool ok[UNR];
+        DySrc<T, NDY> src[UNR];
+        vec<T, 8> x[UNR], z[UNR];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xv = to_f(x[j]);
-            const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
-            o[j] = from_f<T>(fmaf(co[j * 3], d, fmaf(co[j * 3 + 1], xv, co[j * 3 + 2])));
+        for (int u = 0; u < UNR; ++u) {
+            const int t = ii + u * stride;
+            ok[u] = t < per_n;
+            tu[u] = ok[u] ? t : ii;
+            iu[u] = base + tu[u];
         }
-        store8(dr + i * 8, o);
-        if (DUAL) {
-            const vec<T, 8> z = load8((const T*)a.r2 + i * 8);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            src[u].issue(a, iu[u], n, tu[u] >> lc, c0);
+            x[u] = load8(r + iu[u] * 8);
+            if (DUAL) z[u] = load8((const T*)a.r2 + iu[u] * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            float dy[8];
+            src[u].sum(dy);
+            vec<T, 8> o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float zv = to_f(z[j]);
-                const float d = (fmaf(sc2[j], zv, sh2[j]) > 0.f) ? dy[j] : 0.f;
-                o[j] = from_f<T>(fmaf(co2[j * 3], d, fmaf(co2[j * 3 + 1], zv, co2[j * 3 + 2])));
+                const float xv = to_f(x[u][j]);
+                const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
+                o[j] = from_f<T>(fmaf(co[j * 3], d, fmaf(co[j * 3 + 1], xv, co[j * 3 + 2])));
             }
-            store8((T*)a.dr2 + i * 8, o);
+            if (ok[u]) store8(dr + iu[u] * 8, o);
+            if (DUAL) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float zv = to_f(z[u][j]);
+                    const float d = (fmaf(sc2[j], zv, sh2[j]) > 0.f) ? dy[j] : 0.f;
+                    o[j] = from_f<T>(fmaf(co2[j * 3], d, fmaf(co2[j * 3 + 1], zv, co2[j * 3 + 2])));
+                }
+                if (ok[u]) store8((T*)a.dr2 + iu[u] * 8, o);
+            }
         }
     }
 }
@@ -591,10 +645,13 @@ void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
         if (bx > per_n) bx = per_n;
     }
     dim3 grid(bx, a.N);
-#define SEG_ACT(T_) { if (a.fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, true>), grid, dim3(256), 0, s, a); \
-                      else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, false>), grid, dim3(256), 0, s, a); }
+#define SEG_ACT2(T_, R2_, RS_) { if (a.fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, true, R2_, RS_>), grid, dim3(256), 0, s, a); \
+                                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, false, R2_, RS_>), grid, dim3(256), 0, s, a); }
+#define SEG_ACT(T_) { if (a.r2 && a.res) SEG_ACT2(T_, true, true) else if (a.r2) SEG_ACT2(T_, true, false) \
+                      else if (a.res) SEG_ACT2(T_, false, true) else SEG_ACT2(T_, false, false) }
     if (dtype == DT_F32) SEG_ACT(float) else if (dtype == DT_F16) SEG_ACT(f16) else SEG_ACT(bf16)
 #undef SEG_ACT
+#undef SEG_ACT2
 }
 
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
@@ -608,10 +665,13 @@ void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
     if (rows > max_rows) rows = max_rows / G * G;
     const int GNB_ROWS = (int)rows;
     dim3 grid(cdiv(a.V, GNB_ROWS), a.N);
-#define SEG_GNR(T_, D_) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<T_, D_>), grid, dim3(256), 0, s, a, GNB_ROWS)
-    if (a.r2) { if (dtype == DT_F32) SEG_GNR(float, true); else if (dtype == DT_F16) SEG_GNR(f16, true); else SEG_GNR(bf16, true); }
-    else { if (dtype == DT_F32) SEG_GNR(float, false); else if (dtype == DT_F16) SEG_GNR(f16, false); else SEG_GNR(bf16, false); }
+    const int nv = dy_variant(a);
+#define SEG_GNR1(T_, D_, K_) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<T_, D_, K_>), grid, dim3(256), 0, s, a, GNB_ROWS)
+#define SEG_GNR(T_, D_) { if (nv == 1) SEG_GNR1(T_, D_, 1); else if (nv == 2) SEG_GNR1(T_, D_, 2); else if (nv == 3) SEG_GNR1(T_, D_, 3); else SEG_GNR1(T_, D_, 0); }
+    if (a.r2) { if (dtype == DT_F32) SEG_GNR(float, true) else if (dtype == DT_F16) SEG_GNR(f16, true) else SEG_GNR(bf16, true) }
+    else { if (dtype == DT_F32) SEG_GNR(float, false) else if (dtype == DT_F16) SEG_GNR(f16, false) else SEG_GNR(bf16, false) }
 #undef SEG_GNR
+#undef SEG_GNR1
 }
 
 // measured on MI355X: one workgroup per (n,g) only wins while the per-sample tensor is <= ~128 KB (the 6^3 level:
@@ -648,11 +708,14 @@ void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s, const GnB
     }
     dim3 grid(bx, a.N);
     const GnBwdFinArgs za = fa ? *fa : GnBwdFinArgs{}, zb = fb ? *fb : GnBwdFinArgs{};
-#define SEG_GNA(T_, D_) { if (fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_, true>), grid, dim3(256), 0, s, a, za, zb); \
-                          else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_, false>), grid, dim3(256), 0, s, a, za, zb); }
+    const int nv = dy_variant(a);
+#define SEG_GNA1(T_, D_, K_) { if (fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_, true, K_>), grid, dim3(256), 0, s, a, za, zb); \
+                               else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_, false, K_>), grid, dim3(256), 0, s, a, za, zb); }
+#define SEG_GNA(T_, D_) { if (nv == 1) SEG_GNA1(T_, D_, 1) else if (nv == 2) SEG_GNA1(T_, D_, 2) else if (nv == 3) SEG_GNA1(T_, D_, 3) else SEG_GNA1(T_, D_, 0) }
     if (a.r2) { if (dtype == DT_F32) SEG_GNA(float, true) else if (dtype == DT_F16) SEG_GNA(f16, true) else SEG_GNA(bf16, true) }
     else { if (dtype == DT_F32) SEG_GNA(float, false) else if (dtype == DT_F16) SEG_GNA(f16, false) else SEG_GNA(bf16, false) }
 #undef SEG_GNA
+#undef SEG_GNA1
 }
 
 }  // namespace seg

@@ -89,17 +89,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, floa
     const int npd = WMT * cpr_p, npx = WMT * cpr_q;
 
     vec<T, 8> dreg[NPC], xreg[NTB][NPC];
+    unsigned xok[NTB];                                  // bit u: piece u of tap t holds data (else zeros go to LDS)
     float sreg[4];
-    auto gload = [&](long long ms) {
+    // tap offsets of this workgroup, read ONCE (a dynamic index into the argument segment is a vector-memory load; inside gload each of
+    // them carried its own s_waitcnt vmcnt(0))
+    int tpd[NTB], tph[NTB], tpw[NTB];
 #pragma unroll
-        for (int u = 0; u < NPC; ++u) {
-            const int pc = u * 256 + tid;
-            if (pc < npd) {
-                const long long m = ms + pc / cpr_p;
-                dreg[u] = (m < mend) ? load8(dr + m * a.P + p0 + (pc % cpr_p) * 8) : zero8<T>();
-            }
-        }
+    for (int t = 0; t < NTB; ++t) {
+        const int tp = STEM ? 0 : tap0 + (t < ntb ? t : 0);
+        tpd[t] = a.taps.d[tp]; tph[t] = a.taps.h[tp]; tpw[t] = a.taps.w[tp];
+        settle(tpd[t]); settle(tph[t]); settle(tpw[t]);
+        xok[t] = 0u;
+    }
+    unsigned dok = 0u;                                  // bit u: piece u of the dR tile holds data
+    auto gload = [&](long long ms) {
         if (STEM) {
+#pragma unroll
+            for (int u = 0; u < NPC; ++u) {
+                const int pc = u * 256 + tid;
+                if (pc < npd) {
+                    const long long m = ms + pc / cpr_p;
+                    dreg[u] = (m < mend) ? load8(dr + m * a.P + p0 + (pc % cpr_p) * 8) : zero8<T>();
+                    dok |= 1u << u;
+                }
+            }
             const int xrow_ = tid >> 3, xcc = tid & 7;
             const long long m = ms + xrow_;
             const bool mv = m < mend;
@@ -116,41 +129,58 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, floa
                 }
                 sreg[j] = xv;
             }
-        } else {
+            return;
+        }
+        // Two phases with a scheduling fence between them: every ADDRESS first, then every load back to back.  Rows past the slice and taps
+        // outside the source read a valid (clamped) address and are zeroed when the piece goes to LDS (dok / xok); a concat source is a
+        // pointer select in front of ONE load.  What this replaces: `cond ? load8(a) : load8(b)` and zero-or-load merges made hipcc put an
+        // s_waitcnt vmcnt(0) behind every piece, and address temporaries allocated on top of load destinations added vmcnt(3..1) waits
+        // between the loads - the "loads in flight while the MFMAs run" arrived one or two at a time.
+        const T* dsrc[NPC];
+        const T* xsrc[NTB][NPC];
 #pragma unroll
-            for (int u = 0; u < NPC; ++u) {
-                const int pc = u * 256 + tid;
-                if (pc < npx) {
-                    const long long m = ms + pc / cpr_q;
-                    const bool mv = m < mend;
-                    const int qc = q0 + (pc % cpr_q) * 8;
-                    if (NTB == 1 && pl.direct) {        // 1^d stride-1 conv: the gathered voxel is the row itself
-                        xreg[0][u] = !mv ? zero8<T>() : (qc < a.C0) ? load8(x0 + m * a.C0 + qc) : load8(x1 + m * a.C1 + (qc - a.C0));
-                        continue;
-                    }
-                    const RowCoord r = decode_row(mv ? m : 0, a.OD, a.OH, a.OW);
+        for (int u = 0; u < NPC; ++u) {
+            const int pc = u * 256 + tid;
+            const int pcd = pc < npd ? pc : 0;
+            const long long md = ms + pcd / cpr_p;
+            const bool dv = pc < npd && md < mend;
+            dsrc[u] = dr + (dv ? md : mbeg) * a.P + p0 + (pcd % cpr_p) * 8;
+            dok = dv ? (dok | (1u << u)) : (dok & ~(1u << u));
+            const int pcx = pc < npx ? pc : 0;
+            const long long m = ms + pcx / cpr_q;
+            const bool mv = pc < npx && m < mend;
+            const long long mc = mv ? m : mbeg;
+            const int qc = q0 + (pcx % cpr_q) * 8;
+            const bool from0 = qc < a.C0;
+            if (NTB == 1 && pl.direct) {                // 1^d stride-1 conv: the gathered voxel is the row itself
+                xsrc[0][u] = from0 ? x0 + mc * a.C0 + qc : x1 + mc * a.C1 + (qc - a.C0);
+                xok[0] = mv ? (xok[0] | (1u << u)) : (xok[0] & ~(1u << u));
+                continue;
+            }
+            const RowCoord r = decode_row(mc, a.OD, a.OH, a.OW);
 #pragma unroll
-                    for (int t = 0; t < NTB; ++t) {
-                        vec<T, 8> v = zero8<T>();
-                        if (mv && t < ntb) {
-                            const int tp = tap0 + t;
-                            const int id = r.d * a.sd + a.taps.d[tp], ih = r.h * a.sh + a.taps.h[tp], iw = r.w * a.sw + a.taps.w[tp];
-                            if ((unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) {
-                                const long long vox = (((long long)r.n * a.ID + id) * a.IH + ih) * a.IW + iw;
-                                v = (qc < a.C0) ? load8(x0 + vox * a.C0 + qc) : load8(x1 + vox * a.C1 + (qc - a.C0));
-                            }
-                        }
-                        xreg[t][u] = v;
-                    }
-                }
+            for (int t = 0; t < NTB; ++t) {
+                const int id = r.d * a.sd + tpd[t], ih = r.h * a.sh + tph[t], iw = r.w * a.sw + tpw[t];
+                const bool inb = mv && t < ntb && (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+                const long long vox = inb ? (((long long)r.n * a.ID + id) * a.IH + ih) * a.IW + iw : 0;
+                xsrc[t][u] = from0 ? x0 + vox * a.C0 + qc : x1 + vox * a.C1 + (qc - a.C0);
+                xok[t] = inb ? (xok[t] | (1u << u)) : (xok[t] & ~(1u << u));
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NPC; ++u) {
+            dreg[u] = load8(dsrc[u]);
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) xreg[t][u] = load8(xsrc[t][u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto sstore = [&]() {
 #pragma unroll
         for (int u = 0; u < NPC; ++u) {
             const int pc = u * 256 + tid;
-            if (pc < npd) store8(&Ds[(pc / cpr_p) * LDW + (pc % cpr_p) * 8], dreg[u]);
+            if (pc < npd) store8(&Ds[(pc / cpr_p) * LDW + (pc % cpr_p) * 8], ((dok >> u) & 1u) ? dreg[u] : zero8<T>());
         }
         if (STEM) {
             const int xrow_ = tid >> 3, xcc = tid & 7;
@@ -162,7 +192,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, floa
                 const int pc = u * 256 + tid;
                 if (pc < npx) {
 #pragma unroll
-                    for (int t = 0; t < NTB; ++t) store8(&Xs[(t * WMT + pc / cpr_q) * LDW + (pc % cpr_q) * 8], xreg[t][u]);
+                    for (int t = 0; t < NTB; ++t)
+                        store8(&Xs[(t * WMT + pc / cpr_q) * LDW + (pc % cpr_q) * 8], ((xok[t] >> u) & 1u) ? xreg[t][u] : zero8<T>());
                 }
             }
         }
