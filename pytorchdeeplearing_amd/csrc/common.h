@@ -163,8 +163,10 @@ __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70)
 // load of the loop body and the "loads in flight" run one after the other
 #ifndef SEG_EMU
 __device__ __forceinline__ void settle(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
 #else
 __device__ __forceinline__ void settle(int&) {}
+__device__ __forceinline__ void settle(float&) {}
 #endif
 
 // labels arrive as u8 / i32 / i64 / f32 class ids (the reference's datasets hand out int64)

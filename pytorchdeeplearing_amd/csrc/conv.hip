@@ -118,7 +118,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int srep) {
         const int t = tid < a.taps.n ? tid : 0;
         tapoff[tid] = (a.taps.d[t] & 255) | ((a.taps.h[t] & 255) << 8) | ((a.taps.w[t] & 255) << 16);
     }
+    // the epilogue's bias values, loaded HERE in one batch (in the epilogue they were NT serial load -> s_waitcnt vmcnt(0) pairs, one L2
+    // round trip each, at the end of a ~5 us workgroup)
+    float bj[NT];
+    {
+        const int co_b = SCATTER ? (cog0 % a.Cout) : cog0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bj[j] = 0.f;
+        if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bj[j] = a.bias[co_b + j * 16 + l15];
+        }
+    }
+    int od_ = 0, oh_ = 0, ow_ = 0;                       // scatter form: the output tap of this block's columns
+    if (SCATTER) { const int tap = cog0 / a.Cout; od_ = a.taps.d[tap]; oh_ = a.taps.h[tap]; ow_ = a.taps.w[tap]; }
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) settle(bj[j]);
+    if (SCATTER) { settle(od_); settle(oh_); settle(ow_); }
 
     vec<T, 8> areg[KS][2], breg[KS];
     bool aok[KS][2];
@@ -192,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int srep) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int col = j * 16 + l15;
-        const float b = a.bias ? a.bias[co_real0 + col] : 0.f;
+        const float b = bj[j];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -201,8 +218,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int srep) {
     __syncthreads();
     const int rows_valid = (int)((M - m0) < BM ? (M - m0) : BM);
     T* out = (T*)a.out;
-    int od_ = 0, oh_ = 0, ow_ = 0;
-    if (SCATTER) { const int tap = cog0 / a.Cout; od_ = a.taps.d[tap]; oh_ = a.taps.h[tap]; ow_ = a.taps.w[tap]; }
     constexpr int CPR = BN / 8;
     for (int ch = tid; ch < BM * CPR; ch += 256) {
         const int row = ch / CPR, cc = ch % CPR;
