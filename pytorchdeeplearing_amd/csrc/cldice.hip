@@ -157,10 +157,26 @@ __global__ __launch_bounds__(256) void skel_iter_kernel(const float* x, float* e
     const int p = b / ntz;
     const long long V = (long long)v.D * v.H * v.W;
     const float* xp = x + (long long)p * V;
-    for (int i = threadIdx.x; i < XZ * XY * XX; i += 256) {
-        const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
-        const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
-        xs[i] = ((unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D) ? xp[((long long)gz * v.H + gy) * v.W + gx] : INF;
+    // all loads of the halo are issued before the first LDS store (out-of-volume slots read element 0 and store +inf): as a rolled
+    // load -> s_waitcnt vmcnt(0) -> ds_write loop the 14 trips of the 4 x 8 x 32 tile were 14 serial memory round trips per workgroup,
+    // which was most of the kernel's time
+    {
+        constexpr int NE = XZ * XY * XX, NIT = (NE + 255) / 256;
+        float hv[NIT];
+        bool hin[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
+            const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
+            hin[k] = i < NE && (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+            hv[k] = xp[hin[k] ? ((long long)gz * v.H + gy) * v.W + gx : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < NE) xs[i] = hin[k] ? hv[k] : INF;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < EZ * EY * EX; i += 256) {
@@ -220,14 +236,55 @@ __global__ __launch_bounds__(256) void skel_bwd_tile_kernel(const float* g, cons
     const int p = b / ntz;
     const long long V = (long long)v.D * v.H * v.W, base = (long long)p * V;
     const float* sp = (PASS_B ? x : e) + base;
-    for (int i = threadIdx.x; i < XZ * XY * XX; i += 256) {
-        const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
-        const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
-        const bool in = (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
-        src[i] = in ? sp[((long long)gz * v.H + gy) * v.W + gx] : (PASS_B ? INF : -INF);      // never the extremum
+    // every global load of the workgroup - the source halo, the per-window inputs (de in pass B; x and g in pass A) and, in pass B, the dx
+    // values the last loop adds to - is issued up front in unrolled batches: as rolled loops each trip was load -> s_waitcnt vmcnt(0) ->
+    // use, 14 + 8 + 4 serial memory round trips per workgroup
+    constexpr int NE = XZ * XY * XX, NIT = (NE + 255) / 256;
+    constexpr int NW = EZ * EY * EX, WIT = (NW + 255) / 256;
+    constexpr int NT = TZ * TY * TX, TIT = (NT + 255) / 256;
+    float w0[WIT], w1[WIT], t0[TIT];
+    {
+        float hv[NIT];
+        bool hin[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
+            const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
+            hin[k] = i < NE && (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+            hv[k] = sp[hin[k] ? ((long long)gz * v.H + gy) * v.W + gx : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < WIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int lx = i % EX, ly = (i / EX) % EY, lz = i / (EX * EY);
+            const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - H1;
+            const bool in = i < NW && (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+            const long long o = in ? base + ((long long)gz * v.H + gy) * v.W + gx : base;
+            w0[k] = PASS_B ? de[o] : x[o];
+            w1[k] = PASS_B ? 0.f : g[o];
+        }
+        if (PASS_B) {
+#pragma unroll
+            for (int k = 0; k < TIT; ++k) {
+                const int i = threadIdx.x + k * 256;
+                const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
+                const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
+                const bool in = i < NT && gx < v.W && gy < v.H && gz < v.D;
+                t0[k] = dx[in ? base + ((long long)gz * v.H + gy) * v.W + gx : base];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < NE) src[i] = hin[k] ? hv[k] : (PASS_B ? INF : -INF);      // never the extremum
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < EZ * EY * EX; i += 256) {
+#pragma unroll
+    for (int k = 0; k < WIT; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i >= NW) continue;
         const int lx = i % EX, ly = (i / EX) % EY, lz = i / (EX * EY);
         const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - H1;
         float wgt = 0.f;
@@ -250,11 +307,11 @@ __global__ __launch_bounds__(256) void skel_bwd_tile_kernel(const float* g, cons
                     }
             const long long o = base + ((long long)gz * v.H + gy) * v.W + gx;
             if (PASS_B) {
-                wgt = de[o];
+                wgt = w0[k];
             } else {
                 const float ec = src[((lz + HZ - H1) * XY + ly + 1) * XX + lx + 1];      // centre of window w
                 const float u = best - ec;
-                const float gt = (x[o] - fmaxf(u, 0.f) > 0.f) ? g[o] : 0.f;
+                const float gt = (w0[k] - fmaxf(u, 0.f) > 0.f) ? w1[k] : 0.f;
                 wgt = u > 0.f ? gt : 0.f;
                 // tile-interior windows also publish the direct term of dx
                 const int tx = lx - 1, ty = ly - 1, tz = lz - H1;
@@ -265,7 +322,10 @@ __global__ __launch_bounds__(256) void skel_bwd_tile_kernel(const float* g, cons
         ams[i] = am;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < TZ * TY * TX; i += 256) {
+#pragma unroll
+    for (int k = 0; k < TIT; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i >= NT) continue;
         const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
         const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
         if (gx >= v.W || gy >= v.H || gz >= v.D) continue;
@@ -281,7 +341,7 @@ __global__ __launch_bounds__(256) void skel_bwd_tile_kernel(const float* g, cons
                     if (ams[wi] == me) acc += gws[wi];
                 }
         const long long o = base + ((long long)gz * v.H + gy) * v.W + gx;
-        if (PASS_B) dx[o] += acc;
+        if (PASS_B) dx[o] = t0[k] + acc;
         else de[o] = gws[((lz + H1) * EY + ly + 1) * EX + lx + 1] - acc;
     }
 }
