@@ -25,6 +25,18 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float* x, T* out, int
     }
 }
 
+// one image channel: NC[D]HW and N[D]HWC are the same memory - a plain conversion, 8 elements per thread (two 16-B loads, one wide store)
+template <class T>
+__global__ __launch_bounds__(256) void ingest1_kernel(const float* x, T* out, long long total8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+        const vec<float, 4> a = *(const vec<float, 4>*)(x + i * 8), b = *(const vec<float, 4>*)(x + i * 8 + 4);
+        vec<T, 8> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = from_f<T>(a[j]); o[4 + j] = from_f<T>(b[j]); }
+        store8(out + i * 8, o);
+    }
+}
+
 // ---------------------------------------------------------------- weight packing
 // One workgroup per destination row (R1 x R2 rows of Kpad elements).  The row's K = T*Cc source elements are read in
 // SOURCE order (the unit-stride index fastest: runs of T consecutive floats for PyTorch's [..][k^d] weight layout) into
@@ -674,6 +686,13 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* masks, long lo
 
 void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s, int Csrc) {
     if (Csrc <= 0 || Csrc > C) Csrc = C;
+    if (C == 1 && Csrc == 1 && dtype != DT_F32 && ((long long)N * V) % 8 == 0 && (((unsigned long long)x | (unsigned long long)out) & 15) == 0) {
+        const long long total8 = (long long)N * V / 8;
+        dim3 g1(ew_blocks(total8));
+        if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest1_kernel<f16>), g1, dim3(256), 0, s, x, (f16*)out, total8);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest1_kernel<bf16>), g1, dim3(256), 0, s, x, (bf16*)out, total8);
+        return;
+    }
     dim3 grid(ew_blocks((long long)N * V * C));
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<float>), grid, dim3(256), 0, s, x, (float*)out, N, C, V, Csrc);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<f16>), grid, dim3(256), 0, s, x, (f16*)out, N, C, V, Csrc);

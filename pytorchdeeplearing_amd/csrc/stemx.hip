@@ -177,11 +177,55 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
             }
         }
     };
+    // ---- per-sample coefficients.  They are loaded for the NEXT box right behind its prefetch and picked up at the top of the next trip,
+    // where everything in flight is waited for anyway.  Loaded in the middle of a trip (as the first version did, behind `a.bias3 ? .. : ..`
+    // tests) every one of them carried an s_waitcnt vmcnt(0) - which, vmcnt retiring in order, also drained the prefetch just issued: the
+    // box pipeline waited for the next box before it multiplied the current one.  All loads branch-free (a missing branch / bias reads a
+    // valid dummy address and is ignored).
+    struct Coefs { float sc3, sh3, sc1, sh1, cf3[3], cf1[3], sw3[4], tw3[4], sw1[4], tw1[4]; };
+    const float* const scale1p = nbr == 2 ? a.scale1 : a.scale3;
+    const float* const shift1p = nbr == 2 ? a.shift1 : a.shift3;
+    auto load_coefs = [&](int n, Coefs& c) {
+        const long long nc = (long long)n * SX_C;
+        if (BWD) {
+            c.sc3 = a.scale3[nc + l15]; c.sh3 = a.shift3[nc + l15];
+            c.sc1 = scale1p[nc + l15]; c.sh1 = shift1p[nc + l15];
+            if (MODE == SX_BWD_APPLY) {
+                const float* const c1p = nbr == 2 ? a.coef1 : a.coef3;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { c.cf3[j] = a.coef3[(nc + l15) * 3 + j]; c.cf1[j] = c1p[(nc + l15) * 3 + j]; }
+            }
+        }
+        if (MODE == SX_FWD_APPLY) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * q + r;
+                c.sw3[r] = a.scale3[nc + co]; c.tw3[r] = a.shift3[nc + co];
+                c.sw1[r] = scale1p[nc + co]; c.tw1[r] = shift1p[nc + co];
+            }
+        }
+    };
+    // biases do not depend on the sample: once, landed before the loop
+    float bs3, bs1, bw3[4], bw1[4];
+    {
+        const float* const b3p = a.bias3 ? a.bias3 : a.scale3;
+        const float* const b1p = (nbr == 2 && a.bias1) ? a.bias1 : a.scale3;
+        bs3 = b3p[l15]; bs1 = b1p[l15];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bw3[r] = b3p[4 * q + r]; bw1[r] = b1p[4 * q + r]; }
+        settle(bs3); settle(bs1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { settle(bw3[r]); settle(bw1[r]); }
+        if (!a.bias3) { bs3 = 0.f; for (int r = 0; r < 4; ++r) bw3[r] = 0.f; }
+        if (!(nbr == 2 && a.bias1)) { bs1 = 0.f; for (int r = 0; r < 4; ++r) bw1[r] = 0.f; }
+    }
+    Coefs cnext{};
     int cur = 0;
     if ((int)blockIdx.x < nbox) {
         const BoxAt p0 = box_at((int)blockIdx.x);
         load_img(p0);
         if (BWD) issue_dy(p0, 0);
+        load_coefs(p0.n, cnext);
     }
     for (int b = blockIdx.x; b < nbox; b += gridDim.x) {
         const BoxAt bp = box_at(b);
@@ -198,38 +242,25 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
                     if (L0 - c >= 0) Xc[hdst[u] + c * B::HVP - c] = himg[u];
             }
         }
-        if (BWD) wait_vmem();                            // this wave's copies of the gradient tiles of box b have landed
+        wait_vmem();                                     // the gradient tiles and the coefficients of box b have landed
+        const Coefs cc = cnext;                          // this box's coefficients (loaded behind its prefetch, one trip ago)
         __syncthreads();
         if (b + (int)gridDim.x < nbox) {
             const BoxAt pn = box_at(b + (int)gridDim.x);
             load_img(pn);
             if (BWD) issue_dy(pn, cur ^ 1);
+            load_coefs(pn.n, cnext);
         }
         const T* DyB = Dy + cur * NDY * B::V * SX_C;
         cur ^= 1;
 
-        // per-sample coefficients of this lane's channel(s)
-        const long long nc = (long long)n * SX_C;
-        float sc3 = 0.f, sh3 = 0.f, sc1 = 0.f, sh1 = 0.f, cf3[3] = {0.f, 0.f, 0.f}, cf1[3] = {0.f, 0.f, 0.f};
-        float bs3 = a.bias3 ? a.bias3[l15] : 0.f, bs1 = (nbr == 2 && a.bias1) ? a.bias1[l15] : 0.f;
-        if (BWD) {
-            sc3 = a.scale3[nc + l15]; sh3 = a.shift3[nc + l15];
-            if (nbr == 2) { sc1 = a.scale1[nc + l15]; sh1 = a.shift1[nc + l15]; }
-            if (MODE == SX_BWD_APPLY) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) { cf3[j] = a.coef3[(nc + l15) * 3 + j]; if (nbr == 2) cf1[j] = a.coef1[(nc + l15) * 3 + j]; }
-            }
-        }
-        float sw3[4], tw3[4], sw1[4], tw1[4], bw3[4], bw1[4];       // swapped layout (SX_FWD_APPLY): this lane's channels 4q .. 4q+3
-        if (MODE == SX_FWD_APPLY) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = 4 * q + r;
-                sw3[r] = a.scale3[nc + co]; tw3[r] = a.shift3[nc + co]; bw3[r] = a.bias3 ? a.bias3[co] : 0.f;
-                sw1[r] = nbr == 2 ? a.scale1[nc + co] : 0.f; tw1[r] = nbr == 2 ? a.shift1[nc + co] : 0.f;
-                bw1[r] = (nbr == 2 && a.bias1) ? a.bias1[co] : 0.f;
-            }
-        }
+        const float sc3 = cc.sc3, sh3 = cc.sh3, sc1 = cc.sc1, sh1 = cc.sh1;
+        const float* const cf3 = cc.cf3;
+        const float* const cf1 = cc.cf1;
+        const float* const sw3 = cc.sw3;
+        const float* const tw3 = cc.tw3;
+        const float* const sw1 = cc.sw1;
+        const float* const tw1 = cc.tw1;
 
 #pragma unroll
         for (int mm = 0; mm < TM; ++mm) {
