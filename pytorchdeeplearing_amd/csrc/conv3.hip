@@ -1000,7 +1000,10 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) {
     const int CP = P >= 32 ? 32 : 16, CQ = Q >= 32 ? 32 : 16;
     const int combos = (P / CP) * (Q / CQ);
-    static const int total = getenv("SEG_W3_TOTAL") ? atoi(getenv("SEG_W3_TOTAL")) : 512;     // tuning knobs
+    // tuning knobs.  512 while the kernel exposed its staging latency (r01: 256 / 384 / 768 -> 691 / 694 / 680 vs 700 volumes/s); with the next
+    // box prefetched into registers one workgroup per CU is enough and a third fewer partial tiles are written and re-read:
+    // 256 vs 512 = 946 vs 941 and 959 vs 953 volumes/s in two sessions (profiles/r03_policy_resweep_ab.log, r03_stemx_coefs_ab.log)
+    static const int total = getenv("SEG_W3_TOTAL") ? atoi(getenv("SEG_W3_TOTAL")) : 256;
     static const int minbox = getenv("SEG_W3_MINBOX") ? atoi(getenv("SEG_W3_MINBOX")) : 6;
     // 16 -> 16 channels (the finest level): four workgroups fit a CU (23 KB LDS, 113 VGPRs) and the partial tile is 27 KB, so the
     // staging latency of one workgroup can hide behind the others

@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256) void stemx_kernel(StemxArgs a) {
     // biases do not depend on the sample: once, landed before the loop
     float bs3, bs1, bw3[4], bw1[4];
     {
-        const float* const b3p = a.bias3 ? a.bias3 : a.scale3;
-        const float* const b1p = (nbr == 2 && a.bias1) ? a.bias1 : a.scale3;
+        const float* const dummy = (const float*)a.w3;            // 16 x 32 weights: always there, always >= 64 bytes
+        const float* const b3p = a.bias3 ? a.bias3 : dummy;
+        const float* const b1p = (nbr == 2 && a.bias1) ? a.bias1 : dummy;
         bs3 = b3p[l15]; bs1 = b1p[l15];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { bw3[r] = b3p[4 * q + r]; bw1[r] = b1p[4 * q + r]; }
