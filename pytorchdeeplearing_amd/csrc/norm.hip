@@ -162,24 +162,34 @@ __device__ __forceinline__ void load_dy_sum(const GnBwdArgs& a, long long i, flo
 
 // NDY = 1..3: exactly that many stored gradient sources and no virtual one - issue() is branch-free, so callers can put the loads of
 // several chunks in flight before the first use; NDY = 0: anything else (the unit below the head), through load_dy_sum.
+// NDY = 4 / 5: the virtual head source of a one-class head (vK == 1: dy[v][c] += dl[n][v] * w[c]) plus 0 / 1 stored sources - the two
+// 96^3 units under the head, the largest GroupNorm-backward launches of the step; one scalar load per chunk, the head weights of the
+// thread's channels are loop-invariant (vw8, loaded by the caller)
 template <class T, int NDY> struct DySrc {
-    vec<T, 8> d[NDY > 0 ? NDY : 1];
+    static constexpr bool VH = NDY >= 4;
+    static constexpr int NS = VH ? NDY - 4 : NDY;
+    vec<T, 8> d[NS > 0 ? NS : 1];
     float g0[8];
+    float dl;
     __device__ __forceinline__ void issue(const GnBwdArgs& a, long long i, int n, long long v, int c0) {
         if (NDY == 0) { load_dy_sum<T>(a, i, g0, n, v, c0); return; }
+        if (VH) dl = a.vdl[(long long)n * a.V + v];
 #pragma unroll
-        for (int k = 0; k < NDY; ++k) d[k] = load8((const T*)a.dy[k] + i * 8);
+        for (int k = 0; k < NS; ++k) d[k] = load8((const T*)a.dy[k] + i * 8);
     }
-    __device__ __forceinline__ void sum(float* g) const {
+    __device__ __forceinline__ void sum(float* g, const vec<float, 8>& vw8) const {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = NDY == 0 ? g0[j] : 0.f;
+        for (int j = 0; j < 8; ++j) g[j] = NDY == 0 ? g0[j] : (VH ? fmaf(dl, vw8[j], 0.f) : 0.f);
 #pragma unroll
-        for (int k = 0; k < NDY; ++k)
+        for (int k = 0; k < NS; ++k)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] += to_f(d[k][j]);          // same order as load_dy_sum: ((0 + d0) + d1) + d2
+            for (int j = 0; j < 8; ++j) g[j] += to_f(d[k][j]);          // same order as load_dy_sum: ((head + d0) + d1) + d2
     }
 };
-__host__ inline int dy_variant(const GnBwdArgs& a) { return (!a.vdl && a.ndy >= 1 && a.ndy <= 3) ? a.ndy : 0; }
+__host__ inline int dy_variant(const GnBwdArgs& a) {
+    if (a.vdl) return (a.vK == 1 && a.ndy >= 0 && a.ndy <= 1) ? 4 + a.ndy : 0;
+    return (a.ndy >= 1 && a.ndy <= 3) ? a.ndy : 0;
+}
 
 // pass 1.  grid = (slabs, N); a block reduces `rows_per_block` voxels of one sample over all channels.
 // thread = (chunk column cc, row group g); LDS tree over row groups; fp64 atomics per (n,c).
@@ -205,7 +215,11 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
 #pragma unroll
     for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; p1[j] = 0.f; p2[j] = 0.f; }
     // RW rows in flight per thread, every load issued before the first use (pure streaming: 2-4 x 16 B loads per row)
-    constexpr int RW = (NDY == 0) ? 1 : ((DUAL || NDY > 1) ? 2 : 4);
+    constexpr int RW = (NDY == 0) ? 1 : ((DUAL || DySrc<T, NDY>::NS > 1) ? 2 : 4);
+    vec<float, 8> vw8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vw8[j] = 0.f;
+    if (DySrc<T, NDY>::VH) vw8 = *(const vec<float, 8>*)(a.vw + cc * 8);
     long long v = v0 + g;
     for (; v < v1; v += (long long)RW * G) {
         long long iu[RW];
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
 #pragma unroll
         for (int u = 0; u < RW; ++u) {
             float dy[8];
-            src[u].sum(dy);
+            src[u].sum(dy, vw8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xv = to_f(x[u][j]);
@@ -414,7 +428,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a, GnBwdFin
         sh2 = *(const vec<float, 8>*)(a.shift2 + (long long)n * a.C + c0);
     }
     // UNR chunks per trip, all loads in front (see gn_act_kernel)
-    constexpr int UNR = (NDY == 0) ? 1 : ((DUAL || NDY > 1) ? 2 : 4);
+    constexpr int UNR = (NDY == 0) ? 1 : ((DUAL || DySrc<T, NDY>::NS > 1) ? 2 : 4);
+    vec<float, 8> vw8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vw8[j] = 0.f;
+    if (DySrc<T, NDY>::VH) vw8 = *(const vec<float, 8>*)(a.vw + c0);
     const int stride = gridDim.x * 256;
     for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += stride * UNR) {
         long long iu[UNR];
@@ -438,7 +456,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a, GnBwdFin
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             float dy[8];
-            src[u].sum(dy);
+            src[u].sum(dy, vw8);
             vec<T, 8> o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -667,7 +685,8 @@ void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
     dim3 grid(cdiv(a.V, GNB_ROWS), a.N);
     const int nv = dy_variant(a);
 #define SEG_GNR1(T_, D_, K_) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_reduce_kernel<T_, D_, K_>), grid, dim3(256), 0, s, a, GNB_ROWS)
-#define SEG_GNR(T_, D_) { if (nv == 1) SEG_GNR1(T_, D_, 1); else if (nv == 2) SEG_GNR1(T_, D_, 2); else if (nv == 3) SEG_GNR1(T_, D_, 3); else SEG_GNR1(T_, D_, 0); }
+#define SEG_GNR(T_, D_) { if (nv == 1) SEG_GNR1(T_, D_, 1); else if (nv == 2) SEG_GNR1(T_, D_, 2); else if (nv == 3) SEG_GNR1(T_, D_, 3); \
+                          else if (nv == 4) SEG_GNR1(T_, D_, 4); else if (nv == 5) SEG_GNR1(T_, D_, 5); else SEG_GNR1(T_, D_, 0); }
     if (a.r2) { if (dtype == DT_F32) SEG_GNR(float, true) else if (dtype == DT_F16) SEG_GNR(f16, true) else SEG_GNR(bf16, true) }
     else { if (dtype == DT_F32) SEG_GNR(float, false) else if (dtype == DT_F16) SEG_GNR(f16, false) else SEG_GNR(bf16, false) }
 #undef SEG_GNR
@@ -711,7 +730,8 @@ void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s, const GnB
     const int nv = dy_variant(a);
 #define SEG_GNA1(T_, D_, K_) { if (fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_, true, K_>), grid, dim3(256), 0, s, a, za, zb); \
                                else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_apply_kernel<T_, D_, false, K_>), grid, dim3(256), 0, s, a, za, zb); }
-#define SEG_GNA(T_, D_) { if (nv == 1) SEG_GNA1(T_, D_, 1) else if (nv == 2) SEG_GNA1(T_, D_, 2) else if (nv == 3) SEG_GNA1(T_, D_, 3) else SEG_GNA1(T_, D_, 0) }
+#define SEG_GNA(T_, D_) { if (nv == 1) SEG_GNA1(T_, D_, 1) else if (nv == 2) SEG_GNA1(T_, D_, 2) else if (nv == 3) SEG_GNA1(T_, D_, 3) \
+                          else if (nv == 4) SEG_GNA1(T_, D_, 4) else if (nv == 5) SEG_GNA1(T_, D_, 5) else SEG_GNA1(T_, D_, 0) }
     if (a.r2) { if (dtype == DT_F32) SEG_GNA(float, true) else if (dtype == DT_F16) SEG_GNA(f16, true) else SEG_GNA(bf16, true) }
     else { if (dtype == DT_F32) SEG_GNA(float, false) else if (dtype == DT_F16) SEG_GNA(f16, false) else SEG_GNA(bf16, false) }
 #undef SEG_GNA
