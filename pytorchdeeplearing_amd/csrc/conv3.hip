@@ -1007,7 +1007,10 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) 
     static const int minbox = getenv("SEG_W3_MINBOX") ? atoi(getenv("SEG_W3_MINBOX")) : 6;
     // 16 -> 16 channels (the finest level): four workgroups fit a CU (23 KB LDS, 113 VGPRs) and the partial tile is 27 KB, so the
     // staging latency of one workgroup can hide behind the others
-    static const int total16 = getenv("SEG_W3_TOTAL16") ? atoi(getenv("SEG_W3_TOTAL16")) : 1024;   // standalone 4x96^3: 512 -> 168 us, 1024 -> 123 us, 2048 -> 137 us (r02_wgrad16_ab.log); step unchanged
+    // round 2 (no prefetch), standalone 4x96^3: 512 -> 168 us, 1024 -> 123 us, 2048 -> 137 us (r02_wgrad16_ab.log), step unchanged.  With the
+    // prefetching kernel inside the step (profiles/r03_wgrad_policy_ab3.log): 128 -> 947, 256 -> 967 / 967, 384 -> 961, 1024 -> 956-958
+    // volumes/s - one workgroup per CU leaves the bandwidth-bound 96^3 GroupNorm passes of the main stream the rest of the machine
+    static const int total16 = getenv("SEG_W3_TOTAL16") ? atoi(getenv("SEG_W3_TOTAL16")) : 256;
     long long nb = (P == 16 && Q == 16 ? total16 : total) / combos;
     if (nb < 1) nb = 1;
     const long long nbox = boxes_for(ndim, N, D, H, W);
