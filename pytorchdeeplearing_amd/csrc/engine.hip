@@ -82,6 +82,7 @@ struct seg_engine {
     size_t ws_bytes = 0;
     size_t off_partial = 0, off_partial_stem1 = 0;
     size_t off_masks = 0, off_stats = 0, stats_bytes = 0, off_Q = 0, Q_bytes = 0, off_packdesc = 0, off_step = 0;
+    bool q_clean = false;       // the forward pass's fill has cleared Q and no backward pass has used it yet
     std::vector<PackDesc> packdescs;   // dst/src stored as OFFSETS until bind
     long long pack_max = 0;
     bool planned = false;
@@ -705,7 +706,10 @@ struct Planner {
         // ------------------------------------------------------------------ forward schedule
         E.fwd_ops.push_back([this_ = &E](hipStream_t st) {
             seg_engine& E = *this_;
-            (void)hipMemsetAsync(E.ws + E.off_stats, 0, E.stats_bytes, st);
+            // the backward sums (Q) sit right behind the forward statistics: ONE fill clears both (a fill is a ~6 us launch on the main
+            // stream); a backward pass that does not follow a forward pass directly clears Q itself
+            (void)hipMemsetAsync(E.ws + E.off_stats, 0, E.stats_bytes + (E.off_Q == E.off_stats + E.stats_bytes ? E.Q_bytes : 0), st);
+            E.q_clean = E.off_Q == E.off_stats + E.stats_bytes;
             const Ten& x = E.tens[E.image_ten];
             launch_ingest(E.cur_x, E.ws + x.off, E.N, x.C, E.vol(0), E.dtype, st, E.in_ch);
         });
@@ -901,7 +905,8 @@ struct Planner {
         E.bwd_writes.push_back({});
         E.bwd_ops.push_back([this_ = &E](hipStream_t st) {
             seg_engine& E = *this_;
-            (void)hipMemsetAsync(E.ws + E.off_Q, 0, E.Q_bytes, st);
+            if (!E.q_clean) (void)hipMemsetAsync(E.ws + E.off_Q, 0, E.Q_bytes, st);
+            E.q_clean = false;
         });
         for (int si = (int)E.steps.size() - 1; si >= 0; --si) {
             Step& s = E.steps[si];
