@@ -1003,7 +1003,11 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) 
     // tuning knobs.  512 while the kernel exposed its staging latency (r01: 256 / 384 / 768 -> 691 / 694 / 680 vs 700 volumes/s); with the next
     // box prefetched into registers one workgroup per CU is enough and a third fewer partial tiles are written and re-read:
     // 256 vs 512 = 946 vs 941 and 959 vs 953 volumes/s in two sessions (profiles/r03_policy_resweep_ab.log, r03_stemx_coefs_ab.log)
-    static const int total = getenv("SEG_W3_TOTAL") ? atoi(getenv("SEG_W3_TOTAL")) : 256;
+    // One box, every BASELINE config (profiles/r03_wgrad_policy_configs_ab.log), total / total16 = 256/256, 512/1024, 256/1024, 512/256:
+    // C3 4.15 / 4.20 / 4.18 / 4.15 ms, C4 4.58 / 4.55 / 4.43 / 4.68, C5 4.55 / 4.61 / 4.57 / 4.58, C2 (2-D) 6.65 / 6.40 / 6.68 / 6.37 -> the
+    // 2-D boxes keep 512 workgroups
+    static const int total_env = getenv("SEG_W3_TOTAL") ? atoi(getenv("SEG_W3_TOTAL")) : 0;
+    const int total = total_env > 0 ? total_env : (ndim == 3 ? 256 : 512);
     static const int minbox = getenv("SEG_W3_MINBOX") ? atoi(getenv("SEG_W3_MINBOX")) : 6;
     // 16 -> 16 channels (the finest level): four workgroups fit a CU (23 KB LDS, 113 VGPRs) and the partial tile is 27 KB, so the
     // staging latency of one workgroup can hide behind the others
