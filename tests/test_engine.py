@@ -366,6 +366,23 @@ def test_virtual_activation_equals_materialised(dev, tag, dtype, monkeypatch):
         assert d <= (0.0 if exact else 2e-3 * float(g0[k].norm()) + 1e-12), k
 
 
+@pytest.mark.parametrize("tag", ["vnet2d_s", "unet2d"])
+def test_virtual_head_gradient_equals_materialised(dev, tag, monkeypatch):
+    """One-class heads (networks/VNet3d.py:83-99): the data-gradient of the 1^d head is never written - the GroupNorm-backward passes of the
+    units under the head evaluate dl[v] * w[c] on the fly (GnBwdArgs::vdl; gn_bwd_*_kernel<..., NDY = 4 / 5>).  With SEG_VHEAD=0 the head
+    writes the tensor and the same passes read it as a stored source (NDY = 1 / 2).  fp32 run dtype: same products, same sums."""
+    res = []
+    for vh in ("1", "0"):
+        monkeypatch.setenv("SEG_VHEAD", vh)
+        e, params, x, y, masks, alpha, loss = build(tag, "f32", dev, True)
+        res.append(run_engine(e, x, y, masks, alpha, loss, dev))
+        del e
+    (l0, p0, o0, g0), (l1, p1, o1, g1) = res
+    assert torch.equal(l0, l1) and float(o0[0]) == float(o1[0])
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm()) <= 2e-6 * float(g1[k].norm()) + 1e-12, k
+
+
 @pytest.mark.gpu
 def test_graph_replay_equals_stream_launches():
     """seg_train_graph_capture / _launch: the train step captured as a HIP graph (weight-gradient stream forked and joined inside the
