@@ -263,8 +263,19 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep) {
 // ends up with 4 consecutive output channels of one voxel -> 8-B coalesced stores, no transpose.  Each wave walks a
 // strided list of 16-voxel tiles of ONE sample, keeping GroupNorm partial sums in registers.
 // ------------------------------------------------------------------------------------------------
-template <class T, int KS, int NTL, bool SCATTER>
-__global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
+// SC: 0 = gather form, 1 = scatter form (ConvTranspose / data-gradient of a strided conv: tile j = tap (j * 16) / Cout), 2 = scatter form
+// with Cout == 16: every tile holds the SAME 16 channels, so one set of bias values and one set of GroupNorm partial sums serves all
+// NTL tiles (84 VGPRs less at NTL = 8: three waves per SIMD instead of two)
+#ifndef SEG_EMU
+#define SEG_STREAM_WAVES(x) __attribute__((amdgpu_waves_per_eu(x)))     // lower bound on resident waves per SIMD = upper bound on VGPRs
+#else
+#define SEG_STREAM_WAVES(x)
+#endif
+template <class T, int KS, int NTL, int SC>
+__global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) void conv_stream_kernel(ConvArgs a) {
+    constexpr bool SCATTER = SC != 0;
+    constexpr bool C16 = SC == 2;
+    constexpr int NJ = C16 ? 1 : NTL;
     __shared__ float red[4][NTL * 16][2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int n = blockIdx.y;
@@ -281,9 +292,9 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < NTL; ++j) wf[ks][j] = load8(wp + (long long)(j * 16 + l15) * a.Kpad + ks * 32 + q * 8);
-    float bs[NTL][4];
+    float bs[NJ][4];
 #pragma unroll
-    for (int j = 0; j < NTL; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bs[j][r] = a.bias ? a.bias[(SCATTER ? (j * 16) % a.Cout : j * 16) + 4 * q + r] : 0.f;
     // reduction coordinates of this lane's 8-element piece in every K step
@@ -297,24 +308,24 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         ci[ks] = SCATTER ? k0 : (k0 & (Cin - 1));
         td[ks] = SCATTER ? 0 : a.taps.d[tap]; th[ks] = SCATTER ? 0 : a.taps.h[tap]; tw[ks] = SCATTER ? 0 : a.taps.w[tap];
     }
-    float s1[NTL][4], s2[NTL][4];
+    float s1[NJ][4], s2[NJ][4];
 #pragma unroll
-    for (int j = 0; j < NTL; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
     // scatter form: the output tap of every 16-channel tile, read ONCE (inside the loop each store sat behind three serial
     // tap-table loads, every one with its own s_waitcnt vmcnt(0))
-    int od[NTL], oh[NTL], ow[NTL];
+    int toff[NTL];               // output-row offset of the tile's tap: (kd * FH + kh) * FW + kw
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
         const int tap = SCATTER ? (j * 16) / a.Cout : 0;
-        od[j] = SCATTER ? a.taps.d[tap] : 0; oh[j] = SCATTER ? a.taps.h[tap] : 0; ow[j] = SCATTER ? a.taps.w[tap] : 0;
-        if (SCATTER) { settle(od[j]); settle(oh[j]); settle(ow[j]); }
+        toff[j] = SCATTER ? (a.taps.d[tap] * a.FH + a.taps.h[tap]) * a.FW + a.taps.w[tap] : 0;
+        if (SCATTER) settle(toff[j]);
     }
 
     const int ntile = (int)(Vrow / 16);
     // U tiles per iteration: all their loads are issued before the first MFMA (>= 4 x 16 B in flight per lane)
-    constexpr int U = KS >= 4 ? 1 : 4 / KS;
+    constexpr int U = KS >= 4 ? 1 : (NTL >= 8 ? 2 : 4 / KS);     // 8 output tiles per input tile: the stores dominate, two tiles keep a third wave per SIMD
     const int step = gridDim.x * 4;
     // the tap-table entries above are vector-memory loads (dynamic index into the argument segment): make them land HERE.  Left
     // pending at the loop entry they made hipcc put s_waitcnt vmcnt(2) / (1) / (0) in front of every tile's address arithmetic, which
@@ -359,15 +370,15 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
             for (int j = 0; j < NTL; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    o[j][r] = from_f<T>(acc[j][r] + bs[j][r]);
+                    o[j][r] = from_f<T>(acc[j][r] + bs[C16 ? 0 : j][r]);
                     const float f = to_f(o[j][r]);
-                    s1[j][r] += f;
-                    s2[j][r] = fmaf(f, f, s2[j][r]);
+                    s1[C16 ? 0 : j][r] += f;
+                    s2[C16 ? 0 : j][r] = fmaf(f, f, s2[C16 ? 0 : j][r]);
                 }
             // address of the 16-channel group of tile j for this lane's voxel
             auto tile_ptr = [&](int j) -> T* {          // j: a compile-time constant at every call site
                 if (SCATTER) {
-                    const long long orow = (((long long)n * a.FD + d_[u] * a.sd + od[j]) * a.FH + h_[u] * a.sh + oh[j]) * a.FW + w_[u] * a.sw + ow[j];
+                    const long long orow = (((long long)n * a.FD + d_[u] * a.sd) * a.FH + h_[u] * a.sh) * a.FW + w_[u] * a.sw + toff[j];
                     return out + orow * a.Cout + (j * 16) % a.Cout;
                 }
                 return out + ((long long)n * Vrow + t * 16 + l15) * a.Cout + j * 16;
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     if (a.stats) {
         // per-channel sums: over the 16 voxel lanes of the wave, then over waves (and taps for the scatter form)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float u = s1[j][r], v = s2[j][r];
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         __syncthreads();
         if (tid < a.Cout) {
             double ts = 0.0, tss = 0.0;
-            for (int col = tid; col < NTL * 16; col += a.Cout)      // gather form: exactly one column
+            for (int col = tid; col < NJ * 16; col += a.Cout)       // gather form: exactly one column
                 for (int k = 0; k < 4; ++k) { ts += red[k][col][0]; tss += red[k][col][1]; }
             double* dst = a.stats + (((long long)(blockIdx.x % STAT_REP) * a.N + n) * a.Cout + tid) * 2;
             atomicAdd(dst, ts);
@@ -456,8 +467,9 @@ bool launch_conv_stream(const ConvArgs& a, hipStream_t s) {
     dim3 grid(gx, a.N);
 #define SEG_STREAM(KS, NTL)                                                                                                   \
     if (ks == KS && ntl == NTL) {                                                                                            \
-        if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, true>), grid, dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, false>), grid, dim3(256), 0, s, a);           \
+        if (a.scatter && a.Cout == 16 && NTL > 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 2>), grid, dim3(256), 0, s, a); \
+        else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 1>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 0>), grid, dim3(256), 0, s, a);               \
         return true;                                                                                                         \
     }
     SEG_STREAM(1, 1) SEG_STREAM(1, 2) SEG_STREAM(1, 4) SEG_STREAM(1, 8) SEG_STREAM(2, 1) SEG_STREAM(2, 2) SEG_STREAM(2, 4)
