@@ -56,8 +56,14 @@ template <> struct TFrag<float> {
 struct WgPlan { int TP, TQ, ntq, ntile, TB, ntg; long long Mc; int parts; int direct; };   // direct: 1^d stride-1 conv, voxel == row
 
 // partial layout per voxel slice: [P][T][Qc]  (Qc = Q, or the (tap,ci) column count of the stem)
+#ifndef SEG_EMU
+#define SEG_WG_WAVES(x) __attribute__((amdgpu_waves_per_eu(x)))     // lower bound on resident waves per SIMD = upper bound on VGPRs
+#else
+#define SEG_WG_WAVES(x)
+#endif
+// (the 8-tap form allocated 184 VGPRs - two waves per SIMD - where its 42 KB of LDS allow three workgroups per CU)
 template <class T, bool STEM, int NTB>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a, WgPlan pl, float* partial) {
+__global__ __launch_bounds__(256) SEG_WG_WAVES(NTB == MAXTB && sizeof(T) == 2 ? 3 : 1) void wgrad_kernel(WgradArgs a, WgPlan pl, float* partial) {
     // voxel rows per staging step: 128 for the single-tap kernels (4 MFMA K-steps per barrier pair), 32 otherwise
     constexpr int WMT = (NTB == 1 && !STEM) ? 128 : WM;
     constexpr int NPC = WMT * 8 / 256;                  // staging pieces (16 B) per thread, upper bound
