@@ -78,7 +78,9 @@ int seg_set_dropout_draws(seg_handle h, long long draws);
 int seg_plan(seg_handle h, int n, int d, int hgt, int wid);
 long long seg_workspace_bytes(seg_handle h);
 /* what the planner decided for the current shape (tests / diagnostics): what = 0: activations applied by their consuming convolution instead
- * of an elementwise launch (the activated tensor is never written), 1: convolution units.  <0: not planned / unknown `what`. */
+ * of an elementwise launch (the activated tensor is never written), 1: convolution units, 2 / 3: of the last backward pass, the fork events
+ * recorded on the caller's stream / the weight gradients released by a completion flag instead (SEG_FORK_FLAG=1, experimental).
+ * <0: not planned / unknown `what`. */
 int seg_plan_count(seg_handle h, int what);
 
 /* Bind caller-owned buffers: flat fp32 params / grads (seg_param_numel floats each) + workspace. */

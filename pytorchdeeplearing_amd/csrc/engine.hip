@@ -127,7 +127,17 @@ struct seg_engine {
     // Weight-gradient launches are queued and released to the side stream in batches under ONE fork event: every
     // hipEventRecord idles the main stream for ~6 us, and the side stream has slack (it only has to finish before the
     // optimiser), so a fork per weight gradient (35 per step) cost more than it bought.
-    std::vector<std::function<void(hipStream_t)>> pending;
+    // SEG_FORK_FLAG=1 (experiment, default off): a weight gradient whose d(raw) comes out of a gn_bwd_apply launch waits
+    // for THAT launch through a flag the launch's last workgroup publishes (GnBwdArgs::sig_flag) and a one-wave wait kernel on the
+    // weight-gradient stream - a batch made of such weight gradients only needs no event record on the main stream (5.4 us each,
+    // profiles/r03_fork_cost_microbench.log).  sig = unit (step index) whose apply pass signals, -1 = needs the event.
+    struct Pend { std::function<void(hipStream_t)> f; int sig; };
+    bool fork_flag = false, side_used = false;
+    int n_event_forks = 0, n_flag_waits = 0;            // of the current / last backward pass (seg_plan_count 2 / 3)
+    size_t off_sig = 0;                 // [steps][2] ints in the workspace: {finished-workgroup counter, published sequence number}
+    int sig_seq = 0;                    // sequence number of the current backward pass (per bind)
+    std::vector<int> sig_unit_seq;      // per unit: the sequence number its apply pass publishes in this backward pass (0 = none)
+    std::vector<Pend> pending;
     int fork_batch = 3;      // measured on MI355X (VNet3d 4x96^3), round 1: 1 -> 641, 3 -> 645, 6 -> 649 volumes/s; round 2 with the
                              // heavy levels released at once: 6 -> 826, 3 -> 838
     // Up to two weight-gradient streams, each with its own partial-tile scratch: the kernels behind them run with 3-512 workgroups,
@@ -158,16 +168,26 @@ struct seg_engine {
     // critical path once its idle time is gone, so the default keeps every weight gradient on the side stream.
     int n_deferred = 0, wgrad_seq = 0, tail_wgrads = 0;       // SEG_TAIL_WGRADS
     size_t off_partial_main = 0;
-    std::vector<std::function<void(hipStream_t)>> tail_pending;
+    std::vector<Pend> tail_pending;
     // SEG_HOLD_HEAVY_LVL=L (experiment, default off = -1): the weight gradients over >= hold_bytes tensors of the DECODER's top levels are
     // not released while the main stream still works on those bandwidth-bound levels; they are held until the backward pass reaches level L
     // (24^3 for L = 2), where the main stream's kernels are small and latency-bound and leave the HBM to the weight gradients
     int hold_lvl = -1;
     double hold_bytes = 64e6;                       // SEG_HOLD_HEAVY_MB
     bool hold_open = false;                         // the release level has been reached in this backward pass
-    std::vector<std::function<void(hipStream_t)>> held;
-    void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> f, double bytes = 0.0, int lvl = 0) {
-        if (!use_side) { cur_partial = off_partial; f(main); return; }
+    std::vector<Pend> held;
+    // the apply pass about to be launched publishes this backward pass's sequence number for unit `ui` (and its twin `uj` of a dual pass)
+    void arm_signal(GnBwdArgs& a, int ui, int uj) {
+        if (!fork_flag || capturing || !use_side || ui < 0 || ui >= (int)sig_unit_seq.size()) return;
+        int* base = (int*)(ws + off_sig) + 2 * ui;
+        a.sig_ctr = base; a.sig_flag = base + 1; a.sig_seq = sig_seq;
+        sig_unit_seq[ui] = sig_seq;
+        if (uj >= 0 && uj < (int)sig_unit_seq.size()) sig_unit_seq[uj] = -1;        // its twin's weight gradient keeps the event (the flag lives in ui's slot)
+    }
+    void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> fn, double bytes = 0.0, int lvl = 0, int sig_unit = -1) {
+        if (!use_side) { cur_partial = off_partial; fn(main); return; }
+        const bool flagged = fork_flag && !capturing && sig_unit >= 0 && sig_unit < (int)sig_unit_seq.size() && sig_unit_seq[sig_unit] == sig_seq;
+        Pend f{std::move(fn), flagged ? sig_unit : -1};
         if (wgrad_seq++ >= n_deferred - tail_wgrads) { tail_pending.push_back(std::move(f)); return; }
         if (hold_lvl >= 0) {
             if (!hold_open && lvl >= hold_lvl) {
@@ -198,28 +218,43 @@ struct seg_engine {
         if (pending.empty()) return;
         ensure_side();
         if (ready_used == ready_ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ready_ev.push_back(e); }
-        hipEvent_t e = ready_ev[ready_used++];
-        (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
-        (void)hipStreamWaitEvent(side, e, 0);
-        if (side2) (void)hipStreamWaitEvent(side2, e, 0);
+        bool need_event = side2 != nullptr;
+        for (auto& f : pending) need_event = need_event || f.sig < 0;
+        if (need_event) {
+            ++n_event_forks;
+            hipEvent_t e = ready_ev[ready_used++];
+            (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
+            (void)hipStreamWaitEvent(side, e, 0);
+            if (side2) (void)hipStreamWaitEvent(side2, e, 0);
+        }
+        if (!need_event) {
+            // flagged batch: the weight-gradient stream waits for the apply passes, not for the main stream's position.  The producers sit on ONE
+            // in-order queue, so the flag of the batch's last item covers the whole batch (held items re-order the list: every flag then)
+            for (size_t i = hold_lvl >= 0 ? 0 : pending.size() - 1; i < pending.size(); ++i) {
+                ++n_flag_waits;
+                launch_wait_flag((const int*)(ws + off_sig) + 2 * pending[i].sig + 1, sig_seq, side);
+            }
+        }
         for (auto& f : pending) {
             const bool second = side2 && (rr++ & 1);
             cur_partial = second ? off_partial2 : off_partial;
-            f(second ? side2 : side);
+            f.f(second ? side2 : side);
         }
+        side_used = true;
         pending.clear();
     }
     void join_side(hipStream_t main) {
         for (auto& h : held) pending.push_back(std::move(h));      // (a network without deep levels never reached the release level)
         held.clear();
         flush_side(main);
-        for (auto& f : tail_pending) { cur_partial = off_partial_main; f(main); }
+        for (auto& f : tail_pending) { cur_partial = off_partial_main; f.f(main); }
         tail_pending.clear();
-        if (use_side && side && ready_used) {
+        if (use_side && side && (ready_used || side_used)) {
             (void)hipEventRecord(side_done, side); (void)hipStreamWaitEvent(main, side_done, 0);
             if (side2) { (void)hipEventRecord(side2_done, side2); (void)hipStreamWaitEvent(main, side2_done, 0); }
         }
         ready_used = 0;
+        side_used = false;
     }
     // one optimisation step captured as a HIP graph (seg_train_graph_*): the host side of a replay is ONE hipGraphLaunch
     hipGraph_t tgraph = nullptr;
@@ -575,6 +610,8 @@ struct Planner {
             }
         // ---- small persistent regions
         E.off_step = alloc(256);
+        E.off_sig = alloc(E.steps.size() * 8 + 8);
+        E.sig_unit_seq.assign(E.steps.size(), 0);
         E.off_masks = alloc((size_t)E.drop_ch.size() * N * E.ld_mask() * 4);
         // forward tensors
         for (auto& t : E.tens) t.off = alloc(ten_bytes(t));
@@ -1052,6 +1089,7 @@ struct Planner {
                         const bool fold = E.use_fold && a.C <= 256;
                         if (!fold) { launch_gn_bwd_finalize(fa, st); launch_gn_bwd_finalize(fb, st); }
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, tb * (a.ndy + 4), 0.0);
+                        E.arm_signal(a, uia, uib);
                         launch_gn_bwd_apply(a, E.dtype, st, fold ? &fa : nullptr, fold ? &fb : nullptr);
                         E.prof_end(st, pi);
                     });
@@ -1070,6 +1108,7 @@ struct Planner {
                         fill(E, ui, gl, a, f);
                         if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
                             const int pg = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
+                            E.arm_signal(a, ui, -1);
                             launch_gn_bwd_group(a, f, E.dtype, st);
                             E.prof_end(st, pg);
                             return;
@@ -1080,6 +1119,7 @@ struct Planner {
                         const bool fold = E.use_fold && a.C <= 256;
                         if (!fold) launch_gn_bwd_finalize(f, st);
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
+                        E.arm_signal(a, ui, -1);
                         launch_gn_bwd_apply(a, E.dtype, st, fold ? &f : nullptr, nullptr);
                         E.prof_end(st, pi);
                     });
@@ -1130,7 +1170,7 @@ struct Planner {
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
                                           s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, nullptr, nullptr, s.cin_par);
                             E.prof_end(ws_, pi);
-                        }, E.tbytes(draw), lo);
+                        }, E.tbytes(draw), lo, s.gn_w >= 0 ? si : -1);
                         int pi;
                         if (g0 >= 0) {
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
@@ -1185,7 +1225,7 @@ struct Planner {
                                                     E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
                         launch_wgrad(w, (float*)(E.ws + E.cur_partial), E.dtype, ws_, s.cin_par);
                         E.prof_end(ws_, pi);
-                    }, E.tbytes(draw), lo < li ? lo : li);
+                    }, E.tbytes(draw), lo < li ? lo : li, s.gn_w >= 0 ? si : -1);
                     // ---- data gradient(s)
                     if (g0 < 0 && g1 < 0) return;
                     ConvArgs a{};
@@ -1263,6 +1303,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (getenv("SEG_GN_VACT")) e->use_vact = atoi(getenv("SEG_GN_VACT")) != 0;
     if (getenv("SEG_GN_FOLD")) e->use_fold = atoi(getenv("SEG_GN_FOLD")) != 0;
     if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
+    if (getenv("SEG_FORK_FLAG")) e->fork_flag = atoi(getenv("SEG_FORK_FLAG")) != 0;
     if (getenv("SEG_TAIL_WGRADS")) e->tail_wgrads = atoi(getenv("SEG_TAIL_WGRADS"));
     if (getenv("SEG_FORK_HEAVY_MB")) e->fork_heavy_bytes = atof(getenv("SEG_FORK_HEAVY_MB")) * 1e6;
     if (getenv("SEG_FLUSH_LATE")) e->flush_late = atoi(getenv("SEG_FLUSH_LATE")) != 0;
@@ -1346,6 +1387,8 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
 }
 int seg_plan_count(seg_handle h, int what) {
     if (!h || !h->planned) return -1;
+    if (what == 2) return h->n_event_forks;             // last backward pass: fork events recorded on the main stream
+    if (what == 3) return h->n_flag_waits;              // last backward pass: weight gradients released by a completion flag (SEG_FORK_FLAG)
     int n = 0;
     for (auto& s : h->steps) {
         if (what == 0) n += s.type == ST_ACT && s.vact;                                   // activations applied by their consumer (never written)
@@ -1374,6 +1417,9 @@ int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
     if (hipMemcpy(h->ws + h->off_packdesc, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice) != hipSuccess)
         return fail("seg_bind: descriptor upload failed");
     if (hipMemset(h->ws + h->off_step, 0, 256) != hipSuccess) return fail("seg_bind: memset failed");
+    if (hipMemset(h->ws + h->off_sig, 0, h->steps.size() * 8 + 8) != hipSuccess) return fail("seg_bind: memset failed");
+    h->sig_seq = 0;
+    std::fill(h->sig_unit_seq.begin(), h->sig_unit_seq.end(), 0);
     if (h->draws && hipMemcpy(h->ws + h->off_step, &h->draws, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
         return fail("seg_bind: counter upload failed");
     return 0;
@@ -1449,7 +1495,7 @@ static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, in
     hipStream_t st = (hipStream_t)stream;
     if (zero_grads && op_begin == 0) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
-    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; }
+    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; ++h->sig_seq; h->n_event_forks = 0; h->n_flag_waits = 0; }
     if (h->pack_bwd_pending) { (void)hipStreamWaitEvent(st, h->pack_done, 0); h->pack_bwd_pending = false; }
     for (int i = op_begin; i < op_end; ++i) { h->bwd_ops[i](st); h->maybe_flush(st); }
     if (join) h->join_side(st);

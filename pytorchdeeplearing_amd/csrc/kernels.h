@@ -136,7 +136,13 @@ struct GnBwdArgs {
     // the fly from the loss gradient (planar fp32) and the head weights instead of being written as a 16-channel tensor and read
     // back by every GroupNorm-backward pass it feeds
     const float* vdl; const float* vw; int vK;    int rep_q;                                  // replicas of Q the reduce pass spreads over; 0 = STAT_REP
+    // optional completion signal of the APPLY pass (SEG_FORK_FLAG=1, engine.hip): the last workgroup to finish publishes sig_seq in *sig_flag
+    // (sig_ctr counts finished workgroups and is left at 0), so that the weight-gradient stream can wait for THIS launch with a one-wave
+    // kernel instead of an event recorded on the main stream
+    int* sig_ctr; int* sig_flag; int sig_seq;
 };
+// one wave spinning until *flag >= seq (the other side of GnBwdArgs::sig_flag)
+void launch_wait_flag(const int* flag, int seq, hipStream_t s);
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
 struct GnBwdFinArgs;
 // fa != null: the backward finalize of the branch(es) runs as a prologue of this launch (no gn_bwd_finalize launch before it)
