@@ -378,9 +378,11 @@ def test_virtual_head_gradient_equals_materialised(dev, tag, monkeypatch):
         res.append(run_engine(e, x, y, masks, alpha, loss, dev))
         del e
     (l0, p0, o0, g0), (l1, p1, o1, g1) = res
-    assert torch.equal(l0, l1) and float(o0[0]) == float(o1[0])
+    exact = dev.type == "cpu"           # on the GPU the fp64 / fp32 atomics of the statistics and the weight-gradient reduce order differently from run to run
+    assert float((l0 - l1).abs().max()) <= (0.0 if exact else 1e-5 * max(1.0, float(l0.abs().max())))
+    assert abs(float(o0[0]) - float(o1[0])) <= (0.0 if exact else 1e-6)
     for k in g0:
-        assert float((g0[k] - g1[k]).norm()) <= 2e-6 * float(g1[k].norm()) + 1e-12, k
+        assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-5) * float(g1[k].norm()) + 1e-12, k
 
 
 @pytest.mark.parametrize("tag", ["vnet2d_s", "unet2d"])
