@@ -24,6 +24,10 @@ namespace {
 thread_local std::string g_err;
 int fail(const std::string& m) { g_err = m; return -1; }
 
+// default of SEG_SUB_MB (group size of the sub-batched finest level, seg_engine::run_chain); 0 = whole-batch launches
+#ifndef SEG_SUB_MB_DEFAULT
+#define SEG_SUB_MB_DEFAULT 0.0
+#endif
 enum ConvKind { CK_K3, CK_K1, CK_K2S2, CK_KT, CK_STEM3, CK_STEM1 };
 enum StepType { ST_UNIT, ST_ACT, ST_POOL, ST_HEAD };
 
@@ -178,14 +182,18 @@ struct seg_engine {
     std::vector<Pend> held;
     // the apply pass about to be launched publishes this backward pass's sequence number for unit `ui` (and its twin `uj` of a dual pass)
     void arm_signal(GnBwdArgs& a, int ui, int uj) {
-        if (!fork_flag || capturing || !use_side || ui < 0 || ui >= (int)sig_unit_seq.size()) return;
+        if (!fork_flag || capturing || sub_active || !use_side || ui < 0 || ui >= (int)sig_unit_seq.size()) return;
         int* base = (int*)(ws + off_sig) + 2 * ui;
         a.sig_ctr = base; a.sig_flag = base + 1; a.sig_seq = sig_seq;
         sig_unit_seq[ui] = sig_seq;
         if (uj >= 0 && uj < (int)sig_unit_seq.size()) sig_unit_seq[uj] = -1;        // its twin's weight gradient keeps the event (the flag lives in ui's slot)
     }
     void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> fn, double bytes = 0.0, int lvl = 0, int sig_unit = -1) {
-        if (!use_side) { cur_partial = off_partial; fn(main); return; }
+        if (sub_active) {                                  // a chain runs group by group: the weight gradient is a whole-batch launch, queued once
+            if (!sub_last) return;
+            bytes *= (double)Nplan / (double)N;
+        }
+        if (!use_side) { const bool was = sub_suspend(); cur_partial = off_partial; fn(main); sub_resume(was); return; }
         const bool flagged = fork_flag && !capturing && sig_unit >= 0 && sig_unit < (int)sig_unit_seq.size() && sig_unit_seq[sig_unit] == sig_seq;
         Pend f{std::move(fn), flagged ? sig_unit : -1};
         if (wgrad_seq++ >= n_deferred - tail_wgrads) { tail_pending.push_back(std::move(f)); return; }
@@ -216,6 +224,11 @@ struct seg_engine {
     }
     void flush_side(hipStream_t main) {
         if (pending.empty()) return;
+        const bool was_sub = sub_suspend();                // the queued launches are whole-batch
+        flush_side_full(main);
+        sub_resume(was_sub);
+    }
+    void flush_side_full(hipStream_t main) {
         ensure_side();
         if (ready_used == ready_ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ready_ev.push_back(e); }
         bool need_event = side2 != nullptr;
@@ -255,6 +268,71 @@ struct seg_engine {
         }
         ready_used = 0;
         side_used = false;
+    }
+    // ---- sub-batch execution of the finest level(s) (SEG_SUB_MB).  At 4 x 96^3 one 16-channel tensor is 113 MB, so a
+    // consumer never finds what its producer just wrote in the 256 MB memory-side cache.  GroupNorm statistics and dropout masks are per sample
+    // (networks/VNet3d.py:9), so maximal runs of consecutive ops whose units all live on the finest level ("chains": the decoder top
+    // convT -> act -> 1^d conv -> act -> LUConv -> act -> head, and its backward twin) are executed group of samples by group of samples: all ops
+    // of the chain for samples [n0, n0 + nb), then the next group.  No kernel knows: the op lambdas read tensor offsets / N / per-unit buffers at
+    // call time, and run_chain shifts exactly those for the duration of a group (a unit's statistics replicas are then laid out
+    // [group][rep][nb][C][2] instead of [rep][N][C][2]; every toucher of a finest-level unit's statistics is a chain op in BOTH passes, so the
+    // layout is consistent).  Weight gradients stay whole-batch: defer_wgrad queues them on the LAST group only, and anything released to the
+    // weight-gradient stream while a group is active runs with the shifts suspended (sub_suspend / sub_resume).
+    int Nplan = 0;                       // the planned batch (N is the group size while a chain runs)
+    int sub_nb = 0;                      // samples per group; 0 = off
+    int sub_lvl = 0;                     // finest levels that are sub-batched (SEG_SUB_LVL)
+    double sub_mb = -1.0;                // SEG_SUB_MB: group size = as many samples as keep a 16-channel finest-level tensor under this many MB (0 = off)
+    std::vector<std::pair<int, int>> fwd_chains, bwd_chains;      // [begin, end) op ranges
+    std::vector<char> bwd_sub;           // planning: per backward op, whether it may run per group
+    bool sub_active = false, sub_last = false;
+    int sub_n0 = 0, sub_cur = 0;
+    void sub_shift(int n0, long long sign) {
+        auto mv = [&](size_t& off, long long per) { off = (size_t)((long long)off + sign * n0 * per); };
+        for (auto& t : tens) mv(t.off, (long long)vol(t.lvl) * t.C * (long long)esz());
+        for (auto& s : steps) {
+            if (s.type != ST_UNIT || s.gn_w < 0) continue;
+            mv(s.stats, (long long)STAT_REP * s.Cout * 2 * 8);
+            mv(s.Q, (long long)STAT_REP * s.Cout * 2 * 8);
+            mv(s.scale, (long long)s.Cout * 4);
+            mv(s.shift, (long long)s.Cout * 4);
+            mv(s.mean, (long long)GN_GROUPS * 4);
+            mv(s.rstd, (long long)GN_GROUPS * 4);
+            mv(s.coef, (long long)s.Cout * 3 * 4);
+        }
+        const long long v0 = vol(0);
+        if (cur_x) cur_x += sign * n0 * in_ch * v0;
+        if (cur_logits) cur_logits += sign * n0 * ncls * v0;
+        if (cur_probs) cur_probs += sign * n0 * ncls * v0;
+        if (cur_dlogits) cur_dlogits += sign * n0 * ncls * v0;
+    }
+    void sub_enter(int n0, int nb) { sub_shift(n0, +1); N = nb; sub_n0 = n0; sub_cur = nb; sub_active = true; }
+    void sub_leave() { sub_shift(sub_n0, -1); N = Nplan; sub_n0 = 0; sub_active = false; }
+    // whole-batch work issued from inside a group (a release of queued weight gradients): shifts off, run, shifts back on
+    bool sub_suspend() { if (!sub_active) return false; const int n0 = sub_n0; sub_leave(); sub_n0 = n0; return true; }
+    void sub_resume(bool was) { if (was) { const int n0 = sub_n0; sub_enter(n0, sub_cur); } }
+    const float* mask_base(int slot) const {          // dropout multipliers of unit `slot`: table [slot][Nplan][ld]; a group starts at its first sample
+        return (const float*)(ws + off_masks) + ((size_t)slot * Nplan + (sub_active ? sub_n0 : 0)) * ld_mask();
+    }
+    void run_chain(std::vector<std::function<void(hipStream_t)>>& ops, int b, int e, hipStream_t st, bool bwd) {
+        const int nb = sub_nb;
+        for (int n0 = 0; n0 < Nplan; n0 += nb) {
+            sub_last = n0 + nb >= Nplan;
+            sub_enter(n0, nb);
+            for (int i = b; i < e; ++i) { ops[i](st); if (bwd && sub_last) maybe_flush(st); }
+            sub_leave();
+        }
+        sub_last = false;
+    }
+    void run_ops(std::vector<std::function<void(hipStream_t)>>& ops, const std::vector<std::pair<int, int>>& chains, int b, int e, hipStream_t st, bool bwd) {
+        size_t ci = 0;
+        for (int i = b; i < e;) {
+            while (ci < chains.size() && chains[ci].second <= i) ++ci;
+            if (sub_nb > 0 && sub_nb < Nplan && ci < chains.size() && chains[ci].first <= i) {
+                const int ce = chains[ci].second < e ? chains[ci].second : e;
+                run_chain(ops, i, ce, st, bwd);
+                i = ce;
+            } else { ops[i](st); if (bwd) maybe_flush(st); ++i; }
+        }
     }
     // one optimisation step captured as a HIP graph (seg_train_graph_*): the host side of a replay is ONE hipGraphLaunch
     hipGraph_t tgraph = nullptr;
@@ -579,6 +657,7 @@ struct Planner {
         seg_engine& E = e;
         const int N = E.N, dt = E.dtype;
         E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_is_bwd.clear(); E.pack_max = 0; E.n_deferred = 0;
+        E.bwd_sub.clear(); E.fwd_chains.clear(); E.bwd_chains.clear();
         // drop gradient tensors of a previous plan
         size_t nfw = 0;
         for (auto& s : E.steps) {
@@ -778,7 +857,7 @@ struct Planner {
                             GnFinArgs f{};
                             f.stats = (double*)(E.ws + u.stats); f.gamma = E.p + E.params[u.gn_w].off; f.beta = E.p + E.params[u.gn_b].off;
                             f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                                     : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                                     : E.mask_base(u.mask_slot);
                             f.mask_ld = E.ld_mask();
                             f.scale = (float*)(E.ws + u.scale); f.shift = (float*)(E.ws + u.shift);
                             f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
@@ -830,7 +909,7 @@ struct Planner {
                         GnFinArgs f{};
                         f.stats = stats; f.gamma = E.p + E.params[s.gn_w].off; f.beta = E.p + E.params[s.gn_b].off;
                         f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                                 : (const float*)(E.ws + E.off_masks) + (size_t)s.mask_slot * E.N * E.ld_mask();
+                                 : E.mask_base(s.mask_slot);
                         f.mask_ld = E.ld_mask();
                         f.scale = (float*)(E.ws + s.scale); f.shift = (float*)(E.ws + s.shift);
                         f.mean = (float*)(E.ws + s.mean); f.rstd = (float*)(E.ws + s.rstd);
@@ -855,7 +934,7 @@ struct Planner {
                             GnFinArgs f{};
                             f.stats = (double*)(E.ws + u.stats); f.gamma = E.p + E.params[u.gn_w].off; f.beta = E.p + E.params[u.gn_b].off;
                             f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                                     : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                                     : E.mask_base(u.mask_slot);
                             f.mask_ld = E.ld_mask();
                             f.scale = (float*)(E.ws + u.scale); f.shift = (float*)(E.ws + u.shift);
                             f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
@@ -874,7 +953,7 @@ struct Planner {
                             f.stats = (double*)(E.ws + ua.stats);
                             f.gamma = E.p + E.params[ua.gn_w].off; f.beta = E.p + E.params[ua.gn_b].off;
                             f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                                     : (const float*)(E.ws + E.off_masks) + (size_t)ua.mask_slot * E.N * E.ld_mask();
+                                     : E.mask_base(ua.mask_slot);
                             f.mask_ld = E.ld_mask();
                             f.scale = (float*)(E.ws + ua.scale); f.shift = (float*)(E.ws + ua.shift);
                             f.mean = (float*)(E.ws + ua.mean); f.rstd = (float*)(E.ws + ua.rstd);
@@ -900,7 +979,7 @@ struct Planner {
                             f = GnFinArgs{};
                             f.stats = (double*)(E.ws + u.stats); f.gamma = E.p + E.params[u.gn_w].off; f.beta = E.p + E.params[u.gn_b].off;
                             f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                                     : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                                     : E.mask_base(u.mask_slot);
                             f.mask_ld = E.ld_mask();
                             f.scale = (float*)(E.ws + u.scale); f.shift = (float*)(E.ws + u.shift);
                             f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
@@ -938,8 +1017,16 @@ struct Planner {
             }
         }
 
+        // a unit whose statistics live in the per-group layout while chains run (seg_engine::run_chain): finest level(s), real kernels
+        auto unit_sub = [&E](int ui) {
+            if (ui < 0) return false;
+            const Step& u = E.steps[ui];
+            if (u.type != ST_UNIT || E.tens[u.raw].lvl > E.sub_lvl || u.vact_prod >= 0) return false;
+            return (u.ck != CK_STEM3 && u.ck != CK_STEM1) || u.fused_stem;
+        };
         // ------------------------------------------------------------------ backward schedule
         E.bwd_writes.push_back({});
+        E.bwd_sub.push_back(0);
         E.bwd_ops.push_back([this_ = &E](hipStream_t st) {
             seg_engine& E = *this_;
             if (!E.q_clean) (void)hipMemsetAsync(E.ws + E.off_Q, 0, E.Q_bytes, st);
@@ -954,6 +1041,7 @@ struct Planner {
                 E.head_step = si;
                 E.tens[s.in].grads.push_back(gin);
                 E.bwd_writes.push_back({s.w, s.b});
+                E.bwd_sub.push_back(1);
                 E.bwd_ops.push_back([this_ = &E, si, gin](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -973,6 +1061,7 @@ struct Planner {
                 E.tens[s.in].grads.push_back(gin);
                 const int gout = gl[0];
                 E.bwd_writes.push_back({});
+                E.bwd_sub.push_back(E.tens[s.in].lvl <= E.sub_lvl ? 1 : 0);
                 E.bwd_ops.push_back([this_ = &E, si, gin, gout](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -1015,7 +1104,7 @@ struct Planner {
                     f.Q = a.Q; f.stats = (double*)(E.ws + u.stats);
                     f.gamma = E.p + E.params[u.gn_w].off;
                     f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                             : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                             : E.mask_base(u.mask_slot);
                     f.mask_ld = E.ld_mask();
                     f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
                     f.dgamma = E.g + E.params[u.gn_w].off; f.dbeta = E.g + E.params[u.gn_b].off;
@@ -1031,6 +1120,7 @@ struct Planner {
                     for (int ui : {s.ua, s.ub})
                         if (ui >= 0) { const Step& u = E.steps[ui]; wr.push_back(u.gn_w); wr.push_back(u.gn_b); wr.push_back(u.b); wr.push_back(u.w); }
                     E.bwd_writes.push_back(wr);
+                    E.bwd_sub.push_back((unit_sub(s.ua) && (s.ub < 0 || unit_sub(s.ub))) ? 1 : 0);
                     E.bwd_ops.push_back([this_ = &E, si, gl](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& s = E.steps[si];
@@ -1049,7 +1139,7 @@ struct Planner {
                             f.Q = (double*)(E.ws + u.Q); f.stats = (double*)(E.ws + u.stats);
                             f.gamma = E.p + E.params[u.gn_w].off;
                             f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                                     : (const float*)(E.ws + E.off_masks) + (size_t)u.mask_slot * E.N * E.ld_mask();
+                                     : E.mask_base(u.mask_slot);
                             f.mask_ld = E.ld_mask();
                             f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
                             f.dgamma = E.g + E.params[u.gn_w].off; f.dbeta = E.g + E.params[u.gn_b].off;
@@ -1075,6 +1165,7 @@ struct Planner {
                     ua.draw = new_grad(ua.raw);
                     ub.draw = new_grad(ub.raw);
                     E.bwd_writes.push_back({ua.gn_w, ua.gn_b, ua.b, ub.gn_w, ub.gn_b, ub.b});
+                    E.bwd_sub.push_back((unit_sub(s.ua) && unit_sub(s.ub)) ? 1 : 0);
                     E.bwd_ops.push_back([this_ = &E, uia = s.ua, uib = s.ub, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
                         GnBwdArgs a, b;
@@ -1099,6 +1190,7 @@ struct Planner {
                     Step& u = E.steps[ui];
                     u.draw = new_grad(u.raw);
                     E.bwd_writes.push_back({u.gn_w, u.gn_b, u.b});      // gamma/beta and (analytically) the conv bias
+                    E.bwd_sub.push_back(unit_sub(ui) ? 1 : 0);
                     E.bwd_ops.push_back([this_ = &E, ui, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& u = E.steps[ui];
@@ -1140,6 +1232,7 @@ struct Planner {
                 if (need_dg0) { g0 = new_grad(s.in0); E.tens[s.in0].grads.push_back(g0); }
                 if (s.in1 >= 0) { g1 = new_grad(s.in1); E.tens[s.in1].grads.push_back(g1); }
                 E.bwd_writes.push_back({s.w, s.gn_w < 0 ? s.b : -1});
+                E.bwd_sub.push_back(unit_sub((int)si) ? 1 : 0);
                 if (s.ck != CK_STEM3 && s.ck != CK_STEM1) ++E.n_deferred;
                 E.bwd_ops.push_back([this_ = &E, si, draw, g0, g1](hipStream_t st) {
                     seg_engine& E = *this_;
@@ -1269,6 +1362,40 @@ struct Planner {
                 });
             }
         }
+        // ---- chains of finest-level ops that run group of samples by group of samples (seg_engine::run_chain)
+        {
+            double mb = E.sub_mb;
+            if (mb < 0.0) mb = SEG_SUB_MB_DEFAULT;
+            E.sub_nb = 0;
+            const double per_sample_mb = (double)E.vol(0) * 16.0 * (double)E.esz() / 1e6;          // one 16-channel finest-level tensor
+            if (mb > 0.0 && !E.use_vact && N > 1) {
+                int nb = (int)(mb / per_sample_mb);
+                if (nb < 1) nb = 1;
+                while (nb > 1 && N % nb) --nb;                    // equal groups only (a unit's replica count is remembered per launch)
+                if (nb < N) E.sub_nb = nb;
+            }
+            auto runs = [](const std::vector<char>& ok, std::vector<std::pair<int, int>>& out) {
+                for (int i = 0; i < (int)ok.size();) {
+                    if (!ok[i]) { ++i; continue; }
+                    int j = i;
+                    while (j < (int)ok.size() && ok[j]) ++j;
+                    out.push_back({i, j});
+                    i = j;
+                }
+            };
+            std::vector<char> fok(E.fwd_ops.size(), 0);           // fwd_ops[0] = fill + ingest, fwd_ops[1 + si] = step si
+            for (size_t si = 0; si < E.steps.size(); ++si) {
+                const Step& s = E.steps[si];
+                bool ok;
+                if (s.type == ST_UNIT) ok = unit_sub((int)si);
+                else if (s.type == ST_ACT) ok = unit_sub(s.ua) && (s.ub < 0 || unit_sub(s.ub));
+                else if (s.type == ST_POOL) ok = E.tens[s.in].lvl <= E.sub_lvl;
+                else ok = true;
+                fok[1 + si] = ok ? 1 : 0;
+            }
+            runs(fok, E.fwd_chains);
+            runs(E.bwd_sub, E.bwd_chains);
+        }
         E.ws_bytes = align_up(cur, 4096);
         E.planned = true;
         (void)dt;
@@ -1314,6 +1441,8 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
     if (getenv("SEG_WGRAD_STREAMS")) e->n_side = atoi(getenv("SEG_WGRAD_STREAMS")) >= 2 ? 2 : 1;
     if (getenv("SEG_FORK_BATCH") && atoi(getenv("SEG_FORK_BATCH")) > 0) e->fork_batch = atoi(getenv("SEG_FORK_BATCH"));
+    if (getenv("SEG_SUB_MB")) e->sub_mb = atof(getenv("SEG_SUB_MB"));
+    if (getenv("SEG_SUB_LVL")) e->sub_lvl = atoi(getenv("SEG_SUB_LVL"));
     Builder b(*e);
     if (net_kind == SEG_NET_VNET) b.build_vnet(); else b.build_unet();
     *out = e;
@@ -1377,7 +1506,7 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
     if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }
     if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->drop_graph();
-    h->N = n; h->D = d; h->H = hgt; h->W = wid;
+    h->N = n; h->Nplan = n; h->D = d; h->H = hgt; h->W = wid;
     g_err.clear();
     Planner pl(*h);
     pl.plan();
@@ -1389,6 +1518,12 @@ int seg_plan_count(seg_handle h, int what) {
     if (!h || !h->planned) return -1;
     if (what == 2) return h->n_event_forks;             // last backward pass: fork events recorded on the main stream
     if (what == 3) return h->n_flag_waits;              // last backward pass: weight gradients released by a completion flag (SEG_FORK_FLAG)
+    if (what == 4) return h->sub_nb;                    // samples per group of the sub-batched finest level (0: whole-batch launches)
+    if (what == 5 || what == 6) {                       // forward / backward ops that run group by group
+        int n = 0;
+        for (auto& c : (what == 5 ? h->fwd_chains : h->bwd_chains)) n += c.second - c.first;
+        return n;
+    }
     int n = 0;
     for (auto& s : h->steps) {
         if (what == 0) n += s.type == ST_ACT && s.vact;                                   // activations applied by their consumer (never written)
@@ -1466,7 +1601,7 @@ int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks,
         ++h->draws;
     }
     h->cur_x = x; h->cur_logits = logits; h->cur_probs = probs;
-    for (auto& op : h->fwd_ops) op(st);
+    h->run_ops(h->fwd_ops, h->fwd_chains, 0, (int)h->fwd_ops.size(), st, false);
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_forward: ") + hipGetErrorString(hipGetLastError()));
 }
 
@@ -1497,7 +1632,7 @@ static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, in
     h->cur_dlogits = dlogits;
     if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; ++h->sig_seq; h->n_event_forks = 0; h->n_flag_waits = 0; }
     if (h->pack_bwd_pending) { (void)hipStreamWaitEvent(st, h->pack_done, 0); h->pack_bwd_pending = false; }
-    for (int i = op_begin; i < op_end; ++i) { h->bwd_ops[i](st); h->maybe_flush(st); }
+    h->run_ops(h->bwd_ops, h->bwd_chains, op_begin, op_end, st, true);
     if (join) h->join_side(st);
     else h->flush_side(st);          // the queued weight gradients of this slice are released; `stream` does not wait for them
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));

@@ -385,6 +385,36 @@ def test_virtual_head_gradient_equals_materialised(dev, tag, monkeypatch):
         assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-5) * float(g1[k].norm()) + 1e-12, k
 
 
+@pytest.mark.parametrize("tag,dtype,mb", [("vnet2d_s", "f32", 0.005), ("unet2d", "f32", 0.04), ("vnet2d", "f16", 0.04),
+                                          pytest.param("vnet3d_48", "f16", 4.0, marks=pytest.mark.gpu),
+                                          pytest.param("unet3d_32", "bf16", 1.1, marks=pytest.mark.gpu)])
+def test_sub_batched_finest_level_equals_whole_batch_launches(dev, tag, dtype, mb, monkeypatch):
+    """SEG_SUB_MB (seg_engine::run_chain): the finest-level op chains (decoder top, input block, and their backward twins) run group of samples
+    by group of samples so that a consumer finds its producer's output in the memory-side cache; GroupNorm statistics and dropout masks are per
+    sample (networks/VNet3d.py:9, 13-15), so every value is computed by the same arithmetic on the same data.  Logits, loss and every gradient
+    must equal the whole-batch launches: bit for bit on the sequential host checker for logits / loss (each statistic is one sample's sum in both
+    modes), to accumulation order for the parameter gradients (the per-group launches add their gamma / beta / bias / head partial sums one after
+    the other).  `mb` picks one- or two-sample groups for the case's volume."""
+    if dtype != "f32" and tag != "vnet2d":
+        conftest.checker_slow(dev, "two 16-bit forward+backward passes on the host checker")
+    res, groups = [], []
+    for sub in ("0", str(mb)):
+        monkeypatch.setenv("SEG_SUB_MB", sub)
+        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
+        run_engine(e, x, y, masks, alpha, loss, dev)              # twice: the second pass starts from the buffers the first one left
+        res.append(run_engine(e, x, y, masks, alpha, loss, dev))
+        groups.append((e.lib.seg_plan_count(e.h, 4), e.lib.seg_plan_count(e.h, 5), e.lib.seg_plan_count(e.h, 6)))
+        del e
+    (l0, p0, o0, g0), (l1, p1, o1, g1) = res
+    n = CASES[tag][2][0]
+    assert groups[0][0] == 0 and 1 <= groups[1][0] < n and groups[1][1] >= 4 and groups[1][2] >= 4, groups
+    exact = dev.type == "cpu"
+    assert float((l0 - l1).abs().max()) <= (0.0 if exact else 2e-3 * max(1.0, float(l0.abs().max())))
+    assert abs(float(o0[0]) - float(o1[0])) <= (0.0 if exact else 1e-5)
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-3) * float(g0[k].norm()) + 1e-12, k
+
+
 @pytest.mark.parametrize("tag", ["vnet2d_s", "unet2d"])
 def test_flag_signalled_forks_equal_event_forks(dev, tag, monkeypatch):
     """SEG_FORK_FLAG=1 (experiment, default off): a weight gradient whose d(raw) comes out of a gn_bwd_apply launch waits on the flag that
