@@ -734,8 +734,33 @@ void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long lon
     hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, a.nb, sP, sQ, qreal);
 }
 
+// 16 -> 16 channels on a large volume (the finest level of the 3-D nets: the longest single launch of the step, 313 us for 226 MB at 4 x 96^3,
+// profiles/r03_rocprofv3_kernel_stats.txt): a 4 x 8 x 16 box.  The kernel is latency-bound (one box in flight per workgroup), so what counts is
+// bytes per round trip and barriers per voxel: 50 KB instead of 23 KB per trip, 2.7x fewer barrier pairs per voxel, and the halo re-read of x
+// drops from 2.8x to 2.1x (PMC round 3: 349 MB fetched for 226 MB algorithmic).  50.5 KB of LDS; 16-bit tensors only (an f32 box would need 127 KB).
+template <class T> struct Wgrad3Big16 {
+    static bool launch(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
+        const char* env = getenv("SEG_W3_BOX16");          // 0: off; 1 (default): where the volume holds enough boxes; 2: wherever the shape fits (tests)
+        const int on = env ? atoi(env) : 1;
+        if (!on || a0.P != 16 || a0.Q != 16 || a0.xsc || !wide_box(a0.W)) return false;
+        const long long nbox = num_boxes<4, 8, 16>(a0.N, a0.D, a0.H, a0.W);
+        if (on < 2 && nbox < 6ll * a0.nb) return false;    // small volumes keep the 3 x 4 x 16 box (enough boxes per workgroup to amortise its partial tile)
+        Wgrad3Args a = a0;
+        if (a.nb > nbox) a.nb = (int)nbox;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3_kernel<T, 4, 8, 16, 3, 16, 16>), dim3(a.nb, 1), dim3(256), 0, s, a);
+        const long long total = 16ll * 16 * 27;
+        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total + 255) / 256), (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, 16, 16, 27,
+                           a.nb, sP, sQ, qreal);
+        return true;
+    }
+};
+template <> struct Wgrad3Big16<float> {
+    static bool launch(const Wgrad3Args&, float*, long long, long long, hipStream_t, int) { return false; }
+};
+
 template <class T>
 void wgrad3_dispatch(const Wgrad3Args& a, int ndim, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
+    if (ndim == 3 && Wgrad3Big16<T>::launch(a, dw, sP, sQ, s, qreal)) return;
     if (ndim == 3) {
         if (wide_box(a.W)) wgrad3_launch_shape<T, 3, 4, 16, 3>(a, dw, sP, sQ, s, qreal);
         else wgrad3_launch_shape<T, 3, 8, 8, 3>(a, dw, sP, sQ, s, qreal);

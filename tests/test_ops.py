@@ -268,6 +268,24 @@ def test_wgrad3_halo_exact(dev, dtype, case, wgrad3_impl):
 
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("sp,N", [((4, 8, 16), 1), ((9, 11, 32), 2), ((8, 16, 12), 1)])
+def test_wgrad3_big_box_16_channels_exact(dev, dtype, sp, N, monkeypatch):
+    """the 4 x 8 x 16-box instantiation of wgrad3_kernel that serves the 16 -> 16 channel convs of the finest level (Wgrad3Big16, conv3.hip; autograd of
+    networks/VNet3d.py:8 at 96^3): whole boxes, ragged boxes on every axis, the 12-wide row of the deep levels; SEG_W3_BOX16=2 forces it
+    onto these small volumes."""
+    monkeypatch.setenv("SEG_WGRAD3X", "0")
+    monkeypatch.setenv("SEG_W3_BOX16", "2")
+    g = torch.Generator().manual_seed(sum(sp) + N)
+    x = ints((N, 16) + sp, -2, 2, g)
+    w = torch.zeros((16, 16, 3, 3, 3), requires_grad=True)
+    y = F.conv3d(x, w, padding=1)
+    dy = ints(tuple(y.shape), -2, 2, g)
+    y.backward(dy)
+    got = ops.wgrad3(to_dev(cl(dy), dtype, dev), to_dev(cl(x), dtype, dev), dtype, 3)
+    assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", [(3, 1, (3, 8, 16), [16, 16], 16), (3, 2, (4, 6, 8), [32, 32], 32), (2, 1, (8, 16), [64, 64], 64),
                                   (3, 1, (7, 9, 17), [32, 32], 64), (2, 2, (11, 13), [16, 16], 32)])

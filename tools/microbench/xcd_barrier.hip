@@ -1,0 +1,110 @@
+// How much does a barrier among the workgroups of ONE XCD cost on MI355X?  (VERDICT r03 task 3: the deep 12^3 / 6^3 levels of VNet3d are
+// ~60 launches at the 5-20 us launch floor; a persistent per-sample chain needs a cross-workgroup barrier that is cheaper than a launch.
+// The guide's 4.1-7.2 us figure is a WHOLE-DEVICE barrier: device-scope release = L2 write-back on this multi-XCD part.)
+//
+// 256 workgroups are launched (one per CU); hardware dispatch deals consecutive workgroups round-robin over the 8 XCDs, so the NP workgroups with
+// blockIdx % 8 == x share XCD x and its L2 (checked: every participant records HW_REG_XCC_ID).  The participants of XCD 0 run R rounds of
+//   mode 0  barrier only: one L2 atomic add (no sc1: executed in the XCD's own L2), then poll with L2 atomics until all NP arrived
+//   mode 1  + every workgroup first publishes a 2 KB piece of a 64 KB tile with plain stores (write-through to L2, s_waitcnt vmcnt(0)) and after the
+//           barrier reads its neighbour's piece with sc1 loads (served by the same L2), checking the round stamp
+//   mode 2  same traffic, but the textbook device-scope version: __threadfence() + agent-scope atomics (what a whole-device barrier pays)
+// and the host measures, for reference, a chain of empty dependent kernel launches on one stream (the cost the barrier has to beat).
+// Build: hipcc --offload-arch=gfx950 -O2 xcd_barrier.hip -o xcd_barrier
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+struct Args { int* ctr; int* tile; int* xcc; long long* cycles; int* errors; int np, rounds, mode, stride; };
+
+__device__ __forceinline__ int l2_add(int* p, int v) {          // L2 atomic of this XCD (workgroup scope: no sc1, not sent to memory)
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int dev_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int load_sc1(const int* p) {          // bypass the CU's vector cache, hit the XCD's L2
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(256) void barrier_kernel(Args a) {
+    const int who = blockIdx.x / a.stride;
+    if (blockIdx.x % a.stride != 0 || who >= a.np) return;
+    if (threadIdx.x == 0) a.xcc[who] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;      // HW_REG_XCC_ID[3:0]
+    __syncthreads();
+    __shared__ int bail;
+    if (threadIdx.x == 0) bail = 0;
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    int bad = 0;
+    for (int r = 1; r <= a.rounds; ++r) {
+        if (a.mode >= 1) {
+            // 2 KB per workgroup = 512 ints: threads 0..255 write two ints each, stamped with the round
+            int* mine = a.tile + who * 512;
+            mine[threadIdx.x] = r; mine[256 + threadIdx.x] = r;
+            if (a.mode == 2) __threadfence();
+            else __builtin_amdgcn_s_waitcnt(0);                  // stores acknowledged by L2
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int spins = 0;                                       // bounded: a participant that never shows up must not hang the GPU box
+            if (a.mode == 2) { dev_add(a.ctr, 1); while (dev_add(a.ctr, 0) < r * a.np && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1); }
+            else { l2_add(a.ctr, 1); while (l2_add(a.ctr, 0) < r * a.np && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1); }
+            if (spins >= (1 << 20)) { atomicAdd(a.errors, 1 << 20); bail = 1; }
+        }
+        __syncthreads();
+        if (bail) break;
+        if (a.mode >= 1) {
+            const int* other = a.tile + ((who + 1) % a.np) * 512;
+            int v;
+            if (a.mode == 2) { __threadfence(); v = __hip_atomic_load(other + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else v = load_sc1(other + threadIdx.x);
+            bad += (v != r);
+        }
+    }
+    const long long t1 = wall_clock64();
+    if (bad) atomicAdd(a.errors, bad);
+    if (threadIdx.x == 0) a.cycles[who] = t1 - t0;
+}
+
+__global__ void empty_kernel(int* p) { if (p[0] == 123456789) p[1] = 1; }
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 2000;
+    int *ctr, *tile, *xcc, *errors; long long* cycles;
+    hipMalloc(&ctr, 256); hipMalloc(&tile, 64 * 512 * 4); hipMalloc(&xcc, 64 * 4); hipMalloc(&errors, 4); hipMalloc(&cycles, 64 * 8);
+    int wall_khz = 100000;                                         // wall_clock64 ticks at 100 MHz on gfx9
+    hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+    hipStream_t st; hipStreamCreate(&st);
+    for (int np : {8, 16, 32}) {
+        for (int stride : {8, 1}) {                                // 8: participants on ONE XCD; 1: the same count spread over all XCDs (device-scope only)
+            for (int mode = 0; mode < 3; ++mode) {
+                if (stride == 1 && mode != 2) continue;            // L2-local atomics are only a barrier inside one XCD
+                hipMemsetAsync(ctr, 0, 256, st); hipMemsetAsync(errors, 0, 4, st); hipMemsetAsync(tile, 0, 64 * 512 * 4, st);
+                Args a{ctr, tile, xcc, cycles, errors, np, rounds, mode, stride};
+                hipLaunchKernelGGL(barrier_kernel, dim3(256), dim3(256), 0, st, a);
+                if (hipStreamSynchronize(st) != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+                std::vector<int> hx(64); std::vector<long long> hc(64); int herr = 0;
+                hipMemcpy(hx.data(), xcc, 64 * 4, hipMemcpyDeviceToHost); hipMemcpy(hc.data(), cycles, 64 * 8, hipMemcpyDeviceToHost);
+                hipMemcpy(&herr, errors, 4, hipMemcpyDeviceToHost);
+                int same = 1; long long mx = 0;
+                for (int i = 0; i < np; ++i) { same &= hx[i] == hx[0]; if (hc[i] > mx) mx = hc[i]; }
+                printf("np %2d %s mode %d (%s): %.3f us per round, participants on one XCD: %s (xcc of the first = %d), stale reads %d\n", np,
+                       stride == 8 ? "one-XCD " : "all-XCDs", mode,
+                       mode == 0 ? "L2 atomics, barrier only" : mode == 1 ? "L2 atomics + 2 KB/WG tile, sc1 reads" : "device scope: threadfence + agent atomics + tile",
+                       (double)mx / rounds / (wall_khz * 1e-3), same ? "yes" : "NO", hx[0], herr);
+            }
+        }
+    }
+    // reference: dependent empty launches on one stream
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, st);
+        for (int i = 0; i < 400; ++i) hipLaunchKernelGGL(empty_kernel, dim3(32), dim3(256), 0, st, ctr);
+        hipEventRecord(e1, st);
+        hipStreamSynchronize(st);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        if (rep) printf("reference: %.3f us per dependent 32-workgroup launch on one stream\n", ms * 1000.f / 400);
+    }
+    return 0;
+}
