@@ -78,9 +78,9 @@ int seg_set_dropout_draws(seg_handle h, long long draws);
 int seg_plan(seg_handle h, int n, int d, int hgt, int wid);
 long long seg_workspace_bytes(seg_handle h);
 /* what the planner decided for the current shape (tests / diagnostics): what = 0: activations applied by their consuming convolution instead
- * of an elementwise launch (the activated tensor is never written), 1: convolution units, 2 / 3: of the last backward pass, the fork events
- * recorded on the caller's stream / the weight gradients released by a completion flag instead (SEG_FORK_FLAG=1, experimental).
- * <0: not planned / unknown `what`. */
+ * of an elementwise launch (the activated tensor is never written), 1: convolution units, 2: fork events the last backward pass recorded on the
+ * caller's stream (3: always 0 since round 4), 4: samples per group of the sub-batched finest level (0 = whole-batch launches; SEG_SUB_MB),
+ * 5 / 6: forward / backward ops that run group by group.  <0: not planned / unknown `what`. */
 int seg_plan_count(seg_handle h, int what);
 
 /* Bind caller-owned buffers: flat fp32 params / grads (seg_param_numel floats each) + workspace. */
@@ -402,7 +402,8 @@ enum {
     SEG_K_HEAD = 8,
     SEG_K_CONV3_SB = 9,       /* every other halo-tile conv (16-channel top level, deep levels) */
     SEG_K_GN_GROUP = 10,      /* one-launch GroupNorm passes of the small tensors (forward and backward) */
-    SEG_K_COUNT = 11
+    SEG_K_MISC = 11,          /* everything else of a train step: fill + ingest, loss reduce / finalize / backward, fused optimiser, weight re-pack */
+    SEG_K_COUNT = 12
 };
 int seg_profile_enable(seg_handle h, unsigned mask);
 int seg_profile_read(seg_handle h, int* calls, float* ms, double* bytes, double* flops);

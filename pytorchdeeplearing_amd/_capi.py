@@ -27,7 +27,7 @@ MASKS_EVAL, MASKS_GIVEN, MASKS_RANDOM = 0, 1, 2
 def label_type(t, binarize=False):
     """C-ABI label type of a target tensor (+ the device-side binarise flag)"""
     return LABEL_TYPES[str(t.dtype)] | (LABEL_BINARIZE if binarize else 0)
-KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head", "conv3_smallbox", "gn_group"]
+KERNEL_CLASSES = ["conv3", "wgrad3", "conv_generic", "wgrad_generic", "stem", "gn_act", "gn_bwd_reduce", "gn_bwd_apply", "head", "conv3_smallbox", "gn_group", "misc"]
 
 _vp, _i, _ll, _f, _d = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
 

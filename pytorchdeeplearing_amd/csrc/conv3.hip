@@ -493,13 +493,32 @@ void conv3_dispatch(const Conv3Args& a, int ndim, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------
+// (p-tile, q-tile) widths of the halo weight gradient.  Round 4: the q-tile is 16 channels wherever the tensors are 16-bit - the 32 x 32 tile keeps
+// 112 accumulator registers per lane next to 48 prefetch registers, which left no room to pipeline the LDS reads (every variant of the pipelined
+// sweep spilled: the compiler's reloads sat between the prefetch loads and serialised them); 32 x 16 needs 56, reads its B fragments a whole K
+// step ahead, writes partial tiles half the size (the reduce pass re-reads half as much) and its 44 KB of LDS / 184 registers leave a halo-conv
+// workgroup of the main stream room on the same CU.  SEG_W3_CQ=32 restores the wide tile.
+inline void wgrad3_tile(int P, int Q, int esz, int* CP, int* CQ) {
+    static const int cq = getenv("SEG_W3_CQ") ? atoi(getenv("SEG_W3_CQ")) : 16;
+    *CP = P >= 32 ? 32 : 16;
+    *CQ = (Q >= 32 && (cq >= 32 || esz == 4)) ? 32 : 16;
+}
+
 struct Wgrad3Args {
     const void* x1; int C0;      // optional second concat source of x
     const void* dr; const void* x; float* partial;
     int N, D, H, W, P, Q;       // channel counts of dr / x
     int nb;                     // workgroups per (p-tile, q-tile) combo
     const float* xsc; const float* xsh;   // [N][Q] or null: x is a RAW conv output, activated while it is staged (stage_halo)
+#ifdef SEG_W3_TRACE
+    unsigned long long* trace;            // diagnostic build (tools/build_variant.py ... -DSEG_W3_TRACE): 8 phase sums per workgroup
+#endif
 };
+#ifdef SEG_W3_TRACE
+#define SEG_W3T(k) do { const unsigned long long t_ = wall_clock64(); ph[k] += t_ - tl; tl = t_; } while (0)
+#else
+#define SEG_W3T(k)
+#endif
 
 template <class T, int C> struct WLd { static constexpr int v = C == 32 ? 48 : 16; };   // 96 B / 32 B rows: conflict-free tr reads
 template <int C> struct WLd<float, C> { static constexpr int v = C + 4; };
@@ -525,8 +544,15 @@ template <int LD> struct TrFrag<float, LD> {
     }
 };
 
+// two waves per SIMD as the register budget whatever the LDS footprint says (above 80 KB of LDS the compiler would otherwise plan for ONE
+// resident workgroup and take 290+ registers: nothing of the main stream's halo convs - 256 registers per wave - fits beside that on a SIMD)
+#ifndef SEG_EMU
+#define SEG_W3_WAVES __attribute__((amdgpu_waves_per_eu(2)))
+#else
+#define SEG_W3_WAVES
+#endif
 template <class T, int TD, int TH, int TW, int KD, int CP, int CQ>
-__global__ __launch_bounds__(256, SEG_W3_OCC) void wgrad3_kernel(Wgrad3Args a) {
+__global__ __launch_bounds__(256, SEG_W3_OCC) SEG_W3_WAVES void wgrad3_kernel(Wgrad3Args a) {
     typedef Box<TD, TH, TW, KD> B;
     constexpr int DLD = WLd<T, CP>::v, XLD = WLd<T, CQ>::v;
     constexpr int PT = CP / 16, QT = CQ / 16;
@@ -551,8 +577,82 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) void wgrad3_kernel(Wgrad3Args a) {
 #pragma unroll
             for (int j = 0; j < QT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one K sweep over the box whose tiles sit in LDS
+    // ---- 16-bit tensors: software-pipelined sweep.  Reading the ISA of the first version (round 4, /tmp listing of wgrad3_kernel<f16,...,16,16>):
+    // the per-tap `if (tap < NTAP)` was a divergent branch (the wave index lived in a VGPR), and inside it the compiler emitted
+    // ds_read x2 -> s_waitcnt lgkmcnt(0) -> v_mfma: one exposed LDS round trip (~100+ clk) per tap with ONE wave per SIMD and nothing to cover
+    // it - 7 taps x 6 K steps x ~130 clk = 2.3 us per 192-voxel box, which is what the kernel measured (3 us per box, 220 us at 4 x 96^3; a
+    // 2.7x larger box changed nothing: 219 vs 221 us standalone, profiles/r04_session_a.log).  Now: the wave index is a scalar
+    // (readfirstlane), every wave runs NTW taps branch-free (the 28th "tap" of the fourth wave re-reads tap 26 into an accumulator that is
+    // never stored), and the B fragments travel W items ahead of the MFMAs that use them (W = all taps of a K step for the narrow tiles,
+    // 2 for 32 x 32 where one item is 4 MFMAs = 64 clk), the A fragments one K step ahead.
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    int toff[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tap = wvs + 4 * t;
+        toff[t] = B::tap_off(tap < B::NTAP ? tap : B::NTAP - 1) * XLD;
+    }
+    // `hook(m)` runs in front of item m = (K step, tap): the prefetch path issues the global loads of the NEXT box there, one piece every few
+    // items.  Round 4 phase trace (tools/trace_wgrad3.py, profiles/r04_wgrad3_phase_trace.log): with all loads of a box issued in one burst in
+    // front of the sweep, a workgroup spent 111 - 157 us of a 220 us launch (16 channels, 4 x 96^3) blocked in that burst - the CU's address /
+    // miss queues fill after a few KB and the wave stalls in order until data returns - and 70 us in the sweep, the two strictly one after the
+    // other: the memory pipe idled during every sweep and the matrix cores during every burst.
+    auto sweep16 = [&](auto&& hook) {
+        if constexpr (sizeof(T) == 2) {
+            typedef typename Mma<T>::frag Frag;
+            constexpr int KS = B::V / 32;
+            constexpr int W = (PT * QT >= 4) ? 2 : NTW;            // B-fragment look-ahead, in (K step, tap) items
+            static_assert(W <= NTW, "pipeline shape");
+            Frag afk[2][PT], bfw[W][QT];
+            int dc[2], xc[2];
+            auto krows = [&](int ks, int (&d)[2], int (&x)[2]) {
+                int lr = 4 * q + (l15 >> 2);
+                settle(lr);                                        // opaque: KS x 4 row offsets hoisted out of the box loop cost more registers than ~10 VALU per K step
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {                      // slot j covers rows 16j + 4q + (l15 >> 2) of the 32-voxel K step
+                    const int v = ks * 32 + 16 * j + lr;
+                    d[j] = v * DLD;
+                    x[j] = B::halo_base(v) * XLD;
+                }
+            };
+            auto ldA = [&](const int (&d)[2], Frag (&o)[PT]) {
+#pragma unroll
+                for (int i = 0; i < PT; ++i) o[i] = TrFrag<T, DLD>::load(Ds, d, i * 16, lane);
+            };
+            auto ldB = [&](int t, const int (&x)[2], Frag (&o)[QT]) {
+#pragma unroll
+                for (int j = 0; j < QT; ++j) o[j] = TrFrag<T, XLD>::load(Xs + toff[t], x, j * 16, lane);
+            };
+            krows(0, dc, xc);
+            ldA(dc, afk[0]);
+#pragma unroll
+            for (int w = 0; w < W; ++w) ldB(w, xc, bfw[w]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {                      // fully unrolled: every register index below is a constant
+                int dn[2], xn[2];
+                krows(ks + 1 < KS ? ks + 1 : 0, dn, xn);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const int m = ks * NTW + t;
+                    if (t == 0 && ks + 1 < KS) ldA(dn, afk[(ks + 1) & 1]);      // the A fragments of the following K step start travelling
+                    hook(m);
+#pragma unroll
+                    for (int j = 0; j < QT; ++j)
+#pragma unroll
+                        for (int i = 0; i < PT; ++i) acc[t][i][j] = Mma<T>::run(afk[ks & 1][i], bfw[m % W][j], acc[t][i][j]);
+                    const int mn = m + W;                          // the item that takes over the slot
+                    if (mn < KS * NTW) {
+                        if (mn / NTW == ks) ldB(mn % NTW, xc, bfw[m % W]);
+                        else ldB(mn % NTW, xn, bfw[m % W]);
+                    }
+                }
+                xc[0] = xn[0]; xc[1] = xn[1];
+            }
+        }
+    };
+    // one K sweep over the box whose tiles sit in LDS (f32 tensors)
     auto sweep = [&]() {
+        if constexpr (sizeof(T) == 2) { sweep16([](int) {}); return; }
 #pragma unroll 1
         for (int ks = 0; ks < B::V / 32; ++ks) {
             int drow[NR], xrow[NR];
@@ -593,50 +693,87 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) void wgrad3_kernel(Wgrad3Args a) {
         const T* x1 = (const T*)a.x1;
         const int C0 = x1 ? a.C0 : a.Q;
         vec<T, 8> dv[DN], xv[XN];
-        auto issue = [&](long long b) {
-            const BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
+        unsigned dok = 0u, xok = 0u;                      // bit u: piece u holds data (else zeros go to LDS)
+        // Branch-free: every piece is loaded from a valid address (voxel 0 where the piece lies outside the volume or past the tile) and zeroed on
+        // its way into LDS.  The first version wrapped each load in `if (inside)`: hipcc put an s_waitcnt vmcnt(0) at the end of every such block
+        // (the destination is live across the join), so the 7 - 12 "prefetch" loads of a box were 7 - 12 serial HBM round trips.
+        // The box-independent part of a piece's address is ONE packed register (z, y, x inside the box / halo; -1 past the tile), made opaque at
+        // its use: left alone the compiler hoists the unpacked coordinates out of the box loop and pays for them in registers.
+        constexpr int NP = DN + XN, NI = (B::V / 32) * NTW;
+        static_assert(NP <= NI, "one piece per item at most");
+        const int c8d = tid % CPV, c8x = tid % CQV;        // 256 % CPV == 0: the channel piece of a thread is the same for every u
+        int pkd[NP];
 #pragma unroll
-            for (int u = 0; u < DN; ++u) {
-                const int i = u * 256 + tid;
-                const int v = i / CPV, c8 = i % CPV;
-                const int xx = bp.x0 + v % TW, yy = bp.y0 + (v / TW) % TH, zz = bp.z0 + v / (TW * TH);
-                dv[u] = zero8<T>();
-                if (i < B::V * CPV && xx < a.W && yy < a.H && zz < a.D)
-                    dv[u] = load8(dr + ((((long long)bp.n * a.D + zz) * a.H + yy) * a.W + xx) * a.P + p0 + c8 * 8);
-            }
+        for (int u = 0; u < DN; ++u) {
+            const int v = (u * 256 + tid) / CPV;
+            pkd[u] = v < B::V ? ((v / (TW * TH)) << 16) | (((v / TW) % TH) << 8) | (v % TW) : -1;
+        }
 #pragma unroll
-            for (int u = 0; u < XN; ++u) {
-                const int i = u * 256 + tid;
-                const int hv = i / CQV, c8 = i % CQV;
-                const int hx = hv % B::HW, hy = (hv / B::HW) % B::HH, hz = hv / (B::HW * B::HH);
-                const int z = bp.z0 + hz - B::PD, y = bp.y0 + hy - 1, xx = bp.x0 + hx - 1;
-                xv[u] = zero8<T>();
-                if (i < B::HV * CQV && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
-                    const long long vox = (((long long)bp.n * a.D + z) * a.H + y) * a.W + xx;
-                    const int ch = q0 + c8 * 8;
-                    const T* src = ch < C0 ? x + vox * C0 + ch : x1 + vox * (a.Q - C0) + (ch - C0);     // one load, pointer select
-                    xv[u] = load8(src);
-                }
+        for (int u = 0; u < XN; ++u) {
+            const int hv = (u * 256 + tid) / CQV;
+            pkd[DN + u] = hv < B::HV ? ((hv / (B::HW * B::HH)) << 16) | (((hv / B::HW) % B::HH) << 8) | (hv % B::HW) : -1;
+        }
+        const int chx = q0 + c8x * 8;
+        const T* xsrc0 = chx < C0 ? x + chx : x1 + (chx - C0);       // concat: a 16-byte piece never straddles the two sources
+        const int xC = chx < C0 ? C0 : a.Q - C0;
+        const T* dsrc0 = dr + p0 + c8d * 8;
+        BoxPos bpn;
+        auto issue_piece = [&](int pc) {                  // pc is a constant wherever this is called (unrolled)
+            int s_ = pkd[pc];
+            settle(s_);
+            if (pc < DN) {
+                const int zz = bpn.z0 + (s_ >> 16), yy = bpn.y0 + ((s_ >> 8) & 255), xx = bpn.x0 + (s_ & 255);
+                const bool ok = s_ >= 0 && xx < a.W && yy < a.H && zz < a.D;
+                const long long vox = ok ? (long long)((bpn.n * a.D + zz) * a.H + yy) * a.W + xx : 0;       // (n, z, y) rows fit an int
+                dok = ok ? (dok | (1u << pc)) : (dok & ~(1u << pc));
+                dv[pc < DN ? pc : 0] = load8(dsrc0 + vox * a.P);
+            } else {
+                const int u = pc - DN;
+                const int z = bpn.z0 + (s_ >> 16) - B::PD, y = bpn.y0 + ((s_ >> 8) & 255) - 1, xx = bpn.x0 + (s_ & 255) - 1;
+                const bool ok = s_ >= 0 && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+                const long long vox = ok ? (long long)((bpn.n * a.D + z) * a.H + y) * a.W + xx : 0;
+                xok = ok ? (xok | (1u << u)) : (xok & ~(1u << u));
+                xv[u >= 0 ? u : 0] = load8(xsrc0 + vox * xC);
             }
         };
         long long b = blockIdx.x;
-        if (b < nbox) issue(b);
+#ifdef SEG_W3_TRACE
+        unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = wall_clock64();
+#endif
+        if (b < nbox) {
+            bpn = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) issue_piece(pc);
+        }
+        SEG_W3T(5);
         for (; b < nbox; b += gridDim.x) {
             __syncthreads();                              // previous box fully consumed
+            SEG_W3T(0);
 #pragma unroll
             for (int u = 0; u < DN; ++u) {
                 const int i = u * 256 + tid;
-                if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], dv[u]);
+                if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], ((dok >> u) & 1u) ? dv[u] : zero8<T>());
             }
 #pragma unroll
             for (int u = 0; u < XN; ++u) {
                 const int i = u * 256 + tid;
-                if (i < B::HV * CQV) store8(&Xs[(i / CQV) * XLD + (i % CQV) * 8], xv[u]);
+                if (i < B::HV * CQV) store8(&Xs[(i / CQV) * XLD + (i % CQV) * 8], ((xok >> u) & 1u) ? xv[u] : zero8<T>());
             }
+            SEG_W3T(1);
             __syncthreads();
-            if (b + gridDim.x < nbox) issue(b + gridDim.x);
-            sweep();
+            SEG_W3T(2);
+            // the next box (the last trip re-reads its own box: harmless, and the sweep stays branch-free)
+            bpn = box_pos<B, TD, TH, TW>(b + gridDim.x < nbox ? b + gridDim.x : b, a.D, a.H, a.W);
+            sweep16([&](int m) {
+                const int p_lo = (m * NP + NI - 1) / NI, p_hi = ((m + 1) * NP + NI - 1) / NI;       // pieces whose slot floor(p * NI / NP) is this item
+                if (p_hi > p_lo) issue_piece(p_lo);
+            });
+            SEG_W3T(4);
         }
+#ifdef SEG_W3_TRACE
+        if (a.trace && tid == 0)
+            for (int k = 0; k < 8; ++k) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = ph[k];
+#endif
     } else {
         for (long long b = blockIdx.x; b < nbox; b += gridDim.x) {
             const BoxPos bp = box_pos<B, TD, TH, TW>(b, a.D, a.H, a.W);
@@ -718,7 +855,8 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial
 template <class T, int TD, int TH, int TW, int KD>
 void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
     Wgrad3Args a = a0;
-    const int CP = a.P >= 32 ? 32 : 16, CQ = a.Q >= 32 ? 32 : 16;
+    int CP, CQ;
+    wgrad3_tile(a.P, a.Q, (int)sizeof(T), &CP, &CQ);
     const int combos = (a.P / CP) * (a.Q / CQ);
     dim3 grid(a.nb, combos);
 #define SEG_W3(CPv, CQv) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3_kernel<T, TD, TH, TW, KD, CPv, CQv>), grid, dim3(256), 0, s, a)
@@ -1022,8 +1160,9 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
     }
 }
 
-int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) {
-    const int CP = P >= 32 ? 32 : 16, CQ = Q >= 32 ? 32 : 16;
+int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, int esz) {
+    int CP, CQ;
+    wgrad3_tile(P, Q, esz, &CP, &CQ);
     const int combos = (P / CP) * (Q / CQ);
     // tuning knobs.  512 while the kernel exposed its staging latency (r01: 256 / 384 / 768 -> 691 / 694 / 680 vs 700 volumes/s); with the next
     // box prefetched into registers one workgroup per CU is enough and a third fewer partial tiles are written and re-read:
@@ -1052,9 +1191,11 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q) 
 }
 
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) {
+    // sized for the wide (32 x 32) tiling: the 16-channel q-tiles of the 16-bit tensors never need more (twice the combos, at most the same
+    // workgroups per combo, half the tile)
     const int CP = P >= 32 ? 32 : 16, CQ = Q >= 32 ? 32 : 16;
     const int combos = (P / CP) * (Q / CQ);
-    return (size_t)combos * wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q) * CP * (ndim == 3 ? 27 : 9) * CQ * sizeof(float);
+    return (size_t)combos * wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q, 4) * CP * (ndim == 3 ? 27 : 9) * CQ * sizeof(float);
 }
 
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
@@ -1093,11 +1234,36 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
     a.x1 = x1; a.C0 = C0;
     a.dr = dr; a.x = x; a.partial = partial;
     a.N = N; a.D = D; a.H = H; a.W = W; a.P = P; a.Q = Q;
-    a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q);
+    a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q, dtype == DT_F32 ? 4 : 2);
     a.xsc = xscale; a.xsh = xshift;
+#ifdef SEG_W3_TRACE
+    static unsigned long long* tbuf = nullptr;
+    const size_t tmax = 8192;
+    if (!tbuf) (void)hipMalloc(&tbuf, tmax * 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(tbuf, 0, tmax * 8 * sizeof(unsigned long long), s);
+    a.trace = tbuf;
+#endif
     if (dtype == DT_F32) wgrad3_dispatch<float>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
     else if (dtype == DT_F16) wgrad3_dispatch<f16>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
     else wgrad3_dispatch<bf16>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
+#ifdef SEG_W3_TRACE
+    {
+        (void)hipStreamSynchronize(s);
+        std::vector<unsigned long long> h(tmax * 8);
+        (void)hipMemcpy(h.data(), tbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        size_t n = 0;
+        for (size_t i = 0; i < tmax; ++i) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < 8; ++k) tot += h[i * 8 + k];
+            if (!tot) continue;
+            ++n;
+            for (int k = 0; k < 8; ++k) ph[k] += (double)h[i * 8 + k];
+        }
+        if (n) fprintf(stderr, "[wgrad3 trace] P%d Q%d %dx%dx%dx%d wgs=%zu  mean per workgroup (us): first-issue %.2f | barrier1 %.2f  wait+store %.2f  barrier2 %.2f  issue %.2f  sweep %.2f\n",
+                       P, Q, N, D, H, W, n, ph[5] / n * 0.01, ph[0] / n * 0.01, ph[1] / n * 0.01, ph[2] / n * 0.01, ph[3] / n * 0.01, ph[4] / n * 0.01);
+    }
+#endif
 }
 
 }  // namespace seg

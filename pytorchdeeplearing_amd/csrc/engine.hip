@@ -131,16 +131,12 @@ struct seg_engine {
     // Weight-gradient launches are queued and released to the side stream in batches under ONE fork event: every
     // hipEventRecord idles the main stream for ~6 us, and the side stream has slack (it only has to finish before the
     // optimiser), so a fork per weight gradient (35 per step) cost more than it bought.
-    // SEG_FORK_FLAG=1 (experiment, default off): a weight gradient whose d(raw) comes out of a gn_bwd_apply launch waits
-    // for THAT launch through a flag the launch's last workgroup publishes (GnBwdArgs::sig_flag) and a one-wave wait kernel on the
-    // weight-gradient stream - a batch made of such weight gradients only needs no event record on the main stream (5.4 us each,
-    // profiles/r03_fork_cost_microbench.log).  sig = unit (step index) whose apply pass signals, -1 = needs the event.
-    struct Pend { std::function<void(hipStream_t)> f; int sig; };
-    bool fork_flag = false, side_used = false;
-    int n_event_forks = 0, n_flag_waits = 0;            // of the current / last backward pass (seg_plan_count 2 / 3)
-    size_t off_sig = 0;                 // [steps][2] ints in the workspace: {finished-workgroup counter, published sequence number}
-    int sig_seq = 0;                    // sequence number of the current backward pass (per bind)
-    std::vector<int> sig_unit_seq;      // per unit: the sequence number its apply pass publishes in this backward pass (0 = none)
+    // (round 3 built completion-flag forks - gn_bwd_apply publishing a per-unit sequence number, a one-wave kernel on the weight-gradient stream
+    // spinning on it - to save the event record; on hardware the step ran at 451 vs 988 volumes/s with wrong gradients, profiles/r04_fork_flag_stress.json:
+    // removed in round 4)
+    struct Pend { std::function<void(hipStream_t)> f; };
+    bool side_used = false;
+    int n_event_forks = 0;              // of the current / last backward pass (seg_plan_count 2)
     std::vector<Pend> pending;
     int fork_batch = 3;      // measured on MI355X (VNet3d 4x96^3), round 1: 1 -> 641, 3 -> 645, 6 -> 649 volumes/s; round 2 with the
                              // heavy levels released at once: 6 -> 826, 3 -> 838
@@ -180,22 +176,14 @@ struct seg_engine {
     double hold_bytes = 64e6;                       // SEG_HOLD_HEAVY_MB
     bool hold_open = false;                         // the release level has been reached in this backward pass
     std::vector<Pend> held;
-    // the apply pass about to be launched publishes this backward pass's sequence number for unit `ui` (and its twin `uj` of a dual pass)
-    void arm_signal(GnBwdArgs& a, int ui, int uj) {
-        if (!fork_flag || capturing || sub_active || !use_side || ui < 0 || ui >= (int)sig_unit_seq.size()) return;
-        int* base = (int*)(ws + off_sig) + 2 * ui;
-        a.sig_ctr = base; a.sig_flag = base + 1; a.sig_seq = sig_seq;
-        sig_unit_seq[ui] = sig_seq;
-        if (uj >= 0 && uj < (int)sig_unit_seq.size()) sig_unit_seq[uj] = -1;        // its twin's weight gradient keeps the event (the flag lives in ui's slot)
-    }
     void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> fn, double bytes = 0.0, int lvl = 0, int sig_unit = -1) {
         if (sub_active) {                                  // a chain runs group by group: the weight gradient is a whole-batch launch, queued once
             if (!sub_last) return;
             bytes *= (double)Nplan / (double)N;
         }
         if (!use_side) { const bool was = sub_suspend(); cur_partial = off_partial; fn(main); sub_resume(was); return; }
-        const bool flagged = fork_flag && !capturing && sig_unit >= 0 && sig_unit < (int)sig_unit_seq.size() && sig_unit_seq[sig_unit] == sig_seq;
-        Pend f{std::move(fn), flagged ? sig_unit : -1};
+        (void)sig_unit;
+        Pend f{std::move(fn)};
         if (wgrad_seq++ >= n_deferred - tail_wgrads) { tail_pending.push_back(std::move(f)); return; }
         if (hold_lvl >= 0) {
             if (!hold_open && lvl >= hold_lvl) {
@@ -231,23 +219,11 @@ struct seg_engine {
     void flush_side_full(hipStream_t main) {
         ensure_side();
         if (ready_used == ready_ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ready_ev.push_back(e); }
-        bool need_event = side2 != nullptr;
-        for (auto& f : pending) need_event = need_event || f.sig < 0;
-        if (need_event) {
-            ++n_event_forks;
-            hipEvent_t e = ready_ev[ready_used++];
-            (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
-            (void)hipStreamWaitEvent(side, e, 0);
-            if (side2) (void)hipStreamWaitEvent(side2, e, 0);
-        }
-        if (!need_event) {
-            // flagged batch: the weight-gradient stream waits for the apply passes, not for the main stream's position.  The producers sit on ONE
-            // in-order queue, so the flag of the batch's last item covers the whole batch (held items re-order the list: every flag then)
-            for (size_t i = hold_lvl >= 0 ? 0 : pending.size() - 1; i < pending.size(); ++i) {
-                ++n_flag_waits;
-                launch_wait_flag((const int*)(ws + off_sig) + 2 * pending[i].sig + 1, sig_seq, side);
-            }
-        }
+        ++n_event_forks;
+        hipEvent_t e = ready_ev[ready_used++];
+        (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
+        (void)hipStreamWaitEvent(side, e, 0);
+        if (side2) (void)hipStreamWaitEvent(side2, e, 0);
         for (auto& f : pending) {
             const bool second = side2 && (rr++ & 1);
             cur_partial = second ? off_partial2 : off_partial;
@@ -689,8 +665,6 @@ struct Planner {
             }
         // ---- small persistent regions
         E.off_step = alloc(256);
-        E.off_sig = alloc(E.steps.size() * 8 + 8);
-        E.sig_unit_seq.assign(E.steps.size(), 0);
         E.off_masks = alloc((size_t)E.drop_ch.size() * N * E.ld_mask() * 4);
         // forward tensors
         for (auto& t : E.tens) t.off = alloc(ten_bytes(t));
@@ -824,10 +798,13 @@ struct Planner {
             seg_engine& E = *this_;
             // the backward sums (Q) sit right behind the forward statistics: ONE fill clears both (a fill is a ~6 us launch on the main
             // stream); a backward pass that does not follow a forward pass directly clears Q itself
-            (void)hipMemsetAsync(E.ws + E.off_stats, 0, E.stats_bytes + (E.off_Q == E.off_stats + E.stats_bytes ? E.Q_bytes : 0), st);
-            E.q_clean = E.off_Q == E.off_stats + E.stats_bytes;
             const Ten& x = E.tens[E.image_ten];
+            const size_t fill = E.stats_bytes + (E.off_Q == E.off_stats + E.stats_bytes ? E.Q_bytes : 0);
+            const int pi = E.prof_begin(st, SEG_K_MISC, (double)fill + (double)E.N * E.vol(0) * (4.0 * E.in_ch + (double)x.C * E.esz()), 0.0);
+            (void)hipMemsetAsync(E.ws + E.off_stats, 0, fill, st);
+            E.q_clean = E.off_Q == E.off_stats + E.stats_bytes;
             launch_ingest(E.cur_x, E.ws + x.off, E.N, x.C, E.vol(0), E.dtype, st, E.in_ch);
+            E.prof_end(st, pi);
         });
         for (size_t si = 0; si < E.steps.size(); ++si) {
             Step& s = E.steps[si];
@@ -1012,7 +989,9 @@ struct Planner {
                     a.in = E.ws + E.tens[s.in].off; a.w = E.p + E.params[s.w].off; a.bias = E.p + E.params[s.b].off;
                     a.logits = E.cur_logits; a.probs = E.cur_probs;
                     a.N = E.N; a.V = (int)E.vol(0); a.Cin = s.Cin; a.C = s.Cout;
+                    const int pi = E.prof_begin(st, SEG_K_HEAD, E.tbytes(s.in) + 2.0 * 4.0 * E.N * E.vol(0) * s.Cout, 0.0);
                     launch_head_fwd(a, E.dtype, st);
+                    E.prof_end(st, pi);
                 });
             }
         }
@@ -1051,7 +1030,9 @@ struct Planner {
                     a.din = E.head_din_needed ? E.ws + E.tens[gin].off : nullptr;
                     a.dw = E.g + E.params[s.w].off; a.db = E.g + E.params[s.b].off;
                     a.N = E.N; a.V = (int)E.vol(0); a.Cin = s.Cin; a.C = s.Cout;
+                    const int pi = E.prof_begin(st, SEG_K_HEAD, E.tbytes(s.in) * (a.din ? 2.0 : 1.0) + 4.0 * E.N * E.vol(0) * s.Cout, 0.0);
                     launch_head_bwd(a, E.dtype, st);
+                    E.prof_end(st, pi);
                 });
             } else if (s.type == ST_POOL) {
                 std::vector<int> gl = E.tens[s.out].grads;
@@ -1180,7 +1161,6 @@ struct Planner {
                         const bool fold = E.use_fold && a.C <= 256;
                         if (!fold) { launch_gn_bwd_finalize(fa, st); launch_gn_bwd_finalize(fb, st); }
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, tb * (a.ndy + 4), 0.0);
-                        E.arm_signal(a, uia, uib);
                         launch_gn_bwd_apply(a, E.dtype, st, fold ? &fa : nullptr, fold ? &fb : nullptr);
                         E.prof_end(st, pi);
                     });
@@ -1200,7 +1180,6 @@ struct Planner {
                         fill(E, ui, gl, a, f);
                         if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
                             const int pg = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
-                            E.arm_signal(a, ui, -1);
                             launch_gn_bwd_group(a, f, E.dtype, st);
                             E.prof_end(st, pg);
                             return;
@@ -1211,7 +1190,6 @@ struct Planner {
                         const bool fold = E.use_fold && a.C <= 256;
                         if (!fold) launch_gn_bwd_finalize(f, st);
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
-                        E.arm_signal(a, ui, -1);
                         launch_gn_bwd_apply(a, E.dtype, st, fold ? &f : nullptr, nullptr);
                         E.prof_end(st, pi);
                     });
@@ -1430,7 +1408,6 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     if (getenv("SEG_GN_VACT")) e->use_vact = atoi(getenv("SEG_GN_VACT")) != 0;
     if (getenv("SEG_GN_FOLD")) e->use_fold = atoi(getenv("SEG_GN_FOLD")) != 0;
     if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
-    if (getenv("SEG_FORK_FLAG")) e->fork_flag = atoi(getenv("SEG_FORK_FLAG")) != 0;
     if (getenv("SEG_TAIL_WGRADS")) e->tail_wgrads = atoi(getenv("SEG_TAIL_WGRADS"));
     if (getenv("SEG_FORK_HEAVY_MB")) e->fork_heavy_bytes = atof(getenv("SEG_FORK_HEAVY_MB")) * 1e6;
     if (getenv("SEG_FLUSH_LATE")) e->flush_late = atoi(getenv("SEG_FLUSH_LATE")) != 0;
@@ -1517,7 +1494,7 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
 int seg_plan_count(seg_handle h, int what) {
     if (!h || !h->planned) return -1;
     if (what == 2) return h->n_event_forks;             // last backward pass: fork events recorded on the main stream
-    if (what == 3) return h->n_flag_waits;              // last backward pass: weight gradients released by a completion flag (SEG_FORK_FLAG)
+    if (what == 3) return 0;                            // (completion-flag forks: removed in round 4)
     if (what == 4) return h->sub_nb;                    // samples per group of the sub-batched finest level (0: whole-batch launches)
     if (what == 5 || what == 6) {                       // forward / backward ops that run group by group
         int n = 0;
@@ -1552,9 +1529,6 @@ int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
     if (hipMemcpy(h->ws + h->off_packdesc, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice) != hipSuccess)
         return fail("seg_bind: descriptor upload failed");
     if (hipMemset(h->ws + h->off_step, 0, 256) != hipSuccess) return fail("seg_bind: memset failed");
-    if (hipMemset(h->ws + h->off_sig, 0, h->steps.size() * 8 + 8) != hipSuccess) return fail("seg_bind: memset failed");
-    h->sig_seq = 0;
-    std::fill(h->sig_unit_seq.begin(), h->sig_unit_seq.end(), 0);
     if (h->draws && hipMemcpy(h->ws + h->off_step, &h->draws, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
         return fail("seg_bind: counter upload failed");
     return 0;
@@ -1630,7 +1604,7 @@ static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, in
     hipStream_t st = (hipStream_t)stream;
     if (zero_grads && op_begin == 0) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
-    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; ++h->sig_seq; h->n_event_forks = 0; h->n_flag_waits = 0; }
+    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; h->n_event_forks = 0; }
     if (h->pack_bwd_pending) { (void)hipStreamWaitEvent(st, h->pack_done, 0); h->pack_bwd_pending = false; }
     h->run_ops(h->bwd_ops, h->bwd_chains, op_begin, op_end, st, true);
     if (join) h->join_side(st);
@@ -1849,17 +1823,25 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
     if (!a->x || !a->target || !a->logits || !a->probs || !a->dlogits || !a->loss_ws || !a->out3)
         return fail("seg_train_step: null tensor");
     if (!a->exp_avg || !a->exp_avg_sq || !a->opt_state) return fail("seg_train_step: optimiser state is null");
+    hipStream_t st = (hipStream_t)stream;
     if (!a->packed && seg_pack_weights(h, stream)) return -1;
     if (seg_forward(h, a->x, a->mask_mode, a->masks, a->seed, a->logits, a->probs, stream)) return -1;
     const long long v = h->vol(0);
+    const double lbytes = (double)h->N * v * (4.0 * h->ncls + ((a->label_type & 15) == SEG_LABEL_U8 ? 1.0 : (a->label_type & 15) == SEG_LABEL_I64 ? 8.0 : 4.0));
+    int pi = h->prof_begin(st, SEG_K_MISC, 2.0 * lbytes + 4.0 * h->N * v * h->ncls, 0.0);
     if (seg_loss_forward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->class_alpha,
                          a->loss_ws, a->out3, stream)) return -1;
     if (seg_loss_backward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->loss_ws,
                           h->loss_scale, a->dlogits, stream)) return -1;
+    h->prof_end(st, pi);
     if (seg_backward(h, a->dlogits, 1, stream)) return -1;
+    // fused optimiser: p, m, v read + written, g read (+ once more by the overflow check); re-pack: fp32 masters read, run-dtype layouts written
+    pi = h->prof_begin(st, SEG_K_MISC, (double)h->nparam * (28.0 + (a->check_finite ? 4.0 : 0.0) + 4.0 + 3.0 * (double)h->esz()), 0.0);
     if (seg_adam_step(h->p, h->g, a->exp_avg, a->exp_avg_sq, h->nparam, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->decoupled,
                       1.0f / (h->loss_scale * (a->grad_div > 0.f ? a->grad_div : 1.f)), a->check_finite, a->opt_state, stream)) return -1;
-    return seg_pack_weights(h, stream);
+    const int rc = seg_pack_weights(h, stream);
+    h->prof_end(st, pi);
+    return rc;
 }
 
 // The same step captured once as a HIP graph and replayed: ~250 launches + ~60 event operations become one hipGraphLaunch on the host.  For

@@ -39,7 +39,7 @@ bool wgrad3x_supported(int dtype, int N, int D, int H, int W, int P, int Q, int 
 void wgrad3x_tiles(int P, int Q, int C0, bool has_x1, int* CP, int* CQ);
 bool launch_wgrad3x(const void* dr, const void* x0, const void* x1, int C0, float* partial, int nb, int N, int D, int H, int W, int P, int Q,
                     int ndim, int dtype, bool wide, hipStream_t s);
-int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q);
+int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, int esz = 2);
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
                    int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, const float* xscale = nullptr, const float* xshift = nullptr,
@@ -136,13 +136,7 @@ struct GnBwdArgs {
     // the fly from the loss gradient (planar fp32) and the head weights instead of being written as a 16-channel tensor and read
     // back by every GroupNorm-backward pass it feeds
     const float* vdl; const float* vw; int vK;    int rep_q;                                  // replicas of Q the reduce pass spreads over; 0 = STAT_REP
-    // optional completion signal of the APPLY pass (SEG_FORK_FLAG=1, engine.hip): the last workgroup to finish publishes sig_seq in *sig_flag
-    // (sig_ctr counts finished workgroups and is left at 0), so that the weight-gradient stream can wait for THIS launch with a one-wave
-    // kernel instead of an event recorded on the main stream
-    int* sig_ctr; int* sig_flag; int sig_seq;
 };
-// one wave spinning until *flag >= seq (the other side of GnBwdArgs::sig_flag)
-void launch_wait_flag(const int* flag, int seq, hipStream_t s);
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
 struct GnBwdFinArgs;
 // fa != null: the backward finalize of the branch(es) runs as a prologue of this launch (no gn_bwd_finalize launch before it)

@@ -477,20 +477,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a, GnBwdFin
             }
         }
     }
-    if (a.sig_flag) {
-        // completion signal (see GnBwdArgs::sig_flag): every thread releases its stores device-wide, the workgroup meets, one thread counts
-        // it in; the workgroup that completes the count publishes the sequence number
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int total = (int)(gridDim.x * gridDim.y);
-            if (atomicAdd(a.sig_ctr, 1) == total - 1) {
-                atomicAdd(a.sig_ctr, -total);
-                __threadfence();
-                atomicMax(a.sig_flag, a.sig_seq);
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -591,18 +577,6 @@ __global__ __launch_bounds__(1024) void gn_bwd_group_kernel(GnBwdGroupArgs a) {
             o[j] = from_f<T>(fmaf(cA[j], d, fmaf(cB[j], xv, cC[j])));
         }
         store8(dr + i * 8, o);
-    }
-    if (a.e.sig_flag) {                         // completion signal, as in gn_bwd_apply_kernel
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int total = (int)(gridDim.x * gridDim.y);
-            if (atomicAdd(a.e.sig_ctr, 1) == total - 1) {
-                atomicAdd(a.e.sig_ctr, -total);
-                __threadfence();
-                atomicMax(a.e.sig_flag, a.e.sig_seq);
-            }
-        }
     }
 }
 
@@ -744,19 +718,6 @@ void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(GN_GROUPS, a.N), dim3(64), 0, s, a);
 }
 
-namespace {
-__global__ __launch_bounds__(64) void wait_flag_kernel(const int* flag, int seq) {
-    if (threadIdx.x) return;
-#ifndef SEG_EMU
-    // bounded (~0.3 s): a missing signal must show up as a wrong gradient in a test, never as a hung queue
-    for (int spin = 0; spin < (1 << 22) && atomicAdd((int*)flag, 0) - seq < 0; ++spin) __builtin_amdgcn_s_sleep(16);
-#else
-    // the host checker runs launches in enqueue order: the producer has finished, or the schedule is wrong
-    if (*flag - seq < 0) { fprintf(stderr, "wait_flag_kernel: flag %d < seq %d - the producer was not enqueued first\n", *flag, seq); abort(); }
-#endif
-}
-}  // namespace
-void launch_wait_flag(const int* flag, int seq, hipStream_t s) { hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, s, flag, seq); }
 
 void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s, const GnBwdFinArgs* fa, const GnBwdFinArgs* fb) {
     int bx = ew_blocks(a.V * (a.C / 8));

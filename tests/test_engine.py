@@ -415,31 +415,6 @@ def test_sub_batched_finest_level_equals_whole_batch_launches(dev, tag, dtype, m
         assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-3) * float(g0[k].norm()) + 1e-12, k
 
 
-@pytest.mark.parametrize("tag", ["vnet2d_s", "unet2d"])
-def test_flag_signalled_forks_equal_event_forks(dev, tag, monkeypatch):
-    """SEG_FORK_FLAG=1 (experiment, default off): a weight gradient whose d(raw) comes out of a gn_bwd_apply launch waits on the flag that
-    launch's last workgroup publishes (GnBwdArgs::sig_flag + a one-wave wait kernel on the weight-gradient stream) instead of an event
-    recorded on the main stream.  Same kernels on the same data: logits, loss and every gradient must equal the event path - bit for bit
-    on the sequential host checker (whose wait kernel aborts if a producer was not enqueued first), to atomics noise on the GPU.  Two
-    backward passes: the sequence number moves on, the counters return to zero."""
-    if dev.type != "cpu":
-        pytest.skip("SEG_FORK_FLAG is an un-measured experiment: its device-side wait has not run on hardware yet (DESIGN.md section 7, item 1)")
-    res, forks = [], []
-    for ff in ("0", "1"):
-        monkeypatch.setenv("SEG_FORK_FLAG", ff)
-        e, params, x, y, masks, alpha, loss = build(tag, "f32", dev, True)
-        run_engine(e, x, y, masks, alpha, loss, dev)
-        res.append(run_engine(e, x, y, masks, alpha, loss, dev))
-        forks.append((e.lib.seg_plan_count(e.h, 2), e.lib.seg_plan_count(e.h, 3)))
-        del e
-    (l0, p0, o0, g0), (l1, p1, o1, g1) = res
-    assert forks[0][1] == 0 and forks[1][1] > 0 and forks[1][0] < forks[0][0], forks      # fewer events, some flag waits
-    exact = dev.type == "cpu"
-    assert torch.equal(l0, l1) and float(o0[0]) == float(o1[0])
-    for k in g0:
-        assert float((g0[k] - g1[k]).norm()) <= (0.0 if exact else 2e-6 * float(g0[k].norm()) + 1e-12), k
-
-
 @pytest.mark.gpu
 def test_graph_replay_equals_stream_launches():
     """seg_train_graph_capture / _launch: the train step captured as a HIP graph (weight-gradient stream forked and joined inside the
