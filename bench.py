@@ -9,8 +9,9 @@ configs[2], the configuration the metric is quoted on.
 One process per GPU; the batch shards on the batch axis (weak scaling: 4 volumes per GPU); the flat
 fp32 gradient buffer is all-reduced over RCCL (sum, then 1/N) before the fused optimiser step.  Inputs
 are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with the extra objects
-  "roofline"           – the dominant kernel class, timed live with HIP events in R instrumented steps run AFTER the timed region
-                         (the K timed steps carry no brackets, so `value` does not depend on --steps)
+  "roofline"           – the kernel FAMILY with the most GPU time of the step, chosen from the complete table (every launch of both streams bracketed with HIP
+                         events in R instrumented steps run AFTER the timed region); "roofline_2" / "roofline_3" are the next two, "kernel_families" the table
+  "other_configs"      – ms per train step of the other BASELINE.json configs and of the f32 (parity-exact) run dtype of the headline workload, 10 steps each
   "cpu_baseline"       – the oracle (torch-CPU port of the reference path) on this box's host cores
   "gpu_torch_baseline" – the same oracle functions on this GPU through stock PyTorch-ROCm / MIOpen (fp32 and autocast f16):
                          the number the hand-written engine has to beat.
@@ -33,17 +34,37 @@ GFLOP_PER_VOLUME_96 = 216.5
 GB_PER_VOLUME_96 = 2.85
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 PEAK_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA
-# kernel classes whose launches are ONE kernel symbol each (so rocprofv3's per-kernel average is comparable)
-KERNEL_SYMBOL = {"gn_bwd_reduce": "gn_bwd_reduce_kernel<f16, DUAL=0|1>", "gn_bwd_apply": "gn_bwd_apply_kernel<f16, DUAL=0|1, FOLD=1>",
-                 "gn_act": "gn_act_kernel<f16, FOLD=1>",
-                 "conv3": "c3x::conv3x_kernel<f16, XBox<4,8,8>, TM=4, TN=2, 4x1 waves, PF=8> (tiling 17; 48^3 level, 32 -> 32 channels)"}
-MFMA_BOUND = {"conv3_smallbox", "conv3", "wgrad3"}
-# PMC summary keys (profiles/summarize_pmc.py), matched by prefix: the GroupNorm-backward classes have a single- and a dual-branch
-# instantiation of the same template: the traffic figure is the launch-weighted mean over both
-PMC_KEY = {"conv3": ["_ZN3seg3c3x13conv3x_kernel<DF16_NS0_4XBoxILi4ELi8ELi8ELi3ELi8EEELi4ELi2ELi4ELi1ELi1E"],      # the 4x8x8-box TM4 TN2 tilings (14 / 17)
-           "gn_bwd_reduce": ["gn_bwd_reduce_kernel<DF16_"],
-           "gn_bwd_apply": ["gn_bwd_apply_kernel<DF16_"],
-           "gn_act": ["gn_act_kernel<DF16_"]}
+# Kernel FAMILIES of the train step (every launch of the step belongs to exactly one; the profile classes of include/segengine.h grouped):
+# which roofline bounds the family, what it is, and which kernel symbols of the rocprofv3 PMC summary (profiles/summarize_pmc.py) belong to it
+# ("count": the symbols whose launches are one bracketed op of the family - a weight gradient is main kernel + partial-tile reduce).
+FAMILIES = {
+    "halo_conv": dict(classes=["conv3", "conv3_smallbox"], bound="mfma", queue="main",
+                      what="3^d halo convolutions, forward + data-gradient (c3x::conv3x_kernel / conv3x16_kernel, all tilings)",
+                      pmc=["_ZN3seg3c3x13conv3x_kernel", "_ZN3seg3c3x15conv3x16_kernel", "conv3_kernel"], count=None),
+    "halo_wgrad": dict(classes=["wgrad3"], bound="mfma", queue="weight-gradient stream",
+                       what="weight gradients of the 3^d convolutions (wgrad3_kernel + wgrad3_reduce_kernel)",
+                       pmc=["wgrad3_kernel", "wgrad3_reduce_kernel"], count=["wgrad3_kernel"]),
+    "generic_wgrad": dict(classes=["wgrad_generic"], bound="hbm", queue="weight-gradient stream",
+                          what="weight gradients of the 2^d stride-2 / transposed / 1^d convolutions (wgrad_kernel + wgrad_reduce_kernel)",
+                          pmc=["wgrad_kernel", "wgrad_reduce_kernel"], count=["wgrad_kernel"]),
+    "generic_conv": dict(classes=["conv_generic"], bound="hbm", queue="main",
+                         what="2^d stride-2, transposed and 1^d convolutions, forward + data-gradient (conv_stream_kernel / conv_igemm_kernel)",
+                         pmc=["conv_stream_kernel", "conv_igemm_kernel"], count=None),
+    "input_block": dict(classes=["stem"], bound="hbm", queue="main", what="fused input block, forward and backward (stemx_kernel, 4 passes)",
+                        pmc=["stemx_kernel", "stemx_wgrad_reduce_kernel", "gn_finalize_kernel", "gn_bwd_finalize_kernel"], count=["stemx_kernel"]),
+    "gn_act": dict(classes=["gn_act"], bound="hbm", queue="main", what="GroupNorm + dropout + ReLU (+ residual) forward (gn_act_kernel)",
+                   pmc=["gn_act_kernel"], count=None),
+    "gn_bwd_reduce": dict(classes=["gn_bwd_reduce"], bound="hbm", queue="main", what="GroupNorm backward, reduction pass (gn_bwd_reduce_kernel)",
+                          pmc=["gn_bwd_reduce_kernel"], count=None),
+    "gn_bwd_apply": dict(classes=["gn_bwd_apply"], bound="hbm", queue="main", what="GroupNorm backward, elementwise pass (gn_bwd_apply_kernel)",
+                         pmc=["gn_bwd_apply_kernel"], count=None),
+    "gn_small": dict(classes=["gn_group"], bound="hbm", queue="main", what="one-launch GroupNorm passes of the 6^3 level (gn_fwd/bwd_group_kernel)",
+                     pmc=["gn_fwd_group_kernel", "gn_bwd_group_kernel"], count=None),
+    "head": dict(classes=["head"], bound="hbm", queue="main", what="1^d head forward / backward (head_fwd_kernel, head_bwd_kernel)",
+                 pmc=["head_fwd_kernel", "head_bwd_kernel"], count=None),
+    "misc": dict(classes=["misc"], bound="hbm", queue="main", what="fill + ingest, loss, fused AdamW, weight re-pack",
+                 pmc=["ingest", "loss_", "adam_kernel", "grad_check_kernel", "pack_kernel", "__amd_rocclr_fillBufferAligned", "dropout_mask_kernel"], count=None),
+}
 
 
 def _pmc_file():
@@ -54,18 +75,69 @@ def _pmc_file():
     return c[-1] if c else None
 
 
-def pmc_traffic(kclass):
-    """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes committed under profiles/
-    (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled for gfx950 as
-    MI355X_MICROARCH.md prescribes).  None when the summary is not available."""
+def pmc_traffic(family):
+    """HBM bytes per bracketed op of a kernel family from the rocprofv3 PMC passes committed under profiles/ (separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes): (bytes per op, file).
+    (None, None) when the summary is not available."""
     try:
-        with open(_pmc_file()) as f:
-            table = json.load(f)
-        rows = [v for k, v in table.items() if any(k.startswith(p) for p in PMC_KEY[kclass])]
-        n = sum(r["launches"] for r in rows)
-        return int(sum(r["launches"] * (2.0 * r["fetch_kb_raw_per_launch"] + r["write_kb_per_launch"]) for r in rows) / n * 1024)
+        f = _pmc_file()
+        with open(f) as fh:
+            table = json.load(fh)
+        fam = FAMILIES[family]
+        rows = {k: v for k, v in table.items() if k != "_total" and any(k.startswith(p) or (p in k and not p.startswith("_Z")) for p in fam["pmc"])}
+        # a family name that is a prefix of another family's symbol must not swallow it (wgrad_kernel vs wgrad3_kernel)
+        if family == "generic_wgrad":
+            rows = {k: v for k, v in rows.items() if "wgrad3" not in k}
+        if family == "generic_conv":
+            rows = rows
+        total = sum(r["launches"] * (2.0 * r["fetch_kb_raw_per_launch"] + (r["write_kb_per_launch"] or 0.0)) for r in rows.values()) * 1024
+        cnt = fam["count"]
+        n = sum(r["launches"] for k, r in rows.items() if cnt is None or any(k.startswith(c) for c in cnt))
+        return (int(total / n), os.path.basename(f)) if n else (None, None)
     except Exception:
-        return None
+        return None, None
+
+
+# the other BASELINE.json configs (and the headline config in its parity-exact f32 run dtype), timed after the headline measurement:
+# tag -> (net, ndim, shape, classes, loss, run dtype, soft-clDice weight, fused-bound GB per step from SURVEY.md section 8d)
+OTHER_CONFIGS = {
+    "C2 VNet2d 16x512^2 f16, 2 classes (BASELINE configs[1])": ("vnet", 2, (16, 1, 512, 512), 2, "MutilDiceLoss", "f16", 0.0, 21.72),
+    "C4 UNet3d 2x128^3 f16, 4 classes (BASELINE configs[3], per-GPU shard)": ("unet", 3, (2, 1, 128, 128, 128), 4, "MutilDiceLoss", "f16", 0.0, 11.34),
+    "C5 VNet3d 1x160^3 bf16, BCE + Dice (BASELINE configs[4] without the clDice term)": ("vnet", 3, (1, 1, 160, 160, 160), 1, "BinaryCrossEntropyDiceLoss", "bf16", 0.0, 13.14),
+    "C5 VNet3d 1x160^3 bf16, Dice + soft-clDice (BASELINE configs[4] as worded)": ("vnet", 3, (1, 1, 160, 160, 160), 1, "BinaryDiceLoss", "bf16", 1.0, 13.14),
+    "C3 VNet3d 4x96^3 in the f32 run dtype (the parity-exact mode: masks identical to the fp32 reference)": ("vnet", 3, (4, 1, 96, 96, 96), 1, "BinaryDiceLoss", "f32", 0.0, 22.5),
+}
+
+
+def other_configs(dev, steps=10):
+    """ms per train step of the other BASELINE configs on this GPU (10 timed steps after 3 warm-up steps each, inputs resident): driver-visible
+    numbers for configs[1], [3], [4] and for the f32 run dtype of the headline workload."""
+    from pytorchdeeplearing_amd import SegEngine, synthetic
+    out = {}
+    for tag, (kind, ndim, shape, ncls, loss, dt, cld, gb) in OTHER_CONFIGS.items():
+        try:
+            e = SegEngine(kind, ndim, shape[1], ncls, dtype=dt, device=dev)
+            synthetic.init_engine(e, seed=0)
+            x, y = synthetic.synthetic_batch(shape[0], shape[2:], shape[1], ncls, seed=1)
+            x, y = x.to(dev), y.to(dev)
+            kw = {"class_alpha": torch.ones(ncls, device=dev)}
+            if cld:
+                kw["cldice_weight"] = cld
+            for _ in range(3):
+                e.train_step(x, y, loss, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out3 = e.train_step(x, y, loss, **kw)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            out[tag] = {"ms_per_step": round(ms, 3), "samples_per_s": round(shape[0] / ms * 1e3, 1), "steps": steps, "final_loss": round(float(out3[0]), 5),
+                        "fused_bound_GB_per_step": gb, "hbm_frac_of_fused_bound": round(gb / ms / PEAK_HBM_GBS * 1e3, 4)}
+            del e, x, y
+            torch.cuda.empty_cache()
+        except Exception as ex:          # a side measurement must not take the contract line down
+            out[tag] = {"error": str(ex)[:200]}
+    return out
 
 
 def parse(argv=None):
@@ -81,13 +153,10 @@ def parse(argv=None):
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("SEG_LANES", "1")), help="intra-GPU batch lanes (pytorchdeeplearing_amd/lanes.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline / dice_vs_ref / gpu_torch_baseline legs")
-    ap.add_argument("--roofline-kernel", default="auto", help="kernel class bracketed with HIP events in the timed region; auto = "
-                    "whichever of the two largest kernel symbols of the step (gn_bwd_reduce / gn_bwd_apply, rocprofv3 --stats summary "
-                    "under profiles/) accumulates more event time in this run")
-    ap.add_argument("--mfma-kernel", default="conv3", help="second bracketed class, reported as \"roofline_mfma\" (largest MFMA symbol)")
-    ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented steps run AFTER the timed region: every launch of the roofline "
-                    "kernel classes is bracketed by HIP events on its launch stream (each bracket idles the stream for ~6 us, so none of "
-                    "them is inside the timed region)")
+    ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented steps run AFTER the timed region: EVERY launch of the step (all kernel "
+                    "families, both streams) is bracketed by HIP events on its launch stream (each bracket idles the stream for ~5 us, so none of "
+                    "them is inside the timed region); the family with the most GPU time is \"roofline\", the next two \"roofline_2\" / \"roofline_3\"")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs leg (the other BASELINE configs + the f32 run dtype, 10 steps each)")
     ap.add_argument("--launch", default="auto", choices=["auto", "stream", "graph"], help="how the single-rank step reaches the GPU: stream = ~250 "
                     "launches enqueued per step by one library call; graph = the step captured once as a HIP graph, one hipGraphLaunch per step; "
                     "auto = both are timed for a few steps inside the un-timed conditioning phase and the faster one runs the warm-up and the "
@@ -95,7 +164,6 @@ def parse(argv=None):
     ap.add_argument("--single-allreduce", action="store_true", help="one blocking all-reduce after backward instead of two overlapped buckets")
     ap.add_argument("--global-loss", action="store_true", help="exact global-batch Dice across ranks (parallel.GlobalBatchLoss: 32 fp64 sums "
                     "all-reduced between the loss reduction and its finalize; gradients summed) instead of DDP semantics")
-    ap.add_argument("--all-classes", action="store_true", help="extra un-timed pass: per-class time table (diagnostics)")
     return ap.parse_args(argv)
 
 
@@ -265,6 +333,10 @@ def _run(a, checker_device):
     """everything between the stdout redirect and the JSON line; returns the line on rank 0, None elsewhere"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if a.gpus != world:
+        # the world size comes from the launcher (one process per GPU): a plain `python bench.py --gpus 8` would silently measure ONE GPU
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d - launch the N-GPU run as `python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...`" % (a.gpus, world, a.gpus, a.gpus))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     on_gpu = checker_device is None
@@ -384,15 +456,14 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
     gpu_sync()
     dt = time.perf_counter() - t0
     loss = float(out3[0])
-    # ---- roofline: R instrumented steps AFTER the timed region.  The largest kernel classes of the step (profiles/ rocprofv3 --stats
-    # summary: GroupNorm-backward apply / reduce, the 48^3 halo conv) are bracketed with hipEventRecord on their launch stream;
-    # "roofline" is whichever accumulated most event time in this run.
-    candidates = ["gn_bwd_reduce", "gn_bwd_apply", a.mfma_kernel or "conv3"] if a.roofline_kernel == "auto" else [a.roofline_kernel]
-    bracketed = candidates + ([a.mfma_kernel] if a.mfma_kernel and a.mfma_kernel not in candidates else [])
+    # ---- roofline: R instrumented steps AFTER the timed region.  EVERY launch of the step (all profile classes, main stream and weight-gradient
+    # stream) is bracketed with hipEventRecord on its launch stream; the classes are grouped into kernel families (FAMILIES) and the family with
+    # the most GPU time is "roofline" - the choice is made from the complete table, not from a short list.
+    from pytorchdeeplearing_amd import _capi
     nprof = max(0, a.roofline_steps)
     prof = {}
-    if nprof:
-        e.profile_enable(bracketed)
+    if nprof and a.lanes == 1:
+        e.profile_enable(_capi.KERNEL_CLASSES)
         if on_gpu:
             step()                            # creates the event pool (hipEventCreate) outside the measured brackets
             gpu_sync()
@@ -421,19 +492,6 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
     ms = dt / a.steps * 1e3
     vols = world * a.batch * a.steps / dt
 
-    table = None
-    if a.all_classes and rank == 0:
-        from pytorchdeeplearing_amd import _capi
-        e.profile_enable(_capi.KERNEL_CLASSES)
-        for _ in range(3):
-            step()
-        gpu_sync()
-        table = {k: {"calls_per_step": v["calls"] // 3, "ms_per_step": round(v["ms"] / 3, 3),
-                     "GBs": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None,
-                     "TFLOPs": round(v["flops"] / v["ms"] / 1e9, 1) if v["flops"] else None}
-                 for k, v in e.profile_read().items()}
-        e.profile_enable([])
-
     if rank == 0:
         scale = (S / 96.0) ** 3
         line = {
@@ -451,61 +509,62 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
             "whole_step": {"hbm_frac_of_fused_bound": round(GB_PER_VOLUME_96 * scale * vols / world / PEAK_HBM_GBS, 4),
                            "mfma_frac": round(GFLOP_PER_VOLUME_96 * scale * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},
         }
-        def roofline_block(k):
-            if k not in prof or prof[k]["ms"] <= 0:
-                return None
-            p = dict(prof[k])
-            raw_ms = p["ms"]
-            p["ms"] = max(raw_ms - p["calls"] * bracket_us * 1e-3, 0.25 * raw_ms)      # minus the empty-bracket time per launch
-            avg_us = p["ms"] / p["calls"] * 1e3
-            if k in MFMA_BOUND:
-                ach, peak, unit, bound = p["flops"] / (p["ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS, "TFLOP/s", "mfma"
-                per_launch = {"algorithmic_flops_per_launch": int(p["flops"] / p["calls"]),
-                              "algorithmic_bytes_per_launch": int(p["bytes"] / p["calls"])}
-            else:
-                ach, peak, unit, bound = p["bytes"] / (p["ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-                per_launch = {"algorithmic_bytes_per_launch": int(p["bytes"] / p["calls"])}
-            blk = {
-                "kernel": KERNEL_SYMBOL.get(k, k), "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit,
-                "frac": round(ach * p["ms"] / raw_ms / peak, 4), "traffic": pmc_traffic(k) if a.dtype == "f16" and S == 96 and a.batch == 4 else None,
-                "launches_per_step": p["calls"] // nprof, "avg_launch_us": round(raw_ms / p["calls"] * 1e3, 2), "ms_per_step": round(raw_ms / nprof, 3),
-                "avg_launch_us_minus_bracket": round(avg_us, 2), "bracket_overhead_us": round(bracket_us, 2),
-                "frac_minus_bracket": round(ach / peak, 4), "instrumented_steps": nprof}
-            blk["achieved"] = round(ach * p["ms"] / raw_ms, 1)
-            blk.update(per_launch)
-            return blk
-        corrected = lambda k: prof.get(k, {}).get("ms", 0.0) - prof.get(k, {}).get("calls", 0) * bracket_us * 1e-3
-        a.roofline_kernel = max(candidates, key=corrected)
+        line["timed_region_s"] = round(dt, 4)
+        # ---- kernel families: the profile classes grouped, event time corrected by the empty-bracket time per launch
+        fams = {}
+        for name, f in FAMILIES.items():
+            calls = sum(prof.get(c, {}).get("calls", 0) for c in f["classes"])
+            raw_ms = sum(prof.get(c, {}).get("ms", 0.0) for c in f["classes"])
+            if not calls or raw_ms <= 0:
+                continue
+            nbytes = sum(prof[c]["bytes"] for c in f["classes"] if c in prof)
+            flops = sum(prof[c]["flops"] for c in f["classes"] if c in prof)
+            ms_c = max(raw_ms - calls * bracket_us * 1e-3, 0.25 * raw_ms)
+            fams[name] = dict(calls=calls, raw_ms=raw_ms, ms=ms_c, bytes=nbytes, flops=flops)
         nprof = max(nprof, 1)
-        NOTE_HBM = ("every launch of this class in %d instrumented steps run after the timed region is bracketed by hipEventRecord on its "
-                    "launch stream (no bracket inside the timed region); achieved = sum of algorithmic bytes / sum of event time (frac_minus_bracket subtracts the "
-                    "empty-bracket time measured live, bracket_overhead_us, per launch); algorithmic bytes per launch = "
-                    "(gradient sources + 1 [+ 1 for the apply pass]) x tensor bytes (DESIGN.md section 5)" % nprof)
-        NOTE_MFMA = ("big-box halo conv of the 48^3 level (32 -> 32 channels, forward and data-gradient: ONE kernel symbol, 8 launches per "
-                     "step); algorithmic flops = 2*voxels*27*Cin*Cout, bytes = input + output tensor; same bracket correction")
-        blk = roofline_block(a.roofline_kernel)
-        if blk:
-            blk["note"] = "largest kernel class of this run (rocprofv3 --stats summary under profiles/); " + \
-                          (NOTE_MFMA if a.roofline_kernel in MFMA_BOUND else NOTE_HBM)
-            if len(candidates) > 1:
-                blk["runner_up"] = {k: round(corrected(k) / nprof, 3) for k in candidates if k in prof}
-            line["roofline"] = blk
-        # always report both views: the largest HBM-bound class and the largest MFMA-bound class
-        hbm_best = max([k for k in candidates if k not in MFMA_BOUND] or [None], key=lambda k: corrected(k) if k else 0.0)
-        if a.roofline_kernel in MFMA_BOUND and hbm_best:
-            blk = roofline_block(hbm_best)
-            if blk:
-                blk["note"] = "largest HBM-bound kernel class; " + NOTE_HBM
-                line["roofline_hbm"] = blk
-        if a.mfma_kernel and a.mfma_kernel != a.roofline_kernel:
-            blk = roofline_block(a.mfma_kernel)
-            if blk:
-                blk["note"] = "largest MFMA kernel class; " + NOTE_MFMA
-                line["roofline_mfma"] = blk
-        if table:
-            line["kernel_classes"] = table
+        order = sorted(fams, key=lambda k: -fams[k]["ms"])
+        total_ms = sum(v["ms"] for v in fams.values()) or 1.0
+
+        def roofline_block(name, rank_):
+            f, p = FAMILIES[name], fams[name]
+            mfma = f["bound"] == "mfma" and p["flops"] > 0
+            if mfma:
+                ach, ach_raw, peak, unit = p["flops"] / (p["ms"] * 1e-3) / 1e12, p["flops"] / (p["raw_ms"] * 1e-3) / 1e12, PEAK_MFMA_TFLOPS, "TFLOP/s"
+            else:
+                ach, ach_raw, peak, unit = p["bytes"] / (p["ms"] * 1e-3) / 1e9, p["bytes"] / (p["raw_ms"] * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+            traffic, tfile = pmc_traffic(name) if (a.dtype == "f16" and S == 96 and a.batch == 4) else (None, None)
+            blk = {"kernel": "%s: %s" % (name, f["what"]), "queue": f["queue"], "bound": "mfma" if mfma else "hbm",
+                   "achieved": round(ach_raw, 1), "peak": peak, "unit": unit, "frac": round(ach_raw / peak, 4),
+                   "traffic": traffic, "traffic_source": tfile,
+                   "launches_per_step": p["calls"] // nprof, "avg_launch_us": round(p["raw_ms"] / p["calls"] * 1e3, 2),
+                   "ms_per_step": round(p["raw_ms"] / nprof, 3), "share_of_gpu_time": round(p["ms"] / total_ms, 4),
+                   "avg_launch_us_minus_bracket": round(p["ms"] / p["calls"] * 1e3, 2), "bracket_overhead_us": round(bracket_us, 2),
+                   "achieved_minus_bracket": round(ach, 1), "frac_minus_bracket": round(ach / peak, 4), "instrumented_steps": nprof,
+                   "algorithmic_bytes_per_launch": int(p["bytes"] / p["calls"])}
+            if p["flops"] > 0:
+                blk["algorithmic_flops_per_launch"] = int(p["flops"] / p["calls"])
+                if mfma:      # the same family against the other roofline (the 16-channel finest-level launches of an MFMA family are HBM-bound)
+                    blk["hbm_GBs_minus_bracket"] = round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1)
+            blk["note"] = ("rank %d of %d kernel families by GPU time (all launches of the step, both streams, bracketed with hipEventRecord on their launch stream in %d "
+                           "instrumented steps AFTER the timed region; the brackets serialise the two streams less than the profiler-free step, so per-launch "
+                           "times are those of the instrumented steps); achieved = sum of algorithmic %s over the family's launches / sum of event time; "
+                           "*_minus_bracket subtracts the empty-bracket time measured live per launch; algorithmic work per launch: DESIGN.md section 5"
+                           % (rank_, len(fams), nprof, "flops (2*voxels*taps*Cin*Cout)" if mfma else "bytes (operands read once + results written once)"))
+            return blk
+
+        for i, name in enumerate(order[:3]):
+            line["roofline" if i == 0 else "roofline_%d" % (i + 1)] = roofline_block(name, i + 1)
+        line["kernel_families"] = {k: {"queue": FAMILIES[k]["queue"], "launches_per_step": fams[k]["calls"] // nprof, "ms_per_step": round(fams[k]["ms"] / nprof, 3),
+                                       "frac": round((fams[k]["flops"] / (fams[k]["ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS) if (FAMILIES[k]["bound"] == "mfma" and fams[k]["flops"] > 0)
+                                                     else (fams[k]["bytes"] / (fams[k]["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS), 4),
+                                       "bound": FAMILIES[k]["bound"]} for k in order}
+        if on_gpu and world == 1 and a.lanes == 1 and not a.no_other_configs:
+            del e
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(dev)
+            e = None
         if not a.no_cpu_baseline and world == 1:
-            sd = e.state_dict() if a.lanes == 1 else e.engines[0].state_dict()
+            sd = None                      # (dice_vs_ref builds its own perturbed weights: the trained ones predict a trivial mask)
             del e
             if on_gpu:
                 torch.cuda.empty_cache()

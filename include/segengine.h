@@ -216,6 +216,24 @@ typedef struct seg_train_args {
     float* exp_avg; float* exp_avg_sq; int* opt_state;
     float lr, beta1, beta2, eps, weight_decay; int decoupled; float grad_div; int check_finite;
     int packed;      /* != 0: the run-dtype weight layouts are current (the previous seg_train_step left them so) */
+    /* ---- data-parallel exchange hooks (world > 1; all null / 0 for a rank-local step).  The library owns the sequencing of the step, the
+     * caller owns the collectives (torch.distributed over RCCL / gloo): each hook is called synchronously from inside seg_train_step at the point
+     * of the schedule where its exchange belongs and ENQUEUES the collective (it must not block the host on the device).
+     * bucket_cb(user, index, offset, count): the gradient slice grads[offset, offset + count) is final on the device - enqueue its SUM
+     *   all-reduce.  The finished slices are suffixes of the flat buffer (gradients finish in reverse registration order); `nfrac` boundaries
+     *   `fractions[]` (finished fraction of the buffer, ascending) cut the backward pass into nfrac + 1 buckets (nfrac = 0: one exchange after the
+     *   whole backward pass).  With `aux_stream` != null (GPU) the hook for every bucket but the last runs after `aux_stream` has been ordered
+     *   behind the caller's stream AND the weight-gradient stream, and is expected to enqueue on `aux_stream`; the caller's stream never waits at
+     *   a bucket boundary and meets `aux_stream` again before the last bucket.  Finally bucket_cb(user, -1, 0, 0): order the caller's stream
+     *   behind every exchange (the optimiser follows).  Return != 0 aborts the step.
+     * loss_cb(user, shared_sums, n_doubles): called between the loss reduction and its finalize with the rank's batch-global fp64 sums (device
+     *   pointer): enqueue their SUM all-reduce on the caller's stream; returns the global sample count (0: take it from the exchanged sums,
+     *   seg_loss_finalize) or < 0 to abort. */
+    int (*bucket_cb)(void* user, int index, long long offset, long long count);
+    long long (*loss_cb)(void* user, double* shared_sums, int n_doubles);
+    void* cb_user;
+    int nfrac; double fractions[4];
+    void* aux_stream;
 } seg_train_args;
 int seg_train_step(seg_handle h, const seg_train_args* a, void* stream);
 /* The same step captured ONCE as a HIP graph (hipStreamBeginCapture around seg_train_step on `stream`, the weight-gradient stream forked and

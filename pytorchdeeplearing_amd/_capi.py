@@ -123,7 +123,12 @@ class TrainArgs(C.Structure):
                 ("mask_mode", _i), ("masks", _vp), ("seed", C.c_ulonglong),
                 ("exp_avg", _vp), ("exp_avg_sq", _vp), ("opt_state", _vp),
                 ("lr", _f), ("beta1", _f), ("beta2", _f), ("eps", _f), ("weight_decay", _f), ("decoupled", _i), ("grad_div", _f),
-                ("check_finite", _i), ("packed", _i)]
+                ("check_finite", _i), ("packed", _i),
+                ("bucket_cb", _vp), ("loss_cb", _vp), ("cb_user", _vp), ("nfrac", _i), ("fractions", C.c_double * 4), ("aux_stream", _vp)]
+
+
+BUCKET_CB = C.CFUNCTYPE(_i, _vp, _i, _ll, _ll)
+LOSS_CB = C.CFUNCTYPE(_ll, _vp, _vp, _i)
 
 
 class SegLib:

@@ -127,6 +127,7 @@ struct seg_engine {
     int side_prio = 1;          // SEG_SIDE_PRIO=0: side stream at the default priority
     std::vector<hipEvent_t> ready_ev;
     hipEvent_t side_done = nullptr;
+    hipEvent_t ar_ev = nullptr;          // orders the gradient-exchange stream behind / in front of the caller's stream (seg_train_step hooks)
     size_t ready_used = 0;
     // Weight-gradient launches are queued and released to the side stream in batches under ONE fork event: every
     // hipEventRecord idles the main stream for ~6 us, and the side stream has slack (it only has to finish before the
@@ -1434,6 +1435,7 @@ void seg_destroy(seg_handle h) {
     if (h->pack_fork) (void)hipEventDestroy(h->pack_fork);
     if (h->pack_done) (void)hipEventDestroy(h->pack_done);
     if (h->side_done) (void)hipEventDestroy(h->side_done);
+    if (h->ar_ev) (void)hipEventDestroy(h->ar_ev);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2_done) (void)hipEventDestroy(h->side2_done);
     if (h->side2) (void)hipStreamDestroy(h->side2);
@@ -1829,11 +1831,45 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
     const long long v = h->vol(0);
     const double lbytes = (double)h->N * v * (4.0 * h->ncls + ((a->label_type & 15) == SEG_LABEL_U8 ? 1.0 : (a->label_type & 15) == SEG_LABEL_I64 ? 8.0 : 4.0));
     int pi = h->prof_begin(st, SEG_K_MISC, 2.0 * lbytes + 4.0 * h->N * v * h->ncls, 0.0);
+    if (a->loss_cb) {
+        // exact global-batch loss: the rank's batch-global sums are exchanged between the reduction and the finalize (parallel.GlobalBatchLoss)
+        if (seg_loss_reduce(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->loss_ws, stream)) return -1;
+        const long long ng = a->loss_cb(a->cb_user, (double*)a->loss_ws, seg_loss_shared_doubles());
+        if (ng < 0) return fail("seg_train_step: the loss exchange hook failed");
+        if (seg_loss_finalize(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->class_alpha,
+                              (int)ng, a->loss_ws, a->out3, stream)) return -1;
+    } else
     if (seg_loss_forward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->class_alpha,
                          a->loss_ws, a->out3, stream)) return -1;
     if (seg_loss_backward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->loss_ws,
                           h->loss_scale, a->dlogits, stream)) return -1;
     h->prof_end(st, pi);
+    if (a->bucket_cb) {
+        // bucketed gradient exchange: every finished suffix of the flat gradient buffer is handed to the caller's hook while the finer levels
+        // still run.  On the GPU the hook runs behind an auxiliary stream that waits for the caller's stream and the
+        // weight-gradient stream, so the backward pass itself never stalls at a bucket boundary.
+        if (a->nfrac < 0 || a->nfrac > 4) return fail("seg_train_step: nfrac must be 0..4");
+        const int nops = (int)h->bwd_ops.size();
+        hipStream_t aux = (hipStream_t)a->aux_stream;
+        if (aux && !h->ar_ev) (void)hipEventCreateWithFlags(&h->ar_ev, hipEventDisableTiming);
+        int prev_k = 0, idx = 0;
+        long long prev_off = h->nparam;
+        for (int f = 0; f < a->nfrac; ++f) {
+            int k = 0; long long off = 0;
+            if (seg_backward_bucket(h, a->fractions[f], &k, &off)) return -1;
+            if (k <= prev_k || k >= nops || off >= prev_off) continue;         // boundaries that coincide are skipped
+            if (backward_slice(h, a->dlogits, 1, prev_k, k, aux ? 0 : 1, stream)) return -1;
+            if (aux) {
+                (void)hipEventRecord(h->ar_ev, st); (void)hipStreamWaitEvent(aux, h->ar_ev, 0);
+                if (seg_side_wait(h, aux)) return -1;
+            }
+            if (a->bucket_cb(a->cb_user, idx++, off, prev_off - off)) return fail("seg_train_step: the gradient exchange hook failed");
+            prev_k = k; prev_off = off;
+        }
+        if (backward_slice(h, a->dlogits, 1, prev_k, nops, 1, stream)) return -1;
+        if (aux && idx) { (void)hipEventRecord(h->ar_ev, aux); (void)hipStreamWaitEvent(st, h->ar_ev, 0); }     // whatever the hooks queued on the auxiliary stream itself
+        if (a->bucket_cb(a->cb_user, idx, 0, prev_off) || a->bucket_cb(a->cb_user, -1, 0, 0)) return fail("seg_train_step: the gradient exchange hook failed");
+    } else
     if (seg_backward(h, a->dlogits, 1, stream)) return -1;
     // fused optimiser: p, m, v read + written, g read (+ once more by the overflow check); re-pack: fp32 masters read, run-dtype layouts written
     pi = h->prof_begin(st, SEG_K_MISC, (double)h->nparam * (28.0 + (a->check_finite ? 4.0 : 0.0) + 4.0 + 3.0 * (double)h->esz()), 0.0);
@@ -1853,6 +1889,7 @@ int seg_train_graph_capture(seg_handle h, const seg_train_args* a, void* stream)
     if (check_handle(h)) return -1;
     if (!a) return fail("seg_train_graph_capture: args is null");
     if (!a->packed) return fail("seg_train_graph_capture: run one ordinary step first (the captured step starts from packed weights)");
+    if (a->bucket_cb || a->loss_cb) return fail("seg_train_graph_capture: a step with exchange hooks cannot be captured (host callbacks)");
     if (h->prof_mask) return fail("seg_train_graph_capture: switch seg_profile_enable off first");
     hipStream_t st = (hipStream_t)stream;
     h->drop_graph();

@@ -388,9 +388,12 @@ class SegEngine:
             # the clDice term is a rank-local ratio: under GlobalBatchLoss the summed (not averaged) gradients would carry it `world` times
             raise NotImplementedError("train_step: cldice_weight together with a global-batch loss exchange is not supported; "
                                       "use the per-rank (DDP) loss semantics for the clDice term")
-        if world == 1 and xworld == 1 and not cldice_weight and _ONE_CALL:
+        if not cldice_weight and _ONE_CALL:
+            # ONE library call per step for every world size: with ranks to exchange with, seg_train_step calls back at the points of its
+            # schedule where a collective belongs (gradient buckets, the loss sums) and this side enqueues it (torch.distributed)
             return self._train_step_one_call(x, target, loss_name, lr, weight_decay, decoupled, focal_alpha, focal_gamma, class_alpha,
-                                             mask_mode, masks, logits, probs, launch)
+                                             mask_mode, masks, logits, probs, launch,
+                                             allreduce if world > 1 else None, loss_exchange if xworld > 1 else None)
         if cldice_weight:
             self.cldice_prepare_target(target, x.shape[0], tuple(x.shape[2:]), cldice_width)     # overlaps the forward pass
         logits, probs = self.forward(x, mask_mode, masks, logits, probs)
@@ -444,8 +447,43 @@ class SegEngine:
         if self.dtype in ("f16", "fp16", "float16") and self._steps_since_check >= self.scale_check_every:
             self.update_loss_scale(blocking=False)
 
+    def _exchange_hooks(self):
+        """ctypes callbacks handed to seg_train_step (created once; they act on the exchange objects of the current step, self._xchg)."""
+        if getattr(self, "_hooks", None) is None:
+            def bucket(_user, idx, off, cnt):
+                try:
+                    st = self._xchg
+                    ar = st["allreduce"]
+                    if idx < 0:                                   # every exchange has been enqueued: the caller's stream waits for them
+                        if getattr(ar, "bucketed", False):
+                            ar.finish(st["works"])
+                        return 0
+                    sl = self.grads[off:off + cnt]
+                    if not getattr(ar, "bucketed", False):
+                        ar(sl)                                    # one blocking / stream-ordered collective after the backward pass
+                    elif off > 0 and st["aux"] is not None:       # an early bucket: behind the auxiliary stream (ordered by the library)
+                        with torch.cuda.stream(st["aux"]):
+                            st["works"].append(ar.start(sl))
+                    else:
+                        st["works"].append(ar.start(sl))
+                    return 0
+                except BaseException as ex:                       # never let an exception unwind through the C frames
+                    self._xchg["error"] = ex
+                    return 1
+
+            def loss(_user, sums_ptr, n_doubles):
+                try:
+                    st = self._xchg
+                    shared = self._loss_ws[:8 * n_doubles].view(torch.float64)
+                    return int(st["loss_exchange"](shared, st["n_local"]))
+                except BaseException as ex:
+                    self._xchg["error"] = ex
+                    return -1
+            self._hooks = (_capi.BUCKET_CB(bucket), _capi.LOSS_CB(loss))
+        return self._hooks
+
     def _train_step_one_call(self, x, target, loss_name, lr, weight_decay, decoupled, focal_alpha, focal_gamma, class_alpha,
-                             mask_mode, masks, logits, probs, launch="stream"):
+                             mask_mode, masks, logits, probs, launch="stream", allreduce=None, loss_exchange=None):
         """The rank-local step as ONE library call (seg_train_step): the argument block is filled once per (shape, buffers) and only
         the pointers that change are rewritten, so the host side of a step is one FFI crossing."""
         assert x.dtype == torch.float32 and x.is_contiguous() and x.device.type == self.device.type
@@ -473,6 +511,39 @@ class SegEngine:
         a.lr, a.weight_decay, a.decoupled = float(lr), float(weight_decay), 1 if decoupled else 0
         a.check_finite = 1 if self.dtype in ("f16", "fp16", "float16") else 0
         a.packed = 1 if self.packed else 0
+        hooked = allreduce is not None or loss_exchange is not None
+        if hooked:
+            bucket_cb, loss_cb = self._exchange_hooks()
+            on_gpu = self.device.type == "cuda"
+            bucketed = allreduce is not None and getattr(allreduce, "bucketed", False)
+            if on_gpu and bucketed and getattr(self, "_ar_stream", None) is None:
+                self._ar_stream = torch.cuda.Stream(device=self.device)
+            aux = self._ar_stream if (on_gpu and bucketed) else None
+            self._xchg = {"allreduce": allreduce, "loss_exchange": loss_exchange, "works": [], "aux": aux, "n_local": int(x.shape[0]), "error": None}
+            a.bucket_cb = C.cast(bucket_cb, C.c_void_p) if allreduce is not None else None
+            a.loss_cb = C.cast(loss_cb, C.c_void_p) if loss_exchange is not None else None
+            fr = (getattr(allreduce, "fractions", None) or (allreduce.tail_fraction,)) if bucketed else ()
+            a.nfrac = min(len(fr), 4)
+            for i in range(4):
+                a.fractions[i] = float(fr[i]) if i < a.nfrac else 0.0
+            a.aux_stream = aux.cuda_stream if aux is not None else None
+            # a global-batch loss sums the ranks' gradients (each already carries the global 1/count); plain data parallelism averages them
+            a.grad_div = 1.0 if loss_exchange is not None else float(getattr(allreduce, "world", 1))
+        else:
+            a.bucket_cb, a.loss_cb, a.nfrac, a.aux_stream, a.grad_div = None, None, 0, None, 1.0
+        if hooked:
+            rc = self.lib.seg_train_step(self.h, C.byref(a), self.stream())
+            err, self._xchg["error"] = self._xchg["error"], None
+            if err is not None:
+                raise err
+            self.lib.check(rc, "seg_train_step")
+            self.packed = True
+            self._pack_pending = True
+            self._keep = (x, mt)
+            self._keep_loss = (target, class_alpha)
+            self._last_probs = probs
+            self._after_step()
+            return self._out3
         if (launch == "graph" and self.packed and self.device.type == "cuda" and mask_mode != _capi.MASKS_GIVEN and
                 not getattr(self, "_graph_refused", False)):
             # the argument block as bytes is the identity of the captured step (pointers, scalars; the loss scale is tracked by the library)

@@ -293,6 +293,19 @@ def test_bucketed_train_step_equals_plain_step(dev):
         res.append({k: v.cpu() for k, v in e.state_dict().items()})
         if ar is not None:
             assert 2 <= len(ar.sizes) <= 4 and sum(ar.sizes) == e.numel and ar.sizes[0] >= ar.sizes[-1]
+    # the exchange-carrying step is ONE library call too (seg_train_step calling back for every bucket), not a Python loop over backward slices
+    e, params, x, y, masks, alpha, loss = build(tag, "f32", dev, True)
+    calls = []
+    for name in ("seg_backward_slice", "seg_backward_range", "seg_forward", "seg_adam_step", "seg_side_wait"):
+        monkeypatch_fn = getattr(e.lib, name)
+        setattr(e.lib, name, (lambda *a, _n=name, _f=monkeypatch_fn: (calls.append(_n), _f(*a))[1]))
+    try:
+        ar = _LoopbackBuckets()
+        e.train_step(x.to(dev), y.to(dev), loss, lr=1e-3, class_alpha=alpha.to(dev), mask_mode=_capi.MASKS_GIVEN, masks=masks, allreduce=ar)
+        assert calls == [] and len(ar.sizes) >= 2, calls
+    finally:
+        for name in ("seg_backward_slice", "seg_backward_range", "seg_forward", "seg_adam_step", "seg_side_wait"):
+            setattr(e.lib, name, getattr(e.lib.dll, name))
     tot = bad = 0
     for k in res[0]:
         d = (res[0][k] - res[1][k]).abs()
