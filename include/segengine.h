@@ -156,12 +156,16 @@ int seg_lovasz_forward(const float* x, const void* target, int label_type, int n
 /* SSIM / SSIM3D (model/lossesSSIM.py:47-99, 102-167): img1, img2 fp32 [n][c][d][h][w] (nd = 2: d = 1), Gaussian window `window` (11 in the
  * reference, sigma 1.5), zero padding, the same window for every channel.  out[0] = mean of the SSIM map (size_average=True),
  * out[1 .. n] = the per-sample means.  seg_ssim_forward leaves the derivative maps in ws (seg_ssim_ws_bytes(n, c, d*h*w) bytes) for
- * seg_ssim_backward: dimg = gscale * d(sum of the map)/d img, gscale[0] (per_sample = 0) or gscale[sample] (per_sample = 1) carrying the
+ * seg_ssim_backward: dimg = gscale * d(sum of the map)/d img, gscale[0] (per_sample = 0), gscale[sample] (per_sample = 1) or gscale[sample][x] (per_sample = row length w >= 2) carrying the
  * incoming gradient times 1/count; dimg1 or dimg2 may be NULL.  The backward pass consumes ws (one backward per forward).
  * Limits: n <= 64, window odd and <= 15. */
 long long seg_ssim_ws_bytes(int n, int c, long long v);
 int seg_ssim_forward(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, float* out,
                      void* stream);
+/* the same forward pass, additionally out_cols[n][w] = the map's means over (c, d, h): what `ssim3D(size_average=False)` returns in the reference (its
+ * `.mean(1).mean(1).mean(1)` of a 5-D map, model/lossesSSIM.py:92-97, leaves (N, W)); seg_ssim_backward takes the matching gscale[n][w] with per_sample = w */
+int seg_ssim_forward_cols(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, float* out,
+                          float* out_cols, void* stream);
 int seg_ssim_backward(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, const float* gscale,
                       int per_sample, float* dimg1, float* dimg2, void* stream);
 /* predict() post-processing on the device (modelVNet.py:670-676): probs [N][C][V] fp32 -> uint8 mask [N][V];

@@ -145,6 +145,12 @@ def make_ssim():
     v = S.SSIM(window_size=11, size_average=False)(xx, b2)
     (v * torch.tensor([1.0, -2.0])).sum().backward()
     out["val_ssim2d_persample"], out["g1_ssim2d_persample"] = _np(v), _np(xx.grad)
+    # ssim3D(size_average=False): `.mean(1).mean(1).mean(1)` of the 5-D map leaves (N, W) (model/lossesSSIM.py:92-97)
+    xx, yy = a3.clone().requires_grad_(True), b3.clone().requires_grad_(True)
+    v = S.ssim3D(xx, yy, window_size=11, size_average=False)
+    wts = torch.linspace(-1.0, 2.0, v.numel()).reshape(v.shape)
+    (v * wts).sum().backward()
+    out["val_ssim3d_cols"], out["w_ssim3d_cols"], out["g1_ssim3d_cols"], out["g2_ssim3d_cols"] = _np(v), _np(wts), _np(xx.grad), _np(yy.grad)
     np.savez_compressed(os.path.join(OUT, "ssim.npz"), **out)
     print("ssim:", {k: np.asarray(v).tolist() for k, v in out.items() if k.startswith("val_")})
 

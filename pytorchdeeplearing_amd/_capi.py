@@ -66,6 +66,7 @@ SIGNATURES = {
     "seg_lovasz_forward": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp]),
     "seg_ssim_ws_bytes": (_ll, [_i, _i, _ll]),
     "seg_ssim_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "seg_ssim_forward_cols": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "seg_ssim_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "seg_predict_mask": (_i, [_vp, _vp, _i, _i, _ll, C.c_float, _i, _vp]),
     "seg_metric": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _vp]),

@@ -316,8 +316,13 @@ struct seg_engine {
     hipGraphExec_t tgraph_exec = nullptr;
     bool capturing = false;
     int tgraph_mask_mode = 0;
+    hipStream_t tgraph_stream = nullptr;        // the stream of the last replay: a replay may still be running when the graph is dropped
     void drop_graph() {
-        if (tgraph_exec) { (void)hipGraphExecDestroy(tgraph_exec); tgraph_exec = nullptr; }
+        if (tgraph_exec) {
+            if (tgraph_stream) (void)hipStreamSynchronize(tgraph_stream);
+            (void)hipGraphExecDestroy(tgraph_exec); tgraph_exec = nullptr;
+        }
+        tgraph_stream = nullptr;
         if (tgraph) { (void)hipGraphDestroy(tgraph); tgraph = nullptr; }
     }
     // measurement (seg_profile_*)
@@ -1731,6 +1736,14 @@ int seg_ssim_forward(const float* img1, const float* img2, int n, int c, int d, 
     if (launch_ssim_forward(img1, img2, n, c, nd == 3 ? d : 1, h, w, nd, window, ws, out, (hipStream_t)stream)) return fail("seg_ssim_forward: bad arguments");
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_ssim_forward: launch failed");
 }
+int seg_ssim_forward_cols(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, float* out,
+                          float* out_cols, void* stream) {
+    if (ssim_check("seg_ssim_forward_cols", img1, img2, ws, n, c, d, h, w, nd, window) || !out || !out_cols)
+        return (out && out_cols) ? -1 : fail("seg_ssim_forward_cols: out is null");
+    if (launch_ssim_forward(img1, img2, n, c, nd == 3 ? d : 1, h, w, nd, window, ws, out, (hipStream_t)stream, out_cols))
+        return fail("seg_ssim_forward_cols: bad arguments");
+    return hipGetLastError() == hipSuccess ? 0 : fail("seg_ssim_forward_cols: launch failed");
+}
 int seg_ssim_backward(const float* img1, const float* img2, int n, int c, int d, int h, int w, int nd, int window, void* ws, const float* gscale,
                       int per_sample, float* dimg1, float* dimg2, void* stream) {
     if (ssim_check("seg_ssim_backward", img1, img2, ws, n, c, d, h, w, nd, window)) return -1;
@@ -1925,6 +1938,8 @@ int seg_train_graph_launch(seg_handle h, void* stream) {
     if (!h->tgraph_exec) return fail("seg_train_graph_launch: no captured step (seg_train_graph_capture; a re-plan, re-bind or loss-scale change drops it)");
     if (hipGraphLaunch(h->tgraph_exec, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return fail("seg_train_graph_launch: hipGraphLaunch failed"); }
     if (h->tgraph_mask_mode == SEG_MASKS_RANDOM) ++h->draws;
+    h->tgraph_stream = (hipStream_t)stream;
+    h->q_clean = false;          // the replayed backward pass used the GroupNorm-backward sums: an eager backward that follows must clear them
     return 0;
 }
 int seg_train_graph_ready(seg_handle h) { return (h && h->tgraph_exec) ? 1 : 0; }

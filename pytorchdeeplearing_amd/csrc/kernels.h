@@ -215,7 +215,7 @@ int launch_lovasz(const float* x, const void* target, int label_type, int N, int
 
 // SSIM / SSIM3D (ssim.hip; model/lossesSSIM.py): planar fp32 [N][C][D][H][W]; out = {mean, per-sample means[N]}; ws keeps the derivative maps
 long long ssim_ws_bytes(int planes, long long v);
-int launch_ssim_forward(const float* x1, const float* x2, int N, int C, int D, int H, int W, int nd, int window, void* ws, float* out, hipStream_t s);
+int launch_ssim_forward(const float* x1, const float* x2, int N, int C, int D, int H, int W, int nd, int window, void* ws, float* out, hipStream_t s, float* out_cols = nullptr);
 int launch_ssim_backward(const float* x1, const float* x2, int N, int C, int D, int H, int W, int nd, int window, void* ws, const float* gscale,
                          int per_sample_scale, float* dx1, float* dx2, hipStream_t s);
 

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void ssim_blur_kernel(const float* in, float* 
 
 // map + derivative maps (in place over the five statistics) + per-sample sums of the map (fp64, one atomic per block and sample)
 __global__ __launch_bounds__(256) void ssim_map_kernel(float* mu1, float* mu2, float* e11, float* e22, float* e12, long long per_sample,
-                                                       double* sums) {
+                                                       double* sums, double* colsums, int W) {
     __shared__ double red[4];
     const int n = blockIdx.y;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void ssim_map_kernel(float* mu1, float* mu2, f
         const float inv = 1.f / (B1 * B2);
         const float map = A1 * A2 * inv;
         part += (double)map;
+        if (colsums) atomicAdd(colsums + (long long)n * W + (int)(j % W), (double)map);       // ssim3D(size_average=False): means over (C, D, H) per (n, w)
         // derivatives with mu and e as independent variables (s_ab = e_ab - mu_a mu_b)
         const float d_e12 = 2.f * A1 * inv;
         const float d_e = -map / B2;                                   // d / d e11 = d / d e22
@@ -73,6 +74,11 @@ __global__ __launch_bounds__(256) void ssim_map_kernel(float* mu1, float* mu2, f
     }
 }
 
+__global__ __launch_bounds__(256) void ssim_cols_finalize_kernel(const double* colsums, int NW, double inv_count, float* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < NW) out[i] = (float)(colsums[i] * inv_count);
+}
+
 __global__ __launch_bounds__(64) void ssim_finalize_kernel(const double* sums, int N, long long per_sample, float* out) {
     if (threadIdx.x) return;
     double tot = 0.0;
@@ -85,12 +91,22 @@ __global__ __launch_bounds__(256) void ssim_combine_kernel(const float* x1, cons
                                                            const float* be22, const float* be12, const float* gscale, int per_sample_scale,
                                                            long long per_sample, float* dx1, float* dx2) {
     const int n = blockIdx.y;
-    const float sc = gscale[per_sample_scale ? n : 0];
+    const float sc0 = gscale[per_sample_scale == 1 ? n : 0];
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < per_sample; j += (long long)gridDim.x * 256) {
         const long long i = (long long)n * per_sample + j;
+        const float sc = per_sample_scale >= 2 ? 1.f : sc0;      // >= 2 (row length W, gscale[n][w]): the maps were scaled per voxel before the blur
         const float a = x1[i], b = x2[i], g12 = be12[i];
         if (dx1) dx1[i] = sc * (bmu1[i] + 2.f * a * be11[i] + b * g12);
         if (dx2) dx2[i] = sc * (bmu2[i] + 2.f * b * be22[i] + a * g12);
+    }
+}
+
+// position-dependent output weights (gscale[n][x]): d loss / d map varies inside a sample, so it multiplies the derivative maps BEFORE the adjoint blur
+__global__ __launch_bounds__(256) void ssim_scale_cols_kernel(float* m0, float* m1, float* m2, float* m3, float* m4, const float* gscale, int W,
+                                                              long long per_sample, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float sc = gscale[(i / per_sample) * W + (int)(i % W)];
+        m0[i] *= sc; m1[i] *= sc; m2[i] *= sc; m3[i] *= sc; m4[i] *= sc;
     }
 }
 
@@ -122,7 +138,8 @@ static void blur_all_axes(float* buf, float* tmp, int planes, int D, int H, int 
     if (a != buf) (void)hipMemcpyAsync(buf, a, (size_t)total * 4, hipMemcpyDeviceToDevice, s);
 }
 
-int launch_ssim_forward(const float* x1, const float* x2, int N, int C, int D, int H, int W, int nd, int window, void* ws_, float* out, hipStream_t s) {
+int launch_ssim_forward(const float* x1, const float* x2, int N, int C, int D, int H, int W, int nd, int window, void* ws_, float* out, hipStream_t s,
+                        float* out_cols) {
     if (N > 64 || window < 1 || window > SSIM_MAXW || !(window & 1)) return -1;
     const int planes = N * C;
     const long long v = (long long)D * H * W, total = planes * v;
@@ -140,8 +157,17 @@ int launch_ssim_forward(const float* x1, const float* x2, int N, int C, int D, i
     (void)hipMemsetAsync(sums, 0, 64 * 8, s);
     const long long per_sample = (long long)C * v;
     const unsigned gx = (unsigned)(per_sample / 256 + 1 < 2048 ? per_sample / 256 + 1 : 2048);
-    hipLaunchKernelGGL(ssim_map_kernel, dim3(gx, N), dim3(256), 0, s, mp[0], mp[1], mp[2], mp[3], mp[4], per_sample, sums);
+    // out_cols ([N][W], optional): the means over (C, D, H) - what the reference's `.mean(1).mean(1).mean(1)` of a 5-D map leaves (model/lossesSSIM.py:
+    // 92-97 with size_average=False).  The column sums live in the scratch map, free once the blur passes are done
+    double* colsums = out_cols ? (double*)mp[5] : nullptr;
+    if (colsums) {
+        if ((size_t)N * W * 8 > m) return -1;
+        (void)hipMemsetAsync(colsums, 0, (size_t)N * W * 8, s);
+    }
+    hipLaunchKernelGGL(ssim_map_kernel, dim3(gx, N), dim3(256), 0, s, mp[0], mp[1], mp[2], mp[3], mp[4], per_sample, sums, colsums, W);
     hipLaunchKernelGGL(ssim_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)sums, N, per_sample, out);
+    if (colsums)
+        hipLaunchKernelGGL(ssim_cols_finalize_kernel, dim3((N * W + 255) / 256), dim3(256), 0, s, (const double*)colsums, N * W, 1.0 / ((double)C * D * H), out_cols);
     return 0;
 }
 
@@ -155,8 +181,13 @@ int launch_ssim_backward(const float* x1, const float* x2, int N, int C, int D, 
     float* mp[6];
     for (int i = 0; i < 6; ++i) mp[i] = (float*)(ws + i * m);
     const SsimWin w = make_window(window);
-    for (int i = 0; i < 5; ++i) blur_all_axes(mp[i], mp[5], planes, D, H, W, nd, w, s);      // the derivative maps of the forward pass, in place
     const long long per_sample = (long long)C * v;
+    if (per_sample_scale >= 2) {
+        if (per_sample_scale != W) return -1;
+        hipLaunchKernelGGL(ssim_scale_cols_kernel, dim3((unsigned)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192)), dim3(256), 0, s, mp[0], mp[1], mp[2], mp[3],
+                           mp[4], gscale, W, per_sample, total);
+    }
+    for (int i = 0; i < 5; ++i) blur_all_axes(mp[i], mp[5], planes, D, H, W, nd, w, s);      // the derivative maps of the forward pass, in place
     const unsigned gx = (unsigned)(per_sample / 256 + 1 < 2048 ? per_sample / 256 + 1 : 2048);
     hipLaunchKernelGGL(ssim_combine_kernel, dim3(gx, N), dim3(256), 0, s, x1, x2, (const float*)mp[0], (const float*)mp[1], (const float*)mp[2],
                        (const float*)mp[3], (const float*)mp[4], gscale, per_sample_scale, per_sample, dx1, dx2);

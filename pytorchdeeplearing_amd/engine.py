@@ -557,11 +557,20 @@ class SegEngine:
             if gs is not cur:
                 gs.wait_stream(cur)
             if getattr(self, "_graph_key", None) != key or not self.lib.seg_train_graph_ready(self.h):
-                if self.lib.seg_train_graph_capture(self.h, C.byref(a), gsp) == 0:
+                # every scalar of the step (lr included) is baked into the captured launches: a schedule that changes one of them each step would
+                # re-capture each step (stream syncs + ~250 captured launches + instantiate - slower than the stream launches it replaces)
+                self._graph_recaptures = getattr(self, "_graph_recaptures", 0) + (1 if getattr(self, "_graph_key", None) is not None else 0)
+                if self._graph_recaptures >= 3:                   # three steps in a row (a replay in between resets the count)
+                    import warnings
+                    warnings.warn("segengine: launch='graph' re-captured the step on 3 consecutive steps (lr / buffers change from step to step); falling back to stream launches")
+                    self._graph_key, self._graph_refused = None, True
+                elif self.lib.seg_train_graph_capture(self.h, C.byref(a), gsp) == 0:
                     self._graph_key = key
                 else:                         # not retried step after step: a failed capture costs milliseconds
                     self._graph_key, self._graph_refused = None, True
                     self.graph_error = self.lib.seg_last_error().decode()
+            else:
+                self._graph_recaptures = 0
             if self._graph_key is not None:
                 self.lib.check(self.lib.seg_train_graph_launch(self.h, gsp), "seg_train_graph_launch")
                 if gs is not cur:

@@ -62,12 +62,12 @@ class GlobalBatchLoss:
     finalize kernel with the rank's batch-global sums (32 fp64 values, on the device); returns the global sample count.
     One tiny SUM all-reduce; the parameter gradients are then summed over ranks instead of averaged."""
 
-    def __init__(self, world_size=None, group=None, equal_shards=True):
+    def __init__(self, world_size=None, group=None, equal_shards=False):
         self.group = group
         self.world = world_size if world_size is not None else dist.get_world_size(group)
-        # True: every rank holds the same sample count, the global count is n_local * world.  False (a partial last batch): the
-        # count is taken from the exchanged sums ON THE DEVICE (seg_loss_reduce leaves the local sample count in the shared
-        # doubles, the all-reduce sums it, seg_loss_finalize(n_global = 0) reads it) - neither variant allocates or reads back
+        # False (default): the global sample count is taken from the exchanged sums ON THE DEVICE (seg_loss_reduce leaves the local sample
+        # count in the shared doubles, the all-reduce sums it, seg_loss_finalize(n_global = 0) reads it) - right for a partial last batch
+        # spread unevenly over the ranks, and free (no allocation, no read-back).  True: opt-in shortcut n_local * world for equal shards
         self.equal_shards = equal_shards
 
     def __call__(self, shared_sums: torch.Tensor, n_local: int):

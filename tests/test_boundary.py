@@ -321,8 +321,21 @@ def test_ssim_modules_vs_reference_golden(dev, golden_dir):
     (v * torch.tensor([1.0, -2.0], device=dev)).sum().backward()
     want = G["g1_ssim2d_persample"]
     assert np.abs(a.grad.cpu().numpy() - want).max() < 2e-3 * np.abs(want).max()
-    with pytest.raises(NotImplementedError):
-        S.ssim3D(torch.zeros(1, 1, 4, 4, 4, device=dev), torch.zeros(1, 1, 4, 4, 4, device=dev), size_average=False)
+    # ssim3D(size_average=False): the reference's (N, W) result (means over channel, depth, height), weighted sum differentiated w.r.t. both volumes
+    a = torch.from_numpy(G["a3"]).to(dev).requires_grad_(True)
+    b = torch.from_numpy(G["b3"]).to(dev).requires_grad_(True)
+    v = S.ssim3D(a, b, window_size=11, size_average=False)
+    assert tuple(v.shape) == tuple(G["val_ssim3d_cols"].shape)
+    np.testing.assert_allclose(v.detach().cpu().numpy(), G["val_ssim3d_cols"], rtol=0, atol=1e-5)
+    tot = (v * torch.from_numpy(G["w_ssim3d_cols"]).to(dev)).sum()
+    tot.backward(retain_graph=True)
+    for got, want in ((a.grad, G["g1_ssim3d_cols"]), (b.grad, G["g2_ssim3d_cols"])):
+        assert np.abs(got.cpu().numpy() - want).max() < 2e-3 * np.abs(want).max() + 1e-9
+    # a second traversal of the same node (retain_graph) returns the same gradient: the backward pass rebuilds the maps it consumed
+    g_first = a.grad.clone()
+    a.grad = None
+    tot.backward()
+    assert float((a.grad - g_first).abs().max()) <= 1e-6 * float(g_first.abs().max())
 
 
 @pytest.mark.parametrize("name", ["BinaryDiceLoss", "BinaryCrossEntropyDiceLoss", "BinaryFocalLoss", "BinaryTverskyLoss", "BinarySSLoss", "BinaryJaccardLoss"])
