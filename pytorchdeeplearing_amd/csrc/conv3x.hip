@@ -164,13 +164,17 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
     a.gn = gn ? *gn : GnFinArgs{};
     a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.stat_rep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
-    // diagnostics only (WRONG results): SEG_DIAG_NOSTATS=1 drops the GroupNorm statistics epilogue, to time what it costs inside a step
+#ifdef SEG_DIAG
+    // diagnostic builds only (python tools/build_variant.py diag conv3x.hip -DSEG_DIAG; WRONG results): SEG_DIAG_NOSTATS=1 drops the GroupNorm
+    // statistics epilogue, to time what it costs inside a step.  Not compiled into the product library.
     static const bool nostats = getenv("SEG_DIAG_NOSTATS") && atoi(getenv("SEG_DIAG_NOSTATS"));
     if (nostats) a.stats = nullptr;
+#endif
     a.N = N; a.D = ndim == 3 ? D : 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     static const int remap = getenv("SEG_C3X_REMAP") ? atoi(getenv("SEG_C3X_REMAP")) : 1;      // XCD-aware box order (c3x_box_of_block)
     a.remap = remap;
-    // diagnostics only (tools/trace_gaps.py): SEG_C3X_TWICE=1 launches every conv twice without statistics first, so a kernel trace shows
+#ifdef SEG_DIAG
+    // diagnostic builds only (tools/trace_gaps.py): SEG_C3X_TWICE=1 launches every conv twice without statistics first, so a kernel trace shows
     // the same launch with cold and with warm operands
     static const bool twice = getenv("SEG_C3X_TWICE") && atoi(getenv("SEG_C3X_TWICE"));
     if (twice) {
@@ -178,6 +182,7 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
         if (ndim == 3) { if (dtype == DT_F16) c3x::launch_3d<f16>(cfg, w, s); else c3x::launch_3d<bf16>(cfg, w, s); }
         else { if (dtype == DT_F16) c3x::launch_2d<f16>(cfg, w, s); else c3x::launch_2d<bf16>(cfg, w, s); }
     }
+#endif
     if (a.fuse) {
         if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d_gn<f16>(cfg, a, s) : c3x::launch_3d_gn<bf16>(cfg, a, s);
         return dtype == DT_F16 ? c3x::launch_2d_gn<f16>(cfg, a, s) : c3x::launch_2d_gn<bf16>(cfg, a, s);
