@@ -13,15 +13,45 @@ so here:
   * batches are staged in pinned memory and copied on a dedicated HIP stream; the consumer's stream waits on the copy's
     event, never the host (no `hipDeviceSynchronize` in the loop).
 
+  * `.npy` volume data sets (model/dataset.py:82-115, what `trainprocess` of the 3-D wrappers reads) take a direct path (round 4): every reader
+    thread memory-maps the two files of a sample and writes them straight into its slot of a recycled PINNED batch buffer - image cast to
+    float32, label narrowed to one byte (`!= 0` for the binary nets) in the same pass.  One copy per voxel on the host instead of five
+    (np.load, `.long()`, collate, narrowing, pin_memory - the last one a fresh pinned allocation per batch), which is what it takes to feed a
+    GPU that trains ~1000 volumes/s from the page cache (tools/bench_pipeline.py, profiles/r04_pipeline_end_to_end.json).
+
 Yields (x float32 (N,C,...) contiguous, y uint8/int64 (N,...) contiguous) on `device`, in DataLoader order."""
 import os
 import queue
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
+import numpy as np
 import torch
 
 _END = object()
+
+
+class _PinnedPool:
+    """recycled pinned staging buffers: a buffer goes back to the pool with the event of the copy that read it and is handed out again once
+    that event has completed (a fresh one is allocated while none is free: the pool grows to the pipeline depth and stays there)"""
+
+    def __init__(self, cuda):
+        self.cuda, self.free, self.lock = cuda, {}, threading.Lock()
+
+    def take(self, shape, dtype):
+        key = (tuple(shape), dtype)
+        with self.lock:
+            lst = self.free.setdefault(key, [])
+            for i, (buf, ev) in enumerate(lst):
+                if ev is None or ev.query():
+                    lst.pop(i)
+                    return buf
+        buf = torch.empty(shape, dtype=dtype)
+        return buf.pin_memory() if self.cuda else buf
+
+    def give(self, buf, ev):
+        with self.lock:
+            self.free.setdefault((tuple(buf.shape), buf.dtype), []).append((buf, ev))
 
 
 class DevicePrefetcher:
@@ -30,8 +60,10 @@ class DevicePrefetcher:
         self.cuda = self.device.type == "cuda"
         self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
         if workers is None:
-            workers = int(os.environ.get("SEGENGINE_READER_THREADS", "2"))
+            workers = int(os.environ.get("SEGENGINE_READER_THREADS", "2"))     # 2 / 4 / 8 threads: 0.94 / 0.91 / 0.72 of the resident rate (profiles/r04_pipeline_end_to_end.json)
         self.workers = max(1, int(workers))
+        self.pool = _PinnedPool(self.cuda)
+        self._u8_ok = None                               # multi-class labels of this data set fit one byte (decided on the first batch)
 
     def __len__(self):
         return len(self.loader)
@@ -60,8 +92,39 @@ class DevicePrefetcher:
                 yield self._prepare(batch)
             return
         ds, collate = ld.dataset, ld.collate_fn
+        from .dataset import datasetModelSegwithnpy
+        direct = type(ds) is datasetModelSegwithnpy and os.environ.get("SEGENGINE_DIRECT_NPY", "1") != "0"
+
+        def fetch_direct(indices):
+            """.npy samples written straight into a pinned batch buffer (same values as ds[i] + collate + _prepare)"""
+            c, d, h, w = ds.targetsize
+            n = len(indices)
+            x = self.pool.take((n, c, d, h, w), torch.float32)
+            xn = x.numpy()
+            labs = [np.load(ds.labels[i], mmap_mode="r") for i in indices]
+            if self.binary:
+                y = self.pool.take((n, d, h, w), torch.uint8)
+            else:
+                if self._u8_ok is None:                    # class ids: one byte when they fit (checked once; a later batch that does not fit falls back)
+                    self._u8_ok = all(l.dtype.kind in "bu" and l.dtype.itemsize == 1 or (int(l.min()) >= 0 and int(l.max()) < 256) for l in labs)
+                y = self.pool.take((n, d, h, w), torch.uint8 if self._u8_ok else torch.int64)
+            yn = y.numpy()
+            for k, i in enumerate(indices):
+                img = np.load(ds.images[i], mmap_mode="r")
+                assert img.size == c * d * h * w, (img.shape, ds.targetsize)
+                np.copyto(xn[k], img.reshape(c, d, h, w), casting="unsafe")
+                lab = labs[k].reshape(d, h, w)
+                if self.binary:
+                    np.not_equal(lab, 0, out=yn[k].view(np.bool_))
+                elif self._u8_ok and lab.dtype.itemsize > 1 and (int(lab.min()) < 0 or int(lab.max()) > 255):
+                    raise ValueError("label ids outside 0..255 after the data set was found to fit one byte per voxel: %s" % ds.labels[i])
+                else:
+                    np.copyto(yn[k], lab, casting="unsafe")
+            return x, y, True                             # pooled buffers: recycled after their copy
 
         def fetch(indices):
+            if direct:
+                return fetch_direct(indices)
             return self._prepare(collate([ds[i] for i in indices]))
 
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
@@ -106,13 +169,15 @@ class DevicePrefetcher:
             return None
         if isinstance(item, BaseException):
             raise item
-        x, y = item
+        x, y = item[0], item[1]
         if not self.cuda:
             return x, y, None
         with torch.cuda.stream(self.copy_stream):
             xd, yd = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
+        if len(item) > 2:
+            self.pool.give(x, ev); self.pool.give(y, ev)   # reusable once the copy that reads them has completed
         return xd, yd, ev, (x, y)                          # keep the pinned sources alive until the copy has been waited on
 
     def _ready(self, p):

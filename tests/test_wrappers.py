@@ -334,3 +334,16 @@ def test_reference_entry_script_runs_unchanged(dev, tmp_path, monkeypatch, cls, 
     assert net.numclass == numclass
     out = net.predict(np.load(tr_i[0]).reshape((1,) + dims))
     assert out.shape == dims and out.dtype == np.uint8 and int(out.max()) < numclass
+
+
+@pytest.mark.gpu
+def test_pipeline_feeds_the_engine_end_to_end(tmp_path):
+    """SURVEY.md section 8f N3 / VERDICT r03 item 9: .npy volumes on disk -> reader threads -> pinned staging -> copy stream -> train_step must reach
+    at least 0.8 x the rate of the same engine stepping on a resident batch (tools/bench_pipeline.py is the measurement: 64 volumes of 96^3, three
+    timed epochs, two reader threads - 0.94 on the round-4 box, 0.48 before the direct .npy path; profiles/r04_pipeline_end_to_end.json)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_pipeline", os.path.join(conftest.ROOT, "tools", "bench_pipeline.py"))
+    bp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bp)
+    r = bp.measure(nvol=64, epochs=3, threads=2, tmp=str(tmp_path))
+    assert r["fed_over_resident"] >= 0.8, r
