@@ -498,10 +498,14 @@ void conv3_dispatch(const Conv3Args& a, int ndim, hipStream_t s) {
 // sweep spilled: the compiler's reloads sat between the prefetch loads and serialised them); 32 x 16 needs 56, reads its B fragments a whole K
 // step ahead, writes partial tiles half the size (the reduce pass re-reads half as much) and its 44 KB of LDS / 184 registers leave a halo-conv
 // workgroup of the main stream room on the same CU.  SEG_W3_CQ=32 restores the wide tile.
-inline void wgrad3_tile(int P, int Q, int esz, int* CP, int* CQ) {
-    static const int cq = getenv("SEG_W3_CQ") ? atoi(getenv("SEG_W3_CQ")) : 16;
+// The 2-D nets keep the wide tile (9 taps: 36 accumulator registers per 16 x 16 sub-tile set, the pressure argument does not apply, and
+// C2 VNet2d 16 x 512^2 measures 6.45 ms per step with it against 6.66 with the narrow one; C4 / C5, 3-D: 4.43 / 4.45 against 4.56 / 4.68,
+// profiles/r04_configs_tile_ab.log).
+inline void wgrad3_tile(int P, int Q, int esz, int ndim, int* CP, int* CQ) {
+    static const int cq = getenv("SEG_W3_CQ") ? atoi(getenv("SEG_W3_CQ")) : 0;          // 0: by dimensionality
+    const int want = cq ? cq : (ndim == 3 ? 16 : 32);
     *CP = P >= 32 ? 32 : 16;
-    *CQ = (Q >= 32 && (cq >= 32 || esz == 4)) ? 32 : 16;
+    *CQ = (Q >= 32 && (want >= 32 || esz == 4)) ? 32 : 16;
 }
 
 struct Wgrad3Args {
@@ -856,7 +860,7 @@ template <class T, int TD, int TH, int TW, int KD>
 void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
     Wgrad3Args a = a0;
     int CP, CQ;
-    wgrad3_tile(a.P, a.Q, (int)sizeof(T), &CP, &CQ);
+    wgrad3_tile(a.P, a.Q, (int)sizeof(T), KD == 3 ? 3 : 2, &CP, &CQ);
     const int combos = (a.P / CP) * (a.Q / CQ);
     dim3 grid(a.nb, combos);
 #define SEG_W3(CPv, CQv) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3_kernel<T, TD, TH, TW, KD, CPv, CQv>), grid, dim3(256), 0, s, a)
@@ -880,13 +884,18 @@ template <class T> struct Wgrad3Big16 {
     static bool launch(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
         const char* env = getenv("SEG_W3_BOX16");          // 0: off; 1 (default): where the volume holds enough boxes; 2: wherever the shape fits (tests)
         const int on = env ? atoi(env) : 1;
-        if (!on || a0.P != 16 || a0.Q != 16 || a0.xsc || !wide_box(a0.W)) return false;
+        int CP, CQ;
+        wgrad3_tile(a0.P, a0.Q, 2, 3, &CP, &CQ);
+        // P = 16 with 16-channel q-tiles: the 16 -> 16 LUConv of the VNet top level and the finest-level convs of the UNets (16 -> 16, and
+        // 32 -> 16 over the decoder's concat: two q-tiles, grid.y = 2)
+        if (!on || a0.P != 16 || CQ != 16 || a0.Q % 16 || a0.xsc || !wide_box(a0.W)) return false;
+        const int combos = a0.Q / 16;
         const long long nbox = num_boxes<4, 8, 16>(a0.N, a0.D, a0.H, a0.W);
         if (on < 2 && nbox < 6ll * a0.nb) return false;    // small volumes keep the 3 x 4 x 16 box (enough boxes per workgroup to amortise its partial tile)
         Wgrad3Args a = a0;
         if (a.nb > nbox) a.nb = (int)nbox;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3_kernel<T, 4, 8, 16, 3, 16, 16>), dim3(a.nb, 1), dim3(256), 0, s, a);
-        const long long total = 16ll * 16 * 27;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3_kernel<T, 4, 8, 16, 3, 16, 16>), dim3(a.nb, combos), dim3(256), 0, s, a);
+        const long long total = 16ll * a.Q * 27;
         hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total + 255) / 256), (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, 16, 16, 27,
                            a.nb, sP, sQ, qreal);
         return true;
@@ -1162,7 +1171,7 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
 
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, int esz) {
     int CP, CQ;
-    wgrad3_tile(P, Q, esz, &CP, &CQ);
+    wgrad3_tile(P, Q, esz, ndim, &CP, &CQ);
     const int combos = (P / CP) * (Q / CQ);
     // tuning knobs.  512 while the kernel exposed its staging latency (r01: 256 / 384 / 768 -> 691 / 694 / 680 vs 700 volumes/s); with the next
     // box prefetched into registers one workgroup per CU is enough and a third fewer partial tiles are written and re-read:

@@ -111,6 +111,9 @@ def test_low_precision_vs_fp32_full_size(tag, dtype, flip_tol, dice_tol):
     l, p = e.forward(x)
     d = float(e.loss_forward(l, y, loss)[1])
     flips = float(((p > 0.5) != m32).float().mean())
+    if os.environ.get("SEG_FULLSIZE_REPORT"):
+        with open(os.environ["SEG_FULLSIZE_REPORT"], "a") as f:
+            f.write("forward %s %s vs the engine's own f32 run: mask flips %.3e\n" % (tag, dtype, flips))
     assert flips <= flip_tol, flips
     assert abs(d - d32) <= dice_tol
     # and a full optimisation step runs at this size
@@ -186,6 +189,9 @@ def test_oracle_forward_full_size_low_precision(tag, dtype, flip_tol, dice_tol):
     flips = float(((probs > 0.5) != (ref_probs > 0.5)).float().mean())
     ref_dice = seg.dice_coeff(ref_probs, y) if ncls == 1 else seg.multiclass_dice_coeff(ref_probs, y)
     print("%s %s: mask flips %.2e, Dice %.6f vs oracle %.6f" % (tag, dtype, flips, float(out3[1]), float(ref_dice)))
+    if os.environ.get("SEG_FULLSIZE_REPORT"):
+        with open(os.environ["SEG_FULLSIZE_REPORT"], "a") as f:
+            f.write("forward %s %s vs the fp32 oracle: mask flips %.3e, Dice %.6f vs %.6f\n" % (tag, dtype, flips, float(out3[1]), float(ref_dice)))
     assert flips <= flip_tol, flips
     assert abs(float(out3[1]) - float(ref_dice)) <= dice_tol
 
@@ -296,12 +302,15 @@ def test_oracle_gradients_full_size_f32(tag):
 
 
 @pytest.mark.parametrize("tag", list(GRAD_CASES))
-@pytest.mark.parametrize("dtype,tol,med_tol,cos_tol", [("f16", 0.2, 0.12, 0.98), ("bf16", 0.45, 0.3, 0.9)])
+@pytest.mark.parametrize("dtype,tol,med_tol,cos_tol", [("f16", 0.16, 0.105, 0.99), ("bf16", 0.44, 0.28, 0.92)])
 def test_oracle_gradients_full_size_low_precision(tag, dtype, tol, med_tol, cos_tol):
     """per-tensor report of the 16-bit run dtypes at full size (where the error sits, and how large it is).
-    Bounds = the MI355X measurement (profiles/r02_fullsize_lowp_gradients.txt) + ~50 % margin: f16 worst tensor 0.127 / median 0.077 /
-    cosine >= 0.992, bf16 0.352 / 0.22 / 0.937; the worst tensors are GroupNorm affine gradients of norm 3e-5..9e-5 in the
-    deep levels (activations and gradient tensors are stored in the 16-bit type, 50+ layers deep; accumulation is fp32)."""
+    Bounds = the MI355X measurement (profiles/r03_fullsize_report.txt, unchanged in round 4) + 25 %: f16 worst tensor 0.127 / median 0.083 /
+    cosine >= 0.992, bf16 0.350 / 0.222 / 0.938; the worst tensors are GroupNorm affine gradients of norm 3e-5..9e-5 in the deep levels.
+    Where the error comes from is measured, not assumed (tests/exp_lowp_fidelity.py, profiles/r04_lowp_gradient_error_sources.txt): emulating
+    ONLY the forward storage rounding of conv outputs and activations on the fp32 oracle gives 0.43 / 0.24 (bf16) and 0.124 / 0.071 (f16) at
+    1x48^3, only the backward storage rounding 0.019 / 0.008 - the 16-bit gradient error is the activation storage precision; keeping
+    gradients in fp32 at the deep levels changes nothing (0.433)."""
     kind, ndim, shape, ncls, loss = GRAD_CASES[tag]
     params, x, y, r = oracle_grads(tag)
     e = SegEngine(kind, ndim, shape[1], ncls, dtype=dtype, device=DEV)

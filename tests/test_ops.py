@@ -284,6 +284,14 @@ def test_wgrad3_big_box_16_channels_exact(dev, dtype, sp, N, monkeypatch):
     y.backward(dy)
     got = ops.wgrad3(to_dev(cl(dy), dtype, dev), to_dev(cl(x), dtype, dev), dtype, 3)
     assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
+    # 32 -> 16 over a virtual concat of two 16-channel tensors (the UNet decoder's first conv at the finest level): two q-tiles on the same boxes
+    x2 = ints((N, 32) + sp, -2, 2, g)
+    w2 = torch.zeros((16, 32, 3, 3, 3), requires_grad=True)
+    y2 = F.conv3d(x2, w2, padding=1)
+    y2.backward(dy)
+    xs = torch.split(x2, [16, 16], dim=1)
+    got = ops.wgrad3(to_dev(cl(dy), dtype, dev), to_dev(cl(xs[0]), dtype, dev), dtype, 3, x1=to_dev(cl(xs[1]), dtype, dev))
+    assert torch.equal(got.cpu(), w2.grad), float((got.cpu() - w2.grad).abs().max())
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -13,7 +13,10 @@ CONFIGS = {
     "C5 VNet3d 1x160^3 bf16 binary": ("vnet", 3, (1, 1, 160, 160, 160), 1, "BinaryCrossEntropyDiceLoss", "bf16"),
 }
 dev = torch.device("cuda")
+ONLY = os.environ.get("SEG_BENCH_ONLY", "")          # e.g. "C2,C4": a subset of the configs (A/B sessions); the clDice legs run only without a filter
 for name, (kind, ndim, shape, ncls, loss, dt) in CONFIGS.items():
+    if ONLY and name.split()[0] not in ONLY.split(","):
+        continue
     e = SegEngine(kind, ndim, shape[1], ncls, dtype=dt, device=dev)
     seg.init_engine(e, seed=0)
     x, y = seg.synthetic_batch(shape[0], shape[2:], shape[1], ncls, seed=1)
@@ -31,6 +34,8 @@ for name, (kind, ndim, shape, ncls, loss, dt) in CONFIGS.items():
     del e
     torch.cuda.empty_cache()
 
+if ONLY:
+    sys.exit(0)
 # BASELINE configs[4] as worded: VNet3d 1x160^3 bf16 **+ clDice loss** (Dice on the logits + soft-clDice on the probabilities).
 # clDice is an autograd Function over the HIP skeleton kernels, so this step goes through the module (autograd) path:
 # net(x) -> losses -> loss.backward() (engine backward inside) -> fused AdamW on the engine's flat buffers.

@@ -7,17 +7,17 @@ SEG_FULLSIZE_REPORT=$O/fullsize_report.txt timeout 1200 python -m pytest tests -
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log
 DRV="python bench.py --gpus 1 --steps 20 --warmup 5"
 for i in 1 2 3; do
-  timeout 400 $DRV $( [ $i -gt 1 ] && echo --no-cpu-baseline ) > $O/bench_driver_cmd_$i.json 2> $O/bench_driver_cmd_$i.err
+  timeout 400 $DRV $( [ $i -gt 1 ] && echo --no-cpu-baseline --no-other-configs ) > $O/bench_driver_cmd_$i.json 2> $O/bench_driver_cmd_$i.err
 done
 rm -rf gpurun_out/prof gpurun_out/pmc gpurun_out/trace
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o step -- $DRV --no-cpu-baseline --roofline-steps 0 --launch stream > $O/prof_run.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o step -- $DRV --no-cpu-baseline --no-other-configs --roofline-steps 0 --launch stream > $O/prof_run.log 2>&1
 DB=$(find gpurun_out/prof -name "*.db" | head -1)
 if [ -n "$DB" ]; then python profiles/summarize_rocpd.py $DB 50 > $O/rocprofv3_kernel_stats.txt 2>&1; fi
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -o t -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --roofline-steps 0 --condition-seconds 0.2 --launch stream > $O/trace_run.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -o t -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --roofline-steps 0 --condition-seconds 0.2 --launch stream > $O/trace_run.log 2>&1
 CSV=$(find gpurun_out/trace -name "*kernel_trace.csv" | head -1)
 if [ -n "$CSV" ]; then python tools/trace_gaps.py $CSV > $O/trace_timeline.txt 2>&1; fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc -o $c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --roofline-steps 0 --condition-seconds 0 --launch stream > $O/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc -o $c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --roofline-steps 0 --condition-seconds 0 --launch stream > $O/pmc_$c.log 2>&1
 done
 python profiles/summarize_pmc.py gpurun_out/pmc $O/pmc_fetch_write_per_kernel.json > $O/pmc_summary.log 2>&1
 timeout 300 python tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err

@@ -8,6 +8,8 @@
 //   mode 1  + every workgroup first publishes a 2 KB piece of a 64 KB tile with plain stores (write-through to L2, s_waitcnt vmcnt(0)) and after the
 //           barrier reads its neighbour's piece with sc1 loads (served by the same L2), checking the round stamp
 //   mode 2  same traffic, but the textbook device-scope version: __threadfence() + agent-scope atomics (what a whole-device barrier pays)
+//   modes 3-7  the same L2-atomic barrier with other visibility protocols for the tile (sc1 / sc0 sc1 stores and loads, L2 atomics as stores and loads,
+//           agent-scope release / acquire fences around plain accesses): which one is correct at 16 / 32 workgroups, and what does it cost?
 // and the host measures, for reference, a chain of empty dependent kernel launches on one stream (the cost the barrier has to beat).
 // Build: hipcc --offload-arch=gfx950 -O2 xcd_barrier.hip -o xcd_barrier
 #include <hip/hip_runtime.h>
@@ -21,10 +23,21 @@ __device__ __forceinline__ int l2_add(int* p, int v) {          // L2 atomic of 
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ int dev_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int load_sc1(const int* p) {          // bypass the CU's vector cache, hit the XCD's L2
+__device__ __forceinline__ int load_sc1(const int* p) {          // agent-scope load: bypass the CU's vector cache
     int v;
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
+}
+__device__ __forceinline__ int load_sc0sc1(const int* p) {       // system-scope load
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void store_sc1(int* p, int v) {       // agent-scope store (write-through past this XCD's L2)
+    asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_sc0sc1(int* p, int v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 
 __global__ __launch_bounds__(256) void barrier_kernel(Args a) {
@@ -41,9 +54,13 @@ __global__ __launch_bounds__(256) void barrier_kernel(Args a) {
         if (a.mode >= 1) {
             // 2 KB per workgroup = 512 ints: threads 0..255 write two ints each, stamped with the round
             int* mine = a.tile + who * 512;
-            mine[threadIdx.x] = r; mine[256 + threadIdx.x] = r;
+            if (a.mode == 3 || a.mode == 4) { store_sc1(mine + threadIdx.x, r); store_sc1(mine + 256 + threadIdx.x, r); }
+            else if (a.mode == 5) { store_sc0sc1(mine + threadIdx.x, r); store_sc0sc1(mine + 256 + threadIdx.x, r); }
+            else if (a.mode == 6) { l2_add(mine + threadIdx.x, 1); l2_add(mine + 256 + threadIdx.x, 1); }       // atomics as stores: the tile lives in L2
+            else { mine[threadIdx.x] = r; mine[256 + threadIdx.x] = r; }
             if (a.mode == 2) __threadfence();
-            else __builtin_amdgcn_s_waitcnt(0);                  // stores acknowledged by L2
+            else if (a.mode == 7) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            else __builtin_amdgcn_s_waitcnt(0);                  // stores acknowledged
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -58,8 +75,11 @@ __global__ __launch_bounds__(256) void barrier_kernel(Args a) {
             const int* other = a.tile + ((who + 1) % a.np) * 512;
             int v;
             if (a.mode == 2) { __threadfence(); v = __hip_atomic_load(other + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else if (a.mode == 4 || a.mode == 5) v = load_sc0sc1(other + threadIdx.x);
+            else if (a.mode == 6) v = l2_add((int*)other + threadIdx.x, 0);                     // read back through the L2 atomic unit
+            else if (a.mode == 7) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); v = other[threadIdx.x]; }
             else v = load_sc1(other + threadIdx.x);
-            bad += (v != r);
+            bad += (v != r);                                     // (mode 6 adds 1 per round: the value is the round as well)
         }
     }
     const long long t1 = wall_clock64();
@@ -78,7 +98,7 @@ int main(int argc, char** argv) {
     hipStream_t st; hipStreamCreate(&st);
     for (int np : {8, 16, 32}) {
         for (int stride : {8, 1}) {                                // 8: participants on ONE XCD; 1: the same count spread over all XCDs (device-scope only)
-            for (int mode = 0; mode < 3; ++mode) {
+            for (int mode = 0; mode < 8; ++mode) {
                 if (stride == 1 && mode != 2) continue;            // L2-local atomics are only a barrier inside one XCD
                 hipMemsetAsync(ctr, 0, 256, st); hipMemsetAsync(errors, 0, 4, st); hipMemsetAsync(tile, 0, 64 * 512 * 4, st);
                 Args a{ctr, tile, xcc, cycles, errors, np, rounds, mode, stride};
@@ -91,7 +111,10 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < np; ++i) { same &= hx[i] == hx[0]; if (hc[i] > mx) mx = hc[i]; }
                 printf("np %2d %s mode %d (%s): %.3f us per round, participants on one XCD: %s (xcc of the first = %d), stale reads %d\n", np,
                        stride == 8 ? "one-XCD " : "all-XCDs", mode,
-                       mode == 0 ? "L2 atomics, barrier only" : mode == 1 ? "L2 atomics + 2 KB/WG tile, sc1 reads" : "device scope: threadfence + agent atomics + tile",
+                       mode == 0 ? "L2 atomics, barrier only" : mode == 1 ? "L2 atomics + 2 KB/WG tile: plain stores, sc1 loads"
+                       : mode == 2 ? "device scope: threadfence + agent atomics + tile" : mode == 3 ? "L2-atomic barrier + tile: sc1 stores, sc1 loads"
+                       : mode == 4 ? "L2-atomic barrier + tile: sc1 stores, sc0 sc1 loads" : mode == 5 ? "L2-atomic barrier + tile: sc0 sc1 stores, sc0 sc1 loads"
+                       : mode == 6 ? "L2-atomic barrier + tile written and read with L2 atomics" : "L2-atomic barrier + tile: plain stores, agent release / acquire fences, plain loads",
                        (double)mx / rounds / (wall_khz * 1e-3), same ? "yes" : "NO", hx[0], herr);
             }
         }
