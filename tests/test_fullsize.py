@@ -2,7 +2,7 @@
 Direct comparisons with the CPU oracle (oracle/seg_oracle.py, pinned to the real reference by tests/test_oracle.py):
   * eval forward of every config C2 - C5 on the host (a few seconds each on 32 threads) vs the engine: fp32 run dtype ->
     logits within 1e-3 (BASELINE.json north_star), integer masks identical except at voxels within 5e-5 of the threshold,
-    Dice equal to 1e-6; f16 / bf16 run dtypes -> mask flip fraction <= 2e-3 / 2e-2 against the ORACLE's mask;
+    Dice equal to 1e-6; f16 / bf16 run dtypes -> mask flip fraction <= 7e-4 / 5e-3 against the ORACLE's mask;
   * one 1x96^3 (VNet3d) and one 1x128^3 (UNet3d) forward + backward: per-tensor relative-L2 gradient gate against the
     oracle (the size-dependent policies - 1024-row GroupNorm slabs, weight-gradient partial policy, multi-box stems,
     large index arithmetic - only exist at these sizes), plus a printed per-tensor report for the 16-bit run dtypes.
@@ -100,7 +100,8 @@ def test_directional_derivative_full_size(tag):
 
 
 @pytest.mark.parametrize("tag", ["C3_vnet3d", "C5_vnet3d"])
-@pytest.mark.parametrize("dtype,flip_tol,dice_tol", [("f16", 2e-3, 5e-3), ("bf16", 2e-2, 3e-2)])
+# gates = the MI355X measurement + 25-40 % (profiles/r04_fullsize_report.txt: f16 flips 4.4e-5 ... 4.6e-4, bf16 3.2e-4 ... 3.7e-3; Dice differences <= 2.1e-5 / 8.8e-5)
+@pytest.mark.parametrize("dtype,flip_tol,dice_tol", [("f16", 7e-4, 2e-4), ("bf16", 5e-3, 5e-4)])
 def test_low_precision_vs_fp32_full_size(tag, dtype, flip_tol, dice_tol):
     e32, x, y, ncls, loss = make(tag, "f32")
     l32, p32 = e32.forward(x)
@@ -177,7 +178,8 @@ def test_oracle_forward_full_size_f32(tag):
 
 
 @pytest.mark.parametrize("tag", list(CONFIGS))
-@pytest.mark.parametrize("dtype,flip_tol,dice_tol", [("f16", 2e-3, 5e-3), ("bf16", 2e-2, 3e-2)])
+# gates = the MI355X measurement + 25-40 % (profiles/r04_fullsize_report.txt: f16 flips 4.4e-5 ... 4.6e-4, bf16 3.2e-4 ... 3.7e-3; Dice differences <= 2.1e-5 / 8.8e-5)
+@pytest.mark.parametrize("dtype,flip_tol,dice_tol", [("f16", 7e-4, 2e-4), ("bf16", 5e-3, 5e-4)])
 def test_oracle_forward_full_size_low_precision(tag, dtype, flip_tol, dice_tol):
     kind, ndim, shape, ncls, loss = CONFIGS[tag]
     params, x, y, ref_logits, ref_probs = oracle_eval(tag)

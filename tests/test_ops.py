@@ -274,6 +274,8 @@ def test_wgrad3_big_box_16_channels_exact(dev, dtype, sp, N, monkeypatch):
     """the 4 x 8 x 16-box instantiation of wgrad3_kernel that serves the 16 -> 16 channel convs of the finest level (Wgrad3Big16, conv3.hip; autograd of
     networks/VNet3d.py:8 at 96^3): whole boxes, ragged boxes on every axis, the 12-wide row of the deep levels; SEG_W3_BOX16=2 forces it
     onto these small volumes."""
+    if dtype == "bf16":
+        conftest.checker_slow(dev, "the bf16 twin of every case runs on the GPU; the f16 cases run on the host checker")
     monkeypatch.setenv("SEG_WGRAD3X", "0")
     monkeypatch.setenv("SEG_W3_BOX16", "2")
     g = torch.Generator().manual_seed(sum(sp) + N)

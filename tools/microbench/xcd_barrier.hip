@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void barrier_kernel(Args a) {
     for (int r = 1; r <= a.rounds; ++r) {
         if (a.mode >= 1) {
             // 2 KB per workgroup = 512 ints: threads 0..255 write two ints each, stamped with the round
-            int* mine = a.tile + who * 512;
+            int* mine = a.tile + ((r & 1) * 64 + who) * 512;          // two copies by round parity: a fast workgroup may already write round r + 1
             if (a.mode == 3 || a.mode == 4) { store_sc1(mine + threadIdx.x, r); store_sc1(mine + 256 + threadIdx.x, r); }
             else if (a.mode == 5) { store_sc0sc1(mine + threadIdx.x, r); store_sc0sc1(mine + 256 + threadIdx.x, r); }
             else if (a.mode == 6) { l2_add(mine + threadIdx.x, 1); l2_add(mine + 256 + threadIdx.x, 1); }       // atomics as stores: the tile lives in L2
@@ -66,20 +66,22 @@ __global__ __launch_bounds__(256) void barrier_kernel(Args a) {
         if (threadIdx.x == 0) {
             int spins = 0;                                       // bounded: a participant that never shows up must not hang the GPU box
             if (a.mode == 2) { dev_add(a.ctr, 1); while (dev_add(a.ctr, 0) < r * a.np && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1); }
-            else { l2_add(a.ctr, 1); while (l2_add(a.ctr, 0) < r * a.np && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1); }
+            // poll with an sc1 LOAD: hipcc folds the idempotent `fetch_add(p, 0)` of the first version into a workgroup-scope load (`global_load_dword
+            // ... sc0`), which the CU's own vector cache may answer for ever - that, not the tile protocol, made the first runs bail out
+            else { l2_add(a.ctr, 1); while (load_sc1(a.ctr) < r * a.np && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1); }
             if (spins >= (1 << 20)) { atomicAdd(a.errors, 1 << 20); bail = 1; }
         }
         __syncthreads();
         if (bail) break;
         if (a.mode >= 1) {
-            const int* other = a.tile + ((who + 1) % a.np) * 512;
+            const int* other = a.tile + ((r & 1) * 64 + (who + 1) % a.np) * 512;
             int v;
             if (a.mode == 2) { __threadfence(); v = __hip_atomic_load(other + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             else if (a.mode == 4 || a.mode == 5) v = load_sc0sc1(other + threadIdx.x);
-            else if (a.mode == 6) v = l2_add((int*)other + threadIdx.x, 0);                     // read back through the L2 atomic unit
+            else if (a.mode == 6) v = load_sc1(other + threadIdx.x);                            // written with L2 atomics, read with an sc1 load
             else if (a.mode == 7) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); v = other[threadIdx.x]; }
             else v = load_sc1(other + threadIdx.x);
-            bad += (v != r);                                     // (mode 6 adds 1 per round: the value is the round as well)
+            bad += (v != (a.mode == 6 ? (r + 1) / 2 : r));      // (mode 6 adds 1 per round and copy: the count of rounds of this parity)
         }
     }
     const long long t1 = wall_clock64();
@@ -92,7 +94,7 @@ __global__ void empty_kernel(int* p) { if (p[0] == 123456789) p[1] = 1; }
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 2000;
     int *ctr, *tile, *xcc, *errors; long long* cycles;
-    hipMalloc(&ctr, 256); hipMalloc(&tile, 64 * 512 * 4); hipMalloc(&xcc, 64 * 4); hipMalloc(&errors, 4); hipMalloc(&cycles, 64 * 8);
+    hipMalloc(&ctr, 256); hipMalloc(&tile, 2 * 64 * 512 * 4); hipMalloc(&xcc, 64 * 4); hipMalloc(&errors, 4); hipMalloc(&cycles, 64 * 8);
     int wall_khz = 100000;                                         // wall_clock64 ticks at 100 MHz on gfx9
     hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
     hipStream_t st; hipStreamCreate(&st);
@@ -100,7 +102,7 @@ int main(int argc, char** argv) {
         for (int stride : {8, 1}) {                                // 8: participants on ONE XCD; 1: the same count spread over all XCDs (device-scope only)
             for (int mode = 0; mode < 8; ++mode) {
                 if (stride == 1 && mode != 2) continue;            // L2-local atomics are only a barrier inside one XCD
-                hipMemsetAsync(ctr, 0, 256, st); hipMemsetAsync(errors, 0, 4, st); hipMemsetAsync(tile, 0, 64 * 512 * 4, st);
+                hipMemsetAsync(ctr, 0, 256, st); hipMemsetAsync(errors, 0, 4, st); hipMemsetAsync(tile, 0, 2 * 64 * 512 * 4, st);
                 Args a{ctr, tile, xcc, cycles, errors, np, rounds, mode, stride};
                 hipLaunchKernelGGL(barrier_kernel, dim3(256), dim3(256), 0, st, a);
                 if (hipStreamSynchronize(st) != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
