@@ -34,6 +34,11 @@ const Cfg kCfgs[] = {
     {21, 3, 2, 8, 8, 32, 1, "2x8x8 t8 4x1 waves 2x2 tiles, 1 resident chunk, 4 workgroups/CU"},
     {22, 3, 2, 8, 8, 32, 1, "2x8x8 t8 4x1 waves 2x2 tiles, 1 resident chunk, deep B ring, 3 workgroups/CU"},
     {23, 3, 4, 8, 8, 32, 1, "4x8x8 t8 4x1 waves 4x2 tiles, deep B ring, 3 workgroups/CU"},
+    // the deep 12^3 / 6^3 levels are weight-stream latency chains (one L2 round trip per 8 steps of 6 MFMAs): a whole chunk of taps in flight
+    // (PF = 26), and 32 output channels per workgroup = twice the workgroups, each streaming half the weights
+    {44, 3, 2, 4, 12, 64, 4, "2x4x12 t4 2x2 waves 3x2 tiles, 26-deep B ring"},
+    {45, 3, 2, 4, 12, 32, 4, "2x4x12 t4 2x2 waves 3x1 tiles, 26-deep B ring"},
+    {46, 3, 2, 4, 12, 32, 4, "2x4x12 t4 2x2 waves 3x1 tiles"},
     {18, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {19, 3, 2, 8, 8, 32, 1, "Cin32 persistent: 2x8x8 t8 4x1 waves 2x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {24, 3, 2, 8, 16, 16, 1, "Cin16: 2x8x16 t16 4x1 waves 4x1 tiles", 1},
@@ -126,7 +131,16 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool ha
             // step - one 144 KB workgroup per CU hides less than two 46 KB ones; profiles/r03_persistent_conv_ab.log)
             (void)has_in1;
         }
-        else if (vox <= 16384) id = Cout >= 2 * Cin ? 13 : 7;
+        else if (vox <= 16384) {
+            id = Cout >= 2 * Cin ? 13 : 7;
+            // the deepest level: a launch of 64-channel workgroups fills at most half the CUs and every workgroup is one serial weight stream from L2
+            // (884 KB at 6^3 x 256 channels).  32 output channels per workgroup = twice the streams, each half as long, with a whole chunk of taps in
+            // flight: 19.2 -> 14.4 us at 4 x 6^3 x 256, 19.0 -> 14.3 at 1 x 10^3, 19.4 -> 14.4 at 2 x 8^3, 11.7 -> 9.5 at 2 x 16^3 x 128 -> 64
+            // (profiles/r04_deep_level_tilings.log); +1.0 ... +1.4 % on the train step on two leases.  Only while the doubled grid still fits the
+            // 256 CUs in one round (12^3 x 128 x 4 samples: 144 -> 288 workgroups, 11.5 -> 16.3 us).
+            const long long nb = (long long)N * ((D + 1) / 2) * ((H + 3) / 4) * ((W + 11) / 12);
+            if (Cout % 64 == 0 && nb * (Cout / 64) <= 128) id = 45;
+        }
         else id = Cin >= 128 ? 5 : 3;
     } else {
         if (Cout % 32) id = 37;
