@@ -940,7 +940,7 @@ struct Planner {
                             f.mask_ld = E.ld_mask();
                             f.scale = (float*)(E.ws + ua.scale); f.shift = (float*)(E.ws + ua.shift);
                             f.mean = (float*)(E.ws + ua.mean); f.rstd = (float*)(E.ws + ua.rstd);
-                            f.N = E.N; f.C = ua.Cout; f.V = E.vol(ro.lvl); f.eps = 1e-5f;
+                            f.N = E.N; f.C = ua.Cout; f.V = E.vol(ro.lvl); f.eps = 1e-5f; f.rep = ua.stat_rep;
                             const int pi = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(s.out) * (2 + (s.res >= 0)), 0.0);
                             launch_gn_fwd_group(f, E.ws + ro.off, s.res >= 0 ? E.ws + E.tens[s.res].off : nullptr, E.ws + E.tens[s.out].off,
                                                 E.dtype, st);

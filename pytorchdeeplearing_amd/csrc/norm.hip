@@ -531,8 +531,16 @@ __global__ __launch_bounds__(1024) void gn_bwd_group_kernel(GnBwdGroupArgs a) {
     }
     // forward sum(r) of the group's channels (bias gradient): fold the statistic replicas
     if (tid < cpg) {
+        const int nrep = a.f.rep_s > 0 ? a.f.rep_s : STAT_REP;       // the replicas the forward producer wrote
         double r1 = 0.0;
-        for (int rep = 0; rep < STAT_REP; ++rep) r1 += a.f.stats[(((long long)rep * a.f.N + n) * C + g * cpg + tid) * 2];
+        for (int rep = 0; rep < nrep; rep += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = a.f.stats[(((long long)(rep + u < nrep ? rep + u : 0) * a.f.N + n) * C + g * cpg + tid) * 2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (rep + u < nrep) r1 += v[u];
+        }
         chan[tid][2] = r1;
     }
     __syncthreads();
@@ -594,12 +602,22 @@ __global__ __launch_bounds__(1024) void gn_fwd_group_kernel(GnFwdGroupArgs a) {
     const long long V = a.f.V;
     if (wv == 0) {
         const int RG = 64 / cpg, cl = lane % cpg, rg = lane / cpg, c = g * cpg + cl;
+        // only the replicas the producer wrote (f.rep; 4 at this level, not all 32), four independent 16-B loads per trip: the first version walked
+        // all 32 replicas with one dependent L2 round trip per trip - 16 of them, ~10 of this kernel's 11 us (round-4 single-queue trace)
+        const int nrep = a.f.rep > 0 ? a.f.rep : STAT_REP;
         double s = 0.0, ss = 0.0;
         if (rg < RG)
-            for (int rep = rg; rep < STAT_REP; rep += RG) {
-                const double* st = a.f.stats + (((long long)rep * a.f.N + n) * C + c) * 2;
-                s += st[0];
-                ss += st[1];
+            for (int rep = rg; rep < nrep; rep += 4 * RG) {
+                double v0[4], v1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = rep + u * RG;
+                    const double* st = a.f.stats + (((long long)(rr < nrep ? rr : rg) * a.f.N + n) * C + c) * 2;
+                    v0[u] = st[0]; v1[u] = st[1];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (rep + u * RG < nrep) { s += v0[u]; ss += v1[u]; }
             }
         const double ts = wave_sum_d(s), tss = wave_sum_d(ss);
         const double cnt = (double)cpg * (double)V;
