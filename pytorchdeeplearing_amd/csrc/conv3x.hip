@@ -41,6 +41,8 @@ const Cfg kCfgs[] = {
     {46, 3, 2, 4, 12, 32, 4, "2x4x12 t4 2x2 waves 3x1 tiles"},
     {47, 3, 4, 4, 12, 32, 4, "4x4x12 t4 2x2 waves 6x1 tiles"},
     {48, 3, 4, 4, 12, 32, 4, "4x4x12 t4 2x2 waves 6x1 tiles, 26-deep B ring"},
+    {49, 3, 2, 4, 12, 64, 4, "2x4x12 t4 1x4 waves 6x1 tiles (every wave its own weight columns)"},
+    {50, 3, 2, 4, 12, 64, 4, "2x4x12 t4 1x4 waves 6x1 tiles, 26-deep B ring"},
     {18, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {19, 3, 2, 8, 8, 32, 1, "Cin32 persistent: 2x8x8 t8 4x1 waves 2x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {24, 3, 2, 8, 16, 16, 1, "Cin16: 2x8x16 t16 4x1 waves 4x1 tiles", 1},

@@ -768,7 +768,9 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 45: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 1, 2, 2, 4, 26, 1, FUSE>(a, s); return true;                   \
         case 46: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 1, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
         case 47: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 1, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
-        case 48: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 1, 2, 2, 4, 26, 1, FUSE>(a, s); return true;
+        case 48: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 1, 2, 2, 4, 26, 1, FUSE>(a, s); return true;                   \
+        case 49: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 8, 1, FUSE>(a, s); return true;                    \
+        case 50: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 26, 1, FUSE>(a, s); return true;
 /* Cin == 32 persistent tilings (conv3p_kernel):   box                  TM TN */
 #define SEG_C3X_3D_P_CASES                                                                                            \
         case 18: launch_cfgp<T, XBox<4, 8, 8, 3, 8>, 4, 2>(a, s); return true;                                       \
