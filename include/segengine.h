@@ -79,7 +79,10 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid);
 long long seg_workspace_bytes(seg_handle h);
 /* what the planner decided for the current shape (tests / diagnostics): what = 0: activations applied by their consuming convolution instead
  * of an elementwise launch (the activated tensor is never written), 1: convolution units, 2: fork events the last backward pass recorded on the
- * caller's stream (3: always 0 since round 4), 4: samples per group of the sub-batched finest level (0 = whole-batch launches; SEG_SUB_MB),
+ * caller's stream, 3: flag forks of the last backward pass (no event: the weight-gradient queue's command processor waits on a word in signal
+ * memory that the caller's stream's next kernel stores; default where hipStreamWaitValue32 is available, SEG_FORK=event switches back),
+ * 7 / 8: of those, numbers stored by the next kernel itself / by a one-wave kernel of their own, 9: 1 when no released batch is left waiting,
+ * 4: samples per group of the sub-batched finest level (0 = whole-batch launches; SEG_SUB_MB),
  * 5 / 6: forward / backward ops that run group by group.  <0: not planned / unknown `what`. */
 int seg_plan_count(seg_handle h, int what);
 

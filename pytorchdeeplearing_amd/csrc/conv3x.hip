@@ -172,7 +172,7 @@ int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres
 }
 
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const GnFinArgs* gn) {
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const GnFinArgs* gn, ForkSig sg) {
     const Cfg* c = find_cfg(cfg);
     if (!c || !cfg_fits(*c, ndim, Cin, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
     if (gn && (!conv3x_gn_supported(Cin, in1 != nullptr) || c->cin32)) return false;
@@ -180,6 +180,7 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
     Conv3xArgs a;
     a.fuse = gn ? 1 : 0;
     a.gn = gn ? *gn : GnFinArgs{};
+    a.sig = sg;
     a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.stat_rep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
 #ifdef SEG_DIAG

@@ -59,6 +59,7 @@ struct Conv3xArgs {
     // sample publishes them (plus mean / rstd) for the backward pass, and each lane rewrites the 16-B pieces it copied as
     // relu(scale * x + shift); padding voxels stay zero.  The activated tensor is never written to HBM (the gn_act launch is gone).
     int fuse; GnFinArgs gn;
+    ForkSig sig;                                  // a flag fork carried by this launch (its first thread stores the number)
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md), each with its own L2.  With the
@@ -156,6 +157,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
 
 template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC, bool FUSE>
 __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
+    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     __shared__ double gn_part[FUSE ? 256 : 1][2];
     __shared__ __attribute__((aligned(16))) float gn_coef[2][FUSE ? 256 : 8];
@@ -358,6 +360,7 @@ void launch_cfg(const Conv3xArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <class T, class B, int TM, int TN>
 __global__ __launch_bounds__(256, 1) void conv3p_kernel(Conv3xArgs a) {
+    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     static_assert(4 * TM == B::NTILE, "four waves cover the box");
     constexpr int WM = 4, WN = 1, BN = TN * 16;
@@ -492,6 +495,7 @@ void launch_cfgp(const Conv3xArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <class T, class B, int TM, int TN, int PF, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
+    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     static_assert(B::TX == 16, "x rows of 16 voxels");
     static_assert(4 * TM == B::NTILE, "four waves cover the box");
@@ -598,6 +602,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
 // what the double buffer buys is that the copy of box i + 1 streams while box i is multiplied and written back.
 template <class T, class B, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void conv3p16_kernel(Conv3xArgs a) {
+    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     static_assert(B::TX == 16, "x rows of 16 voxels");
     static_assert(4 * TM == B::NTILE, "four waves cover the box");

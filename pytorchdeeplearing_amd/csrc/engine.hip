@@ -11,6 +11,7 @@
 // fly, so no explicit `add` or `cat` tensor is ever materialised.
 // Reference structure: networks/VNet3d.py:25-158, networks/Unet3d.py:6-86 (+ the 2-D twins).
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <vector>
@@ -177,7 +178,8 @@ struct seg_engine {
     double hold_bytes = 64e6;                       // SEG_HOLD_HEAVY_MB
     bool hold_open = false;                         // the release level has been reached in this backward pass
     std::vector<Pend> held;
-    void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> fn, double bytes = 0.0, int lvl = 0, int sig_unit = -1) {
+    // next_takes: the caller launches a kernel right behind this call that stores a released batch's number itself (take_sig)
+    void defer_wgrad(hipStream_t main, std::function<void(hipStream_t)> fn, double bytes = 0.0, int lvl = 0, int sig_unit = -1, bool next_takes = false) {
         if (sub_active) {                                  // a chain runs group by group: the weight gradient is a whole-batch launch, queued once
             if (!sub_last) return;
             bytes *= (double)Nplan / (double)N;
@@ -198,12 +200,16 @@ struct seg_engine {
         pending.push_back(std::move(f));
         // a full batch is released AFTER the op that queued it has enqueued its own main-stream kernels (maybe_flush): the dozen
         // launches + events of a batch take the host ~45 us, during which the main queue used to run dry (r02 trace: 138 us idle)
-        if ((int)pending.size() >= fork_batch || bytes >= fork_heavy_bytes) { if (flush_late) flush_due = true; else flush_side(main); }
+        if ((int)pending.size() >= fork_batch || bytes >= fork_heavy_bytes) { if (flush_late) flush_due = true; else flush_side(main, next_takes); }
     }
     double fork_heavy_bytes = 16e6;                 // SEG_FORK_HEAVY_MB
-    bool flush_due = false, flush_late = true;      // SEG_FLUSH_LATE=0: release a full batch immediately (round-1 order)
-    void maybe_flush(hipStream_t main) {
-        if (flush_due) { flush_due = false; flush_side(main); }
+    // SEG_FLUSH_LATE=1: a full batch is released after the op that queued it has enqueued its own main-stream kernels (rounds 2-3, when the
+    // host needed ~45 us for a batch and the main queue ran dry meanwhile).  Round 4: released at once - the weight gradients' inputs are final
+    // BEFORE the op's data-gradient kernel, so the second queue starts one convolution earlier: 1028-1029 vs 1016-1017 volumes/s
+    // (profiles/r04_flag_forks_ab.log; 1029 vs 1007 with event forks)
+    bool flush_due = false, flush_late = false;
+    void maybe_flush(hipStream_t main, bool next_takes = false) {
+        if (flush_due) { flush_due = false; flush_side(main, next_takes); }
     }
     void ensure_side() {
         if (side) return;
@@ -211,20 +217,84 @@ struct seg_engine {
         (void)hipEventCreateWithFlags(&side_done, hipEventDisableTiming);
         if (n_side > 1) { side2 = make_side(); (void)hipEventCreateWithFlags(&side2_done, hipEventDisableTiming); }
     }
-    void flush_side(hipStream_t main) {
+    // ---- flag forks (round 4, opt-in: SEG_FORK=flag; tools/microbench/fork_cost.hip, profiles/r04_flag_forks_ab.log).  A hipEventRecord idles the
+    // main queue ~6.4 us (19 forks per step = 3 % of it, profiles/r04_trace_timeline.txt).  With SEG_FORK=flag the weight-gradient queue instead
+    // waits on a word in signal memory (hipStreamWaitValue32) and the word is stored by the first thread of the NEXT kernel the main queue runs
+    // anyway: an in-order queue starts that kernel only after everything launched before it has completed and released its writes.  Sequence
+    // numbers only grow, so a store also releases every older wait.  The kernels that follow a release - the data-gradient convolutions
+    // (ForkSig), the GroupNorm-backward reduce / one-launch passes (GnBwdArgs::sig_flag) - take the number along in their arguments; anywhere else
+    // a one-wave kernel stores it (~3 us).  A captured step (HIP graph) keeps event forks.
+    // Measured: the main queue's fork gaps disappear (median gap 6.4 -> 0.2 us), and the step does not get faster - 1020-1021 vs 1015-1024
+    // volumes/s with event forks on one lease, 1029 vs 1030 on another: with the early release below the weight-gradient queue is busy 92 % of the
+    // backward window, so the main queue's saved 100 us are spent waiting at the join.  With the runtime's DEFAULT hipStreamWaitValue32 (a
+    // one-thread polling kernel, __amd_rocclr_streamOpsWait, on the waiting queue) it is 2 % SLOWER (978-984): the process has to start with
+    // GPU_STREAMOPS_CP_WAIT=1 (barrier-value packet: the command processor waits).  Kept opt-in; SEG_FORK=spin: own sleeping poll kernel (996).
+    int fork_mode = -1;                 // -1: decided on first use; 0: events; 1: flag, hipStreamWaitValue32; 2: flag, own one-lane polling kernel
+    unsigned* fork_flag = nullptr;      // 8 bytes of signal memory
+    unsigned fork_seq = 0;              // last number a weight-gradient queue was told to wait for
+    unsigned sig_pending = 0;           // ... and not yet stored / handed to a kernel: nobody may wait on the side queues before it is
+    int n_flag_forks = 0, n_sig_kernels = 0, n_sig_taken = 0;       // of the current / last backward pass (seg_plan_count 3, 7, 8)
+    std::vector<char> bwd_sig;          // planning: per backward op, whether its first kernel takes a pending number along
+    bool flag_forks() {
+        if (fork_mode < 0) {
+            fork_mode = 0;
+            const char* e = getenv("SEG_FORK");
+            const bool want = e && strcmp(e, "event") != 0;           // opt-in (see above)
+            int can = 0;
+            if (want && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0) == hipSuccess && can) {
+                if (hipExtMallocWithFlags((void**)&fork_flag, 8, hipMallocSignalMemory) == hipSuccess && fork_flag) {
+                    launch_fork_signal(fork_flag, 0u, nullptr);
+                    fork_mode = hipDeviceSynchronize() == hipSuccess ? ((e && !strcmp(e, "spin")) ? 2 : 1) : 0;
+                }
+                (void)hipGetLastError();
+            }
+        }
+        return fork_mode >= 1 && !capturing;
+    }
+    unsigned* take_sig(unsigned& seq) {                    // called by the op whose first kernel stores the number itself
+        if (!sig_pending) return nullptr;
+        seq = sig_pending; sig_pending = 0; ++n_sig_taken;
+        return fork_flag;
+    }
+    void emit_sig(hipStream_t main) {                      // nobody took it: a one-wave kernel on the main stream
+        if (!sig_pending) return;
+        launch_fork_signal(fork_flag, sig_pending, main);
+        sig_pending = 0; ++n_sig_kernels;
+    }
+    void release_waiters() {                               // before the host waits for a weight-gradient queue outside a step (plan / bind / destroy)
+        if (fork_mode >= 1 && fork_flag && fork_seq) { launch_fork_signal(fork_flag, fork_seq, nullptr); sig_pending = 0; }
+    }
+    void flush_side(hipStream_t main, bool next_takes = false) {
         if (pending.empty()) return;
         const bool was_sub = sub_suspend();                // the queued launches are whole-batch
-        flush_side_full(main);
+        flush_side_full(main, next_takes);
         sub_resume(was_sub);
     }
-    void flush_side_full(hipStream_t main) {
+    void flush_side_full(hipStream_t main, bool next_takes) {
         ensure_side();
+        if (flag_forks()) {
+            if (fork_seq >= (1u << 30)) {                  // (once per ~5e7 steps) start the numbers over with both queues drained
+                emit_sig(main);
+                (void)hipStreamSynchronize(main); (void)hipStreamSynchronize(side); if (side2) (void)hipStreamSynchronize(side2);
+                launch_fork_signal(fork_flag, 0u, main); (void)hipStreamSynchronize(main);
+                fork_seq = 0;
+            }
+            const unsigned seq = ++fork_seq;
+            if (fork_mode == 2) { launch_fork_wait(fork_flag, seq, side); if (side2) launch_fork_wait(fork_flag, seq, side2); }
+            else {
+                (void)hipStreamWaitValue32(side, fork_flag, seq, hipStreamWaitValueGte, 0xffffffffu);
+                if (side2) (void)hipStreamWaitValue32(side2, fork_flag, seq, hipStreamWaitValueGte, 0xffffffffu);
+            }
+            sig_pending = seq;                             // (a number still pending from an earlier release is covered by this larger one)
+            ++n_flag_forks;
+        } else {
         if (ready_used == ready_ev.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); ready_ev.push_back(e); }
         ++n_event_forks;
         hipEvent_t e = ready_ev[ready_used++];
         (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
         (void)hipStreamWaitEvent(side, e, 0);
         if (side2) (void)hipStreamWaitEvent(side2, e, 0);
+        }
         for (auto& f : pending) {
             const bool second = side2 && (rr++ & 1);
             cur_partial = second ? off_partial2 : off_partial;
@@ -232,11 +302,13 @@ struct seg_engine {
         }
         side_used = true;
         pending.clear();
+        if (!next_takes) emit_sig(main);
     }
     void join_side(hipStream_t main) {
         for (auto& h : held) pending.push_back(std::move(h));      // (a network without deep levels never reached the release level)
         held.clear();
         flush_side(main);
+        emit_sig(main);                                            // the main stream is about to wait for the weight-gradient queues
         for (auto& f : tail_pending) { cur_partial = off_partial_main; f.f(main); }
         tail_pending.clear();
         if (use_side && side && (ready_used || side_used)) {
@@ -295,7 +367,7 @@ struct seg_engine {
         for (int n0 = 0; n0 < Nplan; n0 += nb) {
             sub_last = n0 + nb >= Nplan;
             sub_enter(n0, nb);
-            for (int i = b; i < e; ++i) { ops[i](st); if (bwd && sub_last) maybe_flush(st); }
+            for (int i = b; i < e; ++i) { ops[i](st); if (bwd) emit_sig(st); if (bwd && sub_last) maybe_flush(st); }
             sub_leave();
         }
         sub_last = false;
@@ -308,7 +380,14 @@ struct seg_engine {
                 const int ce = chains[ci].second < e ? chains[ci].second : e;
                 run_chain(ops, i, ce, st, bwd);
                 i = ce;
-            } else { ops[i](st); if (bwd) maybe_flush(st); ++i; }
+            } else {
+                ops[i](st);
+                if (bwd) {
+                    emit_sig(st);                          // a number the op did not take along (its first kernel was not the expected one)
+                    maybe_flush(st, i + 1 < e && i + 1 < (int)bwd_sig.size() && bwd_sig[i + 1]);
+                }
+                ++i;
+            }
         }
     }
     // one optimisation step captured as a HIP graph (seg_train_graph_*): the host side of a replay is ONE hipGraphLaunch
@@ -639,7 +718,7 @@ struct Planner {
         seg_engine& E = e;
         const int N = E.N, dt = E.dtype;
         E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_is_bwd.clear(); E.pack_max = 0; E.n_deferred = 0;
-        E.bwd_sub.clear(); E.fwd_chains.clear(); E.bwd_chains.clear();
+        E.bwd_sub.clear(); E.bwd_sig.clear(); E.fwd_chains.clear(); E.bwd_chains.clear();
         // drop gradient tensors of a previous plan
         size_t nfw = 0;
         for (auto& s : E.steps) {
@@ -1012,6 +1091,7 @@ struct Planner {
         // ------------------------------------------------------------------ backward schedule
         E.bwd_writes.push_back({});
         E.bwd_sub.push_back(0);
+        E.bwd_sig.push_back(0);
         E.bwd_ops.push_back([this_ = &E](hipStream_t st) {
             seg_engine& E = *this_;
             if (!E.q_clean) (void)hipMemsetAsync(E.ws + E.off_Q, 0, E.Q_bytes, st);
@@ -1027,6 +1107,7 @@ struct Planner {
                 E.tens[s.in].grads.push_back(gin);
                 E.bwd_writes.push_back({s.w, s.b});
                 E.bwd_sub.push_back(1);
+                E.bwd_sig.push_back(0);
                 E.bwd_ops.push_back([this_ = &E, si, gin](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -1049,6 +1130,7 @@ struct Planner {
                 const int gout = gl[0];
                 E.bwd_writes.push_back({});
                 E.bwd_sub.push_back(E.tens[s.in].lvl <= E.sub_lvl ? 1 : 0);
+                E.bwd_sig.push_back(0);
                 E.bwd_ops.push_back([this_ = &E, si, gin, gout](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -1108,6 +1190,7 @@ struct Planner {
                         if (ui >= 0) { const Step& u = E.steps[ui]; wr.push_back(u.gn_w); wr.push_back(u.gn_b); wr.push_back(u.b); wr.push_back(u.w); }
                     E.bwd_writes.push_back(wr);
                     E.bwd_sub.push_back((unit_sub(s.ua) && (s.ub < 0 || unit_sub(s.ub))) ? 1 : 0);
+                    E.bwd_sig.push_back(0);
                     E.bwd_ops.push_back([this_ = &E, si, gl](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& s = E.steps[si];
@@ -1153,12 +1236,14 @@ struct Planner {
                     ub.draw = new_grad(ub.raw);
                     E.bwd_writes.push_back({ua.gn_w, ua.gn_b, ua.b, ub.gn_w, ub.gn_b, ub.b});
                     E.bwd_sub.push_back((unit_sub(s.ua) && unit_sub(s.ub)) ? 1 : 0);
+                    E.bwd_sig.push_back(1);
                     E.bwd_ops.push_back([this_ = &E, uia = s.ua, uib = s.ub, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
                         GnBwdArgs a, b;
                         GnBwdFinArgs fa{}, fb{};
                         fill(E, uia, gl, a, fa);
                         fill(E, uib, gl, b, fb);
+                        a.sig_flag = E.take_sig(a.sig_seq);        // the reduce pass is the first kernel behind a released batch of weight gradients
                         a.r2 = b.r; a.scale2 = b.scale; a.shift2 = b.shift; a.Q2 = b.Q; a.coef2 = b.coef; a.dr2 = b.dr;
                         const double tb = E.tbytes(E.steps[uia].raw);
                         int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, tb * (a.ndy + 2), 0.0);
@@ -1177,6 +1262,7 @@ struct Planner {
                     u.draw = new_grad(u.raw);
                     E.bwd_writes.push_back({u.gn_w, u.gn_b, u.b});      // gamma/beta and (analytically) the conv bias
                     E.bwd_sub.push_back(unit_sub(ui) ? 1 : 0);
+                    E.bwd_sig.push_back(1);
                     E.bwd_ops.push_back([this_ = &E, ui, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& u = E.steps[ui];
@@ -1184,6 +1270,7 @@ struct Planner {
                         GnBwdArgs a;
                         GnBwdFinArgs f{};
                         fill(E, ui, gl, a, f);
+                        a.sig_flag = E.take_sig(a.sig_seq);        // (see the dual-branch op)
                         if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
                             const int pg = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
                             launch_gn_bwd_group(a, f, E.dtype, st);
@@ -1217,6 +1304,7 @@ struct Planner {
                 if (s.in1 >= 0) { g1 = new_grad(s.in1); E.tens[s.in1].grads.push_back(g1); }
                 E.bwd_writes.push_back({s.w, s.gn_w < 0 ? s.b : -1});
                 E.bwd_sub.push_back(unit_sub((int)si) ? 1 : 0);
+                E.bwd_sig.push_back(0);
                 if (s.ck != CK_STEM3 && s.ck != CK_STEM1) ++E.n_deferred;
                 E.bwd_ops.push_back([this_ = &E, si, draw, g0, g1](hipStream_t st) {
                     seg_engine& E = *this_;
@@ -1247,14 +1335,16 @@ struct Planner {
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
                                           s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, nullptr, nullptr, s.cin_par);
                             E.prof_end(ws_, pi);
-                        }, E.tbytes(draw), lo, s.gn_w >= 0 ? si : -1);
+                        }, E.tbytes(draw), lo, s.gn_w >= 0 ? si : -1, g0 >= 0 ? s.x_dg0 >= 0 : (g1 >= 0 && s.x_dg1 >= 0));
                         int pi;
+                        ForkSig sg;                               // a batch released just now: the first data-gradient kernel stores its number
                         if (g0 >= 0) {
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
-                            if (s.x_dg0 >= 0)
+                            if (s.x_dg0 >= 0) {
+                                sg.flag = E.take_sig(sg.seq);
                                 launch_conv3x(s.x_dg0, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr,
-                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st, STAT_REP);
-                            else
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st, STAT_REP, nullptr, sg);
+                            } else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);
@@ -1262,10 +1352,12 @@ struct Planner {
                         if (g1 >= 0) {
                             const int C1 = E.tens[s.in1].C;
                             pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g1), fl * C1 / s.Cin);
-                            if (s.x_dg1 >= 0)
+                            if (s.x_dg1 >= 0) {
+                                sg = ForkSig{};
+                                sg.flag = E.take_sig(sg.seq);     // (null when the first data-gradient took it)
                                 launch_conv3x(s.x_dg1, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr,
-                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st, STAT_REP);
-                            else
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st, STAT_REP, nullptr, sg);
+                            } else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);
@@ -1302,9 +1394,11 @@ struct Planner {
                                                     E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
                         launch_wgrad(w, (float*)(E.ws + E.cur_partial), E.dtype, ws_, s.cin_par);
                         E.prof_end(ws_, pi);
-                    }, E.tbytes(draw), lo < li ? lo : li, s.gn_w >= 0 ? si : -1);
+                    }, E.tbytes(draw), lo < li ? lo : li, s.gn_w >= 0 ? si : -1, g0 >= 0 || g1 >= 0);
                     // ---- data gradient(s)
                     if (g0 < 0 && g1 < 0) return;
+                    ForkSig sg;                                   // a batch released just now: the first data-gradient kernel stores its number
+                    sg.flag = E.take_sig(sg.seq);
                     ConvArgs a{};
                     a.in0 = E.ws + E.tens[draw].off; a.C0 = s.Cout; a.in1 = nullptr; a.C1 = 0;
                     a.bias = nullptr; a.stats = nullptr; a.N = E.N;
@@ -1316,7 +1410,7 @@ struct Planner {
                         a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
                         a.taps = make_taps(E.ndim, 2, 0);
                         a.Cout = s.Cin; a.K = s.Cout; a.Ngemm = a.taps.n * s.Cin; a.Kpad = (a.K + 31) / 32 * 32;
-                        launch_conv_igemm(a, E.dtype, st);
+                        { launch_conv_igemm(a, E.dtype, st, STAT_REP, sg); sg = ForkSig{}; }
                     } else if (s.ck == CK_KT) {
                         // d_X[i][ci] = sum_{a,co} dY[2i+a][co] Wt[ci][co][a] : gather, stride 2 over the fine gradient
                         a.scatter = 0; a.w = E.ws + s.wp_dg0; a.out = E.ws + E.tens[g0].off;
@@ -1325,7 +1419,7 @@ struct Planner {
                         a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
                         a.taps = make_taps(E.ndim, 2, 0);
                         a.Cout = s.Cin; a.Ngemm = s.Cin; a.K = a.taps.n * s.Cout; a.Kpad = (a.K + 31) / 32 * 32;
-                        launch_conv_igemm(a, E.dtype, st);
+                        { launch_conv_igemm(a, E.dtype, st, STAT_REP, sg); sg = ForkSig{}; }
                     } else {
                         // conv 3^d / 1^d: gather conv of d(raw) with flipped taps, once per concat source
                         a.scatter = 0;
@@ -1336,11 +1430,11 @@ struct Planner {
                         a.K = a.taps.n * s.Cout; a.Kpad = (a.K + 31) / 32 * 32;
                         if (g0 >= 0) {
                             a.w = E.ws + s.wp_dg0; a.out = E.ws + E.tens[g0].off; a.Cout = a.Ngemm = E.tens[s.in0].C;
-                            launch_conv_igemm(a, E.dtype, st);
+                            { launch_conv_igemm(a, E.dtype, st, STAT_REP, sg); sg = ForkSig{}; }
                         }
                         if (g1 >= 0) {
                             a.w = E.ws + s.wp_dg1; a.out = E.ws + E.tens[g1].off; a.Cout = a.Ngemm = E.tens[s.in1].C;
-                            launch_conv_igemm(a, E.dtype, st);
+                            { launch_conv_igemm(a, E.dtype, st, STAT_REP, sg); sg = ForkSig{}; }
                         }
                     }
                 });
@@ -1441,9 +1535,11 @@ void seg_destroy(seg_handle h) {
     if (h->pack_done) (void)hipEventDestroy(h->pack_done);
     if (h->side_done) (void)hipEventDestroy(h->side_done);
     if (h->ar_ev) (void)hipEventDestroy(h->ar_ev);
+    h->release_waiters();
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2_done) (void)hipEventDestroy(h->side2_done);
     if (h->side2) (void)hipStreamDestroy(h->side2);
+    if (h->fork_flag) { (void)hipDeviceSynchronize(); (void)hipFree(h->fork_flag); }
     delete h;
 }
 
@@ -1472,6 +1568,7 @@ int seg_set_dropout_draws(seg_handle h, long long draws) {
     if (draws < 0 || draws > 0x7fffffffll) return fail("seg_set_dropout_draws: counter out of range");
     h->draws = (int)draws;
     if (h->ws) {          // bound: the device-side counter follows (seg_bind restores it from the host copy otherwise)
+        h->release_waiters();
         if (h->side) (void)hipStreamSynchronize(h->side);
         if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h->ws + h->off_step, &h->draws, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
             return fail("seg_set_dropout_draws: counter upload failed");
@@ -1487,6 +1584,7 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
         return fail("seg_plan: spatial dims must be multiples of 16 (four 2x down-samplings)");
     // a backward-only weight pack of the previous step may still be running on the (non-blocking) side stream into the workspace the
     // caller is about to replace
+    h->release_waiters();
     if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }
     if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->drop_graph();
@@ -1501,7 +1599,15 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
 int seg_plan_count(seg_handle h, int what) {
     if (!h || !h->planned) return -1;
     if (what == 2) return h->n_event_forks;             // last backward pass: fork events recorded on the main stream
-    if (what == 3) return 0;                            // (completion-flag forks: removed in round 4)
+    if (what == 3) return h->n_flag_forks;              // ... flag forks (the weight-gradient queue's command processor waits on a word the main queue's next kernel stores)
+    if (what == 7) return h->n_sig_taken;               // ... of which the next kernel of the main stream stored the number itself
+    if (what == 8) return h->n_sig_kernels;             // ... and one-wave kernels that stored it
+    if (what == 9) {                                    // 1: no released batch is left waiting (the host checker also reads the flag word itself)
+#ifdef SEG_EMU
+        if (h->fork_flag && *h->fork_flag != h->fork_seq) return 0;
+#endif
+        return h->sig_pending == 0;
+    }
     if (what == 4) return h->sub_nb;                    // samples per group of the sub-batched finest level (0: whole-batch launches)
     if (what == 5 || what == 6) {                       // forward / backward ops that run group by group
         int n = 0;
@@ -1523,6 +1629,7 @@ int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
     if (!h->planned) return fail("seg_bind: call seg_plan first");
     if (!params || !workspace) return fail("seg_bind: params/workspace must not be null");
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)workspace) & 255) return fail("seg_bind: buffers must be 256-byte aligned");
+    h->release_waiters();
     if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }     // see seg_plan
     if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->drop_graph();
@@ -1596,6 +1703,7 @@ int seg_backward_slice(seg_handle h, const float* dlogits, int zero_grads, int o
 int seg_side_wait(seg_handle h, void* stream) {
     if (check_handle(h)) return -1;
     hipStream_t st = (hipStream_t)stream;
+    h->emit_sig(st);
     if (h->use_side && h->side) {
         (void)hipEventRecord(h->side_done, h->side); (void)hipStreamWaitEvent(st, h->side_done, 0);
         if (h->side2) { (void)hipEventRecord(h->side2_done, h->side2); (void)hipStreamWaitEvent(st, h->side2_done, 0); }
@@ -1611,11 +1719,11 @@ static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, in
     hipStream_t st = (hipStream_t)stream;
     if (zero_grads && op_begin == 0) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
-    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; h->n_event_forks = 0; }
+    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; h->n_event_forks = 0; h->n_flag_forks = 0; h->n_sig_kernels = 0; h->n_sig_taken = 0; }
     if (h->pack_bwd_pending) { (void)hipStreamWaitEvent(st, h->pack_done, 0); h->pack_bwd_pending = false; }
     h->run_ops(h->bwd_ops, h->bwd_chains, op_begin, op_end, st, true);
     if (join) h->join_side(st);
-    else h->flush_side(st);          // the queued weight gradients of this slice are released; `stream` does not wait for them
+    else { h->flush_side(st); h->emit_sig(st); }         // the queued weight gradients of this slice are released; `stream` does not wait for them
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));
 }
 int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* stream) {
@@ -1908,6 +2016,7 @@ int seg_train_graph_capture(seg_handle h, const seg_train_args* a, void* stream)
     h->drop_graph();
     // nothing un-captured may be pending on the streams the capture forks to
     (void)hipStreamSynchronize(st);
+    h->release_waiters();
     if (h->side) (void)hipStreamSynchronize(h->side);
     if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->pack_bwd_pending = false;

@@ -10,7 +10,9 @@ namespace seg {
 typedef seg_taps Taps;
 // Implicit-GEMM convolution arguments: see seg_conv_args in include/segengine.h
 typedef seg_conv_args ConvArgs;
-void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep = STAT_REP);   // stat_rep: LDS-staged kernel only
+// A flag fork carried by a launch (engine.hip, flush_side_full): the kernel's first thread stores `seq` to `flag` (fork_signal_store below)
+struct ForkSig { unsigned* flag = nullptr; unsigned seq = 0; };
+void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep = STAT_REP, ForkSig sg = ForkSig{});   // stat_rep: LDS-staged kernel only
 bool conv_uses_stream_kernel(const ConvArgs& a);   // true: register-resident streaming kernel, false: LDS-staged implicit GEMM
 
 // LDS halo-tile kernels for 3^d stride-1 pad-1 convs (conv3.hip): forward / data-gradient and weight gradient
@@ -26,7 +28,8 @@ struct GnFinArgs;
 // (Conv3xArgs::fuse, conv3x_impl.h).  conv3x_gn_supported: which inputs that variant takes.
 bool conv3x_gn_supported(int Cin, bool has_in1);
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep = STAT_REP, const GnFinArgs* gn = nullptr);
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep = STAT_REP, const GnFinArgs* gn = nullptr,
+                   ForkSig sg = ForkSig{});
 // replicas a statistics producer spreads its atomics over, by voxels per sample: enough to keep same-address fp64 atomics apart,
 // few enough that the consumer-side fold (gn_fold_block) reads ~8 KB
 inline int stat_rep_for(long long V) { return V >= 262144 ? 32 : V >= 65536 ? 16 : V >= 8192 ? 8 : 4; }
@@ -136,7 +139,21 @@ struct GnBwdArgs {
     // the fly from the loss gradient (planar fp32) and the head weights instead of being written as a 16-channel tensor and read
     // back by every GroupNorm-backward pass it feeds
     const float* vdl; const float* vw; int vK;    int rep_q;                                  // replicas of Q the reduce pass spreads over; 0 = STAT_REP
+    // flag fork (engine.hip, seg_engine::flush_side_full): the reduce pass / the one-launch pass is the first main-stream kernel behind a batch of
+    // weight gradients released to the second queue; its first thread stores `sig_seq` to the flag that queue's command processor waits on
+    unsigned* sig_flag = nullptr; unsigned sig_seq = 0;
 };
+// One store to a flag in signal memory (hipMallocSignalMemory) that another queue waits on with hipStreamWaitValue32.  In-order queue: the kernel
+// that executes it starts after everything launched before it has completed and released its writes.
+__device__ __forceinline__ void fork_signal_store(unsigned* flag, unsigned seq) {
+#ifdef SEG_EMU
+    *flag = seq;
+#else
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+void launch_fork_signal(unsigned* flag, unsigned seq, hipStream_t s);      // the same store from a one-wave kernel of its own (misc.hip)
+void launch_fork_wait(const unsigned* flag, unsigned seq, hipStream_t s);   // one polling lane (the alternative to hipStreamWaitValue32)
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
 struct GnBwdFinArgs;
 // fa != null: the backward finalize of the branch(es) runs as a prologue of this launch (no gn_bwd_finalize launch before it)

@@ -198,6 +198,7 @@ template <class T, bool DUAL, int NDY>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB_ROWS) {
     __shared__ float red[256 * 16];
     const int tid = threadIdx.x, n = blockIdx.y;
+    if (a.sig_flag && tid == 0 && blockIdx.x == 0 && n == 0) fork_signal_store(a.sig_flag, a.sig_seq);
     const int CPR = a.C / 8;                  // 2..32 (power of two)
     const int G = 256 / CPR;
     const int cc = tid % CPR, g = tid / CPR;
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_group_kernel(GnBwdGroupArgs a) {
     __shared__ double chan[32][3];           // per channel of the group: Q1, Q2, R1
     __shared__ float coef[32][3];
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (a.e.sig_flag && tid == 0 && g == 0 && n == 0) fork_signal_store(a.e.sig_flag, a.e.sig_seq);
     const int C = a.e.C, cpg = C / GN_GROUPS, CG = cpg / 8, CPR = C / 8;     // CG = 16-B chunks per voxel in this group: 1, 2 or 4
     const long long V = a.e.V;
     const int cg = tid % CG, c0 = g * cpg + cg * 8;

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")      # SEG_FORK=flag (test_flag_forks_equal_event_forks): hipStreamWaitValue32 as a command-processor wait; read when the HIP runtime starts
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

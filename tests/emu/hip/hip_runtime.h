@@ -42,6 +42,14 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind
 inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 template <class P> inline hipError_t hipMalloc(P** p, size_t n) { *p = (P*)malloc(n); return *p ? hipSuccess : 1; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+// stream memory operations (flag forks of the engine): launches run immediately and in program order here, so a wait has nothing to wait for;
+// the flag word itself is ordinary memory the kernels store to (seg_plan_count 9 checks that every number handed out was stored)
+enum hipDeviceAttribute_t { hipDeviceAttributeCanUseStreamWaitValue = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 1; return hipSuccess; }
+constexpr unsigned hipMallocSignalMemory = 2, hipStreamWaitValueGte = 0;
+inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { *p = calloc(1, n); return *p ? hipSuccess : 1; }
+inline hipError_t hipStreamWaitValue32(hipStream_t, void*, uint32_t, unsigned, uint32_t = 0xffffffffu) { return hipSuccess; }
 typedef void* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

@@ -428,6 +428,35 @@ def test_sub_batched_finest_level_equals_whole_batch_launches(dev, tag, dtype, m
         assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-3) * float(g0[k].norm()) + 1e-12, k
 
 
+@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f32"), ("unet2d", "f32"), pytest.param("vnet3d_48", "f16", marks=pytest.mark.gpu),
+                                       pytest.param("unet3d_32", "bf16", marks=pytest.mark.gpu)])
+def test_flag_forks_equal_event_forks(dev, tag, dtype, monkeypatch):
+    """Releasing weight gradients to the second queue without an event (seg_engine::flush_side_full): that queue's command processor waits on a
+    word in signal memory (hipStreamWaitValue32) and the word is stored by the first thread of the next kernel the caller's stream runs anyway -
+    the GroupNorm-backward reduce / one-launch pass (GnBwdArgs::sig_flag) - or by a one-wave kernel where another kernel follows.  Same
+    launches, same data: the gradients equal the event-fork engine's (SEG_FORK=event).  Bookkeeping checked on both boxes: every released
+    batch got its number stored (nothing is left waiting: a forgotten store would hang the weight-gradient queue), most of them by the next
+    kernel itself; the host checker also reads the flag word."""
+    res, counts = [], []
+    for mode in ("event", "flag"):
+        monkeypatch.setenv("SEG_FORK", mode)
+        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
+        run_engine(e, x, y, masks, alpha, loss, dev)              # twice: the sequence numbers keep growing across passes
+        res.append(run_engine(e, x, y, masks, alpha, loss, dev))
+        counts.append([e.lib.seg_plan_count(e.h, w) for w in (2, 3, 7, 8, 9)])
+        del e
+    (l0, p0, o0, g0), (l1, p1, o1, g1) = res
+    ev, fl = counts
+    assert ev[0] >= 2 and ev[1] == 0 and ev[4] == 1, counts
+    assert fl[0] == 0 and fl[1] == ev[0] and 1 <= fl[2] + fl[3] <= fl[1] and fl[2] >= 1 and fl[4] == 1, counts
+    if dtype != "f32":          # the 16-bit kernels behind a release (halo / generic data-gradients, GroupNorm-backward reduce) all carry the number
+        assert fl[2] >= fl[1] // 2, counts
+    exact = dev.type == "cpu"
+    assert float((l0 - l1).abs().max()) <= (0.0 if exact else 2e-3 * max(1.0, float(l0.abs().max())))
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm()) <= (0.0 if exact else 2e-3) * float(g0[k].norm()) + 1e-12, k
+
+
 @pytest.mark.gpu
 def test_graph_replay_equals_stream_launches():
     """seg_train_graph_capture / _launch: the train step captured as a HIP graph (weight-gradient stream forked and joined inside the
