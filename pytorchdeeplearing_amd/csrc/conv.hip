@@ -549,6 +549,8 @@ template <class T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
     __shared__ float ws[MAXCLS * 64 + MAXCLS];
     const int tid = threadIdx.x;
+    if (a.zero_ptr && blockIdx.x == 0)
+        for (long long i = tid; i < a.zero_n; i += 256) a.zero_ptr[i] = 0.0;
     for (int i = tid; i < a.C * a.Cin; i += 256) ws[i] = a.w[i];
     if (tid < a.C) ws[MAXCLS * 64 + tid] = a.bias ? a.bias[tid] : 0.f;
     __syncthreads();

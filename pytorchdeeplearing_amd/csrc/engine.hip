@@ -390,6 +390,12 @@ struct seg_engine {
             }
         }
     }
+    // seg_train_step: bookkeeping stores that ride on the step's own kernels (StepRider, kernels.h) - the dropout draw counter and the clear of
+    // the overflow flag on the image ingest, the optimiser's step counter on the weight re-pack - and the loss workspace cleared by the head kernel
+    bool ride_on = false;
+    StepRider ride_ingest, ride_pack;
+    double* ride_zero = nullptr; long long ride_zero_n = 0;
+    bool head_zeroed = false;
     // one optimisation step captured as a HIP graph (seg_train_graph_*): the host side of a replay is ONE hipGraphLaunch
     hipGraph_t tgraph = nullptr;
     hipGraphExec_t tgraph_exec = nullptr;
@@ -888,7 +894,7 @@ struct Planner {
             const int pi = E.prof_begin(st, SEG_K_MISC, (double)fill + (double)E.N * E.vol(0) * (4.0 * E.in_ch + (double)x.C * E.esz()), 0.0);
             (void)hipMemsetAsync(E.ws + E.off_stats, 0, fill, st);
             E.q_clean = E.off_Q == E.off_stats + E.stats_bytes;
-            launch_ingest(E.cur_x, E.ws + x.off, E.N, x.C, E.vol(0), E.dtype, st, E.in_ch);
+            launch_ingest(E.cur_x, E.ws + x.off, E.N, x.C, E.vol(0), E.dtype, st, E.in_ch, E.ride_on ? E.ride_ingest : StepRider{});
             E.prof_end(st, pi);
         });
         for (size_t si = 0; si < E.steps.size(); ++si) {
@@ -990,6 +996,8 @@ struct Planner {
                         seg_stemx_args x = stemx_args(E, s);
                         const int pi = E.prof_begin(st, SEG_K_STEM, E.tbytes(ua.in0) * 2 + E.tbytes(s.out), 0.0);
                         launch_stemx(x, 0, E.ndim, E.dtype, nullptr, nullptr, st);
+                        GnFinArgs fin[2];
+                        int nfin = 0;
                         for (int ui : {s.ua, s.ub}) {
                             if (ui < 0) continue;
                             const Step& u = E.steps[ui];
@@ -1001,8 +1009,9 @@ struct Planner {
                             f.scale = (float*)(E.ws + u.scale); f.shift = (float*)(E.ws + u.shift);
                             f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
                             f.N = E.N; f.C = u.Cout; f.V = E.vol(0); f.eps = 1e-5f;
-                            launch_gn_finalize(f, st);
+                            fin[nfin++] = f;
                         }
+                        launch_gn_finalize(fin[0], st, nfin > 1 ? &fin[1] : nullptr);      // both branches: one launch
                         launch_stemx(x, 1, E.ndim, E.dtype, nullptr, nullptr, st);
                         E.prof_end(st, pi);
                         return;
@@ -1074,6 +1083,7 @@ struct Planner {
                     a.in = E.ws + E.tens[s.in].off; a.w = E.p + E.params[s.w].off; a.bias = E.p + E.params[s.b].off;
                     a.logits = E.cur_logits; a.probs = E.cur_probs;
                     a.N = E.N; a.V = (int)E.vol(0); a.Cin = s.Cin; a.C = s.Cout;
+                    if (E.ride_on && E.ride_zero) { a.zero_ptr = E.ride_zero; a.zero_n = E.ride_zero_n; E.head_zeroed = true; }
                     const int pi = E.prof_begin(st, SEG_K_HEAD, E.tbytes(s.in) + 2.0 * 4.0 * E.N * E.vol(0) * s.Cout, 0.0);
                     launch_head_fwd(a, E.dtype, st);
                     E.prof_end(st, pi);
@@ -1202,6 +1212,8 @@ struct Planner {
                         int pi = E.prof_begin(st, SEG_K_STEM, tb * x.ndy, 0.0);
                         launch_stemx(x, 2, E.ndim, E.dtype, nullptr, nullptr, st);
                         E.prof_end(st, pi);
+                        GnBwdFinArgs fin[2];
+                        int nfin = 0;
                         for (int ui : {s.ua, s.ub}) {
                             if (ui < 0) continue;
                             const Step& u = E.steps[ui];
@@ -1216,8 +1228,9 @@ struct Planner {
                             f.dbias = u.b >= 0 ? E.g + E.params[u.b].off : nullptr;
                             f.coef = (float*)(E.ws + u.coef);
                             f.N = E.N; f.C = u.Cout; f.V = E.vol(0);
-                            launch_gn_bwd_finalize(f, st);
+                            fin[nfin++] = f;
                         }
+                        launch_gn_bwd_finalize(fin[0], st, nfin > 1 ? &fin[1] : nullptr);  // both branches: one launch
                         pi = E.prof_begin(st, SEG_K_STEM, tb * x.ndy, 0.0);
                         launch_stemx(x, 3, E.ndim, E.dtype, E.g + E.params[E.steps[s.ua].w].off,
                                      s.ub >= 0 ? E.g + E.params[E.steps[s.ub].w].off : nullptr, st);
@@ -1665,9 +1678,9 @@ int seg_pack_weights(seg_handle h, void* stream) {
         launch_pack(descs + h->npack_fwd, nbwd, (int)h->pack_max, h->dtype, h->side);
         (void)hipEventRecord(h->pack_done, h->side);
         h->pack_bwd_pending = true;                        // seg_backward_range waits for it
-        launch_pack(descs, h->npack_fwd, (int)h->pack_max, h->dtype, st);
+        launch_pack(descs, h->npack_fwd, (int)h->pack_max, h->dtype, st, h->ride_on ? h->ride_pack : StepRider{});
     } else {
-        launch_pack(descs, nall, (int)h->pack_max, h->dtype, st);
+        launch_pack(descs, nall, (int)h->pack_max, h->dtype, st, h->ride_on ? h->ride_pack : StepRider{});
     }
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_pack_weights: launch failed");
 }
@@ -1685,7 +1698,7 @@ int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks,
         (void)hipMemcpyAsync(h->ws + h->off_masks, masks, mbytes, hipMemcpyDeviceToDevice, st);
     } else if (mask_mode == SEG_MASKS_RANDOM) {
         launch_dropout_masks((float*)(h->ws + h->off_masks), (int)h->drop_ch.size(), h->N, h->ld_mask(), 0.2f, seed,
-                             (const int*)(h->ws + h->off_step), st);
+                             (const int*)(h->ws + h->off_step), st, !h->ride_on);      // (train step: the ingest kernel advances the counter)
         ++h->draws;
     }
     h->cur_x = x; h->cur_logits = logits; h->cur_probs = probs;
@@ -1922,18 +1935,25 @@ int seg_metric(const float* probs, const void* target, int label_type, int n, in
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_metric: launch failed");
 }
 
-int seg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long numel, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int decoupled, float inv_scale, int check_finite, int* state, void* stream) {
+// riders: the overflow flag was cleared and the step counter will be advanced by StepRiders of neighbouring launches (seg_train_step)
+static int adam_step_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long numel, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int decoupled, float inv_scale, int check_finite, int* state, void* stream,
+                          bool riders) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !state) return fail("seg_adam_step: null pointer");
     hipStream_t st = (hipStream_t)stream;
     AdamArgs a;
     a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = numel;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.decoupled = decoupled;
     a.inv_scale = inv_scale; a.step = state; a.found_inf = state + 1;
-    (void)hipMemsetAsync(state + 1, 0, sizeof(int), st);
+    if (!riders) (void)hipMemsetAsync(state + 1, 0, sizeof(int), st);
     if (check_finite) launch_grad_check(grads, numel, state + 1, st);
-    launch_adam(a, st);
+    launch_adam(a, st, !riders);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_adam_step: launch failed");
+}
+int seg_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long numel, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int decoupled, float inv_scale, int check_finite, int* state, void* stream) {
+    return adam_step_impl(params, grads, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, decoupled, inv_scale, check_finite, state,
+                          stream, false);
 }
 
 // One optimisation step of the reference loop (model/modelVNet.py:570-596) enqueued by ONE call: the host side of a step is then a
@@ -1948,8 +1968,26 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
     if (!a->exp_avg || !a->exp_avg_sq || !a->opt_state) return fail("seg_train_step: optimiser state is null");
     hipStream_t st = (hipStream_t)stream;
     if (!a->packed && seg_pack_weights(h, stream)) return -1;
-    if (seg_forward(h, a->x, a->mask_mode, a->masks, a->seed, a->logits, a->probs, stream)) return -1;
+    // Serial section at the step boundary (profiles/r04_trace_timeline.txt: fill, overflow check, Adam, counter, re-pack, masks, counter, fill,
+    // ingest - nothing overlaps them): the one-wave bookkeeping launches ride on their neighbours.  SEG_STEP_RIDERS=0: separate launches.
+    const char* riders_e = getenv("SEG_STEP_RIDERS");
+    const bool riders_env = !(riders_e && atoi(riders_e) == 0);
+    const bool riders = riders_env && h->sub_nb == 0;
     const long long v = h->vol(0);
+    struct RideGuard { seg_engine* e; ~RideGuard() { e->ride_on = false; e->ride_zero = nullptr; } } ride_guard{h};      // every way out of the step
+    h->ride_on = riders; h->head_zeroed = false;
+    h->ride_ingest = StepRider{}; h->ride_pack = StepRider{};
+    if (riders) {
+        if (a->mask_mode == SEG_MASKS_RANDOM) h->ride_ingest.bump = (int*)(h->ws + h->off_step);      // the dropout draw counter (after the mask kernel read it)
+        h->ride_ingest.clear = a->opt_state + 1;                                                   // this step's overflow flag
+        h->ride_pack.bump = a->opt_state; h->ride_pack.gate = a->opt_state + 1; h->ride_pack.tally = a->opt_state + 2;     // = adam_bump_kernel
+        if (!a->loss_cb) { h->ride_zero = (double*)a->loss_ws; h->ride_zero_n = (long long)loss_sums_count(h->N, h->ncls) * STAT_REP; }
+        else h->ride_zero = nullptr;
+    }
+    const int frc = seg_forward(h, a->x, a->mask_mode, a->masks, a->seed, a->logits, a->probs, stream);
+    const bool zeroed = riders && h->head_zeroed;
+    h->ride_zero = nullptr;
+    if (frc) { h->ride_on = false; return -1; }
     const double lbytes = (double)h->N * v * (4.0 * h->ncls + ((a->label_type & 15) == SEG_LABEL_U8 ? 1.0 : (a->label_type & 15) == SEG_LABEL_I64 ? 8.0 : 4.0));
     int pi = h->prof_begin(st, SEG_K_MISC, 2.0 * lbytes + 4.0 * h->N * v * h->ncls, 0.0);
     if (a->loss_cb) {
@@ -1959,9 +1997,13 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
         if (ng < 0) return fail("seg_train_step: the loss exchange hook failed");
         if (seg_loss_finalize(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->class_alpha,
                               (int)ng, a->loss_ws, a->out3, stream)) return -1;
-    } else
-    if (seg_loss_forward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->class_alpha,
-                         a->loss_ws, a->out3, stream)) return -1;
+    } else {
+        LossArgs la;
+        if (fill_loss(la, a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->loss_ws)) return -1;
+        la.class_alpha = a->class_alpha; la.out = a->out3; la.prezeroed = zeroed ? 1 : 0;      // (the head kernel cleared the workspace)
+        launch_loss_forward(la, st);
+        if (hipGetLastError() != hipSuccess) return fail("seg_train_step: loss launch failed");
+    }
     if (seg_loss_backward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->loss_ws,
                           h->loss_scale, a->dlogits, stream)) return -1;
     h->prof_end(st, pi);
@@ -1994,9 +2036,13 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
     if (seg_backward(h, a->dlogits, 1, stream)) return -1;
     // fused optimiser: p, m, v read + written, g read (+ once more by the overflow check); re-pack: fp32 masters read, run-dtype layouts written
     pi = h->prof_begin(st, SEG_K_MISC, (double)h->nparam * (28.0 + (a->check_finite ? 4.0 : 0.0) + 4.0 + 3.0 * (double)h->esz()), 0.0);
-    if (seg_adam_step(h->p, h->g, a->exp_avg, a->exp_avg_sq, h->nparam, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->decoupled,
-                      1.0f / (h->loss_scale * (a->grad_div > 0.f ? a->grad_div : 1.f)), a->check_finite, a->opt_state, stream)) return -1;
-    const int rc = seg_pack_weights(h, stream);
+    if (adam_step_impl(h->p, h->g, a->exp_avg, a->exp_avg_sq, h->nparam, a->lr, a->beta1, a->beta2, a->eps, a->weight_decay, a->decoupled,
+                       1.0f / (h->loss_scale * (a->grad_div > 0.f ? a->grad_div : 1.f)), a->check_finite, a->opt_state, stream, riders)) {
+        h->ride_on = false;
+        return -1;
+    }
+    const int rc = seg_pack_weights(h, stream);          // (its first thread advances the optimiser's step counter: ride_pack)
+    h->ride_on = false;
     h->prof_end(st, pi);
     return rc;
 }

@@ -10,6 +10,15 @@ namespace seg {
 typedef seg_taps Taps;
 // Implicit-GEMM convolution arguments: see seg_conv_args in include/segengine.h
 typedef seg_conv_args ConvArgs;
+// Bookkeeping stores of the train step that ride on a kernel the step launches anyway instead of being one-wave launches of their own (each
+// costs ~5 us of the main queue at a place where nothing overlaps it: profiles/r04_trace_timeline.txt, step start).  Executed by the first
+// thread of the carrying kernel: an in-order queue starts it after everything launched before it has completed.
+//   bump: *bump += 1 unless *gate is set (then *tally += 1)   = adam_bump_kernel     clear: *clear = 0   = the fill of the overflow flag
+struct StepRider { int* bump = nullptr; const int* gate = nullptr; int* tally = nullptr; int* clear = nullptr; };
+__device__ __forceinline__ void step_rider_run(const StepRider& r) {
+    if (r.bump) { if (!(r.gate && *r.gate)) *r.bump += 1; else if (r.tally) *r.tally += 1; }
+    if (r.clear) *r.clear = 0;
+}
 // A flag fork carried by a launch (engine.hip, flush_side_full): the kernel's first thread stores `seq` to `flag` (fork_signal_store below)
 struct ForkSig { unsigned* flag = nullptr; unsigned seq = 0; };
 void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep = STAT_REP, ForkSig sg = ForkSig{});   // stat_rep: LDS-staged kernel only
@@ -75,6 +84,7 @@ struct HeadArgs {
     float* logits;      // [N][C][V]
     float* probs;       // [N][C][V]
     int N, V, Cin, C;
+    double* zero_ptr = nullptr; long long zero_n = 0;      // (train step) the loss workspace the reduction that follows accumulates into: cleared by workgroup 0
 };
 void launch_head_fwd(const HeadArgs& a, int dtype, hipStream_t s);
 
@@ -105,7 +115,7 @@ struct GnFinArgs {
     float eps;
     int rep;              // replicas of `stats` that hold data (1..STAT_REP, power of two); 0 = STAT_REP
 };
-void launch_gn_finalize(const GnFinArgs& a, hipStream_t s);
+void launch_gn_finalize(const GnFinArgs& a, hipStream_t s, const GnFinArgs* b = nullptr);      // b: a second module in the same launch
 
 // y = relu(scale1*r1+shift1) [+ relu(scale2*r2+shift2)] [+ res]
 struct ActArgs {
@@ -172,7 +182,7 @@ struct GnBwdFinArgs {
     long long V;
     int rep_q, rep_s;                       // replicas of Q / stats that hold data; 0 = STAT_REP
 };
-void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s);
+void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s, const GnBwdFinArgs* b = nullptr);
 // small L2-resident tensors (C >= 64): reduce + finalize + apply in one launch, one workgroup per (sample, group)
 bool gn_bwd_group_eligible(int C, long long V, int esz);
 void launch_gn_fwd_group(const GnFinArgs& f, const void* r, const void* res, void* out, int dtype, hipStream_t s);
@@ -193,11 +203,11 @@ void launch_maxpool_fwd(const PoolArgs& a, int dtype, hipStream_t s);
 void launch_maxpool_bwd(const PoolArgs& a, int dtype, hipStream_t s);
 
 // fp32 NC[D]HW image -> channels-last T
-void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s, int Csrc = 0);      // Csrc < C: zero-padded channels
+void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s, int Csrc = 0, StepRider rd = StepRider{});      // Csrc < C: zero-padded channels
 
 // Generic weight re-layout: see seg_pack_desc in include/segengine.h
 typedef seg_pack_desc PackDesc;
-void launch_pack(const PackDesc* descs_dev, int ndesc, int max_rows, int dtype, hipStream_t s);
+void launch_pack(const PackDesc* descs_dev, int ndesc, int max_rows, int dtype, hipStream_t s, StepRider rd = StepRider{});
 
 // Losses on planar fp32 logits [N][C][V]
 enum LossKind { L_BIN_DICE = 0, L_BIN_CE = 1, L_BIN_FOCAL = 2, L_BIN_CE_DICE = 3, L_MC_CE = 4, L_MC_FOCAL = 5, L_MC_DICE = 6,
@@ -219,6 +229,7 @@ struct LossArgs {
     float grad_scale;           // loss scale folded into dlogits
     int phase;                  // 0: reduce + finalize; 1: reduce + fold replicas only; 2: finalize only (sums exchanged by the caller)
     int n_global;               // samples over ALL ranks for the mean losses (0: N)
+    int prezeroed = 0;          // (train step) `sums` was cleared by the head kernel in front of this launch: no fill
 };
 int loss_shared_count();        // leading doubles of `sums` that are batch-global (summed across ranks in phase 1 -> 2)
 __host__ __device__ size_t loss_sums_count(int N, int C);   // doubles per replica (STAT_REP replicas)
@@ -287,9 +298,9 @@ struct AdamArgs {
     int* found_inf;         // device flag: when nonzero the update is skipped
 };
 void launch_grad_check(const float* g, long long n, int* found_inf, hipStream_t s);
-void launch_adam(const AdamArgs& a, hipStream_t s);
+void launch_adam(const AdamArgs& a, hipStream_t s, bool bump = true);      // bump = false: a StepRider of the next launch advances the counter
 
 // channel-dropout multipliers: masks[l][n][ld] in {0, 1/(1-p)}
-void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s);
+void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s, bool bump = true);
 
 }  // namespace seg

@@ -14,7 +14,8 @@ inline int ew_blocks(long long total_threads, int cap = 16384) {
 
 // ---------------------------------------------------------------- ingest: fp32 NC[D]HW -> T N[D]HWC
 template <class T>
-__global__ __launch_bounds__(256) void ingest_kernel(const float* x, T* out, int N, int C, long long V, int Csrc) {
+__global__ __launch_bounds__(256) void ingest_kernel(const float* x, T* out, int N, int C, long long V, int Csrc, StepRider rd) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) step_rider_run(rd);
     // Csrc < C: the image tensor is zero-padded to C channels (multi-channel 3-D inputs run through the 16-channel halo convs)
     const long long total = (long long)N * V * C;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void ingest_kernel(const float* x, T* out, int
 
 // one image channel: NC[D]HW and N[D]HWC are the same memory - a plain conversion, 8 elements per thread (two 16-B loads, one wide store)
 template <class T>
-__global__ __launch_bounds__(256) void ingest1_kernel(const float* x, T* out, long long total8) {
+__global__ __launch_bounds__(256) void ingest1_kernel(const float* x, T* out, long long total8, StepRider rd) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) step_rider_run(rd);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
         const vec<float, 4> a = *(const vec<float, 4>*)(x + i * 8), b = *(const vec<float, 4>*)(x + i * 8 + 4);
         vec<T, 8> o;
@@ -44,7 +46,8 @@ __global__ __launch_bounds__(256) void ingest1_kernel(const float* x, T* out, lo
 // master weights with a 108-B stride: 670 MB of HBM fetches for a 38 MB re-layout (PMC, profiles/r01_pmc_*).
 constexpr int PACK_MAXK = 27 * 256 + 32;
 template <class T>
-__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs) {
+__global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs, StepRider rd) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_rider_run(rd);
     __shared__ float row_s[PACK_MAXK];
     const PackDesc d = descs[blockIdx.y];
     const long long rows = (long long)d.R1 * d.R2;
@@ -684,19 +687,19 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* masks, long lo
 
 }  // namespace
 
-void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s, int Csrc) {
+void launch_ingest(const float* x, void* out, int N, int C, long long V, int dtype, hipStream_t s, int Csrc, StepRider rd) {
     if (Csrc <= 0 || Csrc > C) Csrc = C;
     if (C == 1 && Csrc == 1 && dtype != DT_F32 && ((long long)N * V) % 8 == 0 && (((unsigned long long)x | (unsigned long long)out) & 15) == 0) {
         const long long total8 = (long long)N * V / 8;
         dim3 g1(ew_blocks(total8));
-        if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest1_kernel<f16>), g1, dim3(256), 0, s, x, (f16*)out, total8);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest1_kernel<bf16>), g1, dim3(256), 0, s, x, (bf16*)out, total8);
+        if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest1_kernel<f16>), g1, dim3(256), 0, s, x, (f16*)out, total8, rd);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest1_kernel<bf16>), g1, dim3(256), 0, s, x, (bf16*)out, total8, rd);
         return;
     }
     dim3 grid(ew_blocks((long long)N * V * C));
-    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<float>), grid, dim3(256), 0, s, x, (float*)out, N, C, V, Csrc);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<f16>), grid, dim3(256), 0, s, x, (f16*)out, N, C, V, Csrc);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<bf16>), grid, dim3(256), 0, s, x, (bf16*)out, N, C, V, Csrc);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<float>), grid, dim3(256), 0, s, x, (float*)out, N, C, V, Csrc, rd);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<f16>), grid, dim3(256), 0, s, x, (f16*)out, N, C, V, Csrc, rd);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(ingest_kernel<bf16>), grid, dim3(256), 0, s, x, (bf16*)out, N, C, V, Csrc, rd);
 }
 
 // predict() post-processing on the device (modelVNet.py:670-676, modelUnet.py:672-680): probs planar fp32 [N][C][V] ->
@@ -724,15 +727,15 @@ void launch_mask(const float* probs, unsigned char* out, int N, int C, long long
     hipLaunchKernelGGL(mask_kernel, dim3(ew_blocks((long long)N * V)), dim3(256), 0, s, probs, out, N, C, V, threshold, scale);
 }
 
-void launch_pack(const PackDesc* descs_dev, int ndesc, int max_elems, int dtype, hipStream_t s) {
+void launch_pack(const PackDesc* descs_dev, int ndesc, int max_elems, int dtype, hipStream_t s, StepRider rd) {
     (void)max_elems;
     // rows are strided over `wgs` workgroups per descriptor.  The 256-channel levels hold most of the bytes in descriptors of 256
     // rows: at 64 workgroups each one walked four 27 KB rows back to back (67 us per step, latency-bound)
     static const int wgs = getenv("SEG_PACK_WGS") ? atoi(getenv("SEG_PACK_WGS")) : 256;
     dim3 grid(wgs, ndesc);
-    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<float>), grid, dim3(256), 0, s, descs_dev);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<f16>), grid, dim3(256), 0, s, descs_dev);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<bf16>), grid, dim3(256), 0, s, descs_dev);
+    if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<float>), grid, dim3(256), 0, s, descs_dev, rd);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<f16>), grid, dim3(256), 0, s, descs_dev, rd);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<bf16>), grid, dim3(256), 0, s, descs_dev, rd);
 }
 
 void launch_maxpool_fwd(const PoolArgs& a, int dtype, hipStream_t s) {
@@ -756,7 +759,7 @@ void launch_loss_forward(const LossArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, a);
         return;
     }
-    (void)hipMemsetAsync(a.sums, 0, loss_sums_count(a.N, a.C) * sizeof(double) * STAT_REP, s);
+    if (!a.prezeroed) (void)hipMemsetAsync(a.sums, 0, loss_sums_count(a.N, a.C) * sizeof(double) * STAT_REP, s);
     dim3 grid(cdiv(a.V, LOSS_VPB), a.N);
     if (a.C <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(loss_reduce_kernel<8>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(loss_reduce_kernel<16>), grid, dim3(256), 0, s, a);
@@ -784,9 +787,9 @@ void launch_colsum(const void* x, float* out, long long M, int C, int dtype, hip
 void launch_grad_check(const float* g, long long n, int* found_inf, hipStream_t s) {
     hipLaunchKernelGGL(grad_check_kernel, dim3(ew_blocks(n, 2048)), dim3(256), 0, s, g, n, found_inf);
 }
-void launch_adam(const AdamArgs& a, hipStream_t s) {
+void launch_adam(const AdamArgs& a, hipStream_t s, bool bump) {
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(a.n, 4096)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, a.step, a.found_inf, 1);
+    if (bump) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, a.step, a.found_inf, 1);
 }
 
 namespace { __global__ __launch_bounds__(64) void fork_signal_kernel(unsigned* flag, unsigned seq) { if (threadIdx.x == 0) fork_signal_store(flag, seq); } }
@@ -806,10 +809,10 @@ __global__ __launch_bounds__(64) void fork_wait_kernel(const unsigned* flag, uns
 }
 void launch_fork_wait(const unsigned* flag, unsigned seq, hipStream_t s) { hipLaunchKernelGGL(fork_wait_kernel, dim3(1), dim3(64), 0, s, flag, seq); }
 
-void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s) {
+void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s, bool bump) {
     const long long total = (long long)L * N * ld;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_blocks(total, 1024)), dim3(256), 0, s, masks, total, p, seed, step);
-    if (step) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, (int*)step, (int*)nullptr, 0);
+    if (step && bump) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, (int*)step, (int*)nullptr, 0);
 }
 
 }  // namespace seg

@@ -15,7 +15,9 @@ namespace {
 
 // GroupNorm statistics are independent per (sample, group): grid = (8 groups, N), 64 threads.  Every thread folds
 // the STAT_REP replicas of (channel, replica-slice) pairs of its group; a wave reduction gives the group moments.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinArgs a) {
+// (grid.z = 2: the two branches of the fused input block in one launch)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinArgs a0, GnFinArgs a1) {
+    const GnFinArgs a = blockIdx.z ? a1 : a0;
     __shared__ double csum[64][2];
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cpg = a.C / GN_GROUPS;                    // 2..32 channels per group
@@ -278,7 +280,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
 }
 
 // backward finalize: grid = (8 groups, N), 64 threads — same decomposition as the forward finalize
-__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a) {
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnBwdFinArgs a0, GnBwdFinArgs a1) {
+    const GnBwdFinArgs a = blockIdx.z ? a1 : a0;
     __shared__ double sh[64][3];
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cpg = a.C / GN_GROUPS, RG = 64 / cpg;
@@ -671,8 +674,8 @@ inline int ew_blocks(long long total_threads) {
 
 }  // namespace
 
-void launch_gn_finalize(const GnFinArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS, a.N), dim3(64), 0, s, a);
+void launch_gn_finalize(const GnFinArgs& a, hipStream_t s, const GnFinArgs* b) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS, a.N, b ? 2 : 1), dim3(64), 0, s, a, b ? *b : a);
 }
 
 void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
@@ -734,8 +737,8 @@ void launch_gn_bwd_group(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, h
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_group_kernel<bf16>), grid, dim3(1024), 0, s, a);
 }
 
-void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(GN_GROUPS, a.N), dim3(64), 0, s, a);
+void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s, const GnBwdFinArgs* b) {
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(GN_GROUPS, a.N, b ? 2 : 1), dim3(64), 0, s, a, b ? *b : a);
 }
 
 

@@ -248,6 +248,121 @@ __global__ __launch_bounds__(256) SEG_WG_WAVES(NTB == MAXTB && sizeof(T) == 2 ? 
     }
 }
 
+// The 1^d stride-1 convolutions on 16-bit tensors (the concat -> 1^d conv of every decoder level, networks/VNet3d.py:66-77): the gathered voxel
+// is the row itself, so the kernel is a pure stream of two channels-last tensors - 340 MB at 96^3 - and wgrad_kernel above ran it at
+// 1.7 TB/s: ONE staging step (128 rows = 12 KB per workgroup) in flight, i.e. 48 KB per CU against a loaded-memory latency of several
+// microseconds (profiles/r04_rocprofv3_kernel_stats.txt: 204 us).  Here DEPTH steps travel at once: each thread keeps DEPTH register sets of
+// its NPD + NPX 16-byte pieces, statically indexed (the step loop is unrolled DEPTH times), so the compiler's vmcnt waits for the OLDEST set
+// only.  Tile extents are template parameters (TP = 16 NPD, TQ = 16 NPX: exactly NPD / NPX pieces per thread and step).  Same partial-tile
+// layout, same order of the fp32 sums over the voxel axis as wgrad_kernel: bit-identical results.
+template <class T, int NPD, int NPX, int DEPTH>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradArgs a, WgPlan pl, float* partial) {
+    constexpr int WMT = 128, TP = 16 * NPD, TQ = 16 * NPX;
+    constexpr int cpr_p = TP / 8, cpr_q = TQ / 8;                // 16-byte pieces per row
+    __shared__ T Ds[WMT * LDW];
+    __shared__ T Xs[WMT * LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = (int)blockIdx.x;
+    const int p0 = (tile / pl.ntq) * TP, q0 = (tile % pl.ntq) * TQ;
+    const long long M = (long long)a.N * a.OD * a.OH * a.OW;
+    const long long mbeg = (long long)blockIdx.y * pl.Mc;
+    const long long mend = (mbeg + pl.Mc < M) ? mbeg + pl.Mc : M;
+    const T* dr = (const T*)a.dr;
+    constexpr int nt_q = NPX, n16 = NPD * NPX;                   // 16x16 output tiles, split over the 4 waves
+    constexpr int MAXW = (n16 + 3) / 4;
+    f32x4 acc[MAXW];
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this thread's pieces: (row inside the step, byte-free element offset of the 8-channel chunk); the x chunk comes from one of the two
+    // concat sources (pointer select once, outside the loop)
+    int drow[NPD], xrow[NPX];
+    const T* dbase[NPD];
+    const T* xbase[NPX];
+    long long xstride[NPX];
+#pragma unroll
+    for (int u = 0; u < NPD; ++u) {
+        const int pc = u * 256 + tid;
+        drow[u] = pc / cpr_p;
+        dbase[u] = dr + p0 + (pc % cpr_p) * 8;
+    }
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+        const int pc = u * 256 + tid;
+        xrow[u] = pc / cpr_q;
+        const int qc = q0 + (pc % cpr_q) * 8;
+        const bool from0 = qc < a.C0;
+        xbase[u] = from0 ? (const T*)a.x0 + qc : (const T*)a.x1 + (qc - a.C0);
+        xstride[u] = from0 ? a.C0 : a.C1;
+    }
+    vec<T, 8> dq[DEPTH][NPD], xq[DEPTH][NPX];
+    unsigned okq[DEPTH];                                         // bit u: d piece u, bit 8 + u: x piece u of that set holds data
+    auto issue = [&](int slot, long long ms) {                   // rows past the slice read a valid (clamped) row and are zeroed on the way to LDS
+        unsigned ok = 0u;
+#pragma unroll
+        for (int u = 0; u < NPD; ++u) {
+            const long long m = ms + drow[u];
+            const bool v = m < mend;
+            ok |= v ? (1u << u) : 0u;
+            dq[slot][u] = load8(dbase[u] + (v ? m : mbeg) * a.P);
+        }
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+            const long long m = ms + xrow[u];
+            const bool v = m < mend;
+            ok |= v ? (1u << (8 + u)) : 0u;
+            xq[slot][u] = load8(xbase[u] + (v ? m : mbeg) * xstride[u]);
+        }
+        okq[slot] = ok;
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1; ++k) issue(k, mbeg + (long long)k * WMT);
+    for (long long ms = mbeg; ms < mend; ms += (long long)DEPTH * WMT) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            // every body runs, also past the end of the slice (zero tiles: exact zeros are added): a conditional around the loads makes the
+            // compiler's vmcnt bookkeeping give up at the join and wait for ALL older sets at once
+            const long long m0 = ms + (long long)k * WMT;
+            {
+                issue((k + DEPTH - 1) % DEPTH, m0 + (long long)(DEPTH - 1) * WMT);
+#pragma unroll
+                for (int u = 0; u < NPD; ++u)
+                    store8(&Ds[drow[u] * LDW + ((u * 256 + tid) % cpr_p) * 8], ((okq[k] >> u) & 1u) ? dq[k][u] : zero8<T>());
+#pragma unroll
+                for (int u = 0; u < NPX; ++u)
+                    store8(&Xs[xrow[u] * LDW + ((u * 256 + tid) % cpr_q) * 8], ((okq[k] >> (8 + u)) & 1u) ? xq[k][u] : zero8<T>());
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < MAXW; ++i) {
+                    const int wi = wv + 4 * i;
+                    if (wi < n16) {
+                        const int pi = wi / nt_q, qi = wi % nt_q;
+#pragma unroll
+                        for (int kk = 0; kk < WMT / 32; ++kk) {
+                            const typename Mma<T>::frag af = TFrag<T>::load(Ds + kk * 32 * LDW, pi * 16, lane);
+                            const typename Mma<T>::frag bf = TFrag<T>::load(Xs + kk * 32 * LDW, qi * 16, lane);
+                            acc[i] = Mma<T>::run(af, bf, acc[i]);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    const int l15 = lane & 15, q = lane >> 4;
+    const int Qc = a.Q;
+    float* dst = partial + (long long)blockIdx.y * a.P * Qc;
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+        const int wi = wv + 4 * i;
+        if (wi < n16) {
+            const int pi = wi / nt_q, qi = wi % nt_q;
+            const int qq = q0 + qi * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(long long)(p0 + pi * 16 + 4 * q + r) * Qc + qq] = acc[i][r];
+        }
+    }
+}
+
 // dw[p*sP + q*sQ + tap*sT] += sum_slices partial[slice][p][tap][q]    (stem: column q = (tap, ci))
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, int P, int Tn, int Qc, int parts, long long sP,
                                                            long long sQ, long long sT, int stem_cimg, int qreal) {
@@ -310,7 +425,18 @@ template <class T>
 void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s, int qreal) {
     const WgPlan pl = make_plan(a);
     dim3 grid(pl.ntg * pl.ntile, pl.parts);
-    if (a.stem) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, true, 1>), grid, dim3(256), 0, s, a, pl, partial);
+    static const bool direct_on = !(getenv("SEG_WG_DIRECT") && atoi(getenv("SEG_WG_DIRECT")) == 0);       // A/B switch
+    bool done = false;
+    if constexpr (sizeof(T) == 2) {
+        if (direct_on && !a.stem && pl.TB == 1 && pl.direct && pl.ntg == 1 && a.C0 % 8 == 0) {
+#define SEG_WGD(ND, NX, DP) if (!done && pl.TP == 16 * ND && pl.TQ == 16 * NX) {                                                                     \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_direct_kernel<T, ND, NX, DP>), grid, dim3(256), 0, s, a, pl, partial); done = true; }
+            SEG_WGD(1, 2, 4) SEG_WGD(2, 4, 3) SEG_WGD(4, 4, 3) SEG_WGD(1, 1, 4) SEG_WGD(2, 2, 4)
+#undef SEG_WGD
+        }
+    }
+    if (done) {}
+    else if (a.stem) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, true, 1>), grid, dim3(256), 0, s, a, pl, partial);
     else if (pl.TB == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, false, 1>), grid, dim3(256), 0, s, a, pl, partial);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, false, MAXTB>), grid, dim3(256), 0, s, a, pl, partial);
     const int Tn = a.stem ? 1 : a.taps.n;

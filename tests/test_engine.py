@@ -222,6 +222,34 @@ def test_random_masks_and_loss_scale_skip(dev):
     assert int(e.opt_state[0]) == 1 and int(e.opt_state[1]) == 1
 
 
+@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16"), pytest.param("vnet3d_48", "f16", marks=pytest.mark.gpu)])
+def test_step_riders_equal_separate_bookkeeping_launches(dev, tag, dtype, monkeypatch):
+    """seg_train_step folds its one-wave bookkeeping launches into neighbours (StepRider, kernels.h): the dropout draw counter and the clear of
+    the overflow flag ride on the image ingest, the optimiser's step counter on the weight re-pack, the loss workspace is cleared by the head
+    kernel, the two GroupNorm finalizes of the fused input block share a launch.  Three steps with engine-drawn masks (the counter feeds the
+    mask hash: a missed or doubled bump changes every later step) must leave the same parameters, losses and counters as SEG_STEP_RIDERS=0; a
+    step with a poisoned gradient is skipped and tallied either way."""
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("SEG_STEP_RIDERS", on)
+        e, params, x, y, _, alpha, loss = build(tag, dtype, dev, False)
+        xd, yd = x.to(dev), y.to(dev)
+        losses = [float(e.train_step(xd, yd, loss, lr=1e-3)[0]) for _ in range(3)]
+        e.loss_scale = 1.0e30                      # the next step's f16 gradients overflow: the update must be refused and tallied
+        p_before = e.params.clone()
+        e.train_step(xd, yd, loss, lr=1e-3)
+        skipped = torch.equal(p_before, e.params)
+        res.append((losses, e.params.clone().cpu(), [int(v) for v in e.opt_state[:3].cpu()], int(e.lib.seg_dropout_draws(e.h)), skipped))
+        del e
+    (l1, p1, s1, d1, k1), (l0, p0, s0, d0, k0) = res
+    exact = dev.type == "cpu"
+    assert s1 == s0 and d1 == d0 and k1 == k0, (s1, s0, d1, d0, k1, k0)
+    assert k1 and s1 == [3, 1, 1] and d1 == 4, (k1, s1, d1)          # three updates, the fourth refused: flag set, one tally; four mask draws
+    for a, b in zip(l1, l0):
+        assert abs(a - b) <= (0.0 if exact else 2e-3 * max(1.0, abs(b)))
+    assert float((p1 - p0).abs().max()) <= (0.0 if exact else 3 * 2e-3)
+
+
 def test_errors_are_reported(dev):
     e = SegEngine("vnet", 3, 1, 1, dtype="f32", device=dev)
     with pytest.raises(RuntimeError, match="multiples of 16"):

@@ -156,11 +156,19 @@ def test_data_gradients_exact(dev, dtype):
     (3, 1, (4, 4, 6), [32], 64, 3, 1, 1),
     (3, 2, (4, 6, 4), [16], 32, 2, 2, 0),
     (3, 2, (3, 5, 4), [16, 16], 16, 1, 1, 0),
+    # 1^d convolutions on a concat: the multi-step streaming kernel of the 16-bit dtypes (wgrad_direct_kernel: 16 x 32, 32 x 64 and 64 x 64 tiles,
+    # several 128-row steps per slice, a ragged last step)
+    (3, 2, (6, 9, 8), [16, 16], 16, 1, 1, 0),
+    (3, 1, (5, 8, 9), [32, 32], 32, 1, 1, 0),
+    (2, 2, (13, 16), [64, 64], 64, 1, 1, 0),
+    (3, 1, (96, 96, 96), [16, 16], 16, 1, 1, 0),      # seven steps per slice: the unrolled register ring wraps around (GPU run only)
     (2, 3, (7, 9), [16], 32, 3, 1, 1),
     (3, 1, (2, 3, 4), [128], 128, 3, 1, 1),
 ])
 def test_wgrad_exact(dev, dtype, case):
     ndim, N, sp, cins, cout, k, stride, pad = case
+    if sp[0] >= 96:
+        conftest.checker_slow(dev, "885 k voxel rows on the host checker")
     g = torch.Generator().manual_seed(5)
     cin = sum(cins)
     x = ints((N, cin) + sp, -2, 2, g)
