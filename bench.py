@@ -45,8 +45,8 @@ FAMILIES = {
                        what="weight gradients of the 3^d convolutions (wgrad3_kernel + wgrad3_reduce_kernel)",
                        pmc=["wgrad3_kernel", "wgrad3_reduce_kernel"], count=["wgrad3_kernel"]),
     "generic_wgrad": dict(classes=["wgrad_generic"], bound="hbm", queue="weight-gradient stream",
-                          what="weight gradients of the 2^d stride-2 / transposed / 1^d convolutions (wgrad_kernel + wgrad_reduce_kernel)",
-                          pmc=["wgrad_kernel", "wgrad_reduce_kernel"], count=["wgrad_kernel"]),
+                          what="weight gradients of the 2^d stride-2 / transposed / 1^d convolutions (wgrad_kernel / wgrad_direct_kernel + wgrad_reduce_kernel)",
+                          pmc=["wgrad_kernel", "wgrad_direct_kernel", "wgrad_reduce_kernel"], count=["wgrad_kernel", "wgrad_direct_kernel"]),
     "generic_conv": dict(classes=["conv_generic"], bound="hbm", queue="main",
                          what="2^d stride-2, transposed and 1^d convolutions, forward + data-gradient (conv_stream_kernel / conv_igemm_kernel)",
                          pmc=["conv_stream_kernel", "conv_igemm_kernel"], count=None),

@@ -229,6 +229,8 @@ def test_step_riders_equal_separate_bookkeeping_launches(dev, tag, dtype, monkey
     kernel, the two GroupNorm finalizes of the fused input block share a launch.  Three steps with engine-drawn masks (the counter feeds the
     mask hash: a missed or doubled bump changes every later step) must leave the same parameters, losses and counters as SEG_STEP_RIDERS=0; a
     step with a poisoned gradient is skipped and tallied either way."""
+    if tag == "vnet3d_48":
+        conftest.checker_slow(dev, "eight 48^3 train steps on the host checker")
     res = []
     for on in ("1", "0"):
         monkeypatch.setenv("SEG_STEP_RIDERS", on)
@@ -465,6 +467,8 @@ def test_flag_forks_equal_event_forks(dev, tag, dtype, monkeypatch):
     launches, same data: the gradients equal the event-fork engine's (SEG_FORK=event).  Bookkeeping checked on both boxes: every released
     batch got its number stored (nothing is left waiting: a forgotten store would hang the weight-gradient queue), most of them by the next
     kernel itself; the host checker also reads the flag word."""
+    if tag in ("vnet3d_48", "unet3d_32"):
+        conftest.checker_slow(dev, "four 3-D 16-bit forward+backward passes on the host checker")
     res, counts = [], []
     for mode in ("event", "flag"):
         monkeypatch.setenv("SEG_FORK", mode)

@@ -2,10 +2,17 @@
 # smoke, three fresh-process bench lines, rocprofv3 kernel stats + kernel trace timeline of the same command, the two PMC passes (separate
 # runs, kernel-trace only), the other BASELINE configs, pre/post-processing, full-size fidelity report.  Outputs under gpurun_out/<tag>/.
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-TAG=${1:-final}; O=gpurun_out/$TAG; mkdir -p $O
+TAG=${1:-final}; O=gpurun_out/$TAG; mkdir -p $O       # $2 (optional): profiles/ prefix of the round, e.g. r04
 SEG_FULLSIZE_REPORT=$O/fullsize_report.txt timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $O/gpu_tests.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log
 DRV="python bench.py --gpus 1 --steps 20 --warmup 5"
+# the PMC passes first: bench.py reads the families' HBM traffic from the newest profiles/rNN_pmc_fetch_write_per_kernel.json, which should be THIS binary's
+rm -rf gpurun_out/pmc
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc -o $c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --roofline-steps 0 --condition-seconds 0 --launch stream > $O/pmc_$c.log 2>&1
+done
+python profiles/summarize_pmc.py gpurun_out/pmc $O/pmc_fetch_write_per_kernel.json > $O/pmc_summary.log 2>&1
+if [ -n "$2" ] && [ -s $O/pmc_fetch_write_per_kernel.json ]; then cp $O/pmc_fetch_write_per_kernel.json profiles/$2_pmc_fetch_write_per_kernel.json; fi
 for i in 1 2 3; do
   timeout 400 $DRV $( [ $i -gt 1 ] && echo --no-cpu-baseline --no-other-configs ) > $O/bench_driver_cmd_$i.json 2> $O/bench_driver_cmd_$i.err
 done
@@ -16,10 +23,6 @@ if [ -n "$DB" ]; then python profiles/summarize_rocpd.py $DB 50 > $O/rocprofv3_k
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -o t -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --roofline-steps 0 --condition-seconds 0.2 --launch stream > $O/trace_run.log 2>&1
 CSV=$(find gpurun_out/trace -name "*kernel_trace.csv" | head -1)
 if [ -n "$CSV" ]; then python tools/trace_gaps.py $CSV > $O/trace_timeline.txt 2>&1; fi
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc -o $c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --roofline-steps 0 --condition-seconds 0 --launch stream > $O/pmc_$c.log 2>&1
-done
-python profiles/summarize_pmc.py gpurun_out/pmc $O/pmc_fetch_write_per_kernel.json > $O/pmc_summary.log 2>&1
 timeout 300 python tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err
 timeout 300 python tools/bench_prepost.py > $O/prepost.jsonl 2> $O/prepost.err
 rm -rf gpurun_out/prof gpurun_out/pmc gpurun_out/trace
