@@ -6,13 +6,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsegengine.so")
-SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "ssim.hip", "cldice.hip", "prepost.hip", "engine.hip"]
+SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "ssim.hip", "cldice.hip", "prepost.hip", "engine.hip", "engine_plan.hip", "capi_ops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
 
 
 def _deps():
-    d = [os.path.join(CSRC, f) for f in SRCS + ["common.h", "kernels.h", "conv3x_impl.h", "gn_fold.h"]]
+    d = [os.path.join(CSRC, f) for f in SRCS + ["common.h", "kernels.h", "conv3x_impl.h", "gn_fold.h", "engine_internal.h"]]
     d.append(os.path.join(os.path.dirname(HERE), "include", "segengine.h"))
     return d
 
@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "conv3x_impl.h", "gn_fold.h")] + [os.path.join(os.path.dirname(HERE), "include", "segengine.h")]
+    hdrs = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "conv3x_impl.h", "gn_fold.h", "engine_internal.h")] + [os.path.join(os.path.dirname(HERE), "include", "segengine.h")]
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
     procs, objs = [], []
     for s in SRCS:

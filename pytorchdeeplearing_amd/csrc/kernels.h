@@ -19,7 +19,7 @@ __device__ __forceinline__ void step_rider_run(const StepRider& r) {
     if (r.bump) { if (!(r.gate && *r.gate)) *r.bump += 1; else if (r.tally) *r.tally += 1; }
     if (r.clear) *r.clear = 0;
 }
-// A flag fork carried by a launch (engine.hip, flush_side_full): the kernel's first thread stores `seq` to `flag` (fork_signal_store below)
+// A flag fork carried by a launch (engine_internal.h, seg_engine::flush_side_full): the kernel's first thread stores `seq` to `flag` (fork_signal_store below)
 struct ForkSig { unsigned* flag = nullptr; unsigned seq = 0; };
 void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep = STAT_REP, ForkSig sg = ForkSig{});   // stat_rep: LDS-staged kernel only
 bool conv_uses_stream_kernel(const ConvArgs& a);   // true: register-resident streaming kernel, false: LDS-staged implicit GEMM
@@ -149,7 +149,7 @@ struct GnBwdArgs {
     // the fly from the loss gradient (planar fp32) and the head weights instead of being written as a 16-channel tensor and read
     // back by every GroupNorm-backward pass it feeds
     const float* vdl; const float* vw; int vK;    int rep_q;                                  // replicas of Q the reduce pass spreads over; 0 = STAT_REP
-    // flag fork (engine.hip, seg_engine::flush_side_full): the reduce pass / the one-launch pass is the first main-stream kernel behind a batch of
+    // flag fork (engine_internal.h, seg_engine::flush_side_full): the reduce pass / the one-launch pass is the first main-stream kernel behind a batch of
     // weight gradients released to the second queue; its first thread stores `sig_seq` to the flag that queue's command processor waits on
     unsigned* sig_flag = nullptr; unsigned sig_seq = 0;
 };

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pytorchdeeplearing_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "libsegengine_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "ssim.hip", "cldice.hip", "prepost.hip", "engine.hip"]
+SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "ssim.hip", "cldice.hip", "prepost.hip", "engine.hip", "engine_plan.hip", "capi_ops.hip"]
 
 
 def build(force=False):
@@ -23,7 +23,7 @@ def build(force=False):
 
 def _build(force=False):
     srcs = [os.path.join(CSRC, s) for s in SRCS]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv3x_impl.h"), os.path.join(CSRC, "gn_fold.h"),
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "conv3x_impl.h"), os.path.join(CSRC, "gn_fold.h"), os.path.join(CSRC, "engine_internal.h"),
                    os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "segengine.h")]
     hdr_t = max(os.path.getmtime(d) for d in deps[len(srcs):])
     # per-object freshness (an object compiled BEFORE an edit of its source must not hide behind a newer link step)
