@@ -234,8 +234,9 @@ struct seg_engine {
     // volumes/s with event forks on one lease, 1029 vs 1030 on another: with the early release below the weight-gradient queue is busy 92 % of the
     // backward window, so the main queue's saved 100 us are spent waiting at the join.  With the runtime's DEFAULT hipStreamWaitValue32 (a
     // one-thread polling kernel, __amd_rocclr_streamOpsWait, on the waiting queue) it is 2 % SLOWER (978-984): the process has to start with
-    // GPU_STREAMOPS_CP_WAIT=1 (barrier-value packet: the command processor waits).  Kept opt-in; SEG_FORK=spin: own sleeping poll kernel (996).
-    int fork_mode = -1;                 // -1: decided on first use; 0: events; 1: flag, hipStreamWaitValue32; 2: flag, own one-lane polling kernel
+    // GPU_STREAMOPS_CP_WAIT=1 (barrier-value packet: the command processor waits).  Kept opt-in.  (An own sleeping one-lane poll kernel on the waiting
+    // queue was measured too: 996-997; removed.)
+    int fork_mode = -1;                 // -1: decided on first use; 0: events; 1: flag (hipStreamWaitValue32)
     unsigned* fork_flag = nullptr;      // 8 bytes of signal memory
     unsigned fork_seq = 0;              // last number a weight-gradient queue was told to wait for
     unsigned sig_pending = 0;           // ... and not yet stored / handed to a kernel: nobody may wait on the side queues before it is
@@ -245,12 +246,12 @@ struct seg_engine {
         if (fork_mode < 0) {
             fork_mode = 0;
             const char* e = getenv("SEG_FORK");
-            const bool want = e && strcmp(e, "event") != 0;           // opt-in (see above)
+            const bool want = e && !strcmp(e, "flag");                // opt-in (see above)
             int can = 0;
             if (want && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0) == hipSuccess && can) {
                 if (hipExtMallocWithFlags((void**)&fork_flag, 8, hipMallocSignalMemory) == hipSuccess && fork_flag) {
                     launch_fork_signal(fork_flag, 0u, nullptr);
-                    fork_mode = hipDeviceSynchronize() == hipSuccess ? ((e && !strcmp(e, "spin")) ? 2 : 1) : 0;
+                    fork_mode = hipDeviceSynchronize() == hipSuccess ? 1 : 0;
                 }
                 (void)hipGetLastError();
             }
@@ -286,11 +287,8 @@ struct seg_engine {
                 fork_seq = 0;
             }
             const unsigned seq = ++fork_seq;
-            if (fork_mode == 2) { launch_fork_wait(fork_flag, seq, side); if (side2) launch_fork_wait(fork_flag, seq, side2); }
-            else {
-                (void)hipStreamWaitValue32(side, fork_flag, seq, hipStreamWaitValueGte, 0xffffffffu);
-                if (side2) (void)hipStreamWaitValue32(side2, fork_flag, seq, hipStreamWaitValueGte, 0xffffffffu);
-            }
+            (void)hipStreamWaitValue32(side, fork_flag, seq, hipStreamWaitValueGte, 0xffffffffu);
+            if (side2) (void)hipStreamWaitValue32(side2, fork_flag, seq, hipStreamWaitValueGte, 0xffffffffu);
             sig_pending = seq;                             // (a number still pending from an earlier release is covered by this larger one)
             ++n_flag_forks;
         } else {

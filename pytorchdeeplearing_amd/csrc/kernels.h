@@ -163,7 +163,6 @@ __device__ __forceinline__ void fork_signal_store(unsigned* flag, unsigned seq) 
 #endif
 }
 void launch_fork_signal(unsigned* flag, unsigned seq, hipStream_t s);      // the same store from a one-wave kernel of its own (misc.hip)
-void launch_fork_wait(const unsigned* flag, unsigned seq, hipStream_t s);   // one polling lane (the alternative to hipStreamWaitValue32)
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
 struct GnBwdFinArgs;
 // fa != null: the backward finalize of the branch(es) runs as a prologue of this launch (no gn_bwd_finalize launch before it)

@@ -794,20 +794,6 @@ void launch_adam(const AdamArgs& a, hipStream_t s, bool bump) {
 
 namespace { __global__ __launch_bounds__(64) void fork_signal_kernel(unsigned* flag, unsigned seq) { if (threadIdx.x == 0) fork_signal_store(flag, seq); } }
 void launch_fork_signal(unsigned* flag, unsigned seq, hipStream_t s) { hipLaunchKernelGGL(fork_signal_kernel, dim3(1), dim3(64), 0, s, flag, seq); }
-namespace {
-// SEG_FORK=spin: one lane polls the word (sleeping between polls) instead of the runtime's hipStreamWaitValue32.  Bounded: ~2 s, then it gives up
-// and lets the queue run on rather than hanging the GPU.
-__global__ __launch_bounds__(64) void fork_wait_kernel(const unsigned* flag, unsigned seq) {
-#ifndef SEG_EMU
-    if (threadIdx.x == 0)
-        for (int spins = 0; spins < (1 << 24); ++spins) {
-            if ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-#endif
-}
-}
-void launch_fork_wait(const unsigned* flag, unsigned seq, hipStream_t s) { hipLaunchKernelGGL(fork_wait_kernel, dim3(1), dim3(64), 0, s, flag, seq); }
 
 void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s, bool bump) {
     const long long total = (long long)L * N * ld;
