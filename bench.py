@@ -75,6 +75,14 @@ def _pmc_file():
     return c[-1] if c else None
 
 
+def _library_build():
+    try:
+        from pytorchdeeplearing_amd import _capi
+        return _capi.product_library().build_info()
+    except Exception:
+        return None
+
+
 def pmc_traffic(family):
     """HBM bytes per bracketed op of a kernel family from the rocprofv3 PMC passes committed under profiles/ (separate --pmc FETCH_SIZE /
     --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes): (bytes per op, file).
@@ -83,8 +91,11 @@ def pmc_traffic(family):
         f = _pmc_file()
         with open(f) as fh:
             table = json.load(fh)
+        # the summary is stamped with seg_build_info() of the binary the PMC passes ran (profiles/summarize_pmc.py): figures of another binary are not reported
+        if table.get("_build") != _library_build():
+            return None, "%s is from build '%s', not the loaded library: traffic dropped" % (os.path.basename(f), table.get("_build"))
         fam = FAMILIES[family]
-        rows = {k: v for k, v in table.items() if k != "_total" and any(k.startswith(p) or (p in k and not p.startswith("_Z")) for p in fam["pmc"])}
+        rows = {k: v for k, v in table.items() if not k.startswith("_") and any(k.startswith(p) or (p in k and not p.startswith("_Z")) for p in fam["pmc"])}
         # a family name that is a prefix of another family's symbol must not swallow it (wgrad_kernel vs wgrad3_kernel)
         if family == "generic_wgrad":
             rows = {k: v for k, v in rows.items() if "wgrad3" not in k}

@@ -36,6 +36,20 @@ def load(path, counter):
     return per
 
 
+def build_info():
+    """seg_build_info() of the library the passes ran (pytorchdeeplearing_amd/build.py stamps a hash of the sources into it): bench.py only
+    reports `traffic` from a summary whose build matches the library it has loaded"""
+    import ctypes
+    import os
+    try:
+        lib = os.environ.get("SEGENGINE_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pytorchdeeplearing_amd", "lib", "libsegengine.so")
+        l = ctypes.CDLL(lib)
+        l.seg_build_info.restype = ctypes.c_char_p
+        return l.seg_build_info().decode()
+    except Exception as ex:
+        return "unknown (%s)" % type(ex).__name__
+
+
 def main():
     d, out = sys.argv[1], sys.argv[2]
     fetch = load("%s/FETCH_SIZE_counter_collection.csv" % d, "FETCH_SIZE")
@@ -46,6 +60,7 @@ def main():
         res[k] = {"launches": n, "fetch_kb_raw_per_launch": round(fetch[k][1] / n, 1),
                   "write_kb_per_launch": round(write[k][1] / write[k][0], 1) if k in write and write[k][0] else None}
     tot_f = sum(v[1] for v in fetch.values()); tot_w = sum(v[1] for v in write.values())
+    res["_build"] = build_info()
     res["_total"] = {"fetch_gb_corrected_all_launches": round(2 * tot_f / 1e6, 3), "write_gb_all_launches": round(tot_w / 1e6, 3)}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)

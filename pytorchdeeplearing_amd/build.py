@@ -7,8 +7,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsegengine.so")
 SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip", "wgrad.hip", "wgrad3x.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "ssim.hip", "cldice.hip", "prepost.hip", "engine.hip", "engine_plan.hip", "capi_ops.hip"]
+ID_UNIT = "engine.hip"          # compiled with -DSEG_BUILD_ID
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
+
+
+def build_id():
+    """sha256 over every source the library is built from (+ the compiler flags), first 12 hex digits: seg_build_info() carries it, the rocprofv3 / PMC
+    summaries under profiles/ are stamped with it and bench.py drops a `traffic` figure measured on another binary."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in sorted(_deps()):
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()[:12]
 
 
 def _deps():
@@ -28,13 +40,17 @@ def build(force=False, verbose=False):
     hdrs = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "conv3x_impl.h", "gn_fold.h", "engine_internal.h")] + [os.path.join(os.path.dirname(HERE), "include", "segengine.h")]
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
     procs, objs = [], []
+    bid = build_id()
+    idfile = os.path.join(objdir, "build_id.txt")
+    last_id = open(idfile).read().strip() if os.path.exists(idfile) else ""
     for s in SRCS:
         o = os.path.join(objdir, s + ".o")
         objs.append(o)
         # per-object freshness: an object compiled before an edit of its source must not hide behind a newer link step
-        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(os.path.join(CSRC, s)), hdr_t):
+        stale_id = s == ID_UNIT and last_id != bid          # the unit that carries the build id follows every source change
+        if not force and not stale_id and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(os.path.join(CSRC, s)), hdr_t):
             continue
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [HIPCC] + FLAGS + (['-DSEG_BUILD_ID="%s"' % bid] if s == ID_UNIT else []) + ["-c", os.path.join(CSRC, s), "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     if not procs and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(o) for o in objs):
         return LIB
@@ -45,6 +61,8 @@ def build(force=False, verbose=False):
         if verbose and out.strip():
             print(out)
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(idfile, "w") as f:
+        f.write(bid)
     return LIB
 
 

@@ -459,7 +459,11 @@ const char* seg_build_info(void) {
 #ifdef SEG_EMU
     return "segengine host-checker build (tests only)";
 #else
+#ifdef SEG_BUILD_ID
+    return "segengine gfx950 " SEG_BUILD_ID;          // build.py: sha256 over the sources + flags (which binary a profile was taken from)
+#else
     return "segengine gfx950";
+#endif
 #endif
 }
 

@@ -382,6 +382,13 @@ class SegEngine:
         once per (buffers, hyper-parameters) as a HIP graph and replayed - for hosts that cannot enqueue ~250 launches per step as fast as
         the GPU runs them (the tensors must then stay at the same addresses from step to step); falls back to "stream" where a capture is
         not possible."""
+        if allreduce is not None and not hasattr(allreduce, "world"):
+            # an exchange object without a world size would be dropped silently (world = 1) and the ranks would train unsynchronised
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise TypeError("train_step: `allreduce` has no `.world` attribute and no torch.distributed process group is initialised; "
+                                "pass parallel.GradAllReduce / BucketedGradAllReduce or set `.world` on the callable")
+            allreduce.world = dist.get_world_size()
         world = getattr(allreduce, "world", 1) if allreduce is not None else 1
         xworld = loss_exchange.world if loss_exchange is not None else 1
         if cldice_weight and xworld > 1:
@@ -467,13 +474,15 @@ class SegEngine:
                     else:
                         st["works"].append(ar.start(sl))
                     return 0
-                except BaseException as ex:                       # never let an exception unwind through the C frames
-                    self._xchg["error"] = ex
+                except BaseException as ex:                       # never let an exception unwind through the C frames: the library returns at
+                    self._xchg["error"] = ex                      # once on a non-zero code and the step re-raises it (KeyboardInterrupt included)
                     return 1
 
             def loss(_user, sums_ptr, n_doubles):
                 try:
                     st = self._xchg
+                    if int(sums_ptr or 0) != self._loss_ws.data_ptr():
+                        raise RuntimeError("seg_train_step handed the loss hook sums at 0x%x, not the loss workspace (0x%x)" % (int(sums_ptr or 0), self._loss_ws.data_ptr()))
                     shared = self._loss_ws[:8 * n_doubles].view(torch.float64)
                     return int(st["loss_exchange"](shared, st["n_local"]))
                 except BaseException as ex:

@@ -102,22 +102,27 @@ class DevicePrefetcher:
             x = self.pool.take((n, c, d, h, w), torch.float32)
             xn = x.numpy()
             labs = [np.load(ds.labels[i], mmap_mode="r") for i in indices]
+
+            def fits_u8(l):                                # class ids after the reference's `.long()` (truncation): 0..255?
+                return l.dtype.kind in "bu" and l.dtype.itemsize == 1 or (int(l.min()) >= 0 and int(l.max()) < 256)
             if self.binary:
                 y = self.pool.take((n, d, h, w), torch.uint8)
             else:
-                if self._u8_ok is None:                    # class ids: one byte when they fit (checked once; a later batch that does not fit falls back)
-                    self._u8_ok = all(l.dtype.kind in "bu" and l.dtype.itemsize == 1 or (int(l.min()) >= 0 and int(l.max()) < 256) for l in labs)
-                y = self.pool.take((n, d, h, w), torch.uint8 if self._u8_ok else torch.int64)
+                if self._u8_ok is None:                    # class ids: one byte when they fit (decided on the first batch)
+                    self._u8_ok = all(fits_u8(l) for l in labs)
+                # a later batch whose ids do not fit takes an int64 buffer for itself (what the generic path yields for it)
+                y = self.pool.take((n, d, h, w), torch.uint8 if (self._u8_ok and all(fits_u8(l) for l in labs)) else torch.int64)
             yn = y.numpy()
             for k, i in enumerate(indices):
                 img = np.load(ds.images[i], mmap_mode="r")
-                assert img.size == c * d * h * w, (img.shape, ds.targetsize)
+                # the data set reshapes (D, H, W) -> (1, D, H, W) and asserts the shape per dimension (model/dataset.py:90-93): a transposed volume must not pass
+                assert img.ndim >= 3 and (1,) + tuple(img.shape[:3]) == (c, d, h, w) and img.size == c * d * h * w, (img.shape, ds.targetsize)
                 np.copyto(xn[k], img.reshape(c, d, h, w), casting="unsafe")
                 lab = labs[k].reshape(d, h, w)
+                if lab.dtype.kind == "f":                  # `.long()` truncates toward zero BEFORE anything compares with 0: 0.5 / -0.5 are background
+                    lab = np.trunc(lab)
                 if self.binary:
                     np.not_equal(lab, 0, out=yn[k].view(np.bool_))
-                elif self._u8_ok and lab.dtype.itemsize > 1 and (int(lab.min()) < 0 or int(lab.max()) > 255):
-                    raise ValueError("label ids outside 0..255 after the data set was found to fit one byte per voxel: %s" % ds.labels[i])
                 else:
                     np.copyto(yn[k], lab, casting="unsafe")
             return x, y, True                             # pooled buffers: recycled after their copy

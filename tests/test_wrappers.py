@@ -244,6 +244,50 @@ def test_device_prefetcher_order_labels_and_early_exit(dev, tmp_path, binary):
         list(DevicePrefetcher(DataLoader(Broken(), batch_size=1), dev, binary))
 
 
+def test_direct_npy_path_follows_the_dataset_semantics(tmp_path):
+    """the memory-mapped `.npy` path of the prefetcher must give what `ds[i]` + collate + narrowing give.  (1) float labels are truncated
+    toward zero by `.long()` (model/dataset.py:107) BEFORE anything compares them with 0: 0.5 and -0.5 are background; (2) a batch whose class ids
+    do not fit one byte after the first batch did takes an int64 buffer instead of raising; (3) int8 ids are range-checked as well; (4) a volume
+    whose shape is a permutation of the target size is refused like the data set's own assert refuses it."""
+    from torch.utils.data import DataLoader
+    from pytorchdeeplearing_amd.model.dataset import datasetModelSegwithnpy
+    from pytorchdeeplearing_amd.model.pipeline import DevicePrefetcher
+    dev, shape, tmp = torch.device("cpu"), (2, 3, 4), str(tmp_path)
+    g = np.random.RandomState(0)
+
+    def save(tag, i, img, lab):
+        ip, lp = os.path.join(tmp, "%s_img%d.npy" % (tag, i)), os.path.join(tmp, "%s_lab%d.npy" % (tag, i))
+        np.save(ip, img); np.save(lp, lab)
+        return ip, lp
+
+    def both(imgs, labs, binary):
+        ds = datasetModelSegwithnpy(np.array(imgs), np.array(labs), targetsize=(1,) + shape)
+        loader = DataLoader(ds, shuffle=False, batch_size=1, num_workers=0)
+        return list(DevicePrefetcher(loader, dev, binary, workers=2)), list(loader)
+    # (1) float labels
+    vals = np.array([0.5, 1.0, -0.5, 0.0, 2.7, -1.2, 0.99, -0.99], np.float32)
+    lab = np.resize(vals, shape).astype(np.float32)
+    pairs = [save("f", i, g.randn(*shape).astype(np.float32), lab) for i in range(2)]
+    got, want = both([p[0] for p in pairs], [p[1] for p in pairs], True)
+    for (x, y), b in zip(got, want):
+        ref = b["label"].clone()
+        ref[ref != 0] = 1
+        assert y.dtype == torch.uint8 and torch.equal(y.long(), ref) and torch.equal(x, b["image"])
+    assert int(got[0][1].sum()) == int((np.trunc(lab) != 0).sum()) < int((lab != 0).sum())
+    # (2) + (3) class ids: first batch fits a byte, later batches hold 300 / a negative int8
+    labs = [g.randint(0, 3, shape).astype(np.int16), np.full(shape, 300, np.int16), np.full(shape, -2, np.int8)]
+    pairs = [save("m", i, g.randn(*shape).astype(np.float32), l) for i, l in enumerate(labs)]
+    got, want = both([p[0] for p in pairs], [p[1] for p in pairs], False)
+    assert [y.dtype for _, y in got] == [torch.uint8, torch.int64, torch.int64]
+    for (x, y), b in zip(got, want):
+        assert torch.equal(y.long(), b["label"])
+    # (4) transposed volume
+    ip, lp = save("t", 0, g.randn(4, 3, 2).astype(np.float32), np.zeros((4, 3, 2), np.uint8))
+    ds = datasetModelSegwithnpy(np.array([ip]), np.array([lp]), targetsize=(1,) + shape)
+    with pytest.raises(AssertionError):
+        list(DevicePrefetcher(DataLoader(ds, batch_size=1, num_workers=0), dev, True, workers=2))
+
+
 def test_reader_threads_keep_order_and_device_side_binarise(dev):
     """several reader threads (items finish out of order) still deliver the sampler's order, one batch per
     sampler entry; uint8 0/255 masks reach the device as stored and the kernels read them as (label != 0) (SEG_LABEL_BINARIZE):
