@@ -8,7 +8,8 @@
 Per kernel symbol (template arguments kept): launches, average duration under the counter pass (dispatches are serialised there, so this is the kernel
 ALONE, not next to the other queue), every counter averaged per launch, and the derived figures
 
-  mfma_util      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)          (the MfmaUtil formula of counter_defs.yaml; 256 CUs x 4)
+  mfma_util      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)      (MfmaUtil of counter_defs.yaml; GRBM_GUI_ACTIVE arrives SUMMED over the 8 XCDs:
+                   847 118 for a 41.6 us kernel = 8 x 2.54 GHz x 41.6 us; one 16x16x32 f16 MFMA = 32 MOPS = 16 busy cycles on its SIMD)
   mfma_tflops    = SQ_INSTS_VALU_MFMA_MOPS_F16 x 512 flops / duration                  (what the matrix cores actually executed, padding included)
   mfma_frac_peak = mfma_tflops / 2500                                                  (dense f16 peak, MI355X_MICROARCH.md)
   lds_wait_frac  = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES,  wait_any_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES     (both in quad-cycles)
@@ -26,6 +27,7 @@ from summarize_pmc import build_info, short      # noqa: E402
 
 PEAK_TF = 2500.0
 SIMDS = 1024.0
+XCDS = 8.0
 
 
 def find(d, prefix, suffix):
@@ -67,7 +69,7 @@ def main():
         r = {"launches": n, "avg_us_alone": round(avg_ns * 1e-3, 2), "counters_per_launch": {a: round(b, 1) for a, b in sorted(c.items())}}
         g = c.get("GRBM_GUI_ACTIVE")
         if g and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-            r["mfma_util"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (g * SIMDS), 4)
+            r["mfma_util"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (g / XCDS * SIMDS), 4)
         if avg_ns and "SQ_INSTS_VALU_MFMA_MOPS_F16" in c:
             tf = c["SQ_INSTS_VALU_MFMA_MOPS_F16"] * 512.0 / avg_ns * 1e-3
             r["mfma_tflops"] = round(tf, 1)

@@ -154,3 +154,101 @@ def test_inference_py_file_runs_against_this_package(tmp_path, monkeypatch):
         assert os.path.basename(str(p).replace("\\", "/")).startswith("case")
         assert img.arr.shape == (20, 18, 22) and img.arr.dtype == np.uint8          # mask on the SOURCE grid ...
         assert img.GetSpacing() == (0.8, 0.8, 1.5) and img.GetOrigin() == (1.0, 2.0, 3.0)      # ... carrying the source geometry (modelUnet.py:990-997)
+
+
+def test_flask_app_py_file_serves_predictions_from_this_package(tmp_path, monkeypatch):
+    """north_star names flask_app.py beside train.py / inference.py: the file text is executed unmodified as a module
+    (not as __main__, so the server is not started), then driven through `app.test_client()`: POST /predict with a volume file, GET /getresult
+    for the mask.  The harness supplies only the outside world of /root/reference/flask_app.py:16-18,30-41: SimpleITK (stand-in, as above), the
+    `D:/` upload directories (created relative to a temporary cwd), the checkpoint path, and `send_file`'s `attachment_filename` keyword that
+    Flask >= 2.2 renamed to `download_name`.  Two requests are in flight at once to exercise the lock around the shared model object."""
+    conftest.emu_library()
+    flask = pytest.importorskip("flask")
+    import io
+    import threading
+    import model
+    from pytorchdeeplearing_amd import networks
+    from pytorchdeeplearing_amd.model import _io, seg_models
+    monkeypatch.setenv("SEGENGINE_DTYPE", "f32")
+    monkeypatch.chdir(tmp_path)
+    sitk = types.ModuleType("SimpleITK")
+    sitk.Image = _FakeImage
+    sitk.ReadImage = lambda p: _FakeImage(np.load(p), spacing=(0.8, 0.8, 1.5), origin=(1.0, 2.0, 3.0))
+    written = {}
+
+    def write_image(img, p):
+        written[os.path.basename(p)] = img
+        with open(p, "wb") as f:                       # (np.save on a file object: no ".npy" is appended to the name the app chose)
+            np.save(f, img.arr)
+    sitk.WriteImage = write_image
+    sitk.GetArrayFromImage = lambda img: img.arr
+    sitk.GetImageFromArray = lambda a: _FakeImage(a)
+    monkeypatch.setitem(sys.modules, "SimpleITK", sitk)
+    monkeypatch.setattr(_io, "sitk", sitk)
+    pth = str(tmp_path / "unet3d.pth")
+    torch.save(networks.UNet3d(1, 1).state_dict(), pth)
+    record = {}
+    active, peak = [0], [0]
+    Base = _shim(seg_models.MutilUNet3dModel, record, model_path=pth)
+
+    class Counting(Base):                              # how many request threads are inside the network at once (must be 1: the lock)
+        def _predict_device(self, *a, **k):
+            import time
+            active[0] += 1
+            peak[0] = max(peak[0], active[0])
+            try:
+                time.sleep(0.05)                        # long enough for the other request thread to arrive
+                return Base._predict_device(self, *a, **k)
+            finally:
+                active[0] -= 1
+    Counting.__name__ = "MutilUNet3dModel"
+    monkeypatch.setattr(model, "MutilUNet3dModel", Counting)
+    real_send = flask.send_file
+
+    def send_file(path, *a, attachment_filename=None, **k):
+        if attachment_filename is not None:
+            k["download_name"] = attachment_filename
+        return real_send(os.path.abspath(path), *a, **k)
+    monkeypatch.setattr(flask, "send_file", send_file)
+    path = os.path.join(REF, "flask_app.py")
+    with open(path) as f:
+        text = f.read()
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", ""))
+    monkeypatch.setenv("CUDA_LAUNCH_BLOCKING", os.environ.get("CUDA_LAUNCH_BLOCKING", ""))
+    ns = {"__name__": "flask_app_under_test", "__file__": path}
+    exec(compile(text, path, "exec"), ns)
+    app = ns["app"]
+    c = record["ctor"]                                 # flask_app.py:16-18
+    assert (c["image_depth"], c["image_height"], c["image_width"], c["numclass"], c["inference"], c["loss_name"]) == (128, 112, 112, 1, True, "MutilFocalLoss")
+    assert os.path.isdir("D:/uploads/Image") and os.path.isdir("D:/uploads/Mask")
+    rng = np.random.default_rng(3)
+    vols = {"case%d.npy" % i: (rng.standard_normal((20, 18, 22)) * 200).astype(np.float32) for i in range(2)}
+    replies = {}
+
+    def post(name):
+        buf = io.BytesIO()
+        np.save(buf, vols[name])
+        buf.seek(0)
+        replies[name] = app.test_client().post("/predict", data={"file": (buf, name)}, content_type="multipart/form-data")
+    threads = [threading.Thread(target=post, args=(n,)) for n in vols]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for name in vols:
+        assert replies[name].status_code == 200 and replies[name].get_data(as_text=True) == "Segmentation Success!"
+    assert peak[0] == 1, "two requests were inside the shared model at once"
+    assert record["inference"] == [(112, 112, 128)] * 2                      # newSize of flask_app.py:15
+    cl = app.test_client()
+    assert cl.post("/predict").get_data(as_text=True) == "No file uploaded"
+    assert cl.get("/getresult").get_data(as_text=True) == "Missing parameter: file"
+    assert cl.get("/getresult?file=absent.npy").get_data(as_text=True) == "The file does not exist"
+    for name in vols:
+        r = cl.get("/getresult?file=" + name)
+        assert r.status_code == 200 and name in r.headers.get("Content-Disposition", "")
+        mask = np.load(io.BytesIO(r.get_data()))
+        assert mask.shape == (20, 18, 22) and mask.dtype == np.uint8 and np.array_equal(mask, written[name].arr)
+        assert written[name].GetSpacing() == (0.8, 0.8, 1.5)
+    # the served mask is what the wrapper's own inference gives for the same volume (one model object, deterministic eval forward)
+    again = ns["Unet3d"].inference(_FakeImage(vols["case0.npy"], spacing=(0.8, 0.8, 1.5), origin=(1.0, 2.0, 3.0)), (112, 112, 128))
+    assert np.array_equal(again.arr, written["case0.npy"].arr)
