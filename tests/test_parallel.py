@@ -203,6 +203,111 @@ def test_bench_control_flow_two_ranks_on_the_checker(extra):
     assert line["conditioning_steps"] == 1                 # the un-timed conditioning loop ran on both ranks (rank 0 decides when it ends)
 
 
+def _worker_eight(rank, world, port, q):
+    """rank r trains on ITS shard: one sample on ranks 0 .. world-2, TWO on the last rank (an unequal last batch), four gradient buckets,
+    the loss sums exchanged (sample count taken from the exchanged sums on the device)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import conftest
+    conftest.emu_library()
+    from oracle import seg_oracle as seg
+    from pytorchdeeplearing_amd import SegEngine, _capi
+    from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GlobalBatchLoss, broadcast_parameters
+    kind, ncls, loss = "unet", 1, "BinaryCrossEntropyDiceLoss"
+    nloc = 2 if rank == world - 1 else 1
+    e = SegEngine(kind, 2, 1, ncls, dtype="f32", device="cpu")
+    if rank == 0:
+        e.load_state_dict(seg.perturb_params(seg.init_params(kind, 2, 1, ncls, seed=0), seed=7))
+    else:
+        e.params.fill_(-7.0)
+    broadcast_parameters(e)
+    x, y = seg.synthetic_batch(nloc, (16, 16), 1, ncls, seed=100 + rank)
+    ar, ex = BucketedGradAllReduce(fractions=(0.5, 0.8, 0.97, 0.995)), GlobalBatchLoss(equal_shards=False)
+    seen = []
+    start = ar.start
+    ar.start = lambda sl: (seen.append(int(sl.numel())), start(sl))[1]          # which buckets were exchanged, in which order
+    losses = []
+    for it in range(2):
+        masks = seg.draw_masks(kind, nloc, generator=torch.Generator().manual_seed(10 * it + rank))
+        out3 = e.train_step(x, y, loss, lr=1e-3, mask_mode=_capi.MASKS_GIVEN, masks=masks, allreduce=ar, loss_exchange=ex)
+        losses.append(float(out3[0]))
+    if rank in (0, world - 1):
+        q.put((rank, {k: v.numpy().copy() for k, v in e.state_dict().items()}, losses, seen, e.numel))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_unequal_shards_four_buckets_and_global_loss_equal_one_process():
+    """VERDICT r04 item 9 (multi-GPU readiness without hardware; UNMEASURED on xGMI): the callback sequencing of seg_train_step with EIGHT ranks -
+    gradient buckets + the loss-sum exchange + an unequal last batch (9 samples over 8 ranks) - reproduces ONE oracle process on the 9-sample
+    batch: the loss of both steps to 2e-5 and the AdamW update; every rank exchanged the same bucket sequence, which tiles the flat buffer."""
+    from oracle import seg_oracle as seg
+    world, port = 8, 32500 + (os.getpid() * 7) % 1000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_eight, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict((r, rest) for r, *rest in (q.get(timeout=900) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    kind, ncls, loss = "unet", 1, "BinaryCrossEntropyDiceLoss"
+    cur = seg.perturb_params(seg.init_params(kind, 2, 1, ncls, seed=0), seed=7)
+    nloc = [2 if r == world - 1 else 1 for r in range(world)]
+    shards = [seg.synthetic_batch(nloc[r], (16, 16), 1, ncls, seed=100 + r) for r in range(world)]
+    x = torch.cat([s[0] for s in shards]); y = torch.cat([s[1] for s in shards])
+    st, ref_losses = {}, []
+    for it in range(2):
+        per_rank = [seg.draw_masks(kind, nloc[r], generator=torch.Generator().manual_seed(10 * it + r)) for r in range(world)]
+        masks = [torch.cat([per_rank[r][i] for r in range(world)]) for i in range(len(per_rank[0]))]
+        r = seg.forward_backward(kind, cur, x, y, loss, masks=masks)
+        ref_losses.append(float(r["loss"]))
+        cur = seg.adamw_step(cur, r["grads"], st)
+    for rank in (0, world - 1):
+        got, losses, seen, numel = outs[rank]
+        for a, b in zip(losses, ref_losses):
+            assert abs(a - b) < 2e-5, (rank, losses, ref_losses)
+        assert len(seen) % 2 == 0 and seen[:len(seen) // 2] == seen[len(seen) // 2:]          # the same bucket sequence in both steps
+        assert len(seen) // 2 >= 2 and sum(seen[:len(seen) // 2]) == numel                    # ... which tiles the flat gradient buffer
+        tot = bad = 0
+        for k in cur:
+            d = (torch.from_numpy(got[k]) - cur[k]).abs()
+            assert float(d.max()) < 2 * 2e-3, k
+            tot += d.numel()
+            bad += int((d > 1e-4).sum())
+        assert bad <= 0.01 * tot, (rank, bad, tot)
+    assert outs[0][2] == outs[world - 1][2]                                                    # every rank holds the same global loss
+
+
+def test_bench_py_under_the_drivers_launch_line_with_eight_ranks():
+    """The driver's multi-GPU command - `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 8 --steps K --warmup W` - with tests/run_bench_on_checker.py in bench.py's place (same launcher, same environment, bench.main() on the host checker
+    with gloo): eight ranks rendezvous, run the bucketed exchange, and rank 0 alone prints ONE JSON line with the whole-job rate.  UNMEASURED on RCCL / xGMI."""
+    import json
+    import subprocess
+    port = 33500 + (os.getpid() * 11) % 1000
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "run_bench_on_checker.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--size", "16", "--batch", "1",
+           "--dtype", "f32", "--no-cpu-baseline", "--condition-seconds", "0.001", "--roofline-steps", "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak"
+    assert line["ms_per_step"] > 0 and abs(line["value"] - 8 * 1e3 / line["ms_per_step"]) <= 0.006
+    # a plain `python bench.py --gpus 8` (no launcher: WORLD_SIZE = 1) must refuse instead of measuring one GPU
+    ref = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert ref.returncode != 0 and "WORLD_SIZE" in (ref.stderr + ref.stdout)
+
+
 def _seed_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
