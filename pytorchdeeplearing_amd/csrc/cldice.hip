@@ -214,6 +214,188 @@ __global__ __launch_bounds__(256) void skel_iter_kernel(const float* x, float* e
     }
 }
 
+// The same iteration with FOUR x-consecutive voxels per thread (round 5).  skel_iter_kernel issues one ds_read_b32 per window element: 81 LDS
+// instructions per output voxel, and the rocprofv3 stats of the C5 + clDice step (profiles/r05_kernel_stats_c5_cldice.txt) put its 20 launches at
+// 44 us each - 0.88 ms of a 6.3 ms step - for 48 MB of traffic per launch (1.1 TB/s: not the memory system, the LDS instruction stream).  Here a
+// thread reads a window ROW of its four voxels as one ds_read_b128 + one ds_read_b64 (six values; rows are 36 floats = 9 x 16 B, groups start at
+// multiples of four, so both reads are aligned), forms the four row minima / maxima with v_min3 / v_max3 and folds the nine rows: 18 LDS
+// instructions per FOUR voxels in either pass, results stored as one 16-B vector.  Same min / max / sub / relu in fp32, same operand values: the
+// outputs are bit-identical to skel_iter_kernel (tests/test_cldice.py compares both against the per-voxel reference form).
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+template <int TZ, int TY, int TX, bool ND3>
+__global__ __launch_bounds__(256) void skel_iter4_kernel(const float* x, float* e_out, float* x_out, Vol v) {
+    static_assert(TX % 4 == 0, "four voxels per thread along x");
+    constexpr int HZ = ND3 ? 2 : 0, H1 = ND3 ? 1 : 0;
+    constexpr int XZ = TZ + 2 * HZ, XY = TY + 4, XX = TX + 4;               // x with a 2-voxel halo; XX is a multiple of 4 (16-B rows)
+    constexpr int EZ = TZ + 2 * H1, EY = TY + 2, EX = TX + 2, EXP = TX + 4; // e on the 1-voxel halo; row pitch padded to a multiple of 4
+    constexpr int NKZ = ND3 ? 3 : 1;
+    __shared__ __attribute__((aligned(16))) float xs[XZ * XY * XX + 4];     // (+4: the last group of the last row reads two floats past it)
+    __shared__ __attribute__((aligned(16))) float es[EZ * EY * EXP + 4];
+    const float INF = __builtin_huge_valf();
+    const int ntx = (v.W + TX - 1) / TX, nty = (v.H + TY - 1) / TY, ntz = (v.D + TZ - 1) / TZ;
+    int b = blockIdx.x;
+    const int x0 = (b % ntx) * TX; b /= ntx;
+    const int y0 = (b % nty) * TY; b /= nty;
+    const int z0 = (b % ntz) * TZ;
+    const int p = b / ntz;
+    const long long V = (long long)v.D * v.H * v.W;
+    const float* xp = x + (long long)p * V;
+    {
+        constexpr int NE = XZ * XY * XX, NIT = (NE + 255) / 256;
+        float hv[NIT];
+        bool hin[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
+            const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
+            hin[k] = i < NE && (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+            hv[k] = xp[hin[k] ? ((long long)gz * v.H + gy) * v.W + gx : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < NE) xs[i] = hin[k] ? hv[k] : INF;
+        }
+        if (threadIdx.x < 4) xs[NE + threadIdx.x] = INF;
+    }
+    __syncthreads();
+    // ---- e = minpool3(x) on the 1-voxel halo: groups of four e values (e index a .. a+3 <-> x indices a .. a+5)
+    constexpr int EG = (EX + 3) / 4, NEG = EZ * EY * EG;
+    for (int i = threadIdx.x; i < NEG; i += 256) {
+        const int a = (i % EG) * 4, ly = (i / EG) % EY, lz = i / (EG * EY);
+        float m[4] = {INF, INF, INF, INF};
+#pragma unroll
+        for (int dz = 0; dz < NKZ; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* row = &xs[((lz + dz) * XY + ly + dy) * XX + a];
+                const vec<float, 4> q4 = *(const vec<float, 4>*)row;
+                const vec<float, 2> q2 = *(const vec<float, 2>*)(row + 4);
+                m[0] = fminf(m[0], min3f(q4[0], q4[1], q4[2]));
+                m[1] = fminf(m[1], min3f(q4[1], q4[2], q4[3]));
+                m[2] = fminf(m[2], min3f(q4[2], q4[3], q2[0]));
+                m[3] = fminf(m[3], min3f(q4[3], q2[0], q2[1]));
+            }
+        const int gy = y0 + ly - 1, gz = z0 + lz - H1;
+        const bool rin = (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+        vec<float, 4> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (rin && (unsigned)(x0 + a + j - 1) < (unsigned)v.W) ? m[j] : -INF;   // outside the volume: ignored by the max-pool
+        *(vec<float, 4>*)&es[(lz * EY + ly) * EXP + a] = o;
+    }
+    if (threadIdx.x < 4) es[EZ * EY * EXP + threadIdx.x] = -INF;
+    __syncthreads();
+    // ---- update: four outputs at x index o4 .. o4+3 <-> e indices o4 .. o4+5
+    constexpr int OG = TX / 4, NOG = TZ * TY * OG;
+    for (int i = threadIdx.x; i < NOG; i += 256) {
+        const int o4 = (i % OG) * 4, ly = (i / OG) % TY, lz = i / (OG * TY);
+        const int gx = x0 + o4, gy = y0 + ly, gz = z0 + lz;
+        if (gx >= v.W || gy >= v.H || gz >= v.D) continue;
+        float mx[4] = {-INF, -INF, -INF, -INF}, ev[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dz = 0; dz < NKZ; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* row = &es[((lz + dz) * EY + ly + dy) * EXP + o4];
+                const vec<float, 4> q4 = *(const vec<float, 4>*)row;
+                const vec<float, 2> q2 = *(const vec<float, 2>*)(row + 4);
+                mx[0] = fmaxf(mx[0], max3f(q4[0], q4[1], q4[2]));
+                mx[1] = fmaxf(mx[1], max3f(q4[1], q4[2], q4[3]));
+                mx[2] = fmaxf(mx[2], max3f(q4[2], q4[3], q2[0]));
+                mx[3] = fmaxf(mx[3], max3f(q4[3], q2[0], q2[1]));
+                if (dz == H1 && dy == 1) { ev[0] = q4[1]; ev[1] = q4[2]; ev[2] = q4[3]; ev[3] = q2[0]; }      // the centres of the four windows
+            }
+        const float* xr = &xs[((lz + HZ) * XY + ly + 2) * XX + o4 + 2];
+        const vec<float, 2> xa = *(const vec<float, 2>*)xr, xb = *(const vec<float, 2>*)(xr + 2);
+        const float xv[4] = {xa[0], xa[1], xb[0], xb[1]};
+        vec<float, 4> eo, xo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { eo[j] = ev[j]; xo[j] = fmaxf(xv[j] - fmaxf(mx[j] - ev[j], 0.f), 0.f); }
+        const long long o = (long long)p * V + ((long long)gz * v.H + gy) * v.W + gx;
+        if (gx + 3 < v.W && (v.W & 3) == 0) {
+            *(vec<float, 4>*)&e_out[o] = eo;
+            *(vec<float, 4>*)&x_out[o] = xo;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (gx + j < v.W) { e_out[o + j] = eo[j]; x_out[o + j] = xo[j]; }
+        }
+    }
+}
+
+// ---- the skeleton of a BINARY image in bits (round 5).  On a {0, 1} image every step of the iteration stays in {0, 1}: e = minpool3(x) is an erosion,
+// maxpool3(e) a dilation, c = relu(maxpool3(e) - e) = dil(e) & ~e and x' = relu(x - c) = x & ~c.  The target of the binary clDice term is such an
+// image (the train loop binarises the labels before any loss sees them, model/modelVNet.py:576), so its skeleton is computed on a bit image - 32
+// voxels per word along x, 512 KB for a 160^3 volume instead of 16 MB, one word per thread, neighbours from L2 - and expanded to fp32 once at the
+// end: EXACTLY the values the fp32 kernels produce (tests/test_cldice.py: bit-for-bit against skel_iter on the float labels).  Padding follows the
+// pools: outside the volume counts as 1 for the erosion (min-pool ignores it) and as 0 for the dilation.  The bits past W in a row's last word are
+// kept 0.  Two launches per iteration (the dilation needs the eroded neighbours), ~4 us each instead of one 44 us tile pass.
+struct BitVol { int rows_z, D, H, W, WX, nd3; };     // rows_z = planes * D (2-D pooling: every depth slice is its own image, D = 1)
+__device__ __forceinline__ unsigned bit_tail(const BitVol& b, int wx) {     // bits of word wx that lie at x >= W
+    const int n = b.W - wx * 32;
+    return n >= 32 ? 0u : ~((1u << n) - 1u);
+}
+// labels -> {float y = (label != 0), bits}: a wave takes 64 x-consecutive voxels of one row per trip
+__global__ __launch_bounds__(256) void cld_labels_bits_kernel(const void* target, int lt, float* y, unsigned* bits, BitVol b, long long nrows) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwave = ((long long)gridDim.x * 256) >> 6;
+    for (long long r = wave; r < nrows; r += nwave) {
+        for (int xb = 0; xb < b.WX * 32; xb += 64) {
+            const int xx = xb + lane;
+            const bool in = xx < b.W;
+            const int lab = in ? (load_label(target, lt, r * b.W + xx) != 0) : 0;
+            if (in) y[r * b.W + xx] = (float)lab;
+            const unsigned long long m = __ballot(lab);
+            if (lane == 0) {
+                bits[r * b.WX + (xb >> 5)] = (unsigned)m;
+                if ((xb >> 5) + 1 < b.WX) bits[r * b.WX + (xb >> 5) + 1] = (unsigned)(m >> 32);
+            }
+        }
+    }
+}
+// MODE 0: out = erode(in).  MODE 1: out = x & ~(dilate(in) & ~in) with in = the eroded image, x = the image it was eroded from.
+template <int MODE>
+__global__ __launch_bounds__(256) void cld_bits_kernel(const unsigned* in, const unsigned* xsrc, unsigned* out, BitVol b) {
+    const long long total = (long long)b.rows_z * b.H * b.WX;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int wx = (int)(i % b.WX);
+        const long long r = i / b.WX;
+        const int y = (int)(r % b.H);
+        const long long pz = r / b.H;
+        const int z = (int)(pz % b.D);
+        const unsigned tail = bit_tail(b, wx), tl = wx > 0 ? bit_tail(b, wx - 1) : 0u, tr = wx + 1 < b.WX ? bit_tail(b, wx + 1) : 0u;
+        unsigned acc = MODE == 0 ? 0xffffffffu : 0u;
+        for (int dz = (b.nd3 ? -1 : 0); dz <= (b.nd3 ? 1 : 0); ++dz) {
+            if ((unsigned)(z + dz) >= (unsigned)b.D) continue;               // rows outside the volume: neutral for both pools
+            for (int dy = -1; dy <= 1; ++dy) {
+                if ((unsigned)(y + dy) >= (unsigned)b.H) continue;
+                const unsigned* row = in + ((pz + dz) * b.H + (y + dy)) * b.WX;
+                unsigned c = row[wx], l = wx > 0 ? row[wx - 1] : 0u, rr = wx + 1 < b.WX ? row[wx + 1] : 0u;
+                if (MODE == 0) {           // erosion: everything outside the row's W voxels reads as 1
+                    c |= tail;
+                    l = wx > 0 ? (l | tl) : 0xffffffffu;
+                    rr = wx + 1 < b.WX ? (rr | tr) : 0xffffffffu;
+                    acc &= c & ((c >> 1) | (rr << 31)) & ((c << 1) | (l >> 31));
+                } else {                   // dilation: outside reads as 0 (the stored tails are 0)
+                    acc |= c | ((c >> 1) | (rr << 31)) | ((c << 1) | (l >> 31));
+                }
+            }
+        }
+        if (MODE == 0) out[i] = acc & ~tail;
+        else out[i] = xsrc[i] & ~(acc & ~in[i]) & ~tail;
+    }
+}
+__global__ __launch_bounds__(256) void cld_bits_expand_kernel(const unsigned* bits, float* out, BitVol b, long long nrows) {
+    const long long total = nrows * b.W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int xx = (int)(i % b.W);
+        const long long r = i / b.W;
+        out[i] = (float)((bits[r * b.WX + (xx >> 5)] >> (xx & 31)) & 1u);
+    }
+}
+
 // Backward of one skeleton iteration as two GATHER passes over LDS tiles (no atomics, no zero-fill, deterministic):
 //   A: for every window w on the tile + 1 halo: u = maxpool(e)(w) - e(w), gt = g * [x - relu(u) > 0], gw = gt * [u > 0] and the
 //      position am(w) of the FIRST maximum of e in w;  dx_direct(q) = gt(q),  de(q) = gw(q) - sum_{w in N(q), am(w) = q} gw(w)
@@ -346,6 +528,182 @@ __global__ __launch_bounds__(256) void skel_bwd_tile_kernel(const float* g, cons
     }
 }
 
+// The same two gather passes with FOUR x-consecutive windows / voxels per thread (round 5; see skel_iter4_kernel): a window row of the four is one
+// ds_read_b128 + one ds_read_b64 of `src` (18 LDS instructions for four windows instead of 108), the gather reads (first-extremum index, weight)
+// rows the same way (36 instead of 216).  Comparisons and additions happen in the same (dz, dy, dx) order per window / voxel as in
+// skel_bwd_tile_kernel, so the results are bit-identical to it.  The 20 launches of that kernel were the largest item of the clDice term:
+// 1.33 ms of the 6.3 ms C5 + clDice step (profiles/r05_kernel_stats_c5_cldice.txt).
+template <int TZ, int TY, int TX, bool ND3, bool PASS_B>
+__global__ __launch_bounds__(256) void skel_bwd_tile4_kernel(const float* g, const float* x, const float* e, float* dx, float* de, Vol v) {
+    static_assert(TX % 4 == 0, "four voxels per thread along x");
+    constexpr int HZ = ND3 ? 2 : 0, H1 = ND3 ? 1 : 0, NKZ = ND3 ? 3 : 1;
+    constexpr int XZ = TZ + 2 * HZ, XY = TY + 4, XX = TX + 4;                  // source (e in pass A, x in pass B) with a 2-voxel halo
+    constexpr int EZ = TZ + 2 * H1, EY = TY + 2, EX = TX + 2, EXP = TX + 4;    // windows: tile + 1 halo; row pitch padded to a multiple of 4
+    __shared__ __attribute__((aligned(16))) float src[XZ * XY * XX + 4];
+    __shared__ __attribute__((aligned(16))) float gws[EZ * EY * EXP + 4];
+    __shared__ __attribute__((aligned(16))) int ams[EZ * EY * EXP + 4];
+    const float INF = __builtin_huge_valf();
+    const int ntx = (v.W + TX - 1) / TX, nty = (v.H + TY - 1) / TY, ntz = (v.D + TZ - 1) / TZ;
+    int b = blockIdx.x;
+    const int x0 = (b % ntx) * TX; b /= ntx;
+    const int y0 = (b % nty) * TY; b /= nty;
+    const int z0 = (b % ntz) * TZ;
+    const int p = b / ntz;
+    const long long V = (long long)v.D * v.H * v.W, base = (long long)p * V;
+    const float* sp = (PASS_B ? x : e) + base;
+    constexpr int NE = XZ * XY * XX, NIT = (NE + 255) / 256;
+    constexpr int EG = (EX + 3) / 4, NEG = EZ * EY * EG, WIT = (NEG + 255) / 256;
+    constexpr int OG = TX / 4, NOG = TZ * TY * OG, TIT = (NOG + 255) / 256;
+    float w0[WIT][4], w1[WIT][4], t0[TIT][4];
+    {
+        float hv[NIT];
+        bool hin[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
+            const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
+            hin[k] = i < NE && (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+            hv[k] = sp[hin[k] ? ((long long)gz * v.H + gy) * v.W + gx : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < WIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int a = (i % EG) * 4, ly = (i / EG) % EY, lz = i / (EG * EY);
+            const int gy = y0 + ly - 1, gz = z0 + lz - H1;
+            const bool rin = i < NEG && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gx = x0 + a + j - 1;
+                const bool in = rin && a + j < EX && (unsigned)gx < (unsigned)v.W;
+                const long long o = in ? base + ((long long)gz * v.H + gy) * v.W + gx : base;
+                w0[k][j] = PASS_B ? de[o] : x[o];
+                w1[k][j] = PASS_B ? 0.f : g[o];
+            }
+        }
+        if (PASS_B) {
+#pragma unroll
+            for (int k = 0; k < TIT; ++k) {
+                const int i = threadIdx.x + k * 256;
+                const int o4 = (i % OG) * 4, ly = (i / OG) % TY, lz = i / (OG * TY);
+                const int gy = y0 + ly, gz = z0 + lz;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gx = x0 + o4 + j;
+                    const bool in = i < NOG && gx < v.W && gy < v.H && gz < v.D;
+                    t0[k][j] = dx[in ? base + ((long long)gz * v.H + gy) * v.W + gx : base];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < NE) src[i] = hin[k] ? hv[k] : (PASS_B ? INF : -INF);      // never the extremum
+        }
+        if (threadIdx.x < 4) src[NE + threadIdx.x] = PASS_B ? INF : -INF;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < WIT; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i >= NEG) continue;
+        const int a = (i % EG) * 4, ly = (i / EG) % EY, lz = i / (EG * EY);
+        const int gy = y0 + ly - 1, gz = z0 + lz - H1;
+        const bool rin = (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
+        float best[4], ec[4] = {0.f, 0.f, 0.f, 0.f};
+        int am[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { best[j] = PASS_B ? INF : -INF; am[j] = -1; }
+        // first extremum of each window in (z, y, x) scan order; the padding holds -/+inf and can never win the strict comparison
+#pragma unroll
+        for (int dz = 0; dz < NKZ; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int rb = ((lz + dz) * XY + ly + dy) * XX + a;
+                const vec<float, 4> q4 = *(const vec<float, 4>*)&src[rb];
+                const vec<float, 2> q2 = *(const vec<float, 2>*)&src[rb + 4];
+                const float q[6] = {q4[0], q4[1], q4[2], q4[3], q2[0], q2[1]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int dx_ = 0; dx_ < 3; ++dx_) {
+                        const float val = q[j + dx_];
+                        const bool better = PASS_B ? val < best[j] : val > best[j];
+                        best[j] = better ? val : best[j];
+                        am[j] = better ? rb + j + dx_ : am[j];
+                    }
+                if (dz == HZ - H1 && dy == 1) { ec[0] = q[1]; ec[1] = q[2]; ec[2] = q[3]; ec[3] = q[4]; }     // the centres of the four windows
+            }
+        vec<float, 4> wo;
+        vec<int, 4> ao;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gx = x0 + a + j - 1;
+            float wgt = 0.f;
+            int amj = -1;
+            if (rin && a + j < EX && (unsigned)gx < (unsigned)v.W) {
+                amj = am[j];
+                if (PASS_B) {
+                    wgt = w0[k][j];
+                } else {
+                    const float u = best[j] - ec[j];
+                    const float gt = (w0[k][j] - fmaxf(u, 0.f) > 0.f) ? w1[k][j] : 0.f;
+                    wgt = u > 0.f ? gt : 0.f;
+                    // tile-interior windows also publish the direct term of dx
+                    const int tx = a + j - 1, ty = ly - 1, tz = lz - H1;
+                    if ((unsigned)tx < (unsigned)TX && (unsigned)ty < (unsigned)TY && (unsigned)tz < (unsigned)TZ)
+                        dx[base + ((long long)gz * v.H + gy) * v.W + gx] = gt;
+                }
+            }
+            wo[j] = wgt; ao[j] = amj;
+        }
+        *(vec<float, 4>*)&gws[(lz * EY + ly) * EXP + a] = wo;
+        *(vec<int, 4>*)&ams[(lz * EY + ly) * EXP + a] = ao;
+    }
+    if (threadIdx.x < 4) { gws[EZ * EY * EXP + threadIdx.x] = 0.f; ams[EZ * EY * EXP + threadIdx.x] = -1; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TIT; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i >= NOG) continue;
+        const int o4 = (i % OG) * 4, ly = (i / OG) % TY, lz = i / (OG * TY);
+        const int gx = x0 + o4, gy = y0 + ly, gz = z0 + lz;
+        if (gx >= v.W || gy >= v.H || gz >= v.D) continue;
+        const int me = ((lz + HZ) * XY + ly + 2) * XX + o4 + 2;          // the first voxel's index in `src`; voxel j sits at me + j
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, gc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dz = 0; dz < NKZ; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int rb = ((lz + dz) * EY + ly + dy) * EXP + o4;
+                const vec<int, 4> a4 = *(const vec<int, 4>*)&ams[rb];
+                const vec<int, 2> a2 = *(const vec<int, 2>*)&ams[rb + 4];
+                const vec<float, 4> g4 = *(const vec<float, 4>*)&gws[rb];
+                const vec<float, 2> g2 = *(const vec<float, 2>*)&gws[rb + 4];
+                const int aa[6] = {a4[0], a4[1], a4[2], a4[3], a2[0], a2[1]};
+                const float gg[6] = {g4[0], g4[1], g4[2], g4[3], g2[0], g2[1]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int dx_ = 0; dx_ < 3; ++dx_)
+                        if (aa[j + dx_] == me + j) acc[j] += gg[j + dx_];
+                if (dz == H1 && dy == 1) { gc[0] = gg[1]; gc[1] = gg[2]; gc[2] = gg[3]; gc[3] = gg[4]; }       // this voxel's own window
+            }
+        const long long o = base + ((long long)gz * v.H + gy) * v.W + gx;
+        vec<float, 4> r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = PASS_B ? t0[k][j] + acc[j] : gc[j] - acc[j];
+        float* dst = PASS_B ? dx : de;
+        if (gx + 3 < v.W && (v.W & 3) == 0) {
+            *(vec<float, 4>*)&dst[o] = r;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (gx + j < v.W) dst[o + j] = r[j];
+        }
+    }
+}
+
 inline int blocks_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -357,29 +715,44 @@ void launch_pool3(const float* x, float* out, int planes, int D, int H, int W, i
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool3_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, s, x, out, v);
 }
 void launch_skel_iter(const float* x, float* e_out, float* x_out, int planes, int D, int H, int W, int nd, hipStream_t s) {
+    // SEG_SKEL_X4=0: one voxel per thread (rounds 1-4); default: four x-consecutive voxels per thread, same bits
+    static const bool x4 = !(getenv("SEG_SKEL_X4") && atoi(getenv("SEG_SKEL_X4")) == 0);
     if (nd == 3) {
         Vol v{planes, D, H, W, 3};
         const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+        if (x4) hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
     } else {
         // 2-D pooling: every depth slice of every plane is an independent image
         Vol v{planes * D, 1, H, W, 2};
         const long long nb = (long long)planes * D * ((H + 15) / 16) * ((W + 63) / 64);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<1, 16, 64, false>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+        if (x4) hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<1, 16, 64, false>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<1, 16, 64, false>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
     }
 }
 void launch_skel_iter_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int D, int H, int W, int nd,
                           hipStream_t s) {
+    static const bool x4 = !(getenv("SEG_SKEL_X4") && atoi(getenv("SEG_SKEL_X4")) == 0);      // 0: one window / voxel per thread (rounds 1-4), same bits
     if (nd == 3) {
         Vol v{planes, D, H, W, 3};
         const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<4, 8, 32, true, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<4, 8, 32, true, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        if (x4) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<4, 8, 32, true, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<4, 8, 32, true, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<4, 8, 32, true, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<4, 8, 32, true, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        }
     } else {
         Vol v{planes * D, 1, H, W, 2};
         const long long nb = (long long)planes * D * ((H + 15) / 16) * ((W + 63) / 64);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<1, 16, 64, false, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<1, 16, 64, false, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        if (x4) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<1, 16, 64, false, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<1, 16, 64, false, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<1, 16, 64, false, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<1, 16, 64, false, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        }
     }
 }
 void launch_skel_update(const float* x, const float* e, float* out, int planes, int D, int H, int W, int nd, hipStream_t s) {
@@ -477,9 +850,29 @@ void launch_cldice_target(const void* target, int label_type, int planes, int D,
     const size_t vol = ((size_t)n * sizeof(float) + 255) / 256 * 256;
     float* y = (float*)(ws + L.y);
     float* t[3] = {(float*)(ws + L.tgt), (float*)(ws + L.tgt + vol), (float*)(ws + L.tgt + 2 * vol)};
-    hipLaunchKernelGGL(cld_labels_kernel, dim3(blocks_for(n)), dim3(256), 0, s, target, label_type, y, n);
-    const float* tc = y;
-    for (int it = 0; it < width; ++it) { float* nx = t[1 + (it & 1)]; launch_skel_iter(tc, t[0], nx, planes, D, H, W, nd, s); tc = nx; }
+    // The target is read as a BINARY mask, y = (label != 0) - what the reference's train loop hands to every loss (model/modelVNet.py:576: labels are
+    // binarised before the loss) - and its skeleton is computed on bits (cld_bits_kernel): exactly the values of the fp32 iteration on that mask.
+    // SEG_CLD_BITS=0 keeps the fp32 tile kernels for the target (rounds 1-4).
+    static const bool use_bits = !(getenv("SEG_CLD_BITS") && atoi(getenv("SEG_CLD_BITS")) == 0);
+    if (!use_bits || width <= 0) {
+        hipLaunchKernelGGL(cld_labels_kernel, dim3(blocks_for(n)), dim3(256), 0, s, target, label_type | LT_BINARIZE, y, n);
+        const float* tc = y;
+        for (int it = 0; it < width; ++it) { float* nx = t[1 + (it & 1)]; launch_skel_iter(tc, t[0], nx, planes, D, H, W, nd, s); tc = nx; }
+        return;
+    }
+    BitVol b{nd == 3 ? planes * D : planes * D, nd == 3 ? D : 1, H, W, (W + 31) / 32, nd == 3 ? 1 : 0};
+    const long long nrows = (long long)planes * D * H, nwords = nrows * b.WX;
+    // three bit images in the fp32 scratch volume t[0] (which the bit path does not need): current x, eroded e, next x
+    unsigned* bx = (unsigned*)t[0];
+    unsigned* be = bx + ((nwords + 63) / 64) * 64;
+    unsigned* bn = be + ((nwords + 63) / 64) * 64;
+    hipLaunchKernelGGL(cld_labels_bits_kernel, dim3(blocks_for(nrows * 64)), dim3(256), 0, s, target, label_type, y, bx, b, nrows);
+    for (int it = 0; it < width; ++it) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cld_bits_kernel<0>), dim3(blocks_for(nwords)), dim3(256), 0, s, (const unsigned*)bx, (const unsigned*)nullptr, be, b);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cld_bits_kernel<1>), dim3(blocks_for(nwords)), dim3(256), 0, s, (const unsigned*)be, (const unsigned*)bx, bn, b);
+        unsigned* sw = bx; bx = bn; bn = sw;
+    }
+    hipLaunchKernelGGL(cld_bits_expand_kernel, dim3(blocks_for(n)), dim3(256), 0, s, (const unsigned*)bx, t[1 + ((width - 1) & 1)], b, nrows);
 }
 
 void launch_cldice_binary(const float* probs, const void* target, int label_type, int planes, int D, int H, int W, int nd, int width,

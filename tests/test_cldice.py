@@ -174,3 +174,41 @@ def test_skel_iter_kernels_agree_with_two_kernel_forms(dev, shape, nd):
         dx2, de2 = torch.empty_like(x), torch.empty_like(x)
         lib.check(lib.seg_op_skel_iter_bwd(gup.data_ptr(), x.data_ptr(), e1.data_ptr(), dx2.data_ptr(), de2.data_ptr(), planes, d, h, w, nd, st), "bwd")
         assert float((de1 - de2).abs().max()) <= 1e-5 and float((dx1 - dx2).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("shape,nd,width", [((1, 5, 9, 33), 3, 10), ((2, 4, 6, 64), 3, 3), ((1, 3, 7, 65), 3, 10), ((1, 6, 12, 31), 3, 4),
+                                            ((2, 3, 10, 70), 2, 10), ((1, 1, 16, 160), 2, 2)])
+def test_target_skeleton_on_bits_equals_the_fp32_iteration(dev, shape, nd, width):
+    """round 5: the label-only half of the one-call clDice term (seg_cldice_target) computes the skeleton of the BINARY mask (label != 0) on a bit
+    image - erosion / dilation as AND / OR of shifted words, 32 voxels per word - and expands it to fp32 once.  It must equal, bit for bit, `width`
+    iterations of the fp32 tile kernel (seg_op_skel_iter) on the float mask, for row lengths that end inside a word, on a word boundary and one
+    past it, for 0/1 and 0/255 labels and every label type, in 3-D and per-slice 2-D pooling.  (White box: the workspace layout of
+    csrc/cldice.hip:cld_layout - y first, then 2 * width work volumes, then the three target volumes.)"""
+    from pytorchdeeplearing_amd import _capi
+    lib, st = _capi.lib_for(dev), _capi.stream_for(dev)
+    planes, d, h, w = shape
+    if nd == 2:                                   # the one-call entry points take 2-D problems as (planes, 1, h, w): every slice is a plane
+        planes, d = planes * d, 1
+        shape = (planes, d, h, w)
+    g0 = torch.Generator().manual_seed(5)
+    # blobs, so that the skeleton is neither empty nor everything
+    blob = torch.nn.functional.avg_pool3d(torch.rand((1, planes, d + 4, h + 4, w + 4), generator=g0), 5, stride=1)[0]
+    mask = (blob > blob.median()).to(torch.uint8)
+    n = planes * d * h * w
+    vol = (n * 4 + 255) // 256 * 256
+    for labels in (mask, mask * 255, mask.to(torch.int64) * 7, mask.to(torch.int32), mask.float() * 2.0):
+        t = labels.contiguous().to(dev)
+        ws = torch.zeros(lib.seg_cldice_ws_bytes(planes, d, h, w, nd, width) // 4 + 64, dtype=torch.float32, device=dev)
+        lib.check(lib.seg_cldice_target(t.data_ptr(), _capi.LABEL_TYPES[str(t.dtype)], planes, d, h, w, nd, width, ws.data_ptr(), st), "seg_cldice_target")
+        y = ws[:n].reshape(shape)
+        off = (vol + 2 * width * vol + (1 + ((width - 1) & 1)) * vol) // 4
+        got = ws[off:off + n].reshape(shape)
+        cur = (labels != 0).float().to(dev).contiguous()
+        assert torch.equal(y, cur)                                  # the float labels the sums use are the binarised ones
+        e = torch.empty_like(cur)
+        for _ in range(width):
+            nx = torch.empty_like(cur)
+            lib.check(lib.seg_op_skel_iter(cur.data_ptr(), e.data_ptr(), nx.data_ptr(), planes, d, h, w, nd, st), "iter")
+            cur = nx
+        assert torch.equal(got, cur)
+        assert 0 < int(cur.sum()) < n
