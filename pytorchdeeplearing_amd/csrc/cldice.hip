@@ -720,7 +720,13 @@ void launch_skel_iter(const float* x, float* e_out, float* x_out, int planes, in
     if (nd == 3) {
         Vol v{planes, D, H, W, 3};
         const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
-        if (x4) hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+        // 8 x 8 x 32 tiles: 1.66 instead of 1.99 halo windows per output voxel (C5 + clDice 5.72 vs 5.81 ms per step, profiles/r05_cldice_tile_ab.log);
+        // SEG_SKEL_TZ=4 keeps the 4 x 8 x 32 tiles, which shallow volumes take anyway
+        static const int tz = getenv("SEG_SKEL_TZ") ? atoi(getenv("SEG_SKEL_TZ")) : 8;
+        if (x4 && tz == 8 && D >= 8) {
+            const long long nb8 = (long long)planes * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 31) / 32);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<8, 8, 32, true>), dim3((unsigned)nb8), dim3(256), 0, s, x, e_out, x_out, v);
+        } else if (x4) hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
     } else {
         // 2-D pooling: every depth slice of every plane is an independent image
@@ -736,7 +742,12 @@ void launch_skel_iter_bwd(const float* g, const float* x, const float* e, float*
     if (nd == 3) {
         Vol v{planes, D, H, W, 3};
         const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
-        if (x4) {
+        static const int tz = getenv("SEG_SKEL_TZ") ? atoi(getenv("SEG_SKEL_TZ")) : 8;
+        if (x4 && tz == 8 && D >= 8) {
+            const long long nb8 = (long long)planes * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 31) / 32);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<8, 8, 32, true, false>), dim3((unsigned)nb8), dim3(256), 0, s, g, x, e, dx, de, v);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<8, 8, 32, true, true>), dim3((unsigned)nb8), dim3(256), 0, s, g, x, e, dx, de, v);
+        } else if (x4) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<4, 8, 32, true, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<4, 8, 32, true, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
         } else {

@@ -36,6 +36,16 @@ CONFIGS = {
 }
 
 
+# 16-bit gates per config = the MI355X measurement + 25-40 % (profiles/r04_fullsize_report.txt, r05_fullsize_report.txt): (mask-flip fraction, Dice difference).
+# C1 is an fp32 config (BASELINE configs[0]); its 16-bit rows are there for completeness - a 2-D net at random initialisation puts more voxels next to
+# the 0.5 threshold (measured: f16 6.4e-4 / 6.5e-4 flips, bf16 5.36e-3 / 5.36e-3; Dice differences 2.6e-5 / 4.5e-4)
+LOWP_GATES = {"C1_unet2d": {"f16": (9e-4, 2e-4), "bf16": (7e-3, 7e-4)}}
+
+
+def lowp_gate(tag, dtype, flip_tol, dice_tol):
+    return LOWP_GATES.get(tag, {}).get(dtype, (flip_tol, dice_tol))
+
+
 def make(tag, dtype):
     kind, ndim, shape, ncls, loss = CONFIGS[tag]
     e = SegEngine(kind, ndim, shape[1], ncls, dtype=dtype, device=DEV)
@@ -104,6 +114,7 @@ def test_directional_derivative_full_size(tag):
 # gates = the MI355X measurement + 25-40 % (profiles/r04_fullsize_report.txt: f16 flips 4.4e-5 ... 4.6e-4, bf16 3.2e-4 ... 3.7e-3; Dice differences <= 2.1e-5 / 8.8e-5)
 @pytest.mark.parametrize("dtype,flip_tol,dice_tol", [("f16", 7e-4, 2e-4), ("bf16", 5e-3, 5e-4)])
 def test_low_precision_vs_fp32_full_size(tag, dtype, flip_tol, dice_tol):
+    flip_tol, dice_tol = lowp_gate(tag, dtype, flip_tol, dice_tol)
     e32, x, y, ncls, loss = make(tag, "f32")
     l32, p32 = e32.forward(x)
     d32 = float(e32.loss_forward(l32, y, loss)[1])
@@ -182,6 +193,7 @@ def test_oracle_forward_full_size_f32(tag):
 # gates = the MI355X measurement + 25-40 % (profiles/r04_fullsize_report.txt: f16 flips 4.4e-5 ... 4.6e-4, bf16 3.2e-4 ... 3.7e-3; Dice differences <= 2.1e-5 / 8.8e-5)
 @pytest.mark.parametrize("dtype,flip_tol,dice_tol", [("f16", 7e-4, 2e-4), ("bf16", 5e-3, 5e-4)])
 def test_oracle_forward_full_size_low_precision(tag, dtype, flip_tol, dice_tol):
+    flip_tol, dice_tol = lowp_gate(tag, dtype, flip_tol, dice_tol)
     kind, ndim, shape, ncls, loss = CONFIGS[tag]
     params, x, y, ref_logits, ref_probs = oracle_eval(tag)
     e = SegEngine(kind, ndim, shape[1], ncls, dtype=dtype, device=DEV)
@@ -403,7 +415,7 @@ def test_c1_unet2d_at_its_own_size_f32_forward_gradients_and_steps():
     """BASELINE configs[0] - UNet2d binary segmentation, 2 x 1 x 256 x 256, fp32, BinaryDiceLoss - is the reference's own CPU-runnable case (VERDICT r04
     item 7b: it had only been run at 32^2).  Here it goes through the engine at ITS size in the f32 run dtype against the oracle: logits within
     north_star's 1e-3, identical integer masks (up to numerically tied voxels) and Dice, loss within 2e-5, every gradient tensor against the float64
-    oracle no further than twice the fp32 oracle's own distance, and three AdamW steps with given dropout-free arithmetic (UNet has no dropout)
+    oracle no further than twice the fp32 oracle's own distance, and three AdamW steps with the same recorded channel-dropout masks on both sides
     tracking the oracle's loss."""
     tag = "C1_unet2d"
     kind, ndim, shape, ncls, loss = CONFIGS[tag]
@@ -433,13 +445,15 @@ def test_c1_unet2d_at_its_own_size_f32_forward_gradients_and_steps():
         worst = max(worst, ee)
         assert ee < 2.0 * oo + 1e-3, (k, ee, oo)
     # three optimisation steps against the oracle's AdamW
+    gm = torch.Generator().manual_seed(3)
+    all_masks = [seg.draw_masks(kind, shape[0], generator=gm) for _ in range(3)]          # the SAME channel-dropout masks on both sides (Unet2d.py:74,83)
     cur, st, ref_curve = {k: v.clone() for k, v in params.items()}, {}, []
-    for _ in range(3):
-        r = seg.forward_backward(kind, cur, x, y, loss)
+    for it in range(3):
+        r = seg.forward_backward(kind, cur, x, y, loss, masks=all_masks[it])
         ref_curve.append(float(r["loss"]))
         cur = seg.adamw_step(cur, r["grads"], st)
     e.load_state_dict(params)
-    curve = [float(e.train_step(xd, yd, loss, lr=1e-3)[0]) for _ in range(3)]
+    curve = [float(e.train_step(xd, yd, loss, lr=1e-3, mask_mode=_capi.MASKS_GIVEN, masks=all_masks[it])[0]) for it in range(3)]
     line = "C1 UNet2d 2x256^2 f32 at its own size: logits max|d| %.2e, mask flips %d, worst gradient tensor vs fp64 %.2e, 3-step loss %s vs oracle %s" % (
         err, int(flip.sum()), worst, ["%.5f" % v for v in curve], ["%.5f" % v for v in ref_curve])
     print(line)
@@ -447,9 +461,16 @@ def test_c1_unet2d_at_its_own_size_f32_forward_gradients_and_steps():
         with open(os.environ["SEG_FULLSIZE_REPORT"], "a") as f:
             f.write(line + "\n")
     assert max(abs(a - b) for a, b in zip(curve, ref_curve)) < 2e-4, line
+    # AdamW moves every weight by <= lr per step whatever its gradient's size: a weight whose gradient sits in the rounding noise may go the other
+    # way (<= 2 lr per step apart); all but a per cent of the weights must agree to 1e-4
     sd = e.state_dict()
+    tot = bad = 0
     for k, v in cur.items():
-        assert float((sd[k].cpu() - v).abs().max()) < 2e-4, k
+        d = (sd[k].cpu() - v).abs()
+        assert float(d.max()) < 3 * 2e-3, k
+        tot += d.numel()
+        bad += int((d > 1e-4).sum())
+    assert bad <= 0.01 * tot, (bad, tot)
 
 
 _LONG_CURVE = {}
@@ -477,8 +498,12 @@ def _oracle_long_curve(steps):
     return _LONG_CURVE[steps]
 
 
-# gate = the MI355X measurement + 25 % (profiles/r05_fullsize_report.txt); the 16-bit curves are compared over ten times the horizon of the test above
-@pytest.mark.parametrize("dtype,tol,tail_tol", [("f16", 2.5e-2, 1.5e-2), ("bf16", 5e-2, 3e-2)])
+# the 16-bit curves are compared over ten times the horizon of the test above
+# measured on MI355X (profiles/r05_fullsize_report.txt): f16 max |diff| 4.9e-3 (step 283), last-50 mean 7.8e-5; bf16 5.6e-3 (step 108), 5.0e-4
+# Two runs of the same binary differ (single trajectories separate chaotically; the order of the statistics' atomics makes runs differ in the last bits):
+# f16 max |diff| 4.9e-3 / 6.8e-3, last-50 mean 7.8e-5 / 9.3e-4; bf16 5.6e-3 / 6.5e-3, 5.0e-4 / 1.4e-3.  Gates = twice the larger observation: a few per cent
+# of the oracle's descent (0.225) at the worst step.
+@pytest.mark.parametrize("dtype,tol,tail_tol", [("f16", 1.4e-2, 3e-3), ("bf16", 1.4e-2, 3e-3)])
 def test_three_hundred_step_loss_curve_follows_the_fp32_oracle(dtype, tol, tail_tol):
     """the only training-level evidence for the 16-bit run dtypes was a 30-step curve.  300 AdamW steps of VNet3d on 1 x 48^3
     (the SAME dropout masks on both sides) against 300 steps of the fp32 oracle from the same weights: the 16-bit loss curve must stay within `tol` of
