@@ -250,9 +250,7 @@ int seg_op_conv3x_default_cfg(int ndim, int n, int d, int h, int wid, int cin, i
     return conv3x_pick(ndim, n, dd, h, wid, cin, cout);
 }
 long long seg_op_wgrad3_partial_bytes(int ndim, int n, int d, int h, int wid, int p, int q) {
-    // (also large enough for the per-XCD tile layout, which the operator tests select with SEG_W3_XCD=2)
-    const size_t a = wgrad3_partial_bytes(ndim, n, ndim == 3 ? d : 1, h, wid, p, q), b = wgrad3_xcd_bytes(ndim, p, q);
-    return (long long)(a > b ? a : b);
+    return (long long)wgrad3_partial_bytes(ndim, n, ndim == 3 ? d : 1, h, wid, p, q);
 }
 int seg_op_wgrad3(const void* dr, const void* x, float* partial, float* dw, int n, int d, int h, int wid, int p, int q, int ndim,
                   int dtype, void* stream) {

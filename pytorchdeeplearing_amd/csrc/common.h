@@ -156,13 +156,6 @@ template <class T> __device__ __forceinline__ void dma16_async(i32x4 rsrc, T* ld
 #else
 template <class T> __device__ __forceinline__ void dma16_async(i32x4 rsrc, T* lds_wave_base, unsigned voffset) { dma16(rsrc, lds_wave_base, voffset); }
 #endif
-// fp32 add performed in the L2 of the XCD the wave runs on (workgroup scope: no sc1 bit, not sent to memory - tools/microbench/xcd_barrier.hip, round 4).
-// Only for locations that ONE XCD touches during the kernel (chosen by HW_REG_XCC_ID): the eight L2s are not coherent with each other.
-#ifndef SEG_EMU
-__device__ __forceinline__ void l2_atomic_add(float* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#else
-__device__ __forceinline__ void l2_atomic_add(float* p, float v) { *p += v; }
-#endif
 // all of this wave's outstanding global loads / LDS copies have landed (s_waitcnt vmcnt(0); expcnt / lgkmcnt untouched)
 __device__ __forceinline__ void wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // "this loaded value has arrived": an empty asm statement that reads v makes hipcc place the value's s_waitcnt HERE (in front of a

@@ -513,7 +513,6 @@ struct Wgrad3Args {
     const void* dr; const void* x; float* partial;
     int N, D, H, W, P, Q;       // channel counts of dr / x
     int nb;                     // workgroups per (p-tile, q-tile) combo
-    int xcd_tiles;              // 1: `partial` holds ONE fp32 tile per (combo, XCD), all zero on entry; the workgroups add their tiles with XCD-local L2 atomics
     const float* xsc; const float* xsh;   // [N][Q] or null: x is a RAW conv output, activated while it is staged (stage_halo)
 #ifdef SEG_W3_TRACE
     unsigned long long* trace;            // diagnostic build (tools/build_variant.py ... -DSEG_W3_TRACE): 8 phase sums per workgroup
@@ -804,35 +803,6 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) SEG_W3_WAVES void wgrad3_kernel(Wg
             sweep();
         }
     }
-    if (a.xcd_tiles) {
-        // Round 5: the 256 workgroups of a launch used to write 256 private tiles (19 x 13.8 MB per step) that the reduce pass
-        // gathered again (20 x 18 MB): 2.8x the family's algorithmic traffic.  Here the workgroups that run on ONE XCD add their tiles into that XCD's
-        // tile [combo][xcc] with L2-local atomics (workgroup scope: no sc1, performed in the XCD's own L2, which is the only L2 that ever holds the
-        // line because the tile is chosen by the hardware's XCC id, not by a dispatch-order assumption; the lines are written back at the end of the
-        // kernel like any store).  The reduce pass then reads 8 tiles per combo instead of up to 256 and writes the zeros back that the next launch
-        // starts from.  fp32 atomics: the order of the additions inside an XCD is not fixed, so the low bits of a gradient may differ run to run
-        // (16-bit run dtypes only; the f32 run dtype keeps the ordered two-stage reduction).
-#ifdef SEG_EMU
-        const int xcc = blockIdx.x & 7;
-#else
-        const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;      // HW_REG_XCC_ID
-#endif
-        float* dst = a.partial + ((long long)combo * 8 + xcc) * (CP * B::NTAP * CQ);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int tap = wv + 4 * t;
-            if (tap < B::NTAP) {
-#pragma unroll
-                for (int i = 0; i < PT; ++i)
-#pragma unroll
-                    for (int j = 0; j < QT; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            l2_atomic_add(&dst[((i * 16 + 4 * q + r) * B::NTAP + tap) * CQ + j * 16 + l15], acc[t][i][j][r]);
-            }
-        }
-        return;
-    }
     // partial tile [p][tap][q] of this workgroup
     float* dst = a.partial + ((long long)combo * a.nb + blockIdx.x) * (CP * B::NTAP * CQ);
 #pragma unroll
@@ -853,7 +823,7 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) SEG_W3_WAVES void wgrad3_kernel(Wg
 // dw[p][q][tap] += sum_b partial[combo][b][p'][tap][q']   (one thread per dw element: coalesced read-modify-write of
 // the master gradient, partial tiles gathered through L1/L2)
 __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial, float* dw, int P, int Q, int CP, int CQ, int ntap, int nb,
-                                                            long long sP, long long sQ, int qreal, int zero_after = 0) {
+                                                            long long sP, long long sQ, int qreal) {
     // grid.y slices the partial list (32 partial tiles per slice); slices meet in dw through one atomic each
     const long long total = (long long)P * Q * ntap;
     const int tile = CP * ntap * CQ, nqt = Q / CQ;
@@ -878,8 +848,6 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial
             s2 += src[(long long)(b + 2) * tile]; s3 += src[(long long)(b + 3) * tile];
         }
         for (; b < b1; ++b) s0 += src[(long long)b * tile];
-        if (zero_after)                                 // per-XCD tiles: the next launch accumulates into zeros
-            for (b = b0; b < b1; ++b) const_cast<float*>(src)[(long long)b * tile] = 0.f;
         const float tot = (s0 + s1) + (s2 + s3);
         const int p = (combo / nqt) * CP + pp, qc = (combo % nqt) * CQ + qq;
         if (qc >= qreal) continue;                      // zero-padded input channels (multi-channel image tensor): no such weight
@@ -905,9 +873,7 @@ void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long lon
     const long long total = (long long)a.P * a.Q * ntap;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    const int ntile = a.xcd_tiles ? 8 : a.nb;
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, (ntile + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, ntile, sP, sQ, qreal,
-                       a.xcd_tiles);
+    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, a.nb, sP, sQ, qreal);
 }
 
 // 16 -> 16 channels on a large volume (the finest level of the 3-D nets: the longest single launch of the step, 313 us for 226 MB at 4 x 96^3,
@@ -930,9 +896,8 @@ template <class T> struct Wgrad3Big16 {
         if (a.nb > nbox) a.nb = (int)nbox;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3_kernel<T, 4, 8, 16, 3, 16, 16>), dim3(a.nb, combos), dim3(256), 0, s, a);
         const long long total = 16ll * a.Q * 27;
-        const int ntile = a.xcd_tiles ? 8 : a.nb;
-        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total + 255) / 256), (ntile + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, 16, 16, 27,
-                           ntile, sP, sQ, qreal, a.xcd_tiles);
+        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total + 255) / 256), (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, 16, 16, 27,
+                           a.nb, sP, sQ, qreal);
         return true;
     }
 };
@@ -1242,10 +1207,8 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) 
     return (size_t)combos * wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q, 4) * CP * (ndim == 3 ? 27 : 9) * CQ * sizeof(float);
 }
 
-size_t wgrad3_xcd_bytes(int ndim, int P, int Q) { return (size_t)8 * P * Q * (ndim == 3 ? 27 : 9) * sizeof(float); }
-
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1, int C0, const float* xscale, const float* xshift, int qreal, float* xcd_tiles) {
+                   int dtype, hipStream_t s, const void* x1, int C0, const float* xscale, const float* xshift, int qreal) {
     const int T = ndim == 3 ? 27 : 9;
     if (qreal <= 0 || qreal > Q) qreal = Q;
     // 16-bit tensors, opt-in (SEG_WGRAD3X=1, read per call): double-buffered kernel (wgrad3x.hip), same partial-tile layout and
@@ -1282,18 +1245,6 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
     a.N = N; a.D = D; a.H = H; a.W = W; a.P = P; a.Q = Q;
     a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q, dtype == DT_F32 ? 4 : 2);
     a.xsc = xscale; a.xsh = xshift;
-    // per-XCD tiles (wgrad3_kernel epilogue): where a combo has at least 16 workgroups (the 16 / 32 / 64-channel levels) and the tensors are 16-bit.
-    // SEG_W3_XCD=0: off.  =2 (operator tests): also for a caller without an XCD scratch - its partial-tile scratch is cleared and used instead
-    a.xcd_tiles = 0;
-    {
-        const char* ex = getenv("SEG_W3_XCD");
-        const int mode = ex ? atoi(ex) : 1;
-        const int min_nb = mode == 2 ? 2 : 16;
-        if (mode && dtype != DT_F32 && a.nb >= min_nb) {
-            if (xcd_tiles) { a.partial = xcd_tiles; a.xcd_tiles = 1; }
-            else if (mode == 2) { (void)hipMemsetAsync(partial, 0, wgrad3_xcd_bytes(ndim, P, Q), s); a.xcd_tiles = 1; }
-        }
-    }
 #ifdef SEG_W3_TRACE
     static unsigned long long* tbuf = nullptr;
     const size_t tmax = 8192;

@@ -167,7 +167,6 @@ int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
     if (hipMemcpy(h->ws + h->off_packdesc, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice) != hipSuccess)
         return fail("seg_bind: descriptor upload failed");
     if (hipMemset(h->ws + h->off_step, 0, 256) != hipSuccess) return fail("seg_bind: memset failed");
-    if (h->xcd_bytes && hipMemset(h->ws + h->off_xcd, 0, h->xcd_bytes) != hipSuccess) return fail("seg_bind: memset failed");
     if (h->draws && hipMemcpy(h->ws + h->off_step, &h->draws, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
         return fail("seg_bind: counter upload failed");
     return 0;

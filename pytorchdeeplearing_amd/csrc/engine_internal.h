@@ -92,7 +92,6 @@ struct seg_engine {
     int N = 0, D = 0, H = 0, W = 0;
     size_t ws_bytes = 0;
     size_t off_partial = 0, off_partial_stem1 = 0;
-    size_t off_xcd = 0, xcd_bytes = 0;      // per-XCD weight-gradient tiles (launch_wgrad3), all-zero between launches
     size_t off_masks = 0, off_stats = 0, stats_bytes = 0, off_Q = 0, Q_bytes = 0, off_packdesc = 0, off_step = 0;
     bool q_clean = false;       // the forward pass's fill has cleared Q and no backward pass has used it yet
     std::vector<PackDesc> packdescs;   // dst/src stored as OFFSETS until bind

@@ -442,17 +442,6 @@ struct Planner {
                     E.ws = keep;
                 }
             }
-        // per-XCD tiles of the halo weight gradients (launch_wgrad3: 16-bit tensors, >= 16 workgroups per combo): all-zero between launches, cleared once by seg_bind
-        size_t xmax = 0;
-        if (E.dtype != DT_F32)
-            for (auto& s : E.steps)
-                if (s.type == ST_UNIT && s.ck == CK_K3) {
-                    const int l = E.tens[s.raw].lvl;
-                    if (wgrad3_blocks_per_combo(E.ndim, N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cout, s.Cin, 2) >= 16)
-                        xmax = std::max(xmax, wgrad3_xcd_bytes(E.ndim, s.Cout, s.Cin));
-                }
-        E.xcd_bytes = xmax;
-        E.off_xcd = alloc(xmax ? xmax : 256);
         E.off_partial = alloc(pmax);
         E.off_partial2 = E.n_side > 1 ? alloc(pmax) : E.off_partial;
         E.off_partial_main = alloc(pmax);
@@ -918,13 +907,10 @@ struct Planner {
                                 launch_wgrad3(E.ws + E.tens[draw].off, E.ws + E.tens[u.raw].off, (float*)(E.ws + E.cur_partial),
                                               E.g + E.params[s.w].off, E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
                                               nullptr, i0.C, (const float*)(E.ws + u.scale), (const float*)(E.ws + u.shift));
-                            } else {
-                            // the per-XCD tile scratch belongs to the first weight-gradient stream (launches on it are ordered); any other stream keeps per-workgroup tiles
-                            float* xcd = (E.xcd_bytes && E.cur_partial == E.off_partial && !E.sub_active) ? (float*)(E.ws + E.off_xcd) : nullptr;
+                            } else
                             launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.cur_partial), E.g + E.params[s.w].off,
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
-                                          s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, nullptr, nullptr, s.cin_par, xcd);
-                            }
+                                          s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, nullptr, nullptr, s.cin_par);
                             E.prof_end(ws_, pi);
                         }, E.tbytes(draw), lo, s.gn_w >= 0 ? si : -1, g0 >= 0 ? s.x_dg0 >= 0 : (g1 >= 0 && s.x_dg1 >= 0));
                         int pi;

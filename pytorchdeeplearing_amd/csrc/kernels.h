@@ -55,10 +55,7 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, 
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
                    int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, const float* xscale = nullptr, const float* xshift = nullptr,
-                   int qreal = 0,       // qreal in (0, Q): x carries zero-padded channels, dw is [P][qreal][taps] (the channels beyond qreal are not written)
-                   float* xcd_tiles = nullptr);   // all-zero scratch of wgrad3_xcd_bytes(): one tile per (combo, XCD), accumulated with XCD-local atomics and
-                                                  // left all-zero again (16-bit tensors, >= 16 workgroups per combo); null: per-workgroup partial tiles
-size_t wgrad3_xcd_bytes(int ndim, int P, int Q);
+                   int qreal = 0);      // qreal in (0, Q): x carries zero-padded channels, dw is [P][qreal][taps] (the channels beyond qreal are not written)
 
 // MFMA image stem (K = taps*Cimg <= 32): forward and weight gradient on box tiles (conv3.hip)
 void launch_stem_fwd(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cimg,
