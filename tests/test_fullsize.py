@@ -448,10 +448,13 @@ def test_c1_unet2d_at_its_own_size_f32_forward_gradients_and_steps():
     gm = torch.Generator().manual_seed(3)
     all_masks = [seg.draw_masks(kind, shape[0], generator=gm) for _ in range(3)]          # the SAME channel-dropout masks on both sides (Unet2d.py:74,83)
     cur, st, ref_curve = {k: v.clone() for k, v in params.items()}, {}, []
+    cur64, st64 = {k: v.double() for k, v in params.items()}, {}
     for it in range(3):
         r = seg.forward_backward(kind, cur, x, y, loss, masks=all_masks[it])
         ref_curve.append(float(r["loss"]))
         cur = seg.adamw_step(cur, r["grads"], st)
+        r = seg.forward_backward(kind, cur64, x.double(), y, loss, masks=[m.double() for m in all_masks[it]])
+        cur64 = seg.adamw_step(cur64, r["grads"], st64)
     e.load_state_dict(params)
     curve = [float(e.train_step(xd, yd, loss, lr=1e-3, mask_mode=_capi.MASKS_GIVEN, masks=all_masks[it])[0]) for it in range(3)]
     line = "C1 UNet2d 2x256^2 f32 at its own size: logits max|d| %.2e, mask flips %d, worst gradient tensor vs fp64 %.2e, 3-step loss %s vs oracle %s" % (
@@ -461,16 +464,19 @@ def test_c1_unet2d_at_its_own_size_f32_forward_gradients_and_steps():
         with open(os.environ["SEG_FULLSIZE_REPORT"], "a") as f:
             f.write(line + "\n")
     assert max(abs(a - b) for a, b in zip(curve, ref_curve)) < 2e-4, line
-    # AdamW moves every weight by <= lr per step whatever its gradient's size: a weight whose gradient sits in the rounding noise may go the other
-    # way (<= 2 lr per step apart); all but a per cent of the weights must agree to 1e-4
+    # AdamW moves every weight by <= lr per step whatever its gradient's size, and at this size a tenth of the gradients are below 2e-9 - the scale of
+    # Adam's eps - so the update of those weights is decided by rounding noise: the fp32 oracle itself ends > 1e-4 away from its float64 twin in 19 % of
+    # the weights.  The yardstick is therefore the float64 run: the engine may disagree with it in at most 1.5x as many weights as the fp32 oracle does.
     sd = e.state_dict()
-    tot = bad = 0
-    for k, v in cur.items():
-        d = (sd[k].cpu() - v).abs()
+    tot = bad = bad_o = 0
+    for k, v in cur64.items():
+        d = (sd[k].cpu().double() - v).abs()
         assert float(d.max()) < 3 * 2e-3, k
         tot += d.numel()
         bad += int((d > 1e-4).sum())
-    assert bad <= 0.01 * tot, (bad, tot)
+        bad_o += int(((cur[k].double() - v).abs() > 1e-4).sum())
+    print("weights > 1e-4 from the float64 oracle after 3 steps: engine %.3f, fp32 oracle %.3f" % (bad / tot, bad_o / tot))
+    assert bad <= 1.5 * bad_o + 0.01 * tot, (bad, bad_o, tot)
 
 
 _LONG_CURVE = {}
