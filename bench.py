@@ -162,7 +162,6 @@ def parse(argv=None):
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=96)
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("SEG_LANES", "1")), help="intra-GPU batch lanes (pytorchdeeplearing_amd/lanes.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline / dice_vs_ref / gpu_torch_baseline legs")
     ap.add_argument("--roofline-steps", type=int, default=5, help="instrumented steps run AFTER the timed region: EVERY launch of the step (all kernel "
                     "families, both streams) is bracketed by HIP events on its launch stream (each bracket idles the stream for ~5 us, so none of "
@@ -377,14 +376,10 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
     S = a.size
     # the other BASELINE configs first, before anything of the headline run exists in the process: measured after the HIP-graph probe of `--launch auto`
     # the clDice config (the one path that uses a second torch stream per step) ran 11 ms instead of 6.4 (profiles/r04_bench_other_configs_order.txt)
-    others = other_configs(dev) if (on_gpu and world == 1 and a.lanes == 1 and rank == 0 and not a.no_other_configs) else None
-    if a.lanes > 1:
-        from pytorchdeeplearing_amd.lanes import LaneEngine
-        e = LaneEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev, lanes=a.lanes)
-    else:
-        e = SegEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev)
+    others = other_configs(dev) if (on_gpu and world == 1 and rank == 0 and not a.no_other_configs) else None
+    e = SegEngine("vnet", 3, 1, 1, dtype=a.dtype, device=dev)
     synthetic.init_engine(e, seed=0)
-    if world > 1 and a.lanes == 1:
+    if world > 1:
         from pytorchdeeplearing_amd.parallel import broadcast_parameters
         broadcast_parameters(e, src=0)          # every replica starts from rank 0's weights (the dropout streams differ per rank)
     x, y = synthetic.synthetic_batch(a.batch, (S, S, S), 1, 1, seed=1234 + rank)
@@ -393,17 +388,15 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
     probs = torch.empty_like(logits)
     allreduce = (GradAllReduce(world) if a.single_allreduce else BucketedGradAllReduce(world)) if world > 1 else None
 
-    exchange = GlobalBatchLoss(world, equal_shards=True) if (a.global_loss and world > 1 and a.lanes == 1) else None
+    exchange = GlobalBatchLoss(world, equal_shards=True) if (a.global_loss and world > 1) else None
     kw = {"loss_exchange": exchange} if exchange is not None else {}
 
-    can_graph = on_gpu and world == 1 and a.lanes == 1
+    can_graph = on_gpu and world == 1
     launch = {"mode": a.launch if (can_graph and a.launch != "auto") else "stream"}
-    if a.lanes == 1:
-        kw["launch"] = "stream"
+    kw["launch"] = "stream"
 
     def step():
-        if a.lanes == 1:
-            kw["launch"] = launch["mode"]
+        kw["launch"] = launch["mode"]
         return e.train_step(x, y, "BinaryDiceLoss", lr=1e-3, allreduce=allreduce, logits=logits, probs=probs, **kw)
 
     probe = None
@@ -476,7 +469,7 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
     from pytorchdeeplearing_amd import _capi
     nprof = max(0, a.roofline_steps)
     prof = {}
-    if nprof and a.lanes == 1:
+    if nprof:
         e.profile_enable(_capi.KERNEL_CLASSES)
         if on_gpu:
             step()                            # creates the event pool (hipEventCreate) outside the measured brackets
@@ -514,7 +507,7 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "VNet3d(1,1) binary seg, %dx1x%d^3 per GPU, BinaryDiceLoss + Dice metric, AdamW, dropout p=0.2 on, "
                                    "random-init weights (BASELINE.json configs[2])" % (a.batch, S),
-                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "lanes_per_gpu": a.lanes,
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                        "loss_semantics": "global-batch (sums exchanged)" if exchange is not None else "per-rank (DDP)"},
             "final_loss": round(loss, 5),
             "conditioning_steps": ncond, "conditioning_seconds": a.condition_seconds,

@@ -9,6 +9,23 @@
  * Errors: every function returns 0 on success, <0 on failure; seg_last_error() gives the message.
  * Threading: calls are stream-ordered and asynchronous; a handle is not thread-safe.
  * All device pointers must be 256-byte aligned.  `stream` is a hipStream_t.
+ *
+ * Environment switches read by the PRODUCT library (each selects a complete path that the parity tests cover; none is needed to run; read once per
+ * process unless noted) - the whole list:
+ *   SEG_WGRAD_STREAM=0   weight gradients on the caller's stream instead of the library's second (low-priority) stream
+ *   SEG_CONV3X=0         16-bit halo convolutions through conv3_kernel (round 1) instead of c3x::conv3x_kernel - bit-identical results
+ *   SEG_STEMX=0          separate image-stem / GroupNorm / stem weight-gradient kernels instead of the fused input block
+ *   SEG_VHEAD=0          the head writes its data-gradient tensor instead of the on-the-fly form
+ *   SEG_GN_FOLD=0        GroupNorm finalize as launches of its own;  SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
+ *   SEG_STEP_RIDERS=0    (read per step) step counters / flag clears as launches of their own instead of riding on neighbouring kernels
+ *   SEG_PACK_SPLIT=0     the weight re-layout as one launch on the caller's stream
+ *   SEG_CONV_STREAM=0    the generic implicit-GEMM kernel also where the register-resident streaming conv applies
+ *   SEG_WG_DIRECT=0      1^d-conv weight gradients through wgrad_kernel instead of the multi-step streaming kernel
+ *   SEG_W3_BOX16=0|2     the 4 x 8 x 16-box weight gradient of the 16-channel level: off / forced onto small volumes (operator tests)
+ *   SEG_C3X_MAP="cin:cout:w=id,..."   per-shape halo-conv tiling override (tools/tune_conv3x.py)
+ * Every other SEG_* knob of rounds 1-5 (workgroup counts, fork policies, and the measured-slower paths: double-buffered weight gradient, GroupNorm in
+ * the consumer conv, persistent halo convs, flag forks, sub-batched levels, second weight-gradient stream - profiles/HISTORY.md) exists only in the
+ * experiments build: `python -m pytorchdeeplearing_amd.build --experiments` -> lib/libsegengine_exp.so (-DSEG_EXPERIMENTS), SEGENGINE_LIB=<that file>.
  */
 #ifndef SEGENGINE_H
 #define SEGENGINE_H
@@ -79,10 +96,10 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid);
 long long seg_workspace_bytes(seg_handle h);
 /* what the planner decided for the current shape (tests / diagnostics): what = 0: activations applied by their consuming convolution instead
  * of an elementwise launch (the activated tensor is never written), 1: convolution units, 2: fork events the last backward pass recorded on the
- * caller's stream, 3: flag forks of the last backward pass (no event: the weight-gradient queue's command processor waits on a word in signal
- * memory that the caller's stream's next kernel stores; default where hipStreamWaitValue32 is available, SEG_FORK=event switches back),
+ * caller's stream, 3: flag forks of the last backward pass (experiments build with SEG_FORK=flag only - opt-in, never the default: the
+ * weight-gradient queue waits on a word in signal memory that the caller's stream's next kernel stores; 0 in the product library),
  * 7 / 8: of those, numbers stored by the next kernel itself / by a one-wave kernel of their own, 9: 1 when no released batch is left waiting,
- * 4: samples per group of the sub-batched finest level (0 = whole-batch launches; SEG_SUB_MB),
+ * 4: samples per group of the sub-batched finest level (0 = whole-batch launches; experiments build, SEG_SUB_MB),
  * 5 / 6: forward / backward ops that run group by group.  <0: not planned / unknown `what`. */
 int seg_plan_count(seg_handle h, int what);
 

@@ -716,13 +716,13 @@ void launch_pool3(const float* x, float* out, int planes, int D, int H, int W, i
 }
 void launch_skel_iter(const float* x, float* e_out, float* x_out, int planes, int D, int H, int W, int nd, hipStream_t s) {
     // SEG_SKEL_X4=0: one voxel per thread (rounds 1-4); default: four x-consecutive voxels per thread, same bits
-    static const bool x4 = !(getenv("SEG_SKEL_X4") && atoi(getenv("SEG_SKEL_X4")) == 0);
+    static const bool x4 = (xknob_i("SEG_SKEL_X4", 1) != 0);
     if (nd == 3) {
         Vol v{planes, D, H, W, 3};
         const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
         // 8 x 8 x 32 tiles: 1.66 instead of 1.99 halo windows per output voxel (C5 + clDice 5.72 vs 5.81 ms per step, profiles/r05_cldice_tile_ab.log);
         // SEG_SKEL_TZ=4 keeps the 4 x 8 x 32 tiles, which shallow volumes take anyway
-        static const int tz = getenv("SEG_SKEL_TZ") ? atoi(getenv("SEG_SKEL_TZ")) : 8;
+        static const int tz = xknob_i("SEG_SKEL_TZ", 8);
         if (x4 && tz == 8 && D >= 8) {
             const long long nb8 = (long long)planes * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 31) / 32);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<8, 8, 32, true>), dim3((unsigned)nb8), dim3(256), 0, s, x, e_out, x_out, v);
@@ -738,11 +738,11 @@ void launch_skel_iter(const float* x, float* e_out, float* x_out, int planes, in
 }
 void launch_skel_iter_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int D, int H, int W, int nd,
                           hipStream_t s) {
-    static const bool x4 = !(getenv("SEG_SKEL_X4") && atoi(getenv("SEG_SKEL_X4")) == 0);      // 0: one window / voxel per thread (rounds 1-4), same bits
+    static const bool x4 = (xknob_i("SEG_SKEL_X4", 1) != 0);      // 0: one window / voxel per thread (rounds 1-4), same bits
     if (nd == 3) {
         Vol v{planes, D, H, W, 3};
         const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
-        static const int tz = getenv("SEG_SKEL_TZ") ? atoi(getenv("SEG_SKEL_TZ")) : 8;
+        static const int tz = xknob_i("SEG_SKEL_TZ", 8);
         if (x4 && tz == 8 && D >= 8) {
             const long long nb8 = (long long)planes * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 31) / 32);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<8, 8, 32, true, false>), dim3((unsigned)nb8), dim3(256), 0, s, g, x, e, dx, de, v);
@@ -864,7 +864,7 @@ void launch_cldice_target(const void* target, int label_type, int planes, int D,
     // The target is read as a BINARY mask, y = (label != 0) - what the reference's train loop hands to every loss (model/modelVNet.py:576: labels are
     // binarised before the loss) - and its skeleton is computed on bits (cld_bits_kernel): exactly the values of the fp32 iteration on that mask.
     // SEG_CLD_BITS=0 keeps the fp32 tile kernels for the target (rounds 1-4).
-    static const bool use_bits = !(getenv("SEG_CLD_BITS") && atoi(getenv("SEG_CLD_BITS")) == 0);
+    static const bool use_bits = (xknob_i("SEG_CLD_BITS", 1) != 0);
     if (!use_bits || width <= 0) {
         hipLaunchKernelGGL(cld_labels_kernel, dim3(blocks_for(n)), dim3(256), 0, s, target, label_type | LT_BINARIZE, y, n);
         const float* tc = y;

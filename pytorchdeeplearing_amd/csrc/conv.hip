@@ -242,7 +242,7 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep, ForkSig sg) {
     const int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     dim3 grid(cdiv(M, BM), a.Ngemm / (16 * nt));
     // two reduction slices per stage where the launch is a latency chain (fewer than two workgroups per CU) and K allows it
-    static const int ks_env = getenv("SEG_IGEMM_KS") ? atoi(getenv("SEG_IGEMM_KS")) : 0;
+    static const int ks_env = xknob_i("SEG_IGEMM_KS", 0);
     const bool ks2 = a.Kpad % (2 * BK) == 0 && a.Kpad >= 4 * BK && (ks_env ? ks_env == 2 : (long long)grid.x * grid.y <= 512);
 #define SEG_LAUNCH_CONV(NT)                                                                          \
     if (ks2) {                                                                                        \
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
 }
 
 bool stream_eligible(const ConvArgs& a) {
-    static const bool off = getenv("SEG_CONV_STREAM") && atoi(getenv("SEG_CONV_STREAM")) == 0;
+    static const bool off = knob_i("SEG_CONV_STREAM", 1) == 0;
     if (off) return false;
     const long long Vrow = (long long)a.OD * a.OH * a.OW;
     if (Vrow % 16 || a.Kpad > 128 || a.Kpad % 32 || a.Ngemm % 16 || a.Ngemm > 128) return false;
@@ -715,7 +715,7 @@ static void head_bwd_dispatch(const HeadBwdArgs& a, dim3 grid, hipStream_t s) {
 void launch_head_bwd(const HeadBwdArgs& a, int dtype, hipStream_t s) {
     const int VPB = 256 / (a.Cin / 8);
     int blocks = cdiv(a.V, 2 * VPB);           // per sample; two voxels per thread and trip
-    static const int cap = getenv("SEG_HEAD_BWD_WGS") ? atoi(getenv("SEG_HEAD_BWD_WGS")) : 1024;      // tuning knob: workgroups per launch
+    static const int cap = xknob_i("SEG_HEAD_BWD_WGS", 1024);      // tuning knob: workgroups per launch
     const int per_n = cap / a.N > 0 ? cap / a.N : 1;
     if (blocks > per_n) blocks = per_n;
     dim3 grid(blocks, a.N);

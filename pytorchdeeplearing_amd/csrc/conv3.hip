@@ -453,18 +453,18 @@ void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
     // measured on MI355X: on the small levels more, narrower workgroups (several resident per CU) beat NT = 4
     // tiles (conv3 class 2.3 ms vs 3.4 ms per step) - the per-workgroup tap loop is latency-bound, so occupancy wins
     while (nt > 1 && nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;
-    static const int force_nt = getenv("SEG_CONV3_NT") ? atoi(getenv("SEG_CONV3_NT")) : 0;     // tuning knob (tools/bench_conv3.py)
+    static const int force_nt = xknob_i("SEG_CONV3_NT", 0);     // tuning knob (tools/bench_conv3.py)
     if (force_nt && a.Cout % (16 * force_nt) == 0 && !(a.Cin == 16 && force_nt == 4)) nt = force_nt;
     // opt-in register-blocked tiling (32 output channels per workgroup): 1 = wherever NT >= 2 was chosen, 2 = every 32-channel-aligned layer
-    static const int rb = getenv("SEG_CONV3_RB") ? atoi(getenv("SEG_CONV3_RB")) : 0;
+    static const int rb = xknob_i("SEG_CONV3_RB", 0);
     if (rb && sizeof(T) == 2 && a.Cin % 32 == 0 && a.Cout % 32 == 0 && (nt >= 2 || rb >= 2) && !force_nt) {
-        static const bool verbose = getenv("SEG_CONV3_RB_VERBOSE") != nullptr;
+        static const bool verbose = xenv("SEG_CONV3_RB_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "[segengine] conv3_rb box %dx%dx%d  %dx%dx%dx%d  Cin %d Cout %d\n", TD, TH, TW, a.N, a.D, a.H, a.W, a.Cin, a.Cout);
         Conv3Rb<T, TD, TH, TW, KD>::launch(a, dim3((unsigned)nbox, a.Cout / 32), s);
         return;
     }
     dim3 grid((unsigned)nbox, a.Cout / (16 * nt));
-    static const int force_wl = getenv("SEG_CONV3_WL") ? atoi(getenv("SEG_CONV3_WL")) : -1;   // tuning knob
+    static const int force_wl = xknob_i("SEG_CONV3_WL", -1);   // tuning knob
     // LDS weight slab (one 16-channel output tile at a time over the resident halo) for every 16-bit tiling; the f32
     // halo is too large to share the LDS with it
     const bool wl = force_wl >= 0 ? (force_wl != 0 || nt == 1) : (nt == 1 || sizeof(T) == 2);
@@ -502,7 +502,7 @@ void conv3_dispatch(const Conv3Args& a, int ndim, hipStream_t s) {
 // C2 VNet2d 16 x 512^2 measures 6.45 ms per step with it against 6.66 with the narrow one; C4 / C5, 3-D: 4.43 / 4.45 against 4.56 / 4.68,
 // profiles/r04_configs_tile_ab.log).
 inline void wgrad3_tile(int P, int Q, int esz, int ndim, int* CP, int* CQ) {
-    static const int cq = getenv("SEG_W3_CQ") ? atoi(getenv("SEG_W3_CQ")) : 0;          // 0: by dimensionality
+    static const int cq = xknob_i("SEG_W3_CQ", 0);          // 0: by dimensionality
     const int want = cq ? cq : (ndim == 3 ? 16 : 32);
     *CP = P >= 32 ? 32 : 16;
     *CQ = (Q >= 32 && (want >= 32 || esz == 4)) ? 32 : 16;
@@ -882,7 +882,7 @@ void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long lon
 // drops from 2.8x to 2.1x (PMC round 3: 349 MB fetched for 226 MB algorithmic).  50.5 KB of LDS; 16-bit tensors only (an f32 box would need 127 KB).
 template <class T> struct Wgrad3Big16 {
     static bool launch(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
-        const char* env = getenv("SEG_W3_BOX16");          // 0: off; 1 (default): where the volume holds enough boxes; 2: wherever the shape fits (tests)
+        const char* env = knob_s("SEG_W3_BOX16");          // 0: off; 1 (default): where the volume holds enough boxes; 2: wherever the shape fits (tests)
         const int on = env ? atoi(env) : 1;
         int CP, CQ;
         wgrad3_tile(a0.P, a0.Q, 2, 3, &CP, &CQ);
@@ -1127,11 +1127,11 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Kpad = ((ndim == 3 ? 27 : 9) * Cin + 31) / 32 * 32;
-    static const int dbg = getenv("SEG_CONV3_DBG") ? atoi(getenv("SEG_CONV3_DBG")) : 0;
+    static const int dbg = xknob_i("SEG_CONV3_DBG", 0);
     a.dbg = dbg;
     a.trace = nullptr;
     // diagnostics (tools/bench_conv3.py): per-workgroup phase timeline of one launch, printed to stderr
-    static const int trace_on = getenv("SEG_CONV3_TRACE") ? atoi(getenv("SEG_CONV3_TRACE")) : 0;
+    static const int trace_on = xknob_i("SEG_CONV3_TRACE", 0);
     static unsigned long long* tbuf = nullptr;
     const size_t tmax = 1 << 18;
     if (trace_on) {
@@ -1179,15 +1179,15 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, 
     // One box, every BASELINE config (profiles/r03_wgrad_policy_configs_ab.log), total / total16 = 256/256, 512/1024, 256/1024, 512/256:
     // C3 4.15 / 4.20 / 4.18 / 4.15 ms, C4 4.58 / 4.55 / 4.43 / 4.68, C5 4.55 / 4.61 / 4.57 / 4.58, C2 (2-D) 6.65 / 6.40 / 6.68 / 6.37 -> the
     // 2-D boxes keep 512 workgroups
-    static const int total_env = getenv("SEG_W3_TOTAL") ? atoi(getenv("SEG_W3_TOTAL")) : 0;
+    static const int total_env = xknob_i("SEG_W3_TOTAL", 0);
     const int total = total_env > 0 ? total_env : (ndim == 3 ? 256 : 512);
-    static const int minbox = getenv("SEG_W3_MINBOX") ? atoi(getenv("SEG_W3_MINBOX")) : 6;
+    static const int minbox = xknob_i("SEG_W3_MINBOX", 6);
     // 16 -> 16 channels (the finest level): four workgroups fit a CU (23 KB LDS, 113 VGPRs) and the partial tile is 27 KB, so the
     // staging latency of one workgroup can hide behind the others
     // round 2 (no prefetch), standalone 4x96^3: 512 -> 168 us, 1024 -> 123 us, 2048 -> 137 us (r02_wgrad16_ab.log), step unchanged.  With the
     // prefetching kernel inside the step (profiles/r03_wgrad_policy_ab3.log): 128 -> 947, 256 -> 967 / 967, 384 -> 961, 1024 -> 956-958
     // volumes/s - one workgroup per CU leaves the bandwidth-bound 96^3 GroupNorm passes of the main stream the rest of the machine
-    static const int total16 = getenv("SEG_W3_TOTAL16") ? atoi(getenv("SEG_W3_TOTAL16")) : 256;
+    static const int total16 = xknob_i("SEG_W3_TOTAL16", 256);
     long long nb = (P == 16 && Q == 16 ? total16 : total) / combos;
     if (nb < 1) nb = 1;
     const long long nbox = boxes_for(ndim, N, D, H, W);
@@ -1211,11 +1211,12 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
                    int dtype, hipStream_t s, const void* x1, int C0, const float* xscale, const float* xshift, int qreal) {
     const int T = ndim == 3 ? 27 : 9;
     if (qreal <= 0 || qreal > Q) qreal = Q;
+#ifdef SEG_EXPERIMENTS
     // 16-bit tensors, opt-in (SEG_WGRAD3X=1, read per call): double-buffered kernel (wgrad3x.hip), same partial-tile layout and
     // reduce.  Measured on MI355X (profiles/r02_wgrad3x_ab.log): op-level 67 vs 67 us at 32ch@48^3, 62 vs 52 us at 64ch@24^3, train
     // step 689 vs 712 volumes/s - one box in flight per CU is still latency-bound and its 112 KB / 512-thread workgroups crowd the
     // main stream's kernels out of the CU, so wgrad3_kernel (three 44 KB workgroups per CU) stays the default.
-    const char* envx = getenv("SEG_WGRAD3X");
+    const char* envx = xenv("SEG_WGRAD3X");
     const bool use_x = envx && atoi(envx) != 0 && !xscale && qreal == Q;      // the double-buffered variant copies x straight into LDS: no activation on the way
     if (use_x && wgrad3x_supported(dtype, N, ndim == 3 ? D : 1, H, W, P, Q, C0, x1 != nullptr)) {
         int CP, CQ;
@@ -1223,8 +1224,8 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
         const int combos = (P / CP) * (Q / CQ);
         // one resident round of workgroups (one 512-thread workgroup per CU); at least `minbox` boxes per workgroup. The scratch
         // sized by wgrad3_partial_bytes (512 tiles of 32 x taps x 32) covers every choice below
-        static const int total = getenv("SEG_W3X_TOTAL") ? atoi(getenv("SEG_W3X_TOTAL")) : 256;
-        static const int minbox = getenv("SEG_W3X_MINBOX") ? atoi(getenv("SEG_W3X_MINBOX")) : 4;
+        static const int total = xknob_i("SEG_W3X_TOTAL", 256);
+        static const int minbox = xknob_i("SEG_W3X_MINBOX", 4);
         const long long nbox = boxes_for(ndim, N, D, H, W);
         long long nb = total / combos;
         if (nb > (nbox + minbox - 1) / minbox) nb = (nbox + minbox - 1) / minbox;
@@ -1239,6 +1240,7 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
                            (long long)Q * T, (long long)T, Q);
         return;
     }
+#endif
     Wgrad3Args a;
     a.x1 = x1; a.C0 = C0;
     a.dr = dr; a.x = x; a.partial = partial;

@@ -1,5 +1,6 @@
 // Host side of the register-blocked halo conv (kernel: conv3x_impl.h; instantiations: conv3x_<dtype>_<nd>.hip): the table of
 // tilings, the default choice per layer shape and the launch entry points declared in kernels.h.
+#include <vector>
 #include "conv3x_impl.h"
 
 namespace seg {
@@ -43,14 +44,18 @@ const Cfg kCfgs[] = {
     {48, 3, 4, 4, 12, 32, 4, "4x4x12 t4 2x2 waves 6x1 tiles, 26-deep B ring"},
     {49, 3, 2, 4, 12, 64, 4, "2x4x12 t4 1x4 waves 6x1 tiles (every wave its own weight columns)"},
     {50, 3, 2, 4, 12, 64, 4, "2x4x12 t4 1x4 waves 6x1 tiles, 26-deep B ring"},
+#ifdef SEG_EXPERIMENTS
     {18, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {19, 3, 2, 8, 8, 32, 1, "Cin32 persistent: 2x8x8 t8 4x1 waves 2x2 tiles, weights in LDS, double-buffered halo", 0, 1},
+#endif
     {24, 3, 2, 8, 16, 16, 1, "Cin16: 2x8x16 t16 4x1 waves 4x1 tiles", 1},
     {25, 3, 4, 8, 16, 16, 1, "Cin16: 4x8x16 t16 4x1 waves 8x1 tiles", 1},
     {26, 3, 2, 8, 16, 32, 1, "Cin16: 2x8x16 t16 4x1 waves 4x2 tiles", 1},
     {27, 3, 4, 8, 16, 32, 1, "Cin16: 4x8x16 t16 4x1 waves 8x2 tiles", 1},
+#ifdef SEG_EXPERIMENTS
     {28, 3, 2, 8, 16, 16, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x1 tiles, weights in LDS, double-buffered halo", 1},
     {29, 3, 2, 8, 16, 32, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 1},
+#endif
     // 2-D
     {32, 2, 1, 16, 16, 32, 1, "16x16 t16 4x1 waves 4x2 tiles"},
     {33, 2, 1, 16, 16, 64, 2, "16x16 t16 2x2 waves 8x2 tiles"},
@@ -60,10 +65,14 @@ const Cfg kCfgs[] = {
     {37, 2, 1, 16, 16, 16, 1, "16x16 t16 4x1 waves 4x1 tiles"},
     {38, 2, 1, 8, 8, 64, 4, "8x8 t8 2x2 waves 2x2 tiles, 4 resident chunks"},
     {39, 2, 1, 8, 16, 32, 2, "8x16 t16 4x1 waves 2x2 tiles, 2 resident chunks"},
+#ifdef SEG_EXPERIMENTS
     {40, 2, 1, 16, 16, 32, 1, "Cin32 persistent: 16x16 t16 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
+#endif
     {56, 2, 1, 16, 16, 16, 1, "Cin16: 16x16 t16 4x1 waves 4x1 tiles", 1},
     {57, 2, 1, 16, 16, 32, 1, "Cin16: 16x16 t16 4x1 waves 4x2 tiles", 1},
+#ifdef SEG_EXPERIMENTS
     {58, 2, 1, 16, 16, 16, 1, "Cin16 persistent: 16x16 t16 4x1 waves 4x1 tiles, weights in LDS, double-buffered halo", 1},
+#endif
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -92,17 +101,21 @@ bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, 
 }
 
 // the FUSE instantiations: one source tensor, 32-channel chunks, per-sample fold of <= 256 channels by 256 threads
+#ifdef SEG_EXPERIMENTS
 bool conv3x_gn_supported(int Cin, bool has_in1) { return !has_in1 && Cin % 32 == 0 && Cin <= 256 && 256 % Cin == 0; }
+#else
+bool conv3x_gn_supported(int, bool) { return false; }
+#endif
 
 // default tiling per problem.  Overrides: SEG_C3X_CFG=<id> (one tiling wherever it fits), SEG_C3X_MAP="cin:cout:w=id,..."
 // (per layer shape; tools/tune_conv3x.py prints the measured table).
 int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool has_in1) {
-    static const int force = getenv("SEG_C3X_CFG") ? atoi(getenv("SEG_C3X_CFG")) : -1;
+    static const int force = xknob_i("SEG_C3X_CFG", -1);
     if (force >= 0) {
         const Cfg* c = find_cfg(force);
         if (c && cfg_fits(*c, ndim, Cin, Cout) && !(c->cin32 && has_in1)) return force;
     }
-    static const char* map = getenv("SEG_C3X_MAP");
+    static const char* map = knob_s("SEG_C3X_MAP");
     if (map) {
         for (const char* p = map; *p;) {
             int ci = 0, co = 0, w = 0, id = -1;
@@ -186,16 +199,53 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
 #ifdef SEG_DIAG
     // diagnostic builds only (python tools/build_variant.py diag conv3x.hip -DSEG_DIAG; WRONG results): SEG_DIAG_NOSTATS=1 drops the GroupNorm
     // statistics epilogue, to time what it costs inside a step.  Not compiled into the product library.
-    static const bool nostats = getenv("SEG_DIAG_NOSTATS") && atoi(getenv("SEG_DIAG_NOSTATS"));
+    static const bool nostats = xknob_i("SEG_DIAG_NOSTATS", 0) != 0;
     if (nostats) a.stats = nullptr;
 #endif
     a.N = N; a.D = ndim == 3 ? D : 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    static const int remap = getenv("SEG_C3X_REMAP") ? atoi(getenv("SEG_C3X_REMAP")) : 1;      // XCD-aware box order (c3x_box_of_block)
+#ifdef SEG_C3X_TRACE
+    // diagnostic build only (python tools/build_variant.py c3xtrace conv3x.hip,conv3x_f16_3d.hip -DSEG_C3X_TRACE; tools/trace_conv3x.py): per-workgroup phase stamps,
+    // read back and summarised after every launch (synchronises the stream)
+    static unsigned long long* tbuf = nullptr;
+    const size_t tmax = 1 << 16;
+    if (!tbuf) (void)hipMalloc(&tbuf, tmax * 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(tbuf, 0, tmax * 8 * sizeof(unsigned long long), s);
+    a.trace = tbuf;
+    struct TraceDump {
+        unsigned long long* buf; size_t tmax; hipStream_t s; int cfg, N, D, H, W, Cin, Cout;
+        ~TraceDump() {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h(tmax * 8);
+            (void)hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            // phases between the stamps 0 -> 4 -> 5 -> 1 -> 2 -> 6 -> 7 -> 3 (a stamp that was not taken - no statistics - repeats its predecessor)
+            const int order[8] = {0, 4, 5, 1, 2, 6, 7, 3};
+            double ph[7] = {0, 0, 0, 0, 0, 0, 0}; size_t n = 0; unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t i = 0; i < tmax; ++i) {
+                unsigned long long r[8];
+                for (int k = 0; k < 8; ++k) r[k] = h[i * 8 + order[k]];
+                if (!r[0] || !r[7]) continue;
+                for (int k = 1; k < 8; ++k) if (!r[k]) r[k] = r[k - 1];
+                ++n;
+                for (int k = 0; k < 7; ++k) ph[k] += (double)(r[k + 1] - r[k]);
+                t0 = r[0] < t0 ? r[0] : t0; t1 = r[7] > t1 ? r[7] : t1;
+            }
+            // wall_clock64 ticks at 100 MHz
+            if (n) {
+                double life = 0; for (int k = 0; k < 7; ++k) life += ph[k];
+                fprintf(stderr, "[conv3x trace] cfg %d  %dx%dx%dx%d Cin %d Cout %d  workgroups %zu  first start -> last end %.2f us | mean per workgroup (us): issue copies %.2f  copies land %.2f  "
+                                "barrier %.2f  taps %.2f  bias+convert+store %.2f  statistics butterfly %.2f  barrier+atomics %.2f  life %.2f\n",
+                        cfg, N, D, H, W, Cin, Cout, n, (t1 - t0) * 0.01, ph[0] / n * 0.01, ph[1] / n * 0.01, ph[2] / n * 0.01, ph[3] / n * 0.01, ph[4] / n * 0.01, ph[5] / n * 0.01,
+                        ph[6] / n * 0.01, life / n * 0.01);
+            }
+        }
+    } dump{tbuf, tmax, s, cfg, N, a.D, H, W, Cin, Cout};
+#endif
+    static const int remap = xknob_i("SEG_C3X_REMAP", 1);      // XCD-aware box order (c3x_box_of_block)
     a.remap = remap;
 #ifdef SEG_DIAG
     // diagnostic builds only (tools/trace_gaps.py): SEG_C3X_TWICE=1 launches every conv twice without statistics first, so a kernel trace shows
     // the same launch with cold and with warm operands
-    static const bool twice = getenv("SEG_C3X_TWICE") && atoi(getenv("SEG_C3X_TWICE"));
+    static const bool twice = xknob_i("SEG_C3X_TWICE", 0) != 0;
     if (twice) {
         Conv3xArgs w = a; w.stats = nullptr;
         if (ndim == 3) { if (dtype == DT_F16) c3x::launch_3d<f16>(cfg, w, s); else c3x::launch_3d<bf16>(cfg, w, s); }
@@ -203,8 +253,12 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
     }
 #endif
     if (a.fuse) {
+#ifdef SEG_EXPERIMENTS      // the FUSE instantiations (conv3x_*_gn.hip: GroupNorm applied by the consumer, bit-exact and 2.3 % slower) are not in the product library
         if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d_gn<f16>(cfg, a, s) : c3x::launch_3d_gn<bf16>(cfg, a, s);
         return dtype == DT_F16 ? c3x::launch_2d_gn<f16>(cfg, a, s) : c3x::launch_2d_gn<bf16>(cfg, a, s);
+#else
+        return false;
+#endif
     }
     if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d<f16>(cfg, a, s) : c3x::launch_3d<bf16>(cfg, a, s);
     return dtype == DT_F16 ? c3x::launch_2d<f16>(cfg, a, s) : c3x::launch_2d<bf16>(cfg, a, s);

@@ -60,7 +60,16 @@ struct Conv3xArgs {
     // relu(scale * x + shift); padding voxels stay zero.  The activated tensor is never written to HBM (the gn_act launch is gone).
     int fuse; GnFinArgs gn;
     ForkSig sig;                                  // a flag fork carried by this launch (its first thread stores the number)
+#ifdef SEG_C3X_TRACE
+    unsigned long long* trace;                    // diagnostic build (tools/trace_conv3x.py): 8 wall_clock64 stamps per workgroup - 0 start, 4 copies issued, 5 copies landed,
+                                                  // 1 barrier passed, 2 tap loops done, 6 tile stored, 7 statistics folded per wave, 3 end
+#endif
 };
+#ifdef SEG_C3X_TRACE
+#define SEG_C3XT(k) do { if (a.trace && threadIdx.x == 0) a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define SEG_C3XT(k)
+#endif
 
 // Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md), each with its own L2.  With the
 // natural order the x / y / z neighbours of a box - which share most of its halo - sit on other XCDs and every halo is fetched
@@ -133,6 +142,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
                 if (ok) *(vec<T, 4>*)(row + j * 16 + 4 * q) = o4[j];
         }
     }
+    SEG_C3XT(6);
     if (a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -143,6 +153,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
                 for (int msk = 1; msk < 16; msk <<= 1) { u += __shfl_xor(u, msk); v += __shfl_xor(v, msk); }
                 if (l15 == 0) { const int col = (wn * TN + j) * 16 + 4 * q + r; red[(wm * BN + col) * 2] = u; red[(wm * BN + col) * 2 + 1] = v; }
             }
+        SEG_C3XT(7);
         __syncthreads();
         if (tid < BN) {
             double ts = 0.0, tss = 0.0;
@@ -158,6 +169,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
 template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC, bool FUSE>
 __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
+    SEG_C3XT(0);
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     __shared__ double gn_part[FUSE ? 256 : 1][2];
     __shared__ __attribute__((aligned(16))) float gn_coef[2][FUSE ? 256 : 8];
@@ -279,7 +291,9 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
             for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, wg + s * wstep);
         if (FUSE && g0 == 0)      // the producer's statistics -> scale / shift of this sample, while the first copies are in flight
             gn_fold_block(a.gn, n, x0 == 0 && y0 == 0 && z0 == 0 && blockIdx.y == 0, gn_part, gn_coef[0], gn_coef[1]);
+        if (g0 == 0) SEG_C3XT(4);
         wait_vmem();
+        if (g0 == 0) SEG_C3XT(5);
         if (FUSE) {
             // each lane activates the pieces it copied itself (lane-linear image: no other lane touches them before the barrier)
 #pragma unroll
@@ -303,6 +317,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
             }
         }
         __syncthreads();
+        if (g0 == 0) SEG_C3XT(1);
         unsigned wo = wg + PF * wstep;                     // byte offset of the step being prefetched
         for (int b = 0; b < nres; ++b) {
             // Software pipeline, written out: while the MFMAs of tap t run, the A fragments of tap t + 1 travel from LDS and
@@ -334,7 +349,9 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
             }
         }
     }
+    SEG_C3XT(2);
     c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0);      // no barrier: nothing of the halo buffer is reused
+    SEG_C3XT(3);
 }
 
 
@@ -346,6 +363,7 @@ void launch_cfg(const Conv3xArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x_kernel<T, B, TM, TN, WM, WN, NRES, PF, OCC, FUSE>), grid, dim3(256), 0, s, a);
 }
 
+#ifdef SEG_EXPERIMENTS      // persistent halo convs (round 3): measured slower than conv3x_kernel standalone and in the step (profiles/r03_persistent_conv_ab.log)
 // ------------------------------------------------------------------------------------------------
 // Cin == 32, 32 output channels per workgroup: PERSISTENT workgroups with LDS-RESIDENT weights and a DOUBLE-BUFFERED halo
 // (the 48^3 x 32-channel LUConv level of VNet3d, networks/VNet3d.py:117-125 down_tr32 / up_tr64: 8 launches per train step).
@@ -477,13 +495,15 @@ template <class T, class B, int TM, int TN>
 void launch_cfgp(const Conv3xArgs& a, hipStream_t s) {
     const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
     // one workgroup per CU of the 256; fewer when there are fewer boxes (grid.x a multiple of 8: workgroups per XCD x 8 XCDs)
-    static const int wgs = getenv("SEG_C3P_WGS") ? atoi(getenv("SEG_C3P_WGS")) : 256;
+    static const int wgs = xknob_i("SEG_C3P_WGS", 256);
     long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
     const long long per = (nbox + 7) / 8;
     if (per_xcd > per) per_xcd = per;
     dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3p_kernel<T, B, TM, TN>), grid, dim3(256), 0, s, a);
 }
+
+#endif  // SEG_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Cin == 16 (the full-resolution LUConv / _block layers: networks/VNet3d.py:117-125 up_tr32.ops, networks/Unet3d.py enc1 / dec1).
@@ -597,6 +617,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
     c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0);
 }
 
+#ifdef SEG_EXPERIMENTS
 // The same persistent scheme for Cin == 16 (conv3x16_kernel's two-taps-per-step arithmetic): the [14 steps][TN][64][8] weight slab (14 / 28 KB)
 // lives in LDS, the 25 KB halo is double-buffered, two workgroups per CU.  These launches are HBM-bound (226 MB at 4 x 96^3):
 // what the double buffer buys is that the copy of box i + 1 streams while box i is multiplied and written back.
@@ -723,13 +744,15 @@ __global__ __launch_bounds__(256, 2) void conv3p16_kernel(Conv3xArgs a) {
 template <class T, class B, int TM, int TN>
 void launch_cfgp16(const Conv3xArgs& a, hipStream_t s) {
     const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
-    static const int wgs = getenv("SEG_C3P16_WGS") ? atoi(getenv("SEG_C3P16_WGS")) : 512;      // two workgroups per CU
+    static const int wgs = xknob_i("SEG_C3P16_WGS", 512);      // two workgroups per CU
     long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
     const long long per = (nbox + 7) / 8;
     if (per_xcd > per) per_xcd = per;
     dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3p16_kernel<T, B, TM, TN>), grid, dim3(256), 0, s, a);
 }
+
+#endif  // SEG_EXPERIMENTS
 
 template <class T, class B, int TM, int TN, int PF, int OCC>
 void launch_cfg16(const Conv3xArgs& a, hipStream_t s) {
@@ -777,16 +800,24 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 49: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 8, 1, FUSE>(a, s); return true;                    \
         case 50: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 26, 1, FUSE>(a, s); return true;
 /* Cin == 32 persistent tilings (conv3p_kernel):   box                  TM TN */
+#ifdef SEG_EXPERIMENTS
 #define SEG_C3X_3D_P_CASES                                                                                            \
         case 18: launch_cfgp<T, XBox<4, 8, 8, 3, 8>, 4, 2>(a, s); return true;                                       \
-        case 19: launch_cfgp<T, XBox<2, 8, 8, 3, 8>, 2, 2>(a, s); return true;
+        case 19: launch_cfgp<T, XBox<2, 8, 8, 3, 8>, 2, 2>(a, s); return true;                                       \
+        case 28: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 1>(a, s); return true;                                    \
+        case 29: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 2>(a, s); return true;
+#define SEG_C3X_2D_P_CASES                                                                                            \
+        case 40: launch_cfgp<T, XBox<1, 16, 16, 1, 16>, 4, 2>(a, s); return true;                                    \
+        case 58: launch_cfgp16<T, XBox<1, 16, 16, 1, 16>, 4, 1>(a, s); return true;
+#else
+#define SEG_C3X_3D_P_CASES
+#define SEG_C3X_2D_P_CASES
+#endif
 #define SEG_C3X_3D_C16_CASES                                                                                          \
         case 24: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2, 4>(a, s); return true;                               \
         case 25: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2, 3>(a, s); return true;                               \
         case 26: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 2, 2, 3>(a, s); return true;                               \
-        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;                               \
-        case 28: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 1>(a, s); return true;                                    \
-        case 29: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 2>(a, s); return true;
+        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;
 #define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_P_CASES SEG_C3X_3D_C16_CASES default: return false; }
 #define SEG_C3X_3D_GN_BODY switch (id) { SEG_C3X_3D_CONV_CASES default: return false; }
 
@@ -800,12 +831,9 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 37: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 1, 4, 1, 1, 8, 3, FUSE>(a, s); return true;                 \
         case 38: launch_cfg<T, XBox<1, 8, 8, 1, 8>, 2, 2, 2, 2, 4, 8, 2, FUSE>(a, s); return true;                    \
         case 39: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 2, 2, 4, 1, 2, 8, 2, FUSE>(a, s); return true;
-#define SEG_C3X_2D_P_CASES                                                                                            \
-        case 40: launch_cfgp<T, XBox<1, 16, 16, 1, 16>, 4, 2>(a, s); return true;
 #define SEG_C3X_2D_C16_CASES                                                                                          \
         case 56: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 1, 2, 4>(a, s); return true;                              \
-        case 57: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 2, 2, 4>(a, s); return true;                              \
-        case 58: launch_cfgp16<T, XBox<1, 16, 16, 1, 16>, 4, 1>(a, s); return true;
+        case 57: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 2, 2, 4>(a, s); return true;
 #define SEG_C3X_2D_BODY switch (id) { SEG_C3X_2D_CONV_CASES SEG_C3X_2D_P_CASES SEG_C3X_2D_C16_CASES default: return false; }
 #define SEG_C3X_2D_GN_BODY switch (id) { SEG_C3X_2D_CONV_CASES default: return false; }
 

@@ -27,25 +27,28 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->kind = net_kind; e->ndim = ndim; e->in_ch = in_channels; e->ncls = num_class; e->feat = init_features; e->dtype = dtype;
     e->pad_img = in_channels > 3 || (ndim == 3 && in_channels > 1);
     e->loss_scale = dtype == DT_F16 ? 16384.f : 1.f;
-    e->use_side = !(getenv("SEG_WGRAD_STREAM") && atoi(getenv("SEG_WGRAD_STREAM")) == 0);
-    if (getenv("SEG_CONV3X")) e->use_conv3x = atoi(getenv("SEG_CONV3X")) != 0;
-    if (getenv("SEG_STEMX")) e->use_stemx = atoi(getenv("SEG_STEMX")) != 0;
-    if (getenv("SEG_PACK_SPLIT")) e->pack_split = atoi(getenv("SEG_PACK_SPLIT")) != 0;
-    if (getenv("SEG_GN_VACT")) e->use_vact = atoi(getenv("SEG_GN_VACT")) != 0;
-    if (getenv("SEG_GN_FOLD")) e->use_fold = atoi(getenv("SEG_GN_FOLD")) != 0;
-    if (getenv("SEG_VHEAD")) e->use_vhead = atoi(getenv("SEG_VHEAD")) != 0;
-    if (getenv("SEG_TAIL_WGRADS")) e->tail_wgrads = atoi(getenv("SEG_TAIL_WGRADS"));
-    if (getenv("SEG_FORK_HEAVY_MB")) e->fork_heavy_bytes = atof(getenv("SEG_FORK_HEAVY_MB")) * 1e6;
-    if (getenv("SEG_FLUSH_LATE")) e->flush_late = atoi(getenv("SEG_FLUSH_LATE")) != 0;
-    if (getenv("SEG_HOLD_HEAVY_LVL")) e->hold_lvl = atoi(getenv("SEG_HOLD_HEAVY_LVL"));
-    if (getenv("SEG_HOLD_HEAVY_MB")) e->hold_bytes = atof(getenv("SEG_HOLD_HEAVY_MB")) * 1e6;
-    if (getenv("SEG_DUAL_GN")) e->dual_gn_bwd = atoi(getenv("SEG_DUAL_GN")) != 0;
-    if (getenv("SEG_STEM_MAIN")) e->stem_on_main = atoi(getenv("SEG_STEM_MAIN")) != 0;
-    if (getenv("SEG_SIDE_PRIO")) e->side_prio = atoi(getenv("SEG_SIDE_PRIO"));
-    if (getenv("SEG_WGRAD_STREAMS")) e->n_side = atoi(getenv("SEG_WGRAD_STREAMS")) >= 2 ? 2 : 1;
-    if (getenv("SEG_FORK_BATCH") && atoi(getenv("SEG_FORK_BATCH")) > 0) e->fork_batch = atoi(getenv("SEG_FORK_BATCH"));
-    if (getenv("SEG_SUB_MB")) e->sub_mb = atof(getenv("SEG_SUB_MB"));
-    if (getenv("SEG_SUB_LVL")) e->sub_lvl = atoi(getenv("SEG_SUB_LVL"));
+    // product switches (documented in include/segengine.h; each selects a complete, tested path of the library)
+    e->use_side = knob_i("SEG_WGRAD_STREAM", 1) != 0;
+    e->use_conv3x = knob_i("SEG_CONV3X", e->use_conv3x) != 0;
+    e->use_stemx = knob_i("SEG_STEMX", e->use_stemx) != 0;
+    e->pack_split = knob_i("SEG_PACK_SPLIT", e->pack_split) != 0;
+    e->use_fold = knob_i("SEG_GN_FOLD", e->use_fold) != 0;
+    e->use_vhead = knob_i("SEG_VHEAD", e->use_vhead) != 0;
+    e->dual_gn_bwd = knob_i("SEG_DUAL_GN", e->dual_gn_bwd) != 0;
+    // experiment knobs: their defaults in the product library, environment variables only in a -DSEG_EXPERIMENTS build (profiles/HISTORY.md says what
+    // each one measured)
+    e->use_vact = xknob_i("SEG_GN_VACT", e->use_vact) != 0;
+    e->tail_wgrads = xknob_i("SEG_TAIL_WGRADS", e->tail_wgrads);
+    e->fork_heavy_bytes = xknob_f("SEG_FORK_HEAVY_MB", e->fork_heavy_bytes / 1e6) * 1e6;
+    e->flush_late = xknob_i("SEG_FLUSH_LATE", e->flush_late) != 0;
+    e->hold_lvl = xknob_i("SEG_HOLD_HEAVY_LVL", e->hold_lvl);
+    e->hold_bytes = xknob_f("SEG_HOLD_HEAVY_MB", e->hold_bytes / 1e6) * 1e6;
+    e->stem_on_main = xknob_i("SEG_STEM_MAIN", e->stem_on_main) != 0;
+    e->side_prio = xknob_i("SEG_SIDE_PRIO", e->side_prio);
+    e->n_side = xknob_i("SEG_WGRAD_STREAMS", 1) >= 2 ? 2 : 1;
+    if (xknob_i("SEG_FORK_BATCH", 0) > 0) e->fork_batch = xknob_i("SEG_FORK_BATCH", 0);
+    e->sub_mb = xknob_f("SEG_SUB_MB", e->sub_mb);
+    e->sub_lvl = xknob_i("SEG_SUB_LVL", e->sub_lvl);
     build_network(*e, net_kind);
     *out = e;
     return 0;
@@ -297,8 +300,7 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
     if (!a->packed && seg_pack_weights(h, stream)) return -1;
     // Serial section at the step boundary (profiles/r04_trace_timeline.txt: fill, overflow check, Adam, counter, re-pack, masks, counter, fill,
     // ingest - nothing overlaps them): the one-wave bookkeeping launches ride on their neighbours.  SEG_STEP_RIDERS=0: separate launches.
-    const char* riders_e = getenv("SEG_STEP_RIDERS");
-    const bool riders_env = !(riders_e && atoi(riders_e) == 0);
+    const bool riders_env = knob_i("SEG_STEP_RIDERS", 1) != 0;
     const bool riders = riders_env && h->sub_nb == 0;
     const long long v = h->vol(0);
     struct RideGuard { seg_engine* e; ~RideGuard() { e->ride_on = false; e->ride_zero = nullptr; } } ride_guard{h};      // every way out of the step
@@ -457,7 +459,11 @@ const char* seg_last_error(void) { return g_err.c_str(); }
 
 const char* seg_build_info(void) {
 #ifdef SEG_EMU
+#ifdef SEG_EXPERIMENTS
+    return "segengine host-checker build (tests only) +experiments";
+#else
     return "segengine host-checker build (tests only)";
+#endif
 #else
 #ifdef SEG_BUILD_ID
     return "segengine gfx950 " SEG_BUILD_ID;          // build.py: sha256 over the sources + flags (which binary a profile was taken from)

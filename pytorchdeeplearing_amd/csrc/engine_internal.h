@@ -245,10 +245,12 @@ struct seg_engine {
     bool flag_forks() {
         if (fork_mode < 0) {
             fork_mode = 0;
-            const char* e = getenv("SEG_FORK");
+            const char* e = xenv("SEG_FORK");
             const bool want = e && !strcmp(e, "flag");                // opt-in (see above)
             int can = 0;
-            if (want && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0) == hipSuccess && can) {
+            int devid = 0;
+            (void)hipGetDevice(&devid);                                // the CURRENT device, not device 0
+            if (want && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, devid) == hipSuccess && can) {
                 if (hipExtMallocWithFlags((void**)&fork_flag, 8, hipMallocSignalMemory) == hipSuccess && fork_flag) {
                     launch_fork_signal(fork_flag, 0u, nullptr);
                     fork_mode = hipDeviceSynchronize() == hipSuccess ? 1 : 0;

@@ -397,7 +397,7 @@ struct Planner {
         // ---- virtual activations: an ACT (one branch, no residual) whose output feeds exactly ONE 3^d conv that runs on conv3x is
         // never written: the consumer applies relu(scale * raw + shift) while it stages its halo, and so does the consumer's weight
         // gradient (LUConv chains of networks/VNet3d.py:5-23, the two convs of networks/Unet3d.py:64-86 _block)
-        if (E.use_vact && dt != DT_F32 && !(getenv("SEG_WGRAD3X") && atoi(getenv("SEG_WGRAD3X")) != 0))
+        if (E.use_vact && dt != DT_F32 && !(xknob_i("SEG_WGRAD3X", 0) != 0))
             for (size_t ai = 0; ai < E.steps.size(); ++ai) {
                 Step& act = E.steps[ai];
                 if (act.type != ST_ACT || act.ub >= 0 || act.res >= 0) continue;

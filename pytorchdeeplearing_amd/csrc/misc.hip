@@ -731,7 +731,7 @@ void launch_pack(const PackDesc* descs_dev, int ndesc, int max_elems, int dtype,
     (void)max_elems;
     // rows are strided over `wgs` workgroups per descriptor.  The 256-channel levels hold most of the bytes in descriptors of 256
     // rows: at 64 workgroups each one walked four 27 KB rows back to back (67 us per step, latency-bound)
-    static const int wgs = getenv("SEG_PACK_WGS") ? atoi(getenv("SEG_PACK_WGS")) : 256;
+    static const int wgs = xknob_i("SEG_PACK_WGS", 256);
     dim3 grid(wgs, ndesc);
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<float>), grid, dim3(256), 0, s, descs_dev, rd);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<f16>), grid, dim3(256), 0, s, descs_dev, rd);

@@ -682,7 +682,7 @@ void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
     int bx = ew_blocks(a.V * (a.C / 8));
     if (a.fold) {
         // every workgroup repeats the fold: fewer, longer-running workgroups on the big levels
-        static const int cap = getenv("SEG_FOLD_WGS") ? atoi(getenv("SEG_FOLD_WGS")) : 2048;
+        static const int cap = xknob_i("SEG_FOLD_WGS", 2048);
         const int per_n = cap / a.N > 0 ? cap / a.N : 1;
         if (bx > per_n) bx = per_n;
     }
@@ -703,7 +703,7 @@ void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
     long long rows = ((long long)a.N * a.V + 2047) / 2048;
     rows = (rows + G - 1) / G * G;
     if (rows < 2 * G) rows = 2 * G;
-    static const int max_rows = getenv("SEG_GNB_MAXROWS") ? atoi(getenv("SEG_GNB_MAXROWS")) : 1024;   // measured: 256 -> 686, 512 -> 688, 1024..4096 -> 690.5 volumes/s
+    static const int max_rows = xknob_i("SEG_GNB_MAXROWS", 1024);   // measured: 256 -> 686, 512 -> 688, 1024..4096 -> 690.5 volumes/s
     if (rows > max_rows) rows = max_rows / G * G;
     const int GNB_ROWS = (int)rows;
     dim3 grid(cdiv(a.V, GNB_ROWS), a.N);
@@ -746,7 +746,7 @@ void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s, const GnB
     int bx = ew_blocks(a.V * (a.C / 8));
     const bool fold = fa != nullptr;
     if (fold) {
-        static const int cap = getenv("SEG_FOLD_WGS") ? atoi(getenv("SEG_FOLD_WGS")) : 2048;
+        static const int cap = xknob_i("SEG_FOLD_WGS", 2048);
         const int per_n = cap / a.N > 0 ? cap / a.N : 1;
         if (bx > per_n) bx = per_n;
     }

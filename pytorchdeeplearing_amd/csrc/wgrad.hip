@@ -401,8 +401,8 @@ WgPlan make_plan(const WgradArgs& a) {
     pl.ntg = (T + pl.TB - 1) / pl.TB;
     const int bx = pl.ntg * pl.ntile;
     // voxel-axis split: ~2048 workgroups in total, at most 1024 slices and 16 MB of partial tiles
-    static const long long total = getenv("SEG_WG_TOTAL") ? atoll(getenv("SEG_WG_TOTAL")) : 2048;        // tuning knobs
-    static const long long pcap = getenv("SEG_WG_CAP") ? atoll(getenv("SEG_WG_CAP")) : (4ll << 20);
+    static const long long total = xknob_ll("SEG_WG_TOTAL", 2048);        // tuning knobs
+    static const long long pcap = xknob_ll("SEG_WG_CAP", (4ll << 20));
     long long parts = total / bx;
     if (parts < 1) parts = 1;
     if (parts > 1024) parts = 1024;
@@ -425,7 +425,7 @@ template <class T>
 void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s, int qreal) {
     const WgPlan pl = make_plan(a);
     dim3 grid(pl.ntg * pl.ntile, pl.parts);
-    static const bool direct_on = !(getenv("SEG_WG_DIRECT") && atoi(getenv("SEG_WG_DIRECT")) == 0);       // A/B switch
+    static const bool direct_on = (knob_i("SEG_WG_DIRECT", 1) != 0);       // A/B switch
     bool done = false;
     if constexpr (sizeof(T) == 2) {
         if (direct_on && !a.stem && pl.TB == 1 && pl.direct && pl.ntg == 1 && a.C0 % 8 == 0) {

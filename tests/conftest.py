@@ -31,9 +31,24 @@ def emu_library():
         sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
         import build_emu
         from pytorchdeeplearing_amd import _capi
-        _emu_lib = _capi.SegLib(build_emu.build())
+        # SEG_TEST_EXPERIMENTS=1: the -DSEG_EXPERIMENTS twin of the checker (the measured-slower paths of rounds 2-4 and every tuning knob);
+        # the default is the product's source list and flags
+        _emu_lib = _capi.SegLib(build_emu.build(experiments=EXPERIMENTS))
         _capi.inject_library(_emu_lib)
     return _emu_lib
+
+
+EXPERIMENTS = bool(os.environ.get("SEG_TEST_EXPERIMENTS"))
+PERSISTENT_CFGS = (18, 19, 28, 29, 40, 58)          # conv3p / conv3p16 tilings: experiments build only
+
+
+def needs_experiments(dev):
+    """Tests of paths that are not in the product library (wgrad3x, GroupNorm in the consumer conv, persistent halo convs, flag forks, sub-batched levels,
+    two weight-gradient streams): they run against the experiments build only - SEG_TEST_EXPERIMENTS=1 on the host checker, and on the GPU additionally
+    SEGENGINE_LIB=pytorchdeeplearing_amd/lib/libsegengine_exp.so (python -m pytorchdeeplearing_amd.build --experiments)."""
+    from pytorchdeeplearing_amd import _capi
+    if "+experiments" not in _capi.lib_for(dev).build_info():
+        pytest.skip("experiments build only (SEG_TEST_EXPERIMENTS=1; on the GPU also SEGENGINE_LIB=.../libsegengine_exp.so)")
 
 
 @pytest.fixture(params=[pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)])

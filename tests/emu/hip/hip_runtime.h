@@ -65,6 +65,7 @@ constexpr unsigned hipStreamNonBlocking = 1;
 constexpr unsigned hipEventDisableTiming = 2;
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

@@ -389,6 +389,7 @@ def test_virtual_activation_equals_materialised(dev, tag, dtype, monkeypatch):
     (Step::vact_prod, conv3x FUSE instantiations; reference chain networks/VNet3d.py:13-15).  Same arithmetic on the same values:
     logits, loss and every gradient must equal the materialised path (SEG_GN_VACT=0) - bit for bit on the sequential host checker, to
     rounding on the GPU (the statistics are accumulated with fp64 atomics whose order varies from launch to launch)."""
+    conftest.needs_experiments(dev)          # not in the product library (profiles/HISTORY.md): runs against the -DSEG_EXPERIMENTS build
     if tag != "vnet2d":       # one 2-D case keeps the fused path on the host checker (~1 min); the 3-D twins take 3-4 min each there
         conftest.checker_slow(dev, "two 3-D forward+backward passes on the host checker")
     res = []
@@ -439,6 +440,7 @@ def test_sub_batched_finest_level_equals_whole_batch_launches(dev, tag, dtype, m
     must equal the whole-batch launches: bit for bit on the sequential host checker for logits / loss (each statistic is one sample's sum in both
     modes), to accumulation order for the parameter gradients (the per-group launches add their gamma / beta / bias / head partial sums one after
     the other).  `mb` picks one- or two-sample groups for the case's volume."""
+    conftest.needs_experiments(dev)          # not in the product library (profiles/HISTORY.md): runs against the -DSEG_EXPERIMENTS build
     if dtype != "f32":
         conftest.checker_slow(dev, "four 16-bit forward+backward passes on the host checker (the f32 cases run there)")
     res, groups = [], []
@@ -468,6 +470,7 @@ def test_flag_forks_equal_event_forks(dev, tag, dtype, monkeypatch):
     launches, same data: the gradients equal the event-fork engine's (SEG_FORK=event).  Bookkeeping checked on both boxes: every released
     batch got its number stored (nothing is left waiting: a forgotten store would hang the weight-gradient queue), most of them by the next
     kernel itself; the host checker also reads the flag word."""
+    conftest.needs_experiments(dev)          # not in the product library (profiles/HISTORY.md): runs against the -DSEG_EXPERIMENTS build
     if tag in ("vnet3d_48", "unet3d_32"):
         conftest.checker_slow(dev, "four 3-D 16-bit forward+backward passes on the host checker")
     res, counts = [], []

@@ -255,6 +255,8 @@ def test_conv3_halo_exact(dev, dtype, case):
 def wgrad3_impl(request, monkeypatch):
     """both halo weight-gradient kernels: wgrad3_kernel (default) and the double-buffered 16-bit wgrad3x_kernel (SEG_WGRAD3X=1)"""
     monkeypatch.setenv("SEG_WGRAD3X", "1" if request.param == "wgrad3x_kernel" else "0")
+    if request.param == "wgrad3x_kernel" and not conftest.EXPERIMENTS:
+        pytest.skip("wgrad3x_kernel (measured slower inside the step, round 2) is in the experiments build only (SEG_TEST_EXPERIMENTS=1)")
     return request.param
 
 

@@ -1,4 +1,7 @@
-"""Intra-GPU batch lanes.
+"""EXPERIMENT, not part of the package (moved out of pytorchdeeplearing_amd/ in round 5): measured 15-50 % slower than one engine on MI355X
+(7.6 / 10 ms vs 6.6 ms per step with 2 / 4 lanes, round 1) - the small kernels of the lanes contend for the same CUs.
+
+Intra-GPU batch lanes.
 
 GroupNorm statistics and channel-dropout masks are per sample, so the network forward/backward of
 disjoint batch slices are independent.  At 4 x 96^3 the 48^3 ... 6^3 levels launch kernels that cannot
@@ -13,8 +16,8 @@ import ctypes as C
 
 import torch
 
-from . import _capi
-from .engine import SegEngine, aligned_empty, _ptr
+from pytorchdeeplearing_amd import _capi
+from pytorchdeeplearing_amd.engine import SegEngine, aligned_empty, _ptr
 
 
 class LaneEngine:

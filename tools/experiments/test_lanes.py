@@ -1,4 +1,6 @@
-"""Intra-GPU batch lanes (pytorchdeeplearing_amd/lanes.py): splitting the batch into independent
+"""EXPERIMENT (not part of the package or of the `tests/` suite; run with `python -m pytest tools/experiments/test_lanes.py -m gpu -p conftest --rootdir tests`
+or simply with tests/ on PYTHONPATH).  Round 1 measured batch lanes 15-50 % SLOWER than one engine (7.6 / 10 ms vs 6.6 ms per step, DESIGN history):
+Intra-GPU batch lanes (tools/experiments/lanes.py): splitting the batch into independent
 lanes with shared parameters, a full-batch loss and summed gradients is the SAME optimisation step as
 one engine at the full batch size."""
 import pytest
@@ -6,7 +8,11 @@ import torch
 
 from oracle import seg_oracle as seg
 from pytorchdeeplearing_amd import SegEngine, _capi
-from pytorchdeeplearing_amd.lanes import LaneEngine
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+from conftest import dev  # noqa: F401,E402  (the fixture)
+from lanes import LaneEngine  # noqa: E402
 
 
 @pytest.mark.parametrize("kind,ndim,shape,ncls,loss", [("vnet", 2, (4, 1, 16, 16), 1, "BinaryDiceLoss"),
