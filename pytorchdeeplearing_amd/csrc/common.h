@@ -102,6 +102,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15); every lane receives its row's total.  Four v_add_f32 with a DPP operand (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror) instead of four ds_bpermute round trips through the LDS crossbar (~120 clk each, and hipcc puts an s_waitcnt behind every one:
+// the 64 bpermutes of the conv3x statistics epilogue were 2.05 us of a 10.9 us workgroup, profiles/r05_conv3x_phase_trace_before.log).  The pairs that are added
+// are the ones a butterfly over masks 1, 2, 4, 8 adds (a + b == b + a), so the result is bit-identical to it.
+#ifndef SEG_EMU
+template <int CTRL> __device__ __forceinline__ float dpp_take(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_take<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+    v += dpp_take<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+    v += dpp_take<0x141>(v);      // row_half_mirror
+    v += dpp_take<0x140>(v);      // row_mirror
+    return v;
+}
+#else
+__device__ __forceinline__ float row_sum16(float v) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+#endif
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

@@ -90,8 +90,11 @@ __device__ __forceinline__ int c3x_box_of_block(int b, int nbox, int remap) {
 // tile to LDS with 2-byte stores, synchronised and read it back; every barrier in this epilogue is worth ~1-2 us per workgroup round,
 // profiles/r03_graph_stats_ab.log).  GroupNorm statistics: per-lane sums over the TM voxels of its 4 x TN channels (values as stored), a
 // butterfly over the 16 voxel lanes, one LDS slot per wave (`red`: WM * BN * 2 floats, its own array), one barrier, fp64 atomics.
+// bias_lds: the BN bias values of this workgroup's output channels, staged in LDS by the caller during its prologue (or null: read from global memory here - eight
+// dependent L2 round trips in front of the first store)
 template <class T, class B, int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, const Conv3xArgs& a, int n, int x0, int y0, int z0, int co0) {
+__device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, const Conv3xArgs& a, int n, int x0, int y0, int z0, int co0,
+                                             const float* bias_lds = nullptr) {
     constexpr int BN = WN * TN * 16;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int wm = wv % WM, wn = wv / WM;
@@ -101,7 +104,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            bs[j][r] = a.bias ? a.bias[co0 + (wn * TN + j) * 16 + 4 * q + r] : 0.f;
+            bs[j][r] = bias_lds ? bias_lds[(wn * TN + j) * 16 + 4 * q + r] : (a.bias ? a.bias[co0 + (wn * TN + j) * 16 + 4 * q + r] : 0.f);
             cs[j][r] = 0.f; css[j][r] = 0.f;
         }
     const bool odd = q & 1;
@@ -148,9 +151,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float u = cs[j][r], v = css[j][r];
-#pragma unroll
-                for (int msk = 1; msk < 16; msk <<= 1) { u += __shfl_xor(u, msk); v += __shfl_xor(v, msk); }
+                const float u = row_sum16(cs[j][r]), v = row_sum16(css[j][r]);      // over the 16 voxel lanes of this (q, r) channel
                 if (l15 == 0) { const int col = (wn * TN + j) * 16 + 4 * q + r; red[(wm * BN + col) * 2] = u; red[(wm * BN + col) * 2 + 1] = v; }
             }
         SEG_C3XT(7);
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     // resident chunk images; the epilogue stores straight from the accumulators and only needs the small statistics exchange array
     __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
     __shared__ float red_s[WM * BN * 2];
+    __shared__ float bias_s[BN];
     constexpr int NI = (B::NINSTR + 3) / 4;               // copy instructions per wave and chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -291,8 +293,12 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
             for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, wg + s * wstep);
         if (FUSE && g0 == 0)      // the producer's statistics -> scale / shift of this sample, while the first copies are in flight
             gn_fold_block(a.gn, n, x0 == 0 && y0 == 0 && z0 == 0 && blockIdx.y == 0, gn_part, gn_coef[0], gn_coef[1]);
+        // the bias of this workgroup's channels travels with the first copies and is parked in LDS for the epilogue
+        float bias_v = 0.f;
+        if (g0 == 0 && a.bias && threadIdx.x < BN) bias_v = a.bias[co0 + threadIdx.x];
         if (g0 == 0) SEG_C3XT(4);
         wait_vmem();
+        if (g0 == 0 && threadIdx.x < BN) bias_s[threadIdx.x] = bias_v;
         if (g0 == 0) SEG_C3XT(5);
         if (FUSE) {
             // each lane activates the pieces it copied itself (lane-linear image: no other lane touches them before the barrier)
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
         }
     }
     SEG_C3XT(2);
-    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0);      // no barrier: nothing of the halo buffer is reused
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s);      // no barrier: nothing of the halo buffer is reused
     SEG_C3XT(3);
 }
 
@@ -525,6 +531,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
     constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
     __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
     __shared__ float red_s[WM * BN * 2];
+    __shared__ float bias_s[BN];
     constexpr int NI = (NINSTR + 3) / 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -581,7 +588,9 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float bias_v = (a.bias && tid < BN) ? a.bias[co0 + tid] : 0.f;      // parked in LDS for the epilogue (see conv3x_kernel)
     wait_vmem();
+    if (tid < BN) bias_s[tid] = bias_v;
     __syncthreads();
 
     unsigned wo = PF * wstep;
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
         if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
-    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0);
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s);
 }
 
 #ifdef SEG_EXPERIMENTS
