@@ -45,6 +45,7 @@ const Cfg kCfgs[] = {
     {49, 3, 2, 4, 12, 64, 4, "2x4x12 t4 1x4 waves 6x1 tiles (every wave its own weight columns)"},
     {50, 3, 2, 4, 12, 64, 4, "2x4x12 t4 1x4 waves 6x1 tiles, 26-deep B ring"},
 #ifdef SEG_EXPERIMENTS
+    {51, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, next halo copied under the epilogue, weights streamed from L2", 0, 1},
     {18, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
     {19, 3, 2, 8, 8, 32, 1, "Cin32 persistent: 2x8x8 t8 4x1 waves 2x2 tiles, weights in LDS, double-buffered halo", 0, 1},
 #endif

@@ -94,7 +94,8 @@ __device__ __forceinline__ int c3x_box_of_block(int b, int nbox, int remap) {
 // dependent L2 round trips in front of the first store)
 template <class T, class B, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, const Conv3xArgs& a, int n, int x0, int y0, int z0, int co0,
-                                             const float* bias_lds = nullptr) {
+                                             const float* bias_lds = nullptr, bool stamp = true) {
+    (void)stamp;                                           // (trace builds: whether this call records its phase stamps)
     constexpr int BN = WN * TN * 16;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int wm = wv % WM, wn = wv / WM;
@@ -145,7 +146,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
                 if (ok) *(vec<T, 4>*)(row + j * 16 + 4 * q) = o4[j];
         }
     }
-    SEG_C3XT(6);
+    if (stamp) SEG_C3XT(6);
     if (a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -154,7 +155,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
                 const float u = row_sum16(cs[j][r]), v = row_sum16(css[j][r]);      // over the 16 voxel lanes of this (q, r) channel
                 if (l15 == 0) { const int col = (wn * TN + j) * 16 + 4 * q + r; red[(wm * BN + col) * 2] = u; red[(wm * BN + col) * 2 + 1] = v; }
             }
-        SEG_C3XT(7);
+        if (stamp) SEG_C3XT(7);
         __syncthreads();
         if (tid < BN) {
             double ts = 0.0, tss = 0.0;
@@ -368,6 +369,194 @@ void launch_cfg(const Conv3xArgs& a, hipStream_t s) {
     dim3 grid(a.remap ? (unsigned)((nbox + 7) / 8 * 8) : (unsigned)nbox, a.Cout / BN);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x_kernel<T, B, TM, TN, WM, WN, NRES, PF, OCC, FUSE>), grid, dim3(256), 0, s, a);
 }
+
+#ifdef SEG_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------
+// Cin == 32 (one resident chunk per box): PERSISTENT workgroups whose next halo is copied UNDER THE EPILOGUE (round 5).
+// The phase trace of conv3x_kernel (profiles/r05_conv3x_phase_trace_*.log) says a 48^3 x 32-channel workgroup lives 9.7 us of which 3.6 us are its PROLOGUE -
+// ~1400 instructions of per-lane index arithmetic, descriptors and copy issue in front of the first MFMA (the copies themselves land 0.3 us after the last one is
+// issued) - 3.0 us the 27 taps and 2.5 us the epilogue; 1728 such workgroups take 38.7 us.  Here a workgroup pays that prologue ONCE and then walks the boxes of its
+// XCD's range with ONE halo buffer: barrier -> taps -> barrier (every wave is done reading the halo) -> the copies of the NEXT box are issued into the same buffer
+// (dma16_async, ~0.3 us) -> epilogue of the current box (bias, statistics, stores: ~2.3 us, which is what hides the copy latency) -> weight-ring prefetch, wait,
+// next box.  No second halo buffer (two of them are 92 KB: one workgroup per CU, which is what made round 3's conv3p_kernel lose, together with its LDS-resident
+// weights); 46 KB of LDS and <= 256 registers keep two workgroups per CU, the weights keep streaming from L2 through the register ring.
+// MEASURED (profiles/r05_conv3q_persistent_*): bit-exact, a box costs 8.2 us in the steady state against the 10.0 us life of a conv3x_kernel workgroup - and the launch
+// takes the same 37-38 us (4 x 48^3: 37.9 vs 36.9 us standalone, step 1031-1033 vs 1030 volumes/s), because 1728 boxes on 512 workgroups leave a quarter of them a
+// fourth box (the hardware's own dispatch of 1728 short workgroups balances better) and because the per-box tail - coordinate divisions, the extra barrier behind the
+// taps, twelve LDS-copy issues - still costs 2.6 us.  The tap loop itself cannot get faster: with TM x TN = 4 x 2 tiles per wave one tap-round of the eight resident
+// waves needs 256 clk of LDS reads (128 B/clk), 256 clk of weight loads through the vector L1 (64 B/clk) and 272 clk of MFMA issue per SIMD - three pipes co-critical,
+// which is why the family sits at 0.22-0.25 of MFMA peak whatever wraps the loop.  Experiments build only (tiling 51).
+// ------------------------------------------------------------------------------------------------
+template <class T, class B, int TM, int TN, int PF>
+__global__ __launch_bounds__(256, 2) void conv3q_kernel(Conv3xArgs a) {
+    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
+    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
+    static_assert(4 * TM == B::NTILE, "four waves cover the box");
+    static_assert(B::NTAP % (PF + 1) == 0, "register ring must divide the tap count");
+    constexpr int WM = 4, WN = 1, BN = TN * 16;
+    constexpr int NI = (B::NINSTR + 3) / 4;
+    __shared__ __attribute__((aligned(16))) T Xs[B::CHUNK_ELEMS];
+    __shared__ float red_s[WM * BN * 2];
+    __shared__ float bias_s[BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
+    const int nbox = a.N * nbz * nby * nbx;
+    const int nvb = a.remap ? (nbox + 7) / 8 * 8 : nbox;           // virtual block ids of the non-persistent launch (c3x_box_of_block: XCD-aware order)
+    const int co0 = blockIdx.y * BN;
+    const int NT_total = a.Cout >> 4;
+    const long long vol = (long long)a.D * a.H * a.W;
+    if (tid < BN) bias_s[tid] = a.bias ? a.bias[co0 + tid] : 0.f;  // visible after the first barrier of the box loop
+
+    // virtual block ids of this workgroup: blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so it stays on its XCD's contiguous box range)
+    auto next_valid = [&](int vb, int& box) {
+        for (; vb < nvb; vb += (int)gridDim.x) {
+            box = c3x_box_of_block(vb, nbox, a.remap);
+            if (box >= 0) return vb;
+        }
+        box = -1;
+        return nvb;
+    };
+    struct Pos { int x0, y0, z0, n; };
+    auto pos_of = [&](int b) {
+        Pos p;
+        p.x0 = (b % nbx) * B::TW; b /= nbx;
+        p.y0 = (b % nby) * B::TH; b /= nby;
+        p.z0 = (b % nbz) * B::TD;
+        p.n = b / nbz;
+        return p;
+    };
+    // Copy pieces of this lane (instruction u of a box: 16 B): what does not depend on the box is computed ONCE - the halo coordinates (packed), the voxel
+    // offset relative to the box origin and the swizzled channel piece - so that a box costs ~13 vector instructions per piece instead of the ~35 of the full
+    // decomposition (the phase trace of the first version of this kernel: the per-box index arithmetic was what kept it at conv3x_kernel's speed)
+    int pk[NI], rel[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = u * 4 + wv;
+        const int g = i * 64 + lane;
+        const int row = g / (B::HWP * 4), rem = g % (B::HWP * 4);
+        const int hx = rem >> 2, slot = rem & 3;
+        const int hz = row / B::HH, hy = row % B::HH;
+        const bool valid = i < B::NINSTR && row < B::ROWS && hx < B::HW;
+        pk[u] = valid ? ((hz << 16) | (hy << 8) | hx) : -1;
+        rel[u] = (((hz - B::PD) * a.H + (hy - 1)) * a.W + (hx - 1)) * 64 + (slot ^ halo_swz_x(row, hx)) * 16;       // bytes (64 per voxel: Cin == 32)
+    }
+    // copy the halo of box p into Xs: zero padding from the buffer's out-of-range rule, swizzle on the source side (conv3x_kernel)
+    auto issue_box = [&](const Pos& p) {
+        const i32x4 rs = make_rsrc((const T*)a.in0 + (long long)p.n * vol * 32, (unsigned)(vol * 64));
+        const int org = ((p.z0 * a.H + p.y0) * a.W + p.x0) * 64;
+        const int zlo = B::PD - p.z0, ylo = 1 - p.y0, xlo = 1 - p.x0;      // halo coordinate of the first in-volume plane / row / column (<= 0: all)
+        const int zhi = a.D + B::PD - p.z0, yhi = a.H + 1 - p.y0, xhi = a.W + 1 - p.x0;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = u * 4 + wv;
+            if (i < B::NINSTR) {
+                const int hz = pk[u] >> 16, hy = (pk[u] >> 8) & 255, hx = pk[u] & 255;
+                const bool ok = pk[u] >= 0 && hz >= zlo && hz < zhi && hy >= ylo && hy < yhi && hx >= xlo && hx < xhi;
+                dma16_async(rs, Xs + i * 512, ok ? (unsigned)(org + rel[u]) : DMA_OOB);
+            }
+        }
+    };
+    // ---- A-fragment addressing (conv3x_kernel)
+    int ab[TM][3];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        int vz, vy, vx;
+        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
+        const int row = vz * B::HH + vy;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) ab[m][kw] = (row * B::HWP + vx) * 32 + ((q ^ halo_swz_x(row, vx + kw)) << 3);
+    }
+    const unsigned wstep = (unsigned)NT_total * 1024u;
+    const i32x4 wr = make_rsrc(a.w, (unsigned)B::NTAP * wstep);
+    const unsigned wl = ((unsigned)(blockIdx.y * TN) * 64u + lane) * 16u;
+
+    int box, nbox_id;
+    int vb = next_valid((int)blockIdx.x, box);
+    if (box < 0) return;
+    Pos p = pos_of(box);
+    issue_box(p);
+#ifdef SEG_C3X_TRACE
+    int kb = 0;                                            // trace builds: the stamps are those of a workgroup's SECOND box (steady state: both resident workgroups busy)
+#define SEG_C3QT(k) do { if (kb == 1) SEG_C3XT(k); } while (0)
+#else
+#define SEG_C3QT(k)
+#endif
+    for (;;) {
+        SEG_C3QT(0);
+        // the first PF weight steps of this box travel while the halo lands
+        typename Mma<T>::frag bq[PF + 1][TN];
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, s * wstep);
+        SEG_C3QT(4);
+        wait_vmem();                                       // this wave's copies into Xs have landed ...
+        SEG_C3QT(5);
+        __syncthreads();                                   // ... everybody's (and the statistics slots of the previous box have been read)
+        SEG_C3QT(1);
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned wo = PF * wstep;
+        typename Mma<T>::frag af[2][TM];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xs[ab[m][0]]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+        for (int t = 0; t < B::NTAP; ++t) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[(t + PF) % (PF + 1)][j] = buffer_load8<T>(wr, wl + j * 1024, wo);
+            wo += wstep;
+            if (t + 1 < B::NTAP) {
+                const int t1 = t + 1, kw = t1 % 3, srow = (t1 / 9) * B::HH + (t1 / 3) % 3;
+                const int toff = (srow * B::HWP + kw) * 32, flip = (srow & 1) << 4;
+#pragma unroll
+                for (int m = 0; m < TM; ++m) af[t1 & 1][m] = load8(&Xs[toff + (ab[m][kw] ^ flip)]);
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bq[t % (PF + 1)][j], af[t & 1][m], acc[m][j]);
+            __builtin_amdgcn_sched_group_barrier(0x020, TN, 0);
+            if (t + 1 < B::NTAP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        SEG_C3QT(2);
+        // every wave is done reading the halo: the next box's copies go into the same buffer and land while this box's epilogue runs
+        const int nvb_id = next_valid(vb + (int)gridDim.x, nbox_id);
+        Pos pn = p;
+        __syncthreads();
+        if (nbox_id >= 0) { pn = pos_of(nbox_id); issue_box(pn); }
+#ifdef SEG_C3X_TRACE
+        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0, bias_s, kb == 1);
+#else
+        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0, bias_s);
+#endif
+        SEG_C3QT(3);
+#ifdef SEG_C3X_TRACE
+        ++kb;
+#endif
+        if (nbox_id < 0) break;
+        p = pn; vb = nvb_id;
+    }
+}
+
+template <class T, class B, int TM, int TN, int PF>
+void launch_cfgq(const Conv3xArgs& a, hipStream_t s) {
+    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
+    // two workgroups per CU of the 256 (46 KB of LDS each); fewer when there are fewer boxes; grid.x a multiple of 8 (workgroups per XCD x 8 XCDs)
+    static const int wgs = xknob_i("SEG_C3Q_WGS", 512);             // (tests: 16 makes every workgroup of a small volume walk several boxes)
+    long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
+    const long long per = (nbox + 7) / 8;
+    if (per_xcd > per) per_xcd = per;
+    dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3q_kernel<T, B, TM, TN, PF>), grid, dim3(256), 0, s, a);
+}
+
+#endif  // SEG_EXPERIMENTS (conv3q_kernel)
 
 #ifdef SEG_EXPERIMENTS      // persistent halo convs (round 3): measured slower than conv3x_kernel standalone and in the step (profiles/r03_persistent_conv_ab.log)
 // ------------------------------------------------------------------------------------------------
@@ -808,6 +997,13 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 48: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 1, 2, 2, 4, 26, 1, FUSE>(a, s); return true;                   \
         case 49: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 8, 1, FUSE>(a, s); return true;                    \
         case 50: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 26, 1, FUSE>(a, s); return true;
+/* Cin == 32, no concat, no FUSE: persistent form of tiling 17 (conv3q_kernel; experiments build) */
+#ifdef SEG_EXPERIMENTS
+#define SEG_C3X_3D_Q_CASES                                                                                            \
+        case 51: launch_cfgq<T, XBox<4, 8, 8, 3, 8>, 4, 2, 8>(a, s); return true;
+#else
+#define SEG_C3X_3D_Q_CASES
+#endif
 /* Cin == 32 persistent tilings (conv3p_kernel):   box                  TM TN */
 #ifdef SEG_EXPERIMENTS
 #define SEG_C3X_3D_P_CASES                                                                                            \
@@ -827,7 +1023,7 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 25: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2, 3>(a, s); return true;                               \
         case 26: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 2, 2, 3>(a, s); return true;                               \
         case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;
-#define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_P_CASES SEG_C3X_3D_C16_CASES default: return false; }
+#define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_Q_CASES SEG_C3X_3D_P_CASES SEG_C3X_3D_C16_CASES default: return false; }
 #define SEG_C3X_3D_GN_BODY switch (id) { SEG_C3X_3D_CONV_CASES default: return false; }
 
 /* halo-conv tilings; FUSE (a constexpr bool in scope) selects the instantiation that applies the producer GroupNorm while staging */

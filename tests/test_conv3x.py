@@ -14,6 +14,7 @@ from test_ops import cl, ncdhw, ints, to_dev
 
 # ndim, N, spatial, Cin (list = concat sources), Cout, tiling ids to run (None: the default pick)
 # the persistent Cin == 32 kernel launches one workgroup per CU; 16 workgroups make every workgroup of these small volumes walk several boxes
+os.environ.setdefault("SEG_C3Q_WGS", "16")       # conv3q_kernel (tiling 51, experiments build): 16 persistent workgroups, so each walks several boxes of these small volumes
 os.environ.setdefault("SEG_C3P_WGS", "16")
 os.environ.setdefault("SEG_C3P16_WGS", "16")
 
@@ -39,6 +40,8 @@ CASES = [
     (2, 1, (9, 16), [128], 128, [36]),
     (3, 2, (9, 17, 18), [32], 32, [18, 19]),               # Cin == 32 persistent tilings: several boxes per workgroup (SEG_C3P_WGS below), both halo buffers
     (2, 2, (33, 40), [32], 32, [40]),
+    (3, 2, (9, 17, 18), [32], 32, [51]),                   # persistent Cin == 32 tiling of round 5 (next halo copied under the epilogue; experiments build): 54 boxes on 16 workgroups
+    (3, 1, (5, 9, 20), [32], 64, [51]),                    # two output-channel slabs (grid.y = 2), ragged boxes on every axis
     (2, 1, (8, 16), [32], 16, [37]),
     (2, 1, (12, 24), [16, 16], 64, [38]),
 ]
