@@ -517,6 +517,7 @@ def _bench(a, dev, on_gpu, gpu_sync, dist, world, rank):
                            "mfma_frac": round(GFLOP_PER_VOLUME_96 * scale * vols / world / 1e3 / PEAK_MFMA_TFLOPS, 4)},
         }
         line["timed_region_s"] = round(dt, 4)
+        line["build"] = _library_build() if on_gpu else None      # seg_build_info() of the loaded library (a sha of its sources): which binary this line is from
         # ---- kernel families: the profile classes grouped, event time corrected by the empty-bracket time per launch
         fams = {}
         for name, f in FAMILIES.items():
