@@ -39,7 +39,7 @@ def _build(force=False, experiments=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     procs = []
     for s, o in todo:
-        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I", HERE, "-I", CSRC, "-Wno-unused-value",
+        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-I", HERE, "-I", CSRC, "-Wno-unused-value",
                "-Wno-vla-cxx-extension"] + (["-DSEG_EXPERIMENTS"] if experiments else []) + ["-c", s, "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:

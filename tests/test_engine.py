@@ -416,6 +416,8 @@ def test_virtual_head_gradient_equals_materialised(dev, tag, monkeypatch):
     """One-class heads (networks/VNet3d.py:83-99): the data-gradient of the 1^d head is never written - the GroupNorm-backward passes of the
     units under the head evaluate dl[v] * w[c] on the fly (GnBwdArgs::vdl; gn_bwd_*_kernel<..., NDY = 4 / 5>).  With SEG_VHEAD=0 the head
     writes the tensor and the same passes read it as a stored source (NDY = 1 / 2).  fp32 run dtype: same products, same sums."""
+    if tag == "vnet2d_s":
+        conftest.checker_slow(dev, "the VNet twin takes ~30 s on the host checker (the UNet case runs there)")
     res = []
     for vh in ("1", "0"):
         monkeypatch.setenv("SEG_VHEAD", vh)

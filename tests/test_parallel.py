@@ -175,7 +175,8 @@ def _worker_bench(rank, world, port, q, extra):
     q.put((rank, buf.getvalue()))
 
 
-@pytest.mark.parametrize("extra", [("--global-loss",)])          # bucketed exchange (the default) + the loss-sum exchange: one ~1 min case
+@pytest.mark.skipif(not FULL, reason="~2 min; bench.py's N > 1 control flow runs under the driver's own launch line with eight ranks below; SEG_TEST_FULL=1 runs this two-rank twin too")
+@pytest.mark.parametrize("extra", [("--global-loss",)])          # bucketed exchange (the default) + the loss-sum exchange
 def test_bench_control_flow_two_ranks_on_the_checker(extra):
     """bench.py's own N > 1 path (process-group set-up, barriers around the timed region, bucketed / single exchange, optional
     global-batch loss, MAX of the rank times, ONE JSON line from rank 0) on the host checker with gloo: the driver launches
@@ -295,7 +296,7 @@ def test_bench_py_under_the_drivers_launch_line_with_eight_ranks():
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "run_bench_on_checker.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--size", "16", "--batch", "1",
-           "--dtype", "f32", "--no-cpu-baseline", "--condition-seconds", "0.001", "--roofline-steps", "0"]
+           "--dtype", "f32", "--no-cpu-baseline", "--condition-seconds", "0.001", "--roofline-steps", "0", "--global-loss"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -303,6 +304,7 @@ def test_bench_py_under_the_drivers_launch_line_with_eight_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak"
     assert line["ms_per_step"] > 0 and abs(line["value"] - 8 * 1e3 / line["ms_per_step"]) <= 0.006
+    assert line["config"]["loss_semantics"].startswith("global-batch") and 0.0 < line["final_loss"] < 1.5 and line["conditioning_steps"] == 1
     # a plain `python bench.py --gpus 8` (no launcher: WORLD_SIZE = 1) must refuse instead of measuring one GPU
     ref = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert ref.returncode != 0 and "WORLD_SIZE" in (ref.stderr + ref.stdout)

@@ -163,6 +163,7 @@ def _oracle_net(kind, sd, scale):
 def test_inference_and_inference_patch_on_arrays(dev, monkeypatch):
     """3-D `inference` (modelUnet.py:684-705) and `inference_patch` (modelUnet.py:707-763) with the whole pre/post chain on
     the device, against the CPU restatement of the same chain around the oracle network."""
+    conftest.checker_slow(dev, "UNet3d inference + inference_patch chains take ~40 s on the host checker")
     import model
     from oracle import prepost_oracle as po, seg_oracle as seg
     monkeypatch.setenv("SEGENGINE_DTYPE", "f32")
