@@ -54,6 +54,8 @@ const Cfg kCfgs[] = {
     {26, 3, 2, 8, 16, 32, 1, "Cin16: 2x8x16 t16 4x1 waves 4x2 tiles", 1},
     {27, 3, 4, 8, 16, 32, 1, "Cin16: 4x8x16 t16 4x1 waves 8x2 tiles", 1},
 #ifdef SEG_EXPERIMENTS
+    {52, 3, 4, 8, 16, 16, 1, "Cin16 persistent: 4x8x16 t16 4x1 waves 8x1 tiles, next halo copied under the epilogue", 1},
+    {53, 3, 2, 8, 16, 16, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x1 tiles, next halo copied under the epilogue", 1},
     {28, 3, 2, 8, 16, 16, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x1 tiles, weights in LDS, double-buffered halo", 1},
     {29, 3, 2, 8, 16, 32, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 1},
 #endif
@@ -72,6 +74,7 @@ const Cfg kCfgs[] = {
     {56, 2, 1, 16, 16, 16, 1, "Cin16: 16x16 t16 4x1 waves 4x1 tiles", 1},
     {57, 2, 1, 16, 16, 32, 1, "Cin16: 16x16 t16 4x1 waves 4x2 tiles", 1},
 #ifdef SEG_EXPERIMENTS
+    {59, 2, 1, 16, 16, 16, 1, "Cin16 persistent: 16x16 t16 4x1 waves 4x1 tiles, next halo copied under the epilogue", 1},
     {58, 2, 1, 16, 16, 16, 1, "Cin16 persistent: 16x16 t16 4x1 waves 4x1 tiles, weights in LDS, double-buffered halo", 1},
 #endif
 };

@@ -816,6 +816,173 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
 }
 
 #ifdef SEG_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------
+// Cin == 16, PERSISTENT (round 5): conv3x16_kernel's arithmetic in the box loop of conv3q_kernel.  The 96^3 x 16-channel launches are byte-bound by design (226 MB in
+// and out) yet ran at 2.9 TB/s alone against the 4.7-5.0 TB/s a copy reaches, because a 512-voxel box is only 112 MFMAs per wave and a workgroup's ~8 us life is
+// mostly its ~3.5 us instruction-bound prologue plus an exposed copy wait; 6912 workgroups pay it 6912 times.  Here 512 workgroups pay it once, then per box:
+// (copies of this box landed under the previous epilogue) barrier -> 14 two-tap MFMA steps -> barrier -> next box's copies issued (per-piece addresses: 13
+// instructions from the precomputed halo coordinates) -> epilogue.  Unlike the 32-channel case (conv3q_kernel: neutral, its tap loop is what binds) there is no
+// tap-loop ceiling here: what is left per box is the memory system.
+// MEASURED (profiles/r05_conv3q16_persistent_*): bit-exact; 4 x 96^3 without statistics 72.5 vs 79.1 us (tiling 25), WITH the GroupNorm statistics 103 vs 87 us (the per-box
+// barrier + fp64 atomics sit on the persistent loop's critical path instead of overlapping with another workgroup's start); 768 workgroups beat 512 and 1024;
+// C4 / C5 shapes 78.6 / 75.4 vs 80.2 / 82.5 us; in the step 1044-1047 vs 1041-1049 volumes/s: neutral.  Experiments build only (tilings 52 / 53 / 59).
+// ------------------------------------------------------------------------------------------------
+template <class T, class B, int TM, int TN, int PF>
+__global__ __launch_bounds__(256, 2) void conv3q16_kernel(Conv3xArgs a) {
+    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
+    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
+    static_assert(B::TX == 16, "x rows of 16 voxels");
+    static_assert(4 * TM == B::NTILE, "four waves cover the box");
+    constexpr int WM = 4, WN = 1, BN = TN * 16;
+    constexpr int NSTEP = (B::NTAP + 1) / 2;
+    static_assert(NSTEP >= PF + 1, "ring deeper than the loop");
+    constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
+    constexpr int NI = (NINSTR + 3) / 4;
+    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
+    __shared__ float red_s[WM * BN * 2];
+    __shared__ float bias_s[BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
+    const int nbox = a.N * nbz * nby * nbx;
+    const int nvb = a.remap ? (nbox + 7) / 8 * 8 : nbox;
+    const int co0 = blockIdx.y * BN;
+    const long long vol = (long long)a.D * a.H * a.W;
+    if (tid < BN) bias_s[tid] = a.bias ? a.bias[co0 + tid] : 0.f;
+
+    auto next_valid = [&](int vb, int& box) {
+        for (; vb < nvb; vb += (int)gridDim.x) {
+            box = c3x_box_of_block(vb, nbox, a.remap);
+            if (box >= 0) return vb;
+        }
+        box = -1;
+        return nvb;
+    };
+    struct Pos { int x0, y0, z0, n; };
+    auto pos_of = [&](int b) {
+        Pos p;
+        p.x0 = (b % nbx) * B::TW; b /= nbx;
+        p.y0 = (b % nby) * B::TH; b /= nby;
+        p.z0 = (b % nbz) * B::TD;
+        p.n = b / nbz;
+        return p;
+    };
+    // copy pieces of this lane, box-independent part (see conv3q_kernel): halo coordinates packed, byte offset relative to the box origin (32 B per voxel)
+    int pk[NI], rel[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = u * 4 + wv;
+        const int g = i * 64 + lane;
+        const int row = g / (B::HWP * 2), rem = g % (B::HWP * 2);
+        const int hx = rem >> 1, piece = rem & 1;
+        const int hz = row / B::HH, hy = row % B::HH;
+        const bool valid = i < NINSTR && row < B::ROWS && hx < B::HW;
+        pk[u] = valid ? ((hz << 16) | (hy << 8) | hx) : -1;
+        rel[u] = (((hz - B::PD) * a.H + (hy - 1)) * a.W + (hx - 1)) * 32 + piece * 16;
+    }
+    auto issue_box = [&](const Pos& p) {
+        const i32x4 rs = make_rsrc((const T*)a.in0 + (long long)p.n * vol * 16, (unsigned)(vol * 32));
+        const int org = ((p.z0 * a.H + p.y0) * a.W + p.x0) * 32;
+        const int zlo = B::PD - p.z0, ylo = 1 - p.y0, xlo = 1 - p.x0;
+        const int zhi = a.D + B::PD - p.z0, yhi = a.H + 1 - p.y0, xhi = a.W + 1 - p.x0;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = u * 4 + wv;
+            if (i < NINSTR) {
+                const int hz = pk[u] >> 16, hy = (pk[u] >> 8) & 255, hx = pk[u] & 255;
+                const bool ok = pk[u] >= 0 && hz >= zlo && hz < zhi && hy >= ylo && hy < yhi && hx >= xlo && hx < xhi;
+                dma16_async(rs, Xs + i * 512, ok ? (unsigned)(org + rel[u]) : DMA_OOB);
+            }
+        }
+    };
+    // ---- weights through the register ring, A addressing: conv3x16_kernel
+    const unsigned wstep = (unsigned)(a.Cout >> 4) * 1024u;
+    const i32x4 wr = make_rsrc(a.w, (unsigned)NSTEP * wstep);
+    const unsigned wl = ((unsigned)(blockIdx.y * TN) * 64u + lane) * 16u;
+    constexpr int D_KW = 16, D_KH = (B::HWP - 2) * 16, D_KD = ((B::HH - 2) * B::HWP - 2) * 16;    // elements
+    const int hi = q >> 1, piece = q & 1;
+    int ab[TM][3];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        int vz, vy, vx;
+        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
+        const int base = ((vz * B::HH + vy) * B::HWP + vx) * 16 + piece * 8;
+        ab[m][0] = base + (hi ? D_KW : 0);
+        ab[m][1] = base + (hi ? D_KH : 0);
+        ab[m][2] = base + (hi ? D_KD : 0);
+    }
+    auto tap_off = [](int t) { return ((t / 9) * B::HH + (t / 3) % 3) * B::HWP + t % 3; };       // halo voxels
+
+    int box, nbox_id;
+    int vb = next_valid((int)blockIdx.x, box);
+    if (box < 0) return;
+    Pos p = pos_of(box);
+    issue_box(p);
+    for (;;) {
+        typename Mma<T>::frag bq[PF + 1][TN];
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, s * wstep);
+        wait_vmem();
+        __syncthreads();
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned wo = PF * wstep;
+        typename Mma<T>::frag af[2][TM];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xs[ab[m][0] + tap_off(0) * 16]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[(s + PF) % (PF + 1)][j] = buffer_load8<T>(wr, wl + j * 1024, wo);
+            wo += wstep;
+            if (s + 1 < NSTEP) {
+                const int t0 = 2 * (s + 1), t1 = t0 + 1;
+                const int d = t1 >= B::NTAP ? -1 : (tap_off(t1) - tap_off(t0) == 1 ? 0 : (t1 % 9 == 0 ? 2 : 1));
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const int basev = d < 0 ? ab[m][0] - (hi ? D_KW : 0) : ab[m][d];
+                    af[(s + 1) & 1][m] = load8(&Xs[basev + tap_off(t0) * 16]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bq[s % (PF + 1)][j], af[s & 1][m], acc[m][j]);
+            __builtin_amdgcn_sched_group_barrier(0x020, TN, 0);
+            if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        // every wave is done reading the halo: the next box's copies go into the same buffer and land while this box's epilogue runs
+        const int nvb_id = next_valid(vb + (int)gridDim.x, nbox_id);
+        Pos pn = p;
+        __syncthreads();
+        if (nbox_id >= 0) { pn = pos_of(nbox_id); issue_box(pn); }
+        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0, bias_s);
+        if (nbox_id < 0) break;
+        p = pn; vb = nvb_id;
+    }
+}
+
+template <class T, class B, int TM, int TN, int PF>
+void launch_cfgq16(const Conv3xArgs& a, hipStream_t s) {
+    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
+    static const int wgs = xknob_i("SEG_C3Q16_WGS", 768);          // three workgroups per CU (155 VGPRs, 39 KB LDS); tests: 16 makes every workgroup of a small volume walk several boxes
+    long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
+    const long long per = (nbox + 7) / 8;
+    if (per_xcd > per) per_xcd = per;
+    dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3q16_kernel<T, B, TM, TN, PF>), grid, dim3(256), 0, s, a);
+}
+
+#endif  // SEG_EXPERIMENTS (conv3q16_kernel)
+
+#ifdef SEG_EXPERIMENTS
 // The same persistent scheme for Cin == 16 (conv3x16_kernel's two-taps-per-step arithmetic): the [14 steps][TN][64][8] weight slab (14 / 28 KB)
 // lives in LDS, the 25 KB halo is double-buffered, two workgroups per CU.  These launches are HBM-bound (226 MB at 4 x 96^3):
 // what the double buffer buys is that the copy of box i + 1 streams while box i is multiplied and written back.
@@ -1010,10 +1177,13 @@ template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s)
         case 18: launch_cfgp<T, XBox<4, 8, 8, 3, 8>, 4, 2>(a, s); return true;                                       \
         case 19: launch_cfgp<T, XBox<2, 8, 8, 3, 8>, 2, 2>(a, s); return true;                                       \
         case 28: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 1>(a, s); return true;                                    \
-        case 29: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 2>(a, s); return true;
+        case 29: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 2>(a, s); return true;                                    \
+        case 52: launch_cfgq16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2>(a, s); return true;                                 \
+        case 53: launch_cfgq16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2>(a, s); return true;
 #define SEG_C3X_2D_P_CASES                                                                                            \
         case 40: launch_cfgp<T, XBox<1, 16, 16, 1, 16>, 4, 2>(a, s); return true;                                    \
-        case 58: launch_cfgp16<T, XBox<1, 16, 16, 1, 16>, 4, 1>(a, s); return true;
+        case 58: launch_cfgp16<T, XBox<1, 16, 16, 1, 16>, 4, 1>(a, s); return true;                                   \
+        case 59: launch_cfgq16<T, XBox<1, 16, 16, 1, 16>, 4, 1, 2>(a, s); return true;
 #else
 #define SEG_C3X_3D_P_CASES
 #define SEG_C3X_2D_P_CASES

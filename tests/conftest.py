@@ -39,7 +39,7 @@ def emu_library():
 
 
 EXPERIMENTS = bool(os.environ.get("SEG_TEST_EXPERIMENTS"))
-PERSISTENT_CFGS = (18, 19, 28, 29, 40, 58, 51)      # conv3p / conv3p16 / conv3q tilings: experiments build only
+PERSISTENT_CFGS = (18, 19, 28, 29, 40, 58, 51, 52, 53, 59)      # conv3p / conv3p16 / conv3q / conv3q16 tilings: experiments build only
 
 
 def needs_experiments(dev):

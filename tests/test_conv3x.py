@@ -14,6 +14,7 @@ from test_ops import cl, ncdhw, ints, to_dev
 
 # ndim, N, spatial, Cin (list = concat sources), Cout, tiling ids to run (None: the default pick)
 # the persistent Cin == 32 kernel launches one workgroup per CU; 16 workgroups make every workgroup of these small volumes walk several boxes
+os.environ.setdefault("SEG_C3Q16_WGS", "16")     # conv3q16_kernel (tilings 52 / 53 / 59, experiments build): 16 persistent workgroups, so each walks several boxes of these small volumes
 os.environ.setdefault("SEG_C3Q_WGS", "16")       # conv3q_kernel (tiling 51, experiments build): 16 persistent workgroups, so each walks several boxes of these small volumes
 os.environ.setdefault("SEG_C3P_WGS", "16")
 os.environ.setdefault("SEG_C3P16_WGS", "16")
@@ -30,7 +31,10 @@ CASES = [
     (3, 1, (2, 4, 8), [64, 64], 64, [None]),
     (3, 1, (3, 9, 18), [16], 16, [24, 25]),                 # Cin == 16: two taps per MFMA step, flat-K weights
     (3, 2, (2, 8, 32), [16], 32, [26, 27]),
-    (3, 2, (5, 17, 34), [16], 16, [28]),                    # Cin == 16 persistent tilings, several boxes per workgroup (SEG_C3P16_WGS)
+    (3, 2, (5, 17, 34), [16], 16, [28]),
+    (3, 2, (9, 17, 34), [16], 16, [52, 53]),                # Cin == 16 persistent tilings of round 5 (next halo copied under the epilogue; experiments build): ragged boxes, several per workgroup
+    (3, 1, (4, 16, 48), [16], 32, [52]),                    # two output-channel slabs (grid.y = 2)
+    (2, 2, (33, 40), [16], 16, [59]),                    # Cin == 16 persistent tilings, several boxes per workgroup (SEG_C3P16_WGS)
     (3, 1, (4, 16, 48), [16], 32, [29]),
     (2, 2, (33, 40), [16], 16, [58]),
     (2, 1, (19, 24), [16], 16, [56]),
