@@ -44,6 +44,15 @@ __global__ __launch_bounds__(256) void ssim_blur_kernel(const float* in, float* 
 __global__ __launch_bounds__(256) void ssim_map_kernel(float* mu1, float* mu2, float* e11, float* e22, float* e12, long long per_sample,
                                                        double* sums, double* colsums, int W) {
     __shared__ double red[4];
+    // column sums of the (N, W) result: gathered per workgroup in LDS and flushed with ONE global atomic per column and workgroup (one
+    // global fp64 atomic per voxel on N * W addresses serialised); rows longer than the LDS table keep the per-voxel atomics
+    constexpr int COLS_MAX = 1024;
+    __shared__ double cols_s[COLS_MAX];
+    const bool cols_lds = colsums && W <= COLS_MAX;
+    if (cols_lds) {
+        for (int c = threadIdx.x; c < W; c += 256) cols_s[c] = 0.0;
+        __syncthreads();
+    }
     const int n = blockIdx.y;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     double part = 0.0;
@@ -56,7 +65,8 @@ __global__ __launch_bounds__(256) void ssim_map_kernel(float* mu1, float* mu2, f
         const float inv = 1.f / (B1 * B2);
         const float map = A1 * A2 * inv;
         part += (double)map;
-        if (colsums) atomicAdd(colsums + (long long)n * W + (int)(j % W), (double)map);       // ssim3D(size_average=False): means over (C, D, H) per (n, w)
+        if (cols_lds) atomicAdd(&cols_s[(int)(j % W)], (double)map);                          // ssim3D(size_average=False): means over (C, D, H) per (n, w)
+        else if (colsums) atomicAdd(colsums + (long long)n * W + (int)(j % W), (double)map);
         // derivatives with mu and e as independent variables (s_ab = e_ab - mu_a mu_b)
         const float d_e12 = 2.f * A1 * inv;
         const float d_e = -map / B2;                                   // d / d e11 = d / d e22
@@ -72,6 +82,9 @@ __global__ __launch_bounds__(256) void ssim_map_kernel(float* mu1, float* mu2, f
         const double s = red[0] + red[1] + red[2] + red[3];
         if (s != 0.0) atomicAdd(sums + n, s);
     }
+    if (cols_lds)
+        for (int c = threadIdx.x; c < W; c += 256)
+            if (cols_s[c] != 0.0) atomicAdd(colsums + (long long)n * W + c, cols_s[c]);
 }
 
 __global__ __launch_bounds__(256) void ssim_cols_finalize_kernel(const double* colsums, int NW, double inv_count, float* out) {
