@@ -100,7 +100,8 @@ long long seg_workspace_bytes(seg_handle h);
  * weight-gradient queue waits on a word in signal memory that the caller's stream's next kernel stores; 0 in the product library),
  * 7 / 8: of those, numbers stored by the next kernel itself / by a one-wave kernel of their own, 9: 1 when no released batch is left waiting,
  * 4: samples per group of the sub-batched finest level (0 = whole-batch launches; experiments build, SEG_SUB_MB),
- * 5 / 6: forward / backward ops that run group by group.  <0: not planned / unknown `what`. */
+ * 5 / 6: forward / backward ops that run group by group, 10: GroupNorm-backward reduce passes folded into the epilogue of the convolution
+ * data-gradient launch that writes the unit's only gradient (known after a backward pass was planned).  <0: not planned / unknown `what`. */
 int seg_plan_count(seg_handle h, int what);
 
 /* Bind caller-owned buffers: flat fp32 params / grads (seg_param_numel floats each) + workspace. */

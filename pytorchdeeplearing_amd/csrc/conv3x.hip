@@ -189,7 +189,7 @@ int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres
 }
 
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const GnFinArgs* gn, ForkSig sg) {
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const GnFinArgs* gn, ForkSig sg, const Conv3xReduce* rq) {
     const Cfg* c = find_cfg(cfg);
     if (!c || !cfg_fits(*c, ndim, Cin, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
     if (gn && (!conv3x_gn_supported(Cin, in1 != nullptr) || c->cin32)) return false;
@@ -200,6 +200,11 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
     a.sig = sg;
     a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.stat_rep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
+    a.rq_y = nullptr; a.rq_scale = nullptr; a.rq_shift = nullptr; a.rq_Q = nullptr;
+    if (rq && rq->Q && !stats) {          // (a launch produces forward statistics OR backward sums, never both)
+        a.rq_y = rq->y; a.rq_scale = rq->scale; a.rq_shift = rq->shift; a.rq_Q = rq->Q;
+        a.stat_rep = (rq->rep > 0 && rq->rep <= STAT_REP) ? rq->rep : STAT_REP;
+    }
 #ifdef SEG_DIAG
     // diagnostic builds only (python tools/build_variant.py diag conv3x.hip -DSEG_DIAG; WRONG results): SEG_DIAG_NOSTATS=1 drops the GroupNorm
     // statistics epilogue, to time what it costs inside a step.  Not compiled into the product library.

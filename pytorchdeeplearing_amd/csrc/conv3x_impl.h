@@ -47,6 +47,13 @@ template <int TD_, int TH_, int TW_, int KD_, int TX_> struct XBox {
     }
 };
 
+#ifdef SEG_EXPERIMENTS
+#define SEG_C3X_RQ(a) ((a).rq_Q != nullptr)
+#define SEG_C3X_RQ_LDS 3
+#else
+#define SEG_C3X_RQ(a) false
+#define SEG_C3X_RQ_LDS 1
+#endif
 struct Conv3xArgs {
     const void* in0; const void* in1; int C0;     // in1: second source of a virtual channel concat (channels C0..Cin-1), or null
     const void* w;                                // fragment-major weights [Cin/32][taps][Cout/16][64 lanes][8]
@@ -60,6 +67,14 @@ struct Conv3xArgs {
     // relu(scale * x + shift); padding voxels stay zero.  The activated tensor is never written to HBM (the gn_act launch is gone).
     int fuse; GnFinArgs gn;
     ForkSig sig;                                  // a flag fork carried by this launch (its first thread stores the number)
+    // EXPERIMENTS BUILD (measured in round 5, profiles/r05_reduce_fold_ab.log: the epilogue grows by what the reduce launches cost at the 24^3 / 12^3 levels where
+    // the fold applies, and the forward kernels lose 0.6 % to the extra prologue work - the product keeps the separate reduce pass).
+    // Data-gradient launches only: the GroupNorm-backward REDUCE pass of the unit that consumes this gradient, folded into
+    // the epilogue.  The tensor written here is d loss / d activation of a [conv -> GroupNorm -> dropout -> ReLU] unit whose ONLY gradient source it is;
+    // rq_y = that unit's raw conv output (same extent as `out`), rq_scale / rq_shift its forward coefficients [N][Cout].  The epilogue adds sum dz and
+    // sum dz * y (dz = dy where scale * y + shift > 0, dy as stored) per (sample, channel) into rq_Q [stat_rep][N][Cout][2] - what gn_bwd_reduce_kernel
+    // computes from two more reads of the tensors, and one launch less.
+    const void* rq_y; const float* rq_scale; const float* rq_shift; double* rq_Q;
 #ifdef SEG_C3X_TRACE
     unsigned long long* trace;                    // diagnostic build (tools/trace_conv3x.py): 8 wall_clock64 stamps per workgroup - 0 start, 4 copies issued, 5 copies landed,
                                                   // 1 barrier passed, 2 tap loops done, 6 tile stored, 7 statistics folded per wave, 3 end
@@ -94,7 +109,7 @@ __device__ __forceinline__ int c3x_box_of_block(int b, int nbox, int remap) {
 // dependent L2 round trips in front of the first store)
 template <class T, class B, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, const Conv3xArgs& a, int n, int x0, int y0, int z0, int co0,
-                                             const float* bias_lds = nullptr, bool stamp = true) {
+                                             const float* bias_lds = nullptr, bool stamp = true, const float* rq_lds = nullptr) {
     (void)stamp;                                           // (trace builds: whether this call records its phase stamps)
     constexpr int BN = WN * TN * 16;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -108,6 +123,23 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
             bs[j][r] = bias_lds ? bias_lds[(wn * TN + j) * 16 + 4 * q + r] : (a.bias ? a.bias[co0 + (wn * TN + j) * 16 + 4 * q + r] : 0.f);
             cs[j][r] = 0.f; css[j][r] = 0.f;
         }
+    // folded GroupNorm-backward reduce: this lane's pieces of the consuming unit's raw output and its forward coefficients are requested FIRST and used
+    // after the tile has been converted and stored (their latency hides behind the store phase)
+    const bool rq = SEG_C3X_RQ(a);
+    vec<T, 4> ry[TM][TN];
+    if (rq) {
+        const T* yb = (const T*)a.rq_y;
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            int vz, vy, vx;
+            B::vox((wm * TM + m) * 16 + l15, vz, vy, vx);
+            const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
+            const bool ok = x < a.W && y < a.H && z < a.D;
+            const T* yrow = yb + ((((long long)n * a.D + (ok ? z : 0)) * a.H + (ok ? y : 0)) * a.W + (ok ? x : 0)) * a.Cout + co0 + wn * TN * 16;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) ry[m][j] = *(const vec<T, 4>*)(yrow + j * 16 + 4 * q);
+        }
+    }
     const bool odd = q & 1;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
@@ -124,6 +156,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
                 const T tv = from_f<T>(acc[m][j][r] + bs[j][r]);
                 o4[j][r] = tv;
                 if (a.stats && ok) { const float f = to_f(tv); cs[j][r] += f; css[j][r] = fmaf(f, f, css[j][r]); }
+                if (rq) acc[m][j][r] = ok ? to_f(tv) : 0.f;          // the gradient AS STORED, kept for the sums below (the accumulator is done)
             }
         if (TN % 2 == 0) {
 #pragma unroll
@@ -147,7 +180,26 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
         }
     }
     if (stamp) SEG_C3XT(6);
-    if (a.stats) {
+    if (rq) {
+        // the unit's forward coefficients of this workgroup's channels: parked in LDS by the kernel prologue ([scale BN][shift BN]) or read here
+        constexpr int BN_ = WN * TN * 16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = (wn * TN + j) * 16 + 4 * q;
+            const vec<float, 4> rsc = rq_lds ? *(const vec<float, 4>*)(rq_lds + cl) : *(const vec<float, 4>*)(a.rq_scale + (long long)n * a.Cout + co0 + cl);
+            const vec<float, 4> rsh = rq_lds ? *(const vec<float, 4>*)(rq_lds + BN_ + cl) : *(const vec<float, 4>*)(a.rq_shift + (long long)n * a.Cout + co0 + cl);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float yf = to_f(ry[m][j][r]);
+                    const float dz = (fmaf(rsc[r], yf, rsh[r]) > 0.f) ? acc[m][j][r] : 0.f;
+                    cs[j][r] += dz;
+                    css[j][r] = fmaf(dz, yf, css[j][r]);
+                }
+        }
+    }
+    if (a.stats || rq) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -161,7 +213,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
             double ts = 0.0, tss = 0.0;
 #pragma unroll
             for (int k = 0; k < WM; ++k) { ts += (double)red[(k * BN + tid) * 2]; tss += (double)red[(k * BN + tid) * 2 + 1]; }
-            double* dst = a.stats + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + tid) * 2;
+            double* dst = (rq ? a.rq_Q : a.stats) + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + tid) * 2;
             atomicAdd(dst, ts);
             atomicAdd(dst + 1, tss);
         }
@@ -182,7 +234,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     // resident chunk images; the epilogue stores straight from the accumulators and only needs the small statistics exchange array
     __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
     __shared__ float red_s[WM * BN * 2];
-    __shared__ float bias_s[BN];
+    __shared__ __attribute__((aligned(16))) float bias_s[SEG_C3X_RQ_LDS * BN];       // bias (| scale, shift of a folded GroupNorm-backward reduce, Conv3xArgs::rq_*)
     constexpr int NI = (B::NINSTR + 3) / 4;               // copy instructions per wave and chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -297,9 +349,15 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
         // the bias of this workgroup's channels travels with the first copies and is parked in LDS for the epilogue
         float bias_v = 0.f;
         if (g0 == 0 && a.bias && threadIdx.x < BN) bias_v = a.bias[co0 + threadIdx.x];
+        float rq_sc = 0.f, rq_sh = 0.f;
+        if (g0 == 0 && SEG_C3X_RQ(a) && threadIdx.x < BN) {
+            rq_sc = a.rq_scale[(long long)n * a.Cout + co0 + threadIdx.x];
+            rq_sh = a.rq_shift[(long long)n * a.Cout + co0 + threadIdx.x];
+        }
         if (g0 == 0) SEG_C3XT(4);
         wait_vmem();
         if (g0 == 0 && threadIdx.x < BN) bias_s[threadIdx.x] = bias_v;
+        if (g0 == 0 && SEG_C3X_RQ(a) && threadIdx.x < BN) { bias_s[(SEG_C3X_RQ_LDS / 3) * BN + threadIdx.x] = rq_sc; bias_s[(SEG_C3X_RQ_LDS / 3) * 2 * BN + threadIdx.x] = rq_sh; }
         if (g0 == 0) SEG_C3XT(5);
         if (FUSE) {
             // each lane activates the pieces it copied itself (lane-linear image: no other lane touches them before the barrier)
@@ -357,7 +415,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
         }
     }
     SEG_C3XT(2);
-    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s);      // no barrier: nothing of the halo buffer is reused
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s, true, bias_s + (SEG_C3X_RQ_LDS / 3) * BN);      // no barrier: nothing of the halo buffer is reused
     SEG_C3XT(3);
 }
 
@@ -720,7 +778,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
     constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
     __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
     __shared__ float red_s[WM * BN * 2];
-    __shared__ float bias_s[BN];
+    __shared__ __attribute__((aligned(16))) float bias_s[SEG_C3X_RQ_LDS * BN];       // (see conv3x_kernel)
     constexpr int NI = (NINSTR + 3) / 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -778,8 +836,11 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float bias_v = (a.bias && tid < BN) ? a.bias[co0 + tid] : 0.f;      // parked in LDS for the epilogue (see conv3x_kernel)
+    float rq_sc = 0.f, rq_sh = 0.f;
+    if (SEG_C3X_RQ(a) && tid < BN) { rq_sc = a.rq_scale[(long long)n * a.Cout + co0 + tid]; rq_sh = a.rq_shift[(long long)n * a.Cout + co0 + tid]; }
     wait_vmem();
     if (tid < BN) bias_s[tid] = bias_v;
+    if (SEG_C3X_RQ(a) && tid < BN) { bias_s[(SEG_C3X_RQ_LDS / 3) * BN + tid] = rq_sc; bias_s[(SEG_C3X_RQ_LDS / 3) * 2 * BN + tid] = rq_sh; }
     __syncthreads();
 
     unsigned wo = PF * wstep;
@@ -812,7 +873,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
         if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
-    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s);
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s, true, bias_s + (SEG_C3X_RQ_LDS / 3) * BN);
 }
 
 #ifdef SEG_EXPERIMENTS

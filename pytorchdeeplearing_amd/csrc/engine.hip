@@ -33,6 +33,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->use_stemx = knob_i("SEG_STEMX", e->use_stemx) != 0;
     e->pack_split = knob_i("SEG_PACK_SPLIT", e->pack_split) != 0;
     e->use_fold = knob_i("SEG_GN_FOLD", e->use_fold) != 0;
+    e->use_rfuse = xknob_i("SEG_GN_RFUSE", 0) != 0;       // experiments build only (measured slower, profiles/r05_reduce_fold_ab.log)
     e->use_vhead = knob_i("SEG_VHEAD", e->use_vhead) != 0;
     e->dual_gn_bwd = knob_i("SEG_DUAL_GN", e->dual_gn_bwd) != 0;
     // experiment knobs: their defaults in the product library, environment variables only in a -DSEG_EXPERIMENTS build (profiles/HISTORY.md says what
@@ -145,6 +146,7 @@ int seg_plan_count(seg_handle h, int what) {
     for (auto& s : h->steps) {
         if (what == 0) n += s.type == ST_ACT && s.vact;                                   // activations applied by their consumer (never written)
         else if (what == 1) n += s.type == ST_UNIT;                                       // convolution units
+        else if (what == 10) n += s.type == ST_UNIT && s.rfused;                          // GroupNorm-backward reduce passes done by a data-gradient epilogue
         else return -1;
     }
     return n;

@@ -45,6 +45,7 @@ struct Ten {
     bool image = false;
     bool virt = false;       // gradient of the head's input kept virtual (evaluated from dlogits and the head weights by its readers)
     std::vector<int> grads;  // gradient contribution tensors (ids)
+    int prod_step = -1, prod_which = 0;   // gradient tensors: the UNIT step whose conv3x data-gradient launch (in0 / in1 part) writes it
 };
 
 struct Step {
@@ -57,6 +58,8 @@ struct Step {
     size_t stats = 0, scale = 0, shift = 0, mean = 0, rstd = 0, Q = 0, coef = 0;
     size_t wp_fwd = 0, wp_dg0 = 0, wp_dg1 = 0;
     bool fused_stem = false;                  // image stem evaluated inside the fused input block of its ACT step (stemx.hip)
+    int rq_unit[2] = {-1, -1};                // UNIT: its data-gradient launch (in0 / in1 part) also runs the GroupNorm-backward reduce of this unit
+    bool rfused = false;                      // UNIT: its GroupNorm-backward reduce is done by the epilogue of the conv that produces its only gradient
     int stat_rep = 0;                         // replicas of the statistics buffers this unit's producers use (0 = STAT_REP)
     bool fold_fin = false;                    // statistics finalize folded into the consuming gn_act launch (no launch of its own)
     int x_fwd = -1, x_dg0 = -1, x_dg1 = -1;   // conv3x tiling of the forward / data-gradient launches (-1: conv3_kernel, row-major weights)
@@ -122,6 +125,8 @@ struct seg_engine {
     // (rounds 2-3 could fold the GroupNorm-backward reduce of a unit into the epilogue of the data-gradient conv producing its only gradient;
     // neutral in round 2, 0.4 % slower in round 3 - profiles/r03_epilogue_ab.log - and gone since the conv epilogue stores straight from the
     // accumulators)
+    bool use_rfuse = false;     // experiments build, SEG_GN_RFUSE=1: the GroupNorm-backward reduce of a unit with a single gradient source runs in the epilogue of the
+                                // conv3x data-gradient launch that writes that gradient (measured in round 5: slower than the separate pass, see Conv3xArgs::rq_*)
     bool use_fold = true;       // SEG_GN_FOLD=0: finalize kernels between the GroupNorm passes (round-1 path)
     bool use_vhead = true;      // SEG_VHEAD=0: head_bwd writes its data-gradient tensor (round-1 path)
     bool head_din_needed = false;   // planning: some reader of the head's data-gradient cannot evaluate it on the fly
@@ -434,6 +439,17 @@ struct seg_engine {
         return (int)prof_used++;
     }
     void prof_end(hipStream_t st, int idx) { if (idx >= 0) (void)hipEventRecord(prof_pool[idx].b, st); }
+    // arguments of a GroupNorm-backward reduce folded into a data-gradient launch (unit index, or -1: none)
+    Conv3xReduce reduce_args(int ui) const {
+        Conv3xReduce r{nullptr, nullptr, nullptr, nullptr, STAT_REP};
+        if (ui < 0) return r;
+        const Step& u = steps[ui];
+        r.y = ws + tens[u.raw].off;
+        r.scale = (const float*)(ws + u.scale); r.shift = (const float*)(ws + u.shift);
+        r.Q = (double*)(ws + u.Q);
+        r.rep = use_fold ? stat_rep_for(vol(tens[u.raw].lvl)) : STAT_REP;
+        return r;
+    }
     double tbytes(int ten) const { return (double)N * vol(tens[ten].lvl) * tens[ten].C * esz(); }
     size_t esz() const { return dtype == DT_F32 ? 4 : 2; }
     int ld_mask() const { return 16 * feat; }

@@ -293,7 +293,7 @@ struct Planner {
         size_t nfw = 0;
         for (auto& s : E.steps) {
             nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1);
-            s.draw = -1; s.vact = false; s.vact_prod = -1;
+            s.draw = -1; s.vact = false; s.vact_prod = -1; s.rq_unit[0] = s.rq_unit[1] = -1; s.rfused = false;
         }
         E.tens.resize(std::max<size_t>(nfw, (size_t)E.image_ten + 1));
         for (auto& t : E.tens) t.grads.clear();
@@ -837,6 +837,12 @@ struct Planner {
                     if (ui < 0) continue;
                     Step& u = E.steps[ui];
                     u.draw = new_grad(u.raw);
+                    // the reduce pass rides on the conv that produces this unit's only gradient (c3x_epilogue, Conv3xArgs::rq_*)
+                    if (E.use_rfuse && s.ub < 0 && gl.size() == 1 && E.tens[gl[0]].prod_step >= 0 && !E.tens[gl[0]].virt &&
+                        !gn_bwd_group_eligible(E.tens[u.raw].C, E.vol(E.tens[u.raw].lvl), (int)E.esz())) {
+                        u.rfused = true;
+                        E.steps[E.tens[gl[0]].prod_step].rq_unit[E.tens[gl[0]].prod_which] = ui;
+                    }
                     E.bwd_writes.push_back({u.gn_w, u.gn_b, u.b});      // gamma/beta and (analytically) the conv bias
                     E.bwd_sub.push_back(unit_sub(ui) ? 1 : 0);
                     E.bwd_sig.push_back(1);
@@ -854,9 +860,12 @@ struct Planner {
                             E.prof_end(st, pg);
                             return;
                         }
-                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
-                        launch_gn_bwd_reduce(a, E.dtype, st);
-                        E.prof_end(st, pi);
+                        int pi = -1;
+                        if (!u.rfused) {
+                            pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
+                            launch_gn_bwd_reduce(a, E.dtype, st);
+                            E.prof_end(st, pi);
+                        }
                         const bool fold = E.use_fold && a.C <= 256;
                         if (!fold) launch_gn_bwd_finalize(f, st);
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
@@ -879,6 +888,10 @@ struct Planner {
                 int g0 = -1, g1 = -1;
                 if (need_dg0) { g0 = new_grad(s.in0); E.tens[s.in0].grads.push_back(g0); }
                 if (s.in1 >= 0) { g1 = new_grad(s.in1); E.tens[s.in1].grads.push_back(g1); }
+                if (s.ck == CK_K3) {      // halo-tile data gradients can carry the GroupNorm-backward reduce of the unit they feed (ACT branch above)
+                    if (g0 >= 0 && s.x_dg0 >= 0) { E.tens[g0].prod_step = (int)si; E.tens[g0].prod_which = 0; }
+                    if (g1 >= 0 && s.x_dg1 >= 0) { E.tens[g1].prod_step = (int)si; E.tens[g1].prod_which = 1; }
+                }
                 E.bwd_writes.push_back({s.w, s.gn_w < 0 ? s.b : -1});
                 E.bwd_sub.push_back(unit_sub((int)si) ? 1 : 0);
                 E.bwd_sig.push_back(0);
@@ -916,11 +929,12 @@ struct Planner {
                         int pi;
                         ForkSig sg;                               // a batch released just now: the first data-gradient kernel stores its number
                         if (g0 >= 0) {
-                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0) * (s.rq_unit[0] >= 0 ? 2 : 1), fl * i0.C / s.Cin);
                             if (s.x_dg0 >= 0) {
                                 sg.flag = E.take_sig(sg.seq);
+                                const Conv3xReduce rq = E.reduce_args(s.rq_unit[0]);
                                 launch_conv3x(s.x_dg0, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr,
-                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st, STAT_REP, nullptr, sg);
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st, STAT_REP, nullptr, sg, &rq);
                             } else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
@@ -928,12 +942,13 @@ struct Planner {
                         }
                         if (g1 >= 0) {
                             const int C1 = E.tens[s.in1].C;
-                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g1), fl * C1 / s.Cin);
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g1) * (s.rq_unit[1] >= 0 ? 2 : 1), fl * C1 / s.Cin);
                             if (s.x_dg1 >= 0) {
                                 sg = ForkSig{};
                                 sg.flag = E.take_sig(sg.seq);     // (null when the first data-gradient took it)
+                                const Conv3xReduce rq = E.reduce_args(s.rq_unit[1]);
                                 launch_conv3x(s.x_dg1, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr,
-                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st, STAT_REP, nullptr, sg);
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st, STAT_REP, nullptr, sg, &rq);
                             } else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);

@@ -36,9 +36,12 @@ struct GnFinArgs;
 // gn != null: in0 is the RAW conv output of the producer unit; its GroupNorm + dropout + ReLU is applied while the halo is staged
 // (Conv3xArgs::fuse, conv3x_impl.h).  conv3x_gn_supported: which inputs that variant takes.
 bool conv3x_gn_supported(int Cin, bool has_in1);
+// GroupNorm-backward REDUCE of the consuming unit folded into a data-gradient launch (Conv3xArgs::rq_*, conv3x_impl.h): y = that unit's raw conv output,
+// scale / shift its forward coefficients [N][Cout], Q its backward sums [rep][N][Cout][2]
+struct Conv3xReduce { const void* y; const float* scale; const float* shift; double* Q; int rep; };
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
                    int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep = STAT_REP, const GnFinArgs* gn = nullptr,
-                   ForkSig sg = ForkSig{});
+                   ForkSig sg = ForkSig{}, const Conv3xReduce* rq = nullptr);
 // replicas a statistics producer spreads its atomics over, by voxels per sample: enough to keep same-address fp64 atomics apart,
 // few enough that the consumer-side fold (gn_fold_block) reads ~8 KB
 inline int stat_rep_for(long long V) { return V >= 262144 ? 32 : V >= 65536 ? 16 : V >= 8192 ? 8 : 4; }

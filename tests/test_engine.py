@@ -358,6 +358,40 @@ def test_conv3x_path_matches_conv3_kernel_path(dev, monkeypatch, tag, dtype):
     check_conv3x_path(dev, monkeypatch, tag, dtype)
 
 
+def check_reduce_fold(dev, monkeypatch, tag, dtype):
+    """GroupNorm-backward reduce inside the conv3x data-gradient epilogue (SEG_GN_RFUSE, read when the engine is created; Conv3xArgs::rq_*) against
+    the reduce kernel: the forward pass is untouched (identical logits / loss), the sums are the same values added in another order (fp32 partials per
+    workgroup, fp64 atomics), so every gradient tensor agrees to summation noise."""
+    conftest.needs_experiments(dev)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SEG_GN_RFUSE", flag)
+        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
+        logits, probs, out3, grads = run_engine(e, x, y, masks, alpha, loss, dev)
+        res.append((logits, out3, grads, e.lib.seg_plan_count(e.h, 10)))
+    assert torch.equal(res[0][0], res[1][0]) and float(res[0][1][0]) == float(res[1][1][0])
+    assert res[0][3] > 0 and res[1][3] == 0, "no reduce pass was folded: the test would compare a path with itself"
+    for k in res[0][2]:
+        a, b = res[0][2][k].double(), res[1][2][k].double()
+        if float(b.norm()) < 1e-12:
+            continue
+        # 16-bit storage of d(raw) rounds the other way when a coefficient moves in its last bit; nothing systematic survives 1e-2
+        assert float((a - b).norm()) / float(b.norm()) < 1e-2, (k, float((a - b).norm()) / float(b.norm()))
+
+
+@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16"), ("unet2d_s", "bf16"), ("vnet3d", "f16")])
+def test_reduce_folded_into_data_gradient_equals_reduce_kernel(dev, monkeypatch, tag, dtype):
+    if tag != "vnet2d_s":
+        conftest.checker_slow(dev, "two whole 16-bit train steps per case: 1-3 min each on the host checker (one small case runs there)")
+    check_reduce_fold(dev, monkeypatch, tag, dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dtype", [("unet3d_32", "bf16"), ("vnet3d_48", "f16")])
+def test_reduce_folded_into_data_gradient_equals_reduce_kernel_gpu(monkeypatch, tag, dtype):
+    check_reduce_fold(torch.device("cuda:0"), monkeypatch, tag, dtype)
+
+
 def check_conv3x_path(dev, monkeypatch, tag, dtype):
     """The register-blocked halo conv (conv3x.hip) against conv3_kernel inside the whole 16-bit train-mode step
     (SEG_CONV3X=0 is read when the engine is created).  The two kernels produce bit-identical convolutions (same K order;
