@@ -95,7 +95,7 @@ def pmc_traffic(family):
         if table.get("_build") != _library_build():
             return None, "%s is from build '%s', not the loaded library: traffic dropped" % (os.path.basename(f), table.get("_build"))
         fam = FAMILIES[family]
-        rows = {k: v for k, v in table.items() if not k.startswith("_") and any(k.startswith(p) or (p in k and not p.startswith("_Z")) for p in fam["pmc"])}
+        rows = {k: v for k, v in table.items() if isinstance(v, dict) and any(k.startswith(p) or (p in k and not p.startswith("_Z")) for p in fam["pmc"])}
         # a family name that is a prefix of another family's symbol must not swallow it (wgrad_kernel vs wgrad3_kernel)
         if family == "generic_wgrad":
             rows = {k: v for k, v in rows.items() if "wgrad3" not in k}
