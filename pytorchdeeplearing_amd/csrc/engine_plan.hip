@@ -904,7 +904,8 @@ struct Planner {
                     const int li = i0.lvl, lo = ro.lvl;
                     const int T = (s.ck == CK_K3 || s.ck == CK_STEM3) ? (E.ndim == 3 ? 27 : 9)
                                   : (s.ck == CK_K2S2 || s.ck == CK_KT) ? (E.ndim == 3 ? 8 : 4) : 1;
-                    // ---- bias gradient of convs without GroupNorm
+                    // ---- bias gradient of convs without GroupNorm (the UNet up-convs): a column sum of d(raw).  On the main queue: the second queue carries the
+                    // critical tail of the UNet steps (moved there in round 5: UNet3d 2 x 128^3 4.46-4.49 vs 4.38-4.44 ms, profiles/r05_colsum_ab.log)
                     if (s.gn_w < 0 && s.b >= 0)
                         launch_colsum(E.ws + E.tens[draw].off, E.g + E.params[s.b].off, (long long)E.N * E.vol(lo), s.Cout, E.dtype, st);
                     if (s.ck == CK_K3) {

@@ -26,10 +26,12 @@ for name, (kind, ndim, shape, ncls, loss, dt) in CONFIGS.items():
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): e.train_step(x, y, loss, class_alpha=alpha)
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
-    e.profile_enable(_capi.KERNEL_CLASSES)
-    for _ in range(2): e.train_step(x, y, loss, class_alpha=alpha)
-    torch.cuda.synchronize()
-    prof = {k: round(v["ms"] / 2, 2) for k, v in e.profile_read().items()}
+    prof = {}
+    if not os.environ.get("SEG_BENCH_NOPROF"):          # (a kernel trace of the un-instrumented step: no per-class event brackets)
+        e.profile_enable(_capi.KERNEL_CLASSES)
+        for _ in range(2): e.train_step(x, y, loss, class_alpha=alpha)
+        torch.cuda.synchronize()
+        prof = {k: round(v["ms"] / 2, 2) for k, v in e.profile_read().items()}
     print(json.dumps({"config": name, "ms_per_step": round(ms, 2), "samples_per_s": round(shape[0] / ms * 1e3, 1), "class_ms": prof}))
     del e
     torch.cuda.empty_cache()
