@@ -534,35 +534,51 @@ __global__ __launch_bounds__(256) void loss_backward_kernel(LossArgs a) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
             const long long n = i / a.V, v = i % a.V;
             const int t = load_label(a.target, a.label_type, i);
+            // every per-class loop is unrolled over the MC slots of the instantiation with the class count as a predicate: the arrays stay in registers
+            // (a loop over the run-time class count indexes them dynamically and sends them to scratch: 78 us at 2 x 128^3 x 4 classes, round 5)
             float z[MC], p[MC], mx = -3.0e38f, se = 0.f;
-            for (int c = 0; c < C; ++c) { z[c] = a.logits[(n * C + c) * a.V + v]; mx = fmaxf(mx, z[c]); }
-            for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - mx); se += p[c]; }
+#pragma unroll
+            for (int c = 0; c < MC; ++c) { z[c] = (c < C) ? a.logits[(n * C + c) * a.V + v] : -3.0e38f; if (c < C) mx = fmaxf(mx, z[c]); }
+#pragma unroll
+            for (int c = 0; c < MC; ++c) { p[c] = (c < C) ? expf(z[c] - mx) : 0.f; if (c < C) se += p[c]; }
             const float inv = 1.f / se;
-            for (int c = 0; c < C; ++c) p[c] *= inv;
+#pragma unroll
+            for (int c = 0; c < MC; ++c) p[c] *= inv;
             const bool dice_like = a.kind == L_MC_DICE || a.kind == L_MC_CE_DICE || a.kind == L_MC_ELDICE || a.kind == L_MC_TVERSKY ||
                                    a.kind == L_MC_SS;
             const bool ce_like = a.kind == L_MC_CE || a.kind == L_MC_FOCAL || a.kind == L_MC_CE_DICE;
             float dz[MC];
-            for (int c = 0; c < C; ++c) dz[c] = 0.f;
+#pragma unroll
+            for (int c = 0; c < MC; ++c) dz[c] = 0.f;
             if (dice_like) {
                 float gsum = 0.f, gc[MC];
-                for (int c = 0; c < C; ++c) {
-                    if (a.kind == L_MC_SS) gc[c] = (c == t) ? (float)K[4 + c] * (p[c] - 1.f) : (float)K[4 + MAXCLS + c] * p[c];
-                    else gc[c] = (float)K[4 + c] * ((c == t) ? 1.f : 0.f) + (float)K[4 + MAXCLS + c];
-                    gsum += p[c] * gc[c];
+#pragma unroll
+                for (int c = 0; c < MC; ++c) {
+                    gc[c] = 0.f;
+                    if (c < C) {
+                        if (a.kind == L_MC_SS) gc[c] = (c == t) ? (float)K[4 + c] * (p[c] - 1.f) : (float)K[4 + MAXCLS + c] * p[c];
+                        else gc[c] = (float)K[4 + c] * ((c == t) ? 1.f : 0.f) + (float)K[4 + MAXCLS + c];
+                        gsum += p[c] * gc[c];
+                    }
                 }
-                for (int c = 0; c < C; ++c) dz[c] += p[c] * (gc[c] - gsum);
+#pragma unroll
+                for (int c = 0; c < MC; ++c) dz[c] += p[c] * (gc[c] - gsum);
             }
             if (ce_like) {
                 float w = kn;
                 if (a.kind == L_MC_FOCAL) {
-                    const float nll = (mx + logf(se)) - z[t];
+                    float zt = 0.f;
+#pragma unroll
+                    for (int c = 0; c < MC; ++c) if (c == t) zt = z[c];
+                    const float nll = (mx + logf(se)) - zt;
                     const float pt = expf(-nll), om = 1.f - pt;
                     w *= powf(om, a.focal_gamma) + a.focal_gamma * powf(om, a.focal_gamma - 1.f) * pt * nll;
                 }
-                for (int c = 0; c < C; ++c) dz[c] += w * (p[c] - ((c == t) ? 1.f : 0.f));
+#pragma unroll
+                for (int c = 0; c < MC; ++c) dz[c] += w * (p[c] - ((c == t) ? 1.f : 0.f));
             }
-            for (int c = 0; c < C; ++c) a.dlogits[(n * C + c) * a.V + v] = dz[c] * gs;
+#pragma unroll
+            for (int c = 0; c < MC; ++c) if (c < C) a.dlogits[(n * C + c) * a.V + v] = dz[c] * gs;
         }
     }
 }
