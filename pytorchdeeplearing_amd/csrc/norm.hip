@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB
             }
         }
     }
-#pragma unroll 1
+#pragma unroll                  // (unrolled: `br ? p1 : q1` under a run-time branch index sent all four accumulator arrays to scratch, 144 B per lane)
     for (int br = 0; br < (DUAL ? 2 : 1); ++br) {
         if (br) __syncthreads();
 #pragma unroll
