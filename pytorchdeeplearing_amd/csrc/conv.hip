@@ -241,11 +241,19 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep, ForkSig sg) {
     const long long M = (long long)a.N * a.OD * a.OH * a.OW;
     const int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     dim3 grid(cdiv(M, BM), a.Ngemm / (16 * nt));
-    // two reduction slices per stage where the launch is a latency chain (fewer than two workgroups per CU) and K allows it
+    // two reduction slices per stage where the launch is a latency chain (fewer than two workgroups per CU) and K allows it; FOUR where the launch does not
+    // even fill half the CUs (the stride-2 / transposed convs of the 12^3 and 6^3 levels: 28 ... 112 workgroups whose life is K / 64 serial load -> LDS ->
+    // barrier stages, 26 us for K = 1024): 16-bit types only (123 KB of LDS, one workgroup per CU - there is one per CU at most anyway)
     static const int ks_env = xknob_i("SEG_IGEMM_KS", 0);
     const bool ks2 = a.Kpad % (2 * BK) == 0 && a.Kpad >= 4 * BK && (ks_env ? ks_env == 2 : (long long)grid.x * grid.y <= 512);
+    const bool ks4 = sizeof(T) == 2 && a.Kpad % (4 * BK) == 0 && a.Kpad >= 8 * BK && (ks_env ? ks_env == 4 : (long long)grid.x * grid.y <= 128);
 #define SEG_LAUNCH_CONV(NT)                                                                          \
-    if (ks2) {                                                                                        \
+    if (ks4) {                                                                                        \
+        if constexpr (sizeof(T) == 2) {                                                               \
+            if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 4>), grid, dim3(256), 0, s, a, srep, sg);  \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 4>), grid, dim3(256), 0, s, a, srep, sg);     \
+        }                                                                                             \
+    } else if (ks2) {                                                                                 \
         if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 2>), grid, dim3(256), 0, s, a, srep, sg);  \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 2>), grid, dim3(256), 0, s, a, srep, sg);     \
     } else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 1>), grid, dim3(256), 0, s, a, srep, sg);  \
