@@ -258,7 +258,8 @@ def _gpu_torch_baseline(seg, batch, size, dev, steps=3):
 
 def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0, batch=4, gpu_leg=False):
     """The oracle (torch-CPU port of the reference path, oracle/seg_oracle.py) on this box's host cores,
-    bounded sample of the same workload: VNet3d 1 x 1 x size^3 train steps (fp32, all cores, dropout on).
+    bounded sample of the same workload: VNet3d `batch` x 1 x size^3 train steps (the benchmark's own 4-volume batch, BASELINE.md 3.3; fp32, dropout on;
+    one warm-up + two timed steps, best of the timed ones - about 15 s).
     Returns (cpu_baseline, dice_vs_ref, gpu_torch_baseline or None): the only place of this file that touches oracle/."""
     from oracle import seg_oracle as seg
     # torch-CPU convolutions stop scaling (and then collapse) beyond a few dozen threads on a many-core host:
@@ -266,13 +267,13 @@ def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0, batch=4, 
     ncores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(ncores)
     params = seg.init_params("vnet", 3, 1, 1, seed=0)
-    x, y = seg.synthetic_batch(1, (size,) * 3, 1, 1, seed=1234)
+    x, y = seg.synthetic_batch(batch, (size,) * 3, 1, 1, seed=1234)
     g = torch.Generator().manual_seed(0)
     st = {}
     times = []
     t_start = time.time()
-    for it in range(4):
-        masks = seg.draw_masks("vnet", 1, generator=g)
+    for it in range(3):
+        masks = seg.draw_masks("vnet", batch, generator=g)
         t0 = time.time()
         r = seg.forward_backward("vnet", params, x, y, "BinaryDiceLoss", masks=masks)
         params = seg.adamw_step(params, r["grads"], st)
@@ -280,9 +281,9 @@ def cpu_baseline(size, trained_state, dev, dtype, seconds_budget=25.0, batch=4, 
         if time.time() - t_start > seconds_budget:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
-    base = {"value": round(1.0 / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
-            "sample": "%d train steps of VNet3d 1x1x%d^3 fp32 (one volume, not the 4-volume batch), torch %s CPU, %d of the %d hardware "
-                      "threads of %s, best step %.3f s" % (len(times), size, torch.__version__, ncores, os.cpu_count() or 1, cpu_model(), best)}
+    base = {"value": round(batch / best, 4), "unit": "volumes/s", "cores": ncores, "kind": "port",
+            "sample": "%d train steps (the first is warm-up) of VNet3d %dx1x%d^3 fp32 - the benchmark's own batch -, torch %s CPU, %d of the %d hardware "
+                      "threads of %s, best step %.3f s" % (len(times), batch, size, torch.__version__, ncores, os.cpu_count() or 1, cpu_model(), best)}
     dice = _dice_vs_reference(seg, trained_state, dev, dtype, size=size)
     return base, dice, (_quiet_stdout(_gpu_torch_baseline, seg, batch, size, dev) if gpu_leg else None)
 

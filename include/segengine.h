@@ -23,9 +23,8 @@
  *   SEG_WG_DIRECT=0      1^d-conv weight gradients through wgrad_kernel instead of the multi-step streaming kernel
  *   SEG_W3_BOX16=0|2     the 4 x 8 x 16-box weight gradient of the 16-channel level: off / forced onto small volumes (operator tests)
  *   SEG_C3X_MAP="cin:cout:w=id,..."   per-shape halo-conv tiling override (tools/tune_conv3x.py)
- * Every other SEG_* knob of rounds 1-5 (workgroup counts, fork policies, and the measured-slower paths: double-buffered weight gradient, GroupNorm in
- * the consumer conv, persistent halo convs, flag forks, sub-batched levels, second weight-gradient stream - profiles/HISTORY.md) exists only in the
- * experiments build: `python -m pytorchdeeplearing_amd.build --experiments` -> lib/libsegengine_exp.so (-DSEG_EXPERIMENTS), SEGENGINE_LIB=<that file>.
+ * The tuning knobs and measured-slower paths of rounds 1-5 (double-buffered weight gradient, GroupNorm in the consumer conv, persistent halo convs, flag
+ * forks, sub-batched levels, second weight-gradient stream) were removed from the sources in round 6; what each measured is in profiles/HISTORY.md.
  */
 #ifndef SEGENGINE_H
 #define SEGENGINE_H
@@ -94,14 +93,8 @@ int seg_set_dropout_draws(seg_handle h, long long draws);
 /* Fix the batch shape (N, D, H, W; D ignored for ndim 2) and size the workspace. */
 int seg_plan(seg_handle h, int n, int d, int hgt, int wid);
 long long seg_workspace_bytes(seg_handle h);
-/* what the planner decided for the current shape (tests / diagnostics): what = 0: activations applied by their consuming convolution instead
- * of an elementwise launch (the activated tensor is never written), 1: convolution units, 2: fork events the last backward pass recorded on the
- * caller's stream, 3: flag forks of the last backward pass (experiments build with SEG_FORK=flag only - opt-in, never the default: the
- * weight-gradient queue waits on a word in signal memory that the caller's stream's next kernel stores; 0 in the product library),
- * 7 / 8: of those, numbers stored by the next kernel itself / by a one-wave kernel of their own, 9: 1 when no released batch is left waiting,
- * 4: samples per group of the sub-batched finest level (0 = whole-batch launches; experiments build, SEG_SUB_MB),
- * 5 / 6: forward / backward ops that run group by group, 10: GroupNorm-backward reduce passes folded into the epilogue of the convolution
- * data-gradient launch that writes the unit's only gradient (known after a backward pass was planned).  <0: not planned / unknown `what`. */
+/* what the planner decided for the current shape (tests / diagnostics): what = 1: convolution units, 2: fork events the last backward pass recorded
+ * on the caller's stream.  <0: not planned / unknown `what`. */
 int seg_plan_count(seg_handle h, int what);
 
 /* Bind caller-owned buffers: flat fp32 params / grads (seg_param_numel floats each) + workspace. */
@@ -261,6 +254,16 @@ typedef struct seg_train_args {
     void* aux_stream;
 } seg_train_args;
 int seg_train_step(seg_handle h, const seg_train_args* a, void* stream);
+/* In-library gradient exchange - no host callback between the slices of the backward pass (the hook form above stays as the fallback, and is what
+ * the CPU tests with gloo use).  `comm` = an ncclComm_t of RCCL (one rank per GPU; e.g. torch.distributed's: ProcessGroupNCCL._comm_ptr()),
+ * `allreduce_fn` = the address of `ncclAllReduce` of the SAME RCCL library that created the communicator:
+ *     ncclResult_t (*)(const void* sendbuf, void* recvbuf, size_t count, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)
+ * (the engine does not link RCCL: the caller hands it the function).  While a communicator is set, a seg_train_step with bucket_cb == NULL issues
+ * ncclAllReduce(ncclFloat, ncclSum), in place, over every finished suffix of the flat gradient buffer (nfrac / fractions[] as above; nfrac = 0: one
+ * all-reduce after the backward pass) on an exchange stream of the library that waits for the caller's stream and the weight-gradient stream (or on
+ * a->aux_stream when given); the caller's stream meets it again in front of the optimiser.  a->grad_div carries the 1/world average.  comm == NULL
+ * removes the communicator.  A step with a communicator cannot be captured as a HIP graph.  seg_backward_* / seg_adam_step are unaffected. */
+int seg_set_rccl_comm(seg_handle h, void* comm, void* allreduce_fn);
 /* The same step captured ONCE as a HIP graph (hipStreamBeginCapture around seg_train_step on `stream`, the weight-gradient stream forked and
  * joined inside) and replayed with one hipGraphLaunch per step: for hosts that cannot enqueue ~250 launches per step as fast as the GPU runs
  * them.  Every pointer / scalar of `a` and the current loss scale are baked into the graph (re-capture to change them; seg_plan, seg_bind and
@@ -420,7 +423,11 @@ int seg_op_plane_axpb(const float* in, const float* a, const float* b, float* ou
  * [n][1][d][h][w] fp32, target = labels of the same extent.  out1[0] = the clDice loss; when dlogits != NULL,
  * grad_scale * d loss / d logit (sigmoid Jacobian included) is ADDED to dlogits, i.e. call it after seg_loss_backward of the
  * companion loss (Dice) with grad_scale = weight * loss scale.  ws: seg_cldice_ws_bytes() bytes planned by the caller; no
- * allocation, no host synchronisation.  nd = 2 (d = 1) or 3. */
+ * allocation, no host synchronisation.  nd = 2 (d = 1) or 3.
+ * The target is ALWAYS read as the binary mask (label != 0), whatever `label_type` says (SEG_LABEL_BINARIZE is implied): that is what the
+ * reference's train loop hands to every loss (model/modelVNet.py:576 binarises the labels first), and it lets the target's skeleton be computed on a
+ * bit image.  A caller with soft (fractional) targets - which Binary_Soft_cldice_loss.forward itself would skeletonise as given - must use the
+ * building blocks above (seg_op_skel_iter, seg_op_plane_dot, ...); the companion loss keeps reading the labels as `label_type` says. */
 long long seg_cldice_ws_bytes(int n, int d, int h, int w, int nd, int width);
 /* optional: the label-only part (float labels + the target skeleton) into ws ahead of time, e.g. on another stream while the forward pass
  * runs; seg_cldice_binary(target_ready = 1) then skips it (the caller orders the two calls with an event). */

@@ -1,9 +1,8 @@
 """ctypes binding of the C-ABI in include/segengine.h.
 
 The product library is the in-tree gfx950 build (pytorchdeeplearing_amd/lib/libsegengine.so).
-There is NO CPU implementation: tensors that are not on an AMD GPU raise.  `inject_library` exists
-only so the repo's CPU test-suite can hand in the host-side kernel-logic checker build
-(tests/emu); nothing in the package calls it."""
+There is NO CPU implementation: tensors that are not on an AMD GPU raise (`lib_for`), a missing library raises
+(`product_library`).  Everything in the package reaches the library through `lib_for(device)` / `host_library()`."""
 import ctypes as C
 import os
 
@@ -109,6 +108,7 @@ SIGNATURES = {
     "seg_op_normalize_percentile": (_i, [_vp, _vp, _ll, _f, _f, _vp, _vp]),
     "seg_op_gather_patches": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "seg_op_stitch_mask": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "seg_set_rccl_comm": (_i, [_vp, _vp, _vp]),
     "seg_profile_enable": (_i, [_vp, C.c_uint]),
     "seg_profile_read": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "seg_last_error": (C.c_char_p, []),
@@ -129,6 +129,7 @@ class TrainArgs(C.Structure):
 
 
 BUCKET_CB = C.CFUNCTYPE(_i, _vp, _i, _ll, _ll)
+NCCL_ALLREDUCE = C.CFUNCTYPE(_i, _vp, _vp, C.c_size_t, _i, _i, _vp, _vp)      # ncclAllReduce(send, recv, count, dtype, op, comm, stream)
 LOSS_CB = C.CFUNCTYPE(_ll, _vp, _vp, _i)
 
 
@@ -151,13 +152,6 @@ class SegLib:
 
 
 _product = None
-_injected = None
-
-
-def inject_library(lib):
-    """TEST-ONLY: route *CPU* tensors to the given library (host-side checker build)."""
-    global _injected
-    _injected = lib
 
 
 def product_library():
@@ -176,9 +170,12 @@ def lib_for(device):
     device = torch.device(device)
     if device.type == "cuda":
         return product_library()
-    if _injected is not None:
-        return _injected
     raise RuntimeError("the segmentation engine runs on AMD MI355X (gfx950) only; got a %s tensor" % device.type)
+
+
+def host_library():
+    """the library for entry points that do no device work (network tables: seg_create / seg_param_info)"""
+    return product_library()
 
 
 def stream_for(device):

@@ -7,12 +7,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsegengine.so")
 SRCS = ["conv.hip", "conv3.hip", "conv3x.hip", "conv3x_f16_3d.hip", "conv3x_f16_2d.hip", "conv3x_bf16_3d.hip", "conv3x_bf16_2d.hip", "wgrad.hip", "stemx.hip", "norm.hip", "misc.hip", "lovasz.hip", "ssim.hip", "cldice.hip", "prepost.hip", "engine.hip", "engine_plan.hip", "capi_ops.hip"]
-# Measured-slower paths of rounds 2-4 (profiles/HISTORY.md): the double-buffered weight gradient, GroupNorm applied by the consuming halo conv, the
-# persistent halo convs, flag forks, sub-batched levels, every tuning knob.  They exist only in the EXPERIMENTS build
-# (`python -m pytorchdeeplearing_amd.build --experiments` -> lib/libsegengine_exp.so, all sources compiled with -DSEG_EXPERIMENTS); the product library
-# neither contains their kernels nor reads their environment variables.
-EXP_SRCS = ["wgrad3x.hip", "conv3x_f16_3d_gn.hip", "conv3x_f16_2d_gn.hip", "conv3x_bf16_3d_gn.hip", "conv3x_bf16_2d_gn.hip"]
-EXP_LIB = os.path.join(HERE, "lib", "libsegengine_exp.so")
 ID_UNIT = "engine.hip"          # compiled with -DSEG_BUILD_ID
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -munsafe-fp-atomics: fp32 / fp64 atomicAdd as the hardware instruction instead of a compare-and-swap loop (every buffer the library adds into is ordinary
@@ -33,7 +27,7 @@ def build_id():
 
 
 def _deps():
-    d = [os.path.join(CSRC, f) for f in SRCS + EXP_SRCS + ["common.h", "kernels.h", "conv3x_impl.h", "gn_fold.h", "engine_internal.h"]]
+    d = [os.path.join(CSRC, f) for f in SRCS + ["common.h", "kernels.h", "conv3x_impl.h", "gn_fold.h", "engine_internal.h"]]
     d.append(os.path.join(os.path.dirname(HERE), "include", "segengine.h"))
     return d
 
@@ -55,41 +49,46 @@ def _dep_time(obj, fallback):
         return fallback
 
 
-def build(force=False, verbose=False, experiments=False):
+def _embedded_id(obj):
+    """the build id compiled INTO an object (engine.hip.o carries -DSEG_BUILD_ID as a string constant): compared with the id of the current sources, so
+    that a cached object of another checkout is never linked under a newer stamp (a tracked side file used to make that possible)"""
+    try:
+        with open(obj, "rb") as f:
+            data = f.read()
+        i = data.find(b"segengine gfx950 ")
+        return data[i + 17:i + 29].decode("ascii", "replace") if i >= 0 else ""
+    except OSError:
+        return ""
+
+
+def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
-    objdir = os.path.join(HERE, "lib", "obj_exp" if experiments else "obj")
+    objdir = os.path.join(HERE, "lib", "obj")
     os.makedirs(objdir, exist_ok=True)
-    srcs = SRCS + (EXP_SRCS if experiments else [])
-    lib = EXP_LIB if experiments else LIB
-    flags = FLAGS + (["-DSEG_EXPERIMENTS"] if experiments else [])
     hdrs = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "conv3x_impl.h", "gn_fold.h", "engine_internal.h")] + [os.path.join(os.path.dirname(HERE), "include", "segengine.h")]
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
     procs, objs = [], []
-    bid = build_id() + ("+experiments" if experiments else "")
-    idfile = os.path.join(objdir, "build_id.txt")
-    last_id = open(idfile).read().strip() if os.path.exists(idfile) else ""
-    for s in srcs:
+    bid = build_id()
+    for s in SRCS:
         o = os.path.join(objdir, s + ".o")
         objs.append(o)
         # per-object freshness: an object compiled before an edit of its source must not hide behind a newer link step
-        stale_id = s == ID_UNIT and last_id != bid          # the unit that carries the build id follows every source change
+        stale_id = s == ID_UNIT and _embedded_id(o) != bid          # the unit that carries the build id follows every source change
         if not force and not stale_id and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(os.path.join(CSRC, s)), _dep_time(o, hdr_t)):
             continue
-        cmd = [HIPCC] + flags + (['-DSEG_BUILD_ID="%s"' % bid] if s == ID_UNIT else []) + ["-MD", "-MF", o + ".d", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [HIPCC] + FLAGS + (['-DSEG_BUILD_ID="%s"' % bid] if s == ID_UNIT else []) + ["-MD", "-MF", o + ".d", "-c", os.path.join(CSRC, s), "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    if not procs and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(o) for o in objs):
-        return lib
+    if not procs and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(o) for o in objs):
+        return LIB
     for s, p in procs:
         out = p.communicate()[0].decode()
         if p.returncode:
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, out))
         if verbose and out.strip():
             print(out)
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
-    with open(idfile, "w") as f:
-        f.write(bid)
-    return lib
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="-f" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))
+    print(build(force="-f" in sys.argv, verbose=True))

@@ -141,86 +141,13 @@ __global__ __launch_bounds__(256) void plane_axpb_kernel(const float* in, const 
 // fp32: bit-identical to the two-kernel form (pool3_kernel + skel_update_kernel), which read every input 27 times from L2.
 // (Round 3 tried SEPARABLE pools - min over x, then y, then z; likewise max: 38 k instead of 83 k LDS reads per tile, same bits - and
 // lost: six more barriers and 46 KB instead of 22 KB of LDS per workgroup; C5 + clDice 7.67 vs 7.38 ms per step.  Not kept.)
-template <int TZ, int TY, int TX, bool ND3>
-__global__ __launch_bounds__(256) void skel_iter_kernel(const float* x, float* e_out, float* x_out, Vol v) {
-    constexpr int HZ = ND3 ? 2 : 0;
-    constexpr int XZ = TZ + 2 * HZ, XY = TY + 4, XX = TX + 4;
-    constexpr int EZ = TZ + HZ, EY = TY + 2, EX = TX + 2;
-    __shared__ float xs[XZ * XY * XX];
-    __shared__ float es[EZ * EY * EX];
-    const float INF = __builtin_huge_valf();
-    const int ntx = (v.W + TX - 1) / TX, nty = (v.H + TY - 1) / TY, ntz = (v.D + TZ - 1) / TZ;
-    int b = blockIdx.x;
-    const int x0 = (b % ntx) * TX; b /= ntx;
-    const int y0 = (b % nty) * TY; b /= nty;
-    const int z0 = (b % ntz) * TZ;
-    const int p = b / ntz;
-    const long long V = (long long)v.D * v.H * v.W;
-    const float* xp = x + (long long)p * V;
-    // all loads of the halo are issued before the first LDS store (out-of-volume slots read element 0 and store +inf): as a rolled
-    // load -> s_waitcnt vmcnt(0) -> ds_write loop the 14 trips of the 4 x 8 x 32 tile were 14 serial memory round trips per workgroup,
-    // which was most of the kernel's time
-    {
-        constexpr int NE = XZ * XY * XX, NIT = (NE + 255) / 256;
-        float hv[NIT];
-        bool hin[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = threadIdx.x + k * 256;
-            const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
-            const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
-            hin[k] = i < NE && (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
-            hv[k] = xp[hin[k] ? ((long long)gz * v.H + gy) * v.W + gx : 0];
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = threadIdx.x + k * 256;
-            if (i < NE) xs[i] = hin[k] ? hv[k] : INF;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < EZ * EY * EX; i += 256) {
-        const int lx = i % EX, ly = (i / EX) % EY, lz = i / (EX * EY);
-        const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - (ND3 ? 1 : 0);
-        float m = -INF;                                     // outside the volume: ignored by the max-pool below
-        if ((unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D) {
-            m = INF;
-#pragma unroll
-            for (int dz = 0; dz < (ND3 ? 3 : 1); ++dz)
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) m = fminf(m, xs[((lz + dz) * XY + ly + dy) * XX + lx + dx]);
-        }
-        es[i] = m;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < TZ * TY * TX; i += 256) {
-        const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
-        const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-        if (gx >= v.W || gy >= v.H || gz >= v.D) continue;
-        float mx = -INF;
-#pragma unroll
-        for (int dz = 0; dz < (ND3 ? 3 : 1); ++dz)
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) mx = fmaxf(mx, es[((lz + dz) * EY + ly + dy) * EX + lx + dx]);
-        const float ev = es[((lz + (ND3 ? 1 : 0)) * EY + ly + 1) * EX + lx + 1];
-        const float xv = xs[((lz + HZ) * XY + ly + 2) * XX + lx + 2];
-        const long long o = (long long)p * V + ((long long)gz * v.H + gy) * v.W + gx;
-        e_out[o] = ev;
-        x_out[o] = fmaxf(xv - fmaxf(mx - ev, 0.f), 0.f);
-    }
-}
-
-// The same iteration with FOUR x-consecutive voxels per thread (round 5).  skel_iter_kernel issues one ds_read_b32 per window element: 81 LDS
+// FOUR x-consecutive voxels per thread (round 5).  The first form (one voxel per thread, rounds 1-4) issued one ds_read_b32 per window element: 81 LDS
 // instructions per output voxel, and the rocprofv3 stats of the C5 + clDice step (profiles/r05_kernel_stats_c5_cldice.txt) put its 20 launches at
 // 44 us each - 0.88 ms of a 6.3 ms step - for 48 MB of traffic per launch (1.1 TB/s: not the memory system, the LDS instruction stream).  Here a
 // thread reads a window ROW of its four voxels as one ds_read_b128 + one ds_read_b64 (six values; rows are 36 floats = 9 x 16 B, groups start at
 // multiples of four, so both reads are aligned), forms the four row minima / maxima with v_min3 / v_max3 and folds the nine rows: 18 LDS
 // instructions per FOUR voxels in either pass, results stored as one 16-B vector.  Same min / max / sub / relu in fp32, same operand values: the
-// outputs are bit-identical to skel_iter_kernel (tests/test_cldice.py compares both against the per-voxel reference form).
+// outputs are bit-identical to the two-kernel form (tests/test_cldice.py).
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 template <int TZ, int TY, int TX, bool ND3>
@@ -401,137 +328,10 @@ __global__ __launch_bounds__(256) void cld_bits_expand_kernel(const unsigned* bi
 //      position am(w) of the FIRST maximum of e in w;  dx_direct(q) = gt(q),  de(q) = gw(q) - sum_{w in N(q), am(w) = q} gw(w)
 //   B: am(w) = first minimum of x in w;  dx(q) = dx_direct(q) + sum_{w in N(q), am(w) = q} de(w)
 // (the scatter form above routes the same terms with fp32 atomics).
-template <int TZ, int TY, int TX, bool ND3, bool PASS_B>
-__global__ __launch_bounds__(256) void skel_bwd_tile_kernel(const float* g, const float* x, const float* e, float* dx, float* de, Vol v) {
-    constexpr int HZ = ND3 ? 2 : 0, H1 = ND3 ? 1 : 0;
-    constexpr int XZ = TZ + 2 * HZ, XY = TY + 4, XX = TX + 4;       // source (e in pass A, x in pass B) with a 2-voxel halo
-    constexpr int EZ = TZ + 2 * H1, EY = TY + 2, EX = TX + 2;       // windows: tile + 1 halo
-    __shared__ float src[XZ * XY * XX];
-    __shared__ float gws[EZ * EY * EX];
-    __shared__ int ams[EZ * EY * EX];
-    const float INF = __builtin_huge_valf();
-    const int ntx = (v.W + TX - 1) / TX, nty = (v.H + TY - 1) / TY, ntz = (v.D + TZ - 1) / TZ;
-    int b = blockIdx.x;
-    const int x0 = (b % ntx) * TX; b /= ntx;
-    const int y0 = (b % nty) * TY; b /= nty;
-    const int z0 = (b % ntz) * TZ;
-    const int p = b / ntz;
-    const long long V = (long long)v.D * v.H * v.W, base = (long long)p * V;
-    const float* sp = (PASS_B ? x : e) + base;
-    // every global load of the workgroup - the source halo, the per-window inputs (de in pass B; x and g in pass A) and, in pass B, the dx
-    // values the last loop adds to - is issued up front in unrolled batches: as rolled loops each trip was load -> s_waitcnt vmcnt(0) ->
-    // use, 14 + 8 + 4 serial memory round trips per workgroup
-    constexpr int NE = XZ * XY * XX, NIT = (NE + 255) / 256;
-    constexpr int NW = EZ * EY * EX, WIT = (NW + 255) / 256;
-    constexpr int NT = TZ * TY * TX, TIT = (NT + 255) / 256;
-    float w0[WIT], w1[WIT], t0[TIT];
-    {
-        float hv[NIT];
-        bool hin[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = threadIdx.x + k * 256;
-            const int lx = i % XX, ly = (i / XX) % XY, lz = i / (XX * XY);
-            const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - HZ;
-            hin[k] = i < NE && (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
-            hv[k] = sp[hin[k] ? ((long long)gz * v.H + gy) * v.W + gx : 0];
-        }
-#pragma unroll
-        for (int k = 0; k < WIT; ++k) {
-            const int i = threadIdx.x + k * 256;
-            const int lx = i % EX, ly = (i / EX) % EY, lz = i / (EX * EY);
-            const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - H1;
-            const bool in = i < NW && (unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D;
-            const long long o = in ? base + ((long long)gz * v.H + gy) * v.W + gx : base;
-            w0[k] = PASS_B ? de[o] : x[o];
-            w1[k] = PASS_B ? 0.f : g[o];
-        }
-        if (PASS_B) {
-#pragma unroll
-            for (int k = 0; k < TIT; ++k) {
-                const int i = threadIdx.x + k * 256;
-                const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
-                const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-                const bool in = i < NT && gx < v.W && gy < v.H && gz < v.D;
-                t0[k] = dx[in ? base + ((long long)gz * v.H + gy) * v.W + gx : base];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int i = threadIdx.x + k * 256;
-            if (i < NE) src[i] = hin[k] ? hv[k] : (PASS_B ? INF : -INF);      // never the extremum
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < WIT; ++k) {
-        const int i = threadIdx.x + k * 256;
-        if (i >= NW) continue;
-        const int lx = i % EX, ly = (i / EX) % EY, lz = i / (EX * EY);
-        const int gx = x0 + lx - 1, gy = y0 + ly - 1, gz = z0 + lz - H1;
-        float wgt = 0.f;
-        int am = -1;
-        if ((unsigned)gx < (unsigned)v.W && (unsigned)gy < (unsigned)v.H && (unsigned)gz < (unsigned)v.D) {
-            // first extremum of the window in (z, y, x) scan order; the padding holds -/+inf and can never win the strict
-            // comparison, so no bounds tests are needed (the centre is always a finite in-volume value)
-            float best = PASS_B ? INF : -INF;
-#pragma unroll
-            for (int dz = 0; dz < (ND3 ? 3 : 1); ++dz)
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx_ = 0; dx_ < 3; ++dx_) {
-                        const int li = ((lz + dz) * XY + ly + dy) * XX + lx + dx_;
-                        const float val = src[li];
-                        const bool better = PASS_B ? val < best : val > best;
-                        best = better ? val : best;
-                        am = better ? li : am;
-                    }
-            const long long o = base + ((long long)gz * v.H + gy) * v.W + gx;
-            if (PASS_B) {
-                wgt = w0[k];
-            } else {
-                const float ec = src[((lz + HZ - H1) * XY + ly + 1) * XX + lx + 1];      // centre of window w
-                const float u = best - ec;
-                const float gt = (w0[k] - fmaxf(u, 0.f) > 0.f) ? w1[k] : 0.f;
-                wgt = u > 0.f ? gt : 0.f;
-                // tile-interior windows also publish the direct term of dx
-                const int tx = lx - 1, ty = ly - 1, tz = lz - H1;
-                if ((unsigned)tx < (unsigned)TX && (unsigned)ty < (unsigned)TY && (unsigned)tz < (unsigned)TZ) dx[o] = gt;
-            }
-        }
-        gws[i] = wgt;
-        ams[i] = am;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < TIT; ++k) {
-        const int i = threadIdx.x + k * 256;
-        if (i >= NT) continue;
-        const int lx = i % TX, ly = (i / TX) % TY, lz = i / (TX * TY);
-        const int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
-        if (gx >= v.W || gy >= v.H || gz >= v.D) continue;
-        const int me = ((lz + HZ) * XY + ly + 2) * XX + lx + 2;          // this voxel's index in `src`
-        float acc = 0.f;
-#pragma unroll
-        for (int dz = 0; dz < (ND3 ? 3 : 1); ++dz)
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx_ = 0; dx_ < 3; ++dx_) {
-                    const int wi = ((lz + dz) * EY + ly + dy) * EX + lx + dx_;
-                    if (ams[wi] == me) acc += gws[wi];
-                }
-        const long long o = base + ((long long)gz * v.H + gy) * v.W + gx;
-        if (PASS_B) dx[o] = t0[k] + acc;
-        else de[o] = gws[((lz + H1) * EY + ly + 1) * EX + lx + 1] - acc;
-    }
-}
-
-// The same two gather passes with FOUR x-consecutive windows / voxels per thread (round 5; see skel_iter4_kernel): a window row of the four is one
+// FOUR x-consecutive windows / voxels per thread (round 5; see skel_iter4_kernel): a window row of the four is one
 // ds_read_b128 + one ds_read_b64 of `src` (18 LDS instructions for four windows instead of 108), the gather reads (first-extremum index, weight)
 // rows the same way (36 instead of 216).  Comparisons and additions happen in the same (dz, dy, dx) order per window / voxel as in
-// skel_bwd_tile_kernel, so the results are bit-identical to it.  The 20 launches of that kernel were the largest item of the clDice term:
+// the one-voxel-per-thread form of rounds 1-4, so the results are bit-identical to it.  The 20 launches of that form were the largest item of the clDice term:
 // 1.33 ms of the 6.3 ms C5 + clDice step (profiles/r05_kernel_stats_c5_cldice.txt).
 template <int TZ, int TY, int TX, bool ND3, bool PASS_B>
 __global__ __launch_bounds__(256) void skel_bwd_tile4_kernel(const float* g, const float* x, const float* e, float* dx, float* de, Vol v) {
@@ -715,55 +515,43 @@ void launch_pool3(const float* x, float* out, int planes, int D, int H, int W, i
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(pool3_kernel<false>), dim3(blocks_for(n)), dim3(256), 0, s, x, out, v);
 }
 void launch_skel_iter(const float* x, float* e_out, float* x_out, int planes, int D, int H, int W, int nd, hipStream_t s) {
-    // SEG_SKEL_X4=0: one voxel per thread (rounds 1-4); default: four x-consecutive voxels per thread, same bits
-    static const bool x4 = (xknob_i("SEG_SKEL_X4", 1) != 0);
+    // four x-consecutive voxels per thread (round 5; the one-voxel-per-thread kernels of rounds 1-4 gave the same bits and are gone)
     if (nd == 3) {
         Vol v{planes, D, H, W, 3};
-        const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
         // 8 x 8 x 32 tiles: 1.66 instead of 1.99 halo windows per output voxel (C5 + clDice 5.72 vs 5.81 ms per step, profiles/r05_cldice_tile_ab.log);
-        // SEG_SKEL_TZ=4 keeps the 4 x 8 x 32 tiles, which shallow volumes take anyway
-        static const int tz = xknob_i("SEG_SKEL_TZ", 8);
-        if (x4 && tz == 8 && D >= 8) {
+        // shallow volumes take 4 x 8 x 32 tiles
+        if (D >= 8) {
             const long long nb8 = (long long)planes * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 31) / 32);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<8, 8, 32, true>), dim3((unsigned)nb8), dim3(256), 0, s, x, e_out, x_out, v);
-        } else if (x4) hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+        } else {
+            const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<4, 8, 32, true>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+        }
     } else {
         // 2-D pooling: every depth slice of every plane is an independent image
         Vol v{planes * D, 1, H, W, 2};
         const long long nb = (long long)planes * D * ((H + 15) / 16) * ((W + 63) / 64);
-        if (x4) hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<1, 16, 64, false>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter_kernel<1, 16, 64, false>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_iter4_kernel<1, 16, 64, false>), dim3((unsigned)nb), dim3(256), 0, s, x, e_out, x_out, v);
     }
 }
 void launch_skel_iter_bwd(const float* g, const float* x, const float* e, float* dx, float* de, int planes, int D, int H, int W, int nd,
                           hipStream_t s) {
-    static const bool x4 = (xknob_i("SEG_SKEL_X4", 1) != 0);      // 0: one window / voxel per thread (rounds 1-4), same bits
     if (nd == 3) {
         Vol v{planes, D, H, W, 3};
-        const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
-        static const int tz = xknob_i("SEG_SKEL_TZ", 8);
-        if (x4 && tz == 8 && D >= 8) {
+        if (D >= 8) {
             const long long nb8 = (long long)planes * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 31) / 32);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<8, 8, 32, true, false>), dim3((unsigned)nb8), dim3(256), 0, s, g, x, e, dx, de, v);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<8, 8, 32, true, true>), dim3((unsigned)nb8), dim3(256), 0, s, g, x, e, dx, de, v);
-        } else if (x4) {
+        } else {
+            const long long nb = (long long)planes * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<4, 8, 32, true, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<4, 8, 32, true, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
-        } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<4, 8, 32, true, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<4, 8, 32, true, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
         }
     } else {
         Vol v{planes * D, 1, H, W, 2};
         const long long nb = (long long)planes * D * ((H + 15) / 16) * ((W + 63) / 64);
-        if (x4) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<1, 16, 64, false, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<1, 16, 64, false, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
-        } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<1, 16, 64, false, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile_kernel<1, 16, 64, false, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
-        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<1, 16, 64, false, false>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(skel_bwd_tile4_kernel<1, 16, 64, false, true>), dim3((unsigned)nb), dim3(256), 0, s, g, x, e, dx, de, v);
     }
 }
 void launch_skel_update(const float* x, const float* e, float* out, int planes, int D, int H, int W, int nd, hipStream_t s) {
@@ -862,10 +650,13 @@ void launch_cldice_target(const void* target, int label_type, int planes, int D,
     float* y = (float*)(ws + L.y);
     float* t[3] = {(float*)(ws + L.tgt), (float*)(ws + L.tgt + vol), (float*)(ws + L.tgt + 2 * vol)};
     // The target is read as a BINARY mask, y = (label != 0) - what the reference's train loop hands to every loss (model/modelVNet.py:576: labels are
-    // binarised before the loss) - and its skeleton is computed on bits (cld_bits_kernel): exactly the values of the fp32 iteration on that mask.
-    // SEG_CLD_BITS=0 keeps the fp32 tile kernels for the target (rounds 1-4).
-    static const bool use_bits = (xknob_i("SEG_CLD_BITS", 1) != 0);
-    if (!use_bits || width <= 0) {
+    // binarised before the loss; include/segengine.h says so for seg_cldice_target / seg_cldice_binary) - and its skeleton is computed on bits
+    // (cld_bits_kernel): exactly the values of the fp32 iteration on that mask.  The three bit images (current x, eroded e, next x; rows padded to whole
+    // 32-voxel words, images to 64 words) live in the fp32 scratch volume t[0]; where they do not fit into it - a few hundred voxels, or rows of one or
+    // two voxels (they used to spill into t[1] / t[2], which the expand pass writes) - the fp32 tile kernels compute the same skeleton.
+    const long long nwords_all = (long long)planes * D * H * ((W + 31) / 32);
+    const bool bits_fit = (size_t)3 * (size_t)((nwords_all + 63) / 64 * 64) * sizeof(unsigned) <= vol;
+    if (width <= 0 || !bits_fit) {
         hipLaunchKernelGGL(cld_labels_kernel, dim3(blocks_for(n)), dim3(256), 0, s, target, label_type | LT_BINARIZE, y, n);
         const float* tc = y;
         for (int it = 0; it < width; ++it) { float* nx = t[1 + (it & 1)]; launch_skel_iter(tc, t[0], nx, planes, D, H, W, nd, s); tc = nx; }

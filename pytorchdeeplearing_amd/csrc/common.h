@@ -207,20 +207,11 @@ __device__ __forceinline__ int load_label(const void* p, int lt, long long i) {
     return (lt & LT_BINARIZE) ? (v != 0) : v;
 }
 
-// ---- environment switches (host side).  The PRODUCT library reads the switches documented in include/segengine.h and nothing else (knob_*):
-// each selects a complete, tested path.  Every tuning / experiment knob of rounds 1-5 (xknob_*: workgroup counts, fork policies, the measured-slower
-// paths recorded in profiles/HISTORY.md) is its compiled-in default unless the library is built with -DSEG_EXPERIMENTS
-// (`python -m pytorchdeeplearing_amd.build --experiments` -> lib/libsegengine_exp.so, select it with SEGENGINE_LIB).
+// ---- environment switches (host side): the library reads the switches documented in include/segengine.h and nothing else; each selects a complete,
+// tested path.  The tuning knobs and measured-slower paths of rounds 1-5 are gone from the sources (round 6); what each one measured is in
+// profiles/HISTORY.md.
 inline const char* knob_s(const char* name) { return getenv(name); }
 inline int knob_i(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-#ifdef SEG_EXPERIMENTS
-inline const char* xenv(const char* name) { return getenv(name); }
-#else
-inline const char* xenv(const char*) { return nullptr; }
-#endif
-inline int xknob_i(const char* name, int dflt) { const char* e = xenv(name); return e ? atoi(e) : dflt; }
-inline long long xknob_ll(const char* name, long long dflt) { const char* e = xenv(name); return e ? atoll(e) : dflt; }
-inline double xknob_f(const char* name, double dflt) { const char* e = xenv(name); return e ? atof(e) : dflt; }
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }

@@ -80,9 +80,8 @@ __device__ __forceinline__ void tile_stats(const T* Os, int ldo, int rows_valid,
 // KS = 32-wide reduction slices per pipeline stage.  The deep levels launch 28..432 workgroups whose time is the serial
 // chain of stages (one global-load latency each): KS = 2 halves the chain with twice the loads in flight.
 template <class T, int NT, bool SCATTER, int KS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int srep, ForkSig sg) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int srep) {
     constexpr int BN = 16 * NT;
-    if (sg.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(sg.flag, sg.seq);
     __shared__ T As[2 * KS * BM * LDT];
     __shared__ T Bs[2 * KS * BN * LDT];
     __shared__ float red[512];
@@ -237,27 +236,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int srep, F
 }
 
 template <class T>
-void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep, ForkSig sg) {
+void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep) {
     const long long M = (long long)a.N * a.OD * a.OH * a.OW;
     const int nt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
     dim3 grid(cdiv(M, BM), a.Ngemm / (16 * nt));
     // two reduction slices per stage where the launch is a latency chain (fewer than two workgroups per CU) and K allows it; FOUR where the launch does not
     // even fill half the CUs (the stride-2 / transposed convs of the 12^3 and 6^3 levels: 28 ... 112 workgroups whose life is K / 64 serial load -> LDS ->
     // barrier stages, 26 us for K = 1024): 16-bit types only (123 KB of LDS, one workgroup per CU - there is one per CU at most anyway)
-    static const int ks_env = xknob_i("SEG_IGEMM_KS", 0);
+    static const int ks_env = 0;
     const bool ks2 = a.Kpad % (2 * BK) == 0 && a.Kpad >= 4 * BK && (ks_env ? ks_env == 2 : (long long)grid.x * grid.y <= 512);
     const bool ks4 = sizeof(T) == 2 && a.Kpad % (4 * BK) == 0 && a.Kpad >= 8 * BK && (ks_env ? ks_env == 4 : (long long)grid.x * grid.y <= 128);
 #define SEG_LAUNCH_CONV(NT)                                                                          \
     if (ks4) {                                                                                        \
         if constexpr (sizeof(T) == 2) {                                                               \
-            if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 4>), grid, dim3(256), 0, s, a, srep, sg);  \
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 4>), grid, dim3(256), 0, s, a, srep, sg);     \
+            if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 4>), grid, dim3(256), 0, s, a, srep);  \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 4>), grid, dim3(256), 0, s, a, srep);     \
         }                                                                                             \
     } else if (ks2) {                                                                                 \
-        if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 2>), grid, dim3(256), 0, s, a, srep, sg);  \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 2>), grid, dim3(256), 0, s, a, srep, sg);     \
-    } else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 1>), grid, dim3(256), 0, s, a, srep, sg);  \
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 1>), grid, dim3(256), 0, s, a, srep, sg);
+        if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 2>), grid, dim3(256), 0, s, a, srep);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 2>), grid, dim3(256), 0, s, a, srep);     \
+    } else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, true, 1>), grid, dim3(256), 0, s, a, srep);  \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, NT, false, 1>), grid, dim3(256), 0, s, a, srep);
     if (nt == 4) { SEG_LAUNCH_CONV(4) } else if (nt == 2) { SEG_LAUNCH_CONV(2) } else { SEG_LAUNCH_CONV(1) }
 #undef SEG_LAUNCH_CONV
 }
@@ -281,9 +280,8 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep, ForkSig sg) {
 #define SEG_STREAM_WAVES(x)
 #endif
 template <class T, int KS, int NTL, int SC>
-__global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) void conv_stream_kernel(ConvArgs a, ForkSig sg) {
+__global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) void conv_stream_kernel(ConvArgs a) {
     constexpr bool SCATTER = SC != 0;
-    if (sg.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(sg.flag, sg.seq);
     constexpr bool C16 = SC == 2;
     constexpr int NJ = C16 ? 1 : NTL;
     __shared__ float red[4][NTL * 16][2];
@@ -466,7 +464,7 @@ bool stream_eligible(const ConvArgs& a) {
 }
 
 template <class T>
-bool launch_conv_stream(const ConvArgs& a, hipStream_t s, ForkSig sg) {
+bool launch_conv_stream(const ConvArgs& a, hipStream_t s) {
     if (!stream_eligible(a)) return false;
     const long long Vrow = (long long)a.OD * a.OH * a.OW;
     const int ks = a.Kpad / 32, ntl = a.Ngemm / 16;
@@ -477,9 +475,9 @@ bool launch_conv_stream(const ConvArgs& a, hipStream_t s, ForkSig sg) {
     dim3 grid(gx, a.N);
 #define SEG_STREAM(KS, NTL)                                                                                                   \
     if (ks == KS && ntl == NTL) {                                                                                            \
-        if (a.scatter && a.Cout == 16 && NTL > 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 2>), grid, dim3(256), 0, s, a, sg); \
-        else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 1>), grid, dim3(256), 0, s, a, sg); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 0>), grid, dim3(256), 0, s, a, sg);               \
+        if (a.scatter && a.Cout == 16 && NTL > 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 2>), grid, dim3(256), 0, s, a); \
+        else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 1>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 0>), grid, dim3(256), 0, s, a);               \
         return true;                                                                                                         \
     }
     SEG_STREAM(1, 1) SEG_STREAM(1, 2) SEG_STREAM(1, 4) SEG_STREAM(1, 8) SEG_STREAM(2, 1) SEG_STREAM(2, 2) SEG_STREAM(2, 4)
@@ -685,11 +683,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
 
 bool conv_uses_stream_kernel(const ConvArgs& a) { return stream_eligible(a); }
 
-void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep, ForkSig sg) {
+void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep) {
     const int srep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
-    if (dtype == DT_F32) { if (!launch_conv_stream<float>(a, s, sg)) conv_dispatch<float>(a, s, srep, sg); }
-    else if (dtype == DT_F16) { if (!launch_conv_stream<f16>(a, s, sg)) conv_dispatch<f16>(a, s, srep, sg); }
-    else { if (!launch_conv_stream<bf16>(a, s, sg)) conv_dispatch<bf16>(a, s, srep, sg); }
+    if (dtype == DT_F32) { if (!launch_conv_stream<float>(a, s)) conv_dispatch<float>(a, s, srep); }
+    else if (dtype == DT_F16) { if (!launch_conv_stream<f16>(a, s)) conv_dispatch<f16>(a, s, srep); }
+    else { if (!launch_conv_stream<bf16>(a, s)) conv_dispatch<bf16>(a, s, srep); }
 }
 
 void launch_conv_stem(const StemArgs& a, int dtype, hipStream_t s) {
@@ -723,7 +721,7 @@ static void head_bwd_dispatch(const HeadBwdArgs& a, dim3 grid, hipStream_t s) {
 void launch_head_bwd(const HeadBwdArgs& a, int dtype, hipStream_t s) {
     const int VPB = 256 / (a.Cin / 8);
     int blocks = cdiv(a.V, 2 * VPB);           // per sample; two voxels per thread and trip
-    static const int cap = xknob_i("SEG_HEAD_BWD_WGS", 1024);      // tuning knob: workgroups per launch
+    static const int cap = 1024;      // tuning knob: workgroups per launch
     const int per_n = cap / a.N > 0 ? cap / a.N : 1;
     if (blocks > per_n) blocks = per_n;
     dim3 grid(blocks, a.N);

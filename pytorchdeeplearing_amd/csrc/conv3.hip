@@ -69,18 +69,8 @@ __device__ __forceinline__ int halo_swz(int row, int x) { return ((row & 1) << 1
 
 template <class T, class B, int CH, int LD, int PITCH = B::HW, bool SWZ = false>
 __device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, const BoxPos& p, int D, int H, int W,
-                                           const T* in1 = nullptr, int C0 = 0, const float* gsc = nullptr, const float* gsh = nullptr) {
+                                           const T* in1 = nullptr, int C0 = 0) {
     if (!in1) C0 = C;
-    // gsc / gsh ([N][C] scale / shift of the producer unit's GroupNorm + dropout + ReLU, published by the forward pass): `in` holds the
-    // producer's RAW conv output and the activation relu(scale * x + shift) is applied on the way into LDS (voxels outside the volume
-    // stay zero) - the weight gradient of a conv whose input tensor is never materialised (Conv3xArgs::fuse).  A thread keeps its
-    // channel piece over the whole copy (256 % (CH / 8) == 0), so the coefficients are loaded once per box.
-    vec<float, 8> gs, gh;
-    if (gsc) {
-        const int chq = c0 + (int)(threadIdx.x % (CH / 8)) * 8;
-        gs = *(const vec<float, 8>*)(gsc + (long long)p.n * C + chq);
-        gh = *(const vec<float, 8>*)(gsh + (long long)p.n * C + chq);
-    }
     // All global loads of a batch are issued before the first LDS store: a load->wait->store loop would
     // serialise ~9 HBM round trips per box (measured: the dominant cost of the first version).
     constexpr int CPV = CH / 8, TOTAL = B::HV * CPV, NIT = (TOTAL + 255) / 256;
@@ -99,10 +89,6 @@ __device__ __forceinline__ void stage_halo(T* Xs, const T* in, int C, int c0, co
                 const long long vox = (((long long)p.n * D + z) * H + y) * W + x;
                 const int ch = c0 + c8 * 8;
                 v[u] = ch < C0 ? load8(in + vox * C0 + ch) : load8(in1 + vox * (C - C0) + (ch - C0));
-                if (gsc) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[u][j] = from_f<T>(fmaxf(fmaf(gs[j], to_f(v[u][j]), gh[j]), 0.f));
-                }
             }
         }
 #pragma unroll
@@ -343,103 +329,6 @@ __global__ __launch_bounds__(256, (c3_occ<CH, NT, TH>())) void conv3_kernel(Conv
     SEG_STAMP(5);
 }
 
-// Register-blocked variant of the 32-channel tiling (opt-in: SEG_CONV3_RB=1; 16-bit types).  The tap loop of conv3_kernel
-// reads one B and MT A fragments from LDS per MT MFMAs (1.33 KB per MFMA with MT = 3) and is capped by the 128 B/clk LDS port
-// well below the MFMA rate.  Here every A fragment feeds TWO 16-channel output tiles: the weight slabs of both tiles are
-// resident for one kd plane at a time ([2][9 taps][16 co][32 k] = 18.4 KB, next plane prefetched into registers), so a tap
-// step is 2 B + MT A reads for 2*MT MFMAs (0.83 KB per MFMA).  Same halo staging, swizzles and epilogue as conv3_kernel;
-// bit-identical results on integer-valued data (tests/test_ops.py with the knob set).
-template <class T, int TD, int TH, int TW, int KD>
-__global__ __launch_bounds__(256, 2) void conv3_rb_kernel(Conv3Args a) {
-    typedef Box<TD, TH, TW, KD> B;
-    static_assert(sizeof(T) == 2, "register-blocked tiling: 16-bit types only");
-    constexpr int CH = 32, NT = 2, XLD = CH, HWP = (B::HW + 3) / 4 * 4, MT = B::V / 64, BN = NT * 16, OLD = BN + 8;
-    constexpr int XS_ELEMS = B::HD * B::HH * HWP * XLD, OS_ELEMS = B::V * OLD, RED_ELEMS = 2048 / sizeof(T);
-    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS > OS_ELEMS + RED_ELEMS ? XS_ELEMS : OS_ELEMS + RED_ELEMS];
-    float* red = (float*)(Xs + OS_ELEMS);
-    constexpr int WSLAB = 9 * 16 * 32;                     // one (kd plane, output tile) slab: [tap][co][k], pieces swizzled by 3*((co>>2)&1)
-    __shared__ __attribute__((aligned(16))) T Ws[NT * WSLAB];
-    static_assert(B::V % 64 == 0, "box must hold a multiple of 64 voxels");
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const BoxPos bp = box_pos<B, TD, TH, TW>(blockIdx.x, a.D, a.H, a.W);
-    const int co0 = blockIdx.y * BN;
-    const T* in = (const T*)a.in;
-    const T* wp = (const T*)a.w;
-
-    int hb[MT], pq[MT][3];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int v = (wv * MT + m) * 16 + l15;
-        const int vx = v % TW, vy = (v / TW) % TH, vz = v / (TW * TH);
-        hb[m] = (vz * B::HH + vy) * HWP + vx;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) pq[m][kw] = (q ^ halo_swz(vz * B::HH + vy, vx + kw)) * 8;
-    }
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    constexpr int PIECES = NT * 9 * 16 * 4, WN = (PIECES + 255) / 256;
-    const int nchunk = a.Cin / CH;
-    for (int cc = 0; cc < nchunk; ++cc) {
-        if (cc) __syncthreads();
-        stage_halo<T, B, CH, XLD, HWP, true>(Xs, in, a.Cin, cc * CH, bp, a.D, a.H, a.W, (const T*)a.in1, a.C0);
-        vec<T, 8> wv_[WN];
-        auto wload = [&](int kd) {
-#pragma unroll
-            for (int u = 0; u < WN; ++u) {
-                const int i = u * 256 + tid;
-                const int c4 = i & 3, tap = (i >> 2) % 9, co = (i / 36) % 16, j = i / (36 * 16);
-                wv_[u] = zero8<T>();
-                if (i < PIECES) wv_[u] = load8(wp + (long long)(co0 + j * 16 + co) * a.Kpad + (kd * 9 + tap) * a.Cin + cc * 32 + c4 * 8);
-            }
-        };
-        auto wstore = [&]() {
-#pragma unroll
-            for (int u = 0; u < WN; ++u) {
-                const int i = u * 256 + tid;
-                const int c4 = i & 3, tap = (i >> 2) % 9, co = (i / 36) % 16, j = i / (36 * 16);
-                if (i < PIECES) store8(&Ws[j * WSLAB + (tap * 16 + co) * 32 + ((c4 ^ (((co >> 2) & 1) * 3)) * 8)], wv_[u]);
-            }
-        };
-        wload(0);
-        wstore();
-        __syncthreads();
-#pragma unroll
-        for (int kd = 0; kd < KD; ++kd) {
-            if (kd + 1 < KD) wload(kd + 1);
-#pragma unroll
-            for (int s9 = 0; s9 < 9; ++s9) {
-                const int woff = (s9 * 16 + l15) * 32 + ((q ^ (((l15 >> 2) & 1) * 3)) * 8);
-                const typename Mma<T>::frag b0 = load8(&Ws[woff]), b1 = load8(&Ws[WSLAB + woff]);
-                const int skw = s9 % 3, srow = kd * B::HH + s9 / 3;
-                const int toff = srow * HWP + skw;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const typename Mma<T>::frag af = load8(&Xs[(hb[m] + toff) * XLD + (pq[m][skw] ^ ((srow & 1) << 4))]);
-                    acc[m][0] = Mma<T>::run(af, b0, acc[m][0]);
-                    acc[m][1] = Mma<T>::run(af, b1, acc[m][1]);
-                }
-            }
-            if (kd + 1 < KD) { __syncthreads(); wstore(); __syncthreads(); }
-        }
-    }
-    __syncthreads();
-    box_epilogue<T, B, TW, TH, MT, NT>(acc, Xs, red, a.bias, (T*)a.out, a.stats, bp, co0, a.N, a.D, a.H, a.W, a.Cout);
-}
-
-template <class T, int TD, int TH, int TW, int KD> struct Conv3Rb {
-    static void launch(const Conv3Args& a, dim3 grid, hipStream_t s) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_rb_kernel<T, TD, TH, TW, KD>), grid, dim3(256), 0, s, a);
-    }
-};
-template <int TD, int TH, int TW, int KD> struct Conv3Rb<float, TD, TH, TW, KD> {
-    static void launch(const Conv3Args&, dim3, hipStream_t) {}
-};
-
 template <int TD, int TH, int TW>
 inline long long num_boxes(int N, int D, int H, int W) {
     return (long long)N * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
@@ -453,21 +342,10 @@ void conv3_launch_shape(const Conv3Args& a, hipStream_t s) {
     // measured on MI355X: on the small levels more, narrower workgroups (several resident per CU) beat NT = 4
     // tiles (conv3 class 2.3 ms vs 3.4 ms per step) - the per-workgroup tap loop is latency-bound, so occupancy wins
     while (nt > 1 && nbox * (a.Cout / (16 * nt)) < 1024) nt /= 2;
-    static const int force_nt = xknob_i("SEG_CONV3_NT", 0);     // tuning knob (tools/bench_conv3.py)
-    if (force_nt && a.Cout % (16 * force_nt) == 0 && !(a.Cin == 16 && force_nt == 4)) nt = force_nt;
-    // opt-in register-blocked tiling (32 output channels per workgroup): 1 = wherever NT >= 2 was chosen, 2 = every 32-channel-aligned layer
-    static const int rb = xknob_i("SEG_CONV3_RB", 0);
-    if (rb && sizeof(T) == 2 && a.Cin % 32 == 0 && a.Cout % 32 == 0 && (nt >= 2 || rb >= 2) && !force_nt) {
-        static const bool verbose = xenv("SEG_CONV3_RB_VERBOSE") != nullptr;
-        if (verbose) fprintf(stderr, "[segengine] conv3_rb box %dx%dx%d  %dx%dx%dx%d  Cin %d Cout %d\n", TD, TH, TW, a.N, a.D, a.H, a.W, a.Cin, a.Cout);
-        Conv3Rb<T, TD, TH, TW, KD>::launch(a, dim3((unsigned)nbox, a.Cout / 32), s);
-        return;
-    }
     dim3 grid((unsigned)nbox, a.Cout / (16 * nt));
-    static const int force_wl = xknob_i("SEG_CONV3_WL", -1);   // tuning knob
     // LDS weight slab (one 16-channel output tile at a time over the resident halo) for every 16-bit tiling; the f32
     // halo is too large to share the LDS with it
-    const bool wl = force_wl >= 0 ? (force_wl != 0 || nt == 1) : (nt == 1 || sizeof(T) == 2);
+    const bool wl = nt == 1 || sizeof(T) == 2;
 #define SEG_C3(CH, NT, WLV) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3_kernel<T, TD, TH, TW, KD, CH, NT, WLV>), grid, dim3(256), 0, s, a)
     if (a.Cin == 16) { if (nt == 1) SEG_C3(16, 1, true); else if (wl) SEG_C3(16, 2, true); else SEG_C3(16, 2, false); }
     else if (nt == 1) SEG_C3(32, 1, true);
@@ -502,7 +380,7 @@ void conv3_dispatch(const Conv3Args& a, int ndim, hipStream_t s) {
 // C2 VNet2d 16 x 512^2 measures 6.45 ms per step with it against 6.66 with the narrow one; C4 / C5, 3-D: 4.43 / 4.45 against 4.56 / 4.68,
 // profiles/r04_configs_tile_ab.log).
 inline void wgrad3_tile(int P, int Q, int esz, int ndim, int* CP, int* CQ) {
-    static const int cq = xknob_i("SEG_W3_CQ", 0);          // 0: by dimensionality
+    static const int cq = 0;          // 0: by dimensionality
     const int want = cq ? cq : (ndim == 3 ? 16 : 32);
     *CP = P >= 32 ? 32 : 16;
     *CQ = (Q >= 32 && (want >= 32 || esz == 4)) ? 32 : 16;
@@ -513,7 +391,6 @@ struct Wgrad3Args {
     const void* dr; const void* x; float* partial;
     int N, D, H, W, P, Q;       // channel counts of dr / x
     int nb;                     // workgroups per (p-tile, q-tile) combo
-    const float* xsc; const float* xsh;   // [N][Q] or null: x is a RAW conv output, activated while it is staged (stage_halo)
 #ifdef SEG_W3_TRACE
     unsigned long long* trace;            // diagnostic build (tools/build_variant.py ... -DSEG_W3_TRACE): 8 phase sums per workgroup
 #endif
@@ -692,7 +569,7 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) SEG_W3_WAVES void wgrad3_kernel(Wg
     // barrier that publishes the current box and land while its MFMAs run (one HBM round trip per box, hidden); the plain loop below
     // spent two exposed round trips per box (dR tile -> wait -> LDS, then the halo -> wait -> LDS) - the kernel is latency-bound, not
     // bandwidth-bound, so that was most of its time.  Costs (DN + XN) x 4 VGPRs (48 at 32 x 32 channels).
-    const bool prefetch = sizeof(T) == 2 && !a.xsc;
+    const bool prefetch = sizeof(T) == 2;
     if (prefetch) {
         const T* x1 = (const T*)a.x1;
         const int C0 = x1 ? a.C0 : a.Q;
@@ -798,7 +675,7 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) SEG_W3_WAVES void wgrad3_kernel(Wg
                 const int i = u * 256 + tid;
                 if (i < B::V * CPV) store8(&Ds[(i / CPV) * DLD + (i % CPV) * 8], dv[u]);
             }
-            stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W, (const T*)a.x1, a.C0, a.xsc, a.xsh);
+            stage_halo<T, B, CQ, XLD>(Xs, x, a.Q, q0, bp, a.D, a.H, a.W, (const T*)a.x1, a.C0);
             __syncthreads();
             sweep();
         }
@@ -888,7 +765,7 @@ template <class T> struct Wgrad3Big16 {
         wgrad3_tile(a0.P, a0.Q, 2, 3, &CP, &CQ);
         // P = 16 with 16-channel q-tiles: the 16 -> 16 LUConv of the VNet top level and the finest-level convs of the UNets (16 -> 16, and
         // 32 -> 16 over the decoder's concat: two q-tiles, grid.y = 2)
-        if (!on || a0.P != 16 || CQ != 16 || a0.Q % 16 || a0.xsc || !wide_box(a0.W)) return false;
+        if (!on || a0.P != 16 || CQ != 16 || a0.Q % 16 || !wide_box(a0.W)) return false;
         const int combos = a0.Q / 16;
         const long long nbox = num_boxes<4, 8, 16>(a0.N, a0.D, a0.H, a0.W);
         if (on < 2 && nbox < 6ll * a0.nb) return false;    // small volumes keep the 3 x 4 x 16 box (enough boxes per workgroup to amortise its partial tile)
@@ -1127,11 +1004,11 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
     a.in = in; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.Kpad = ((ndim == 3 ? 27 : 9) * Cin + 31) / 32 * 32;
-    static const int dbg = xknob_i("SEG_CONV3_DBG", 0);
+    static const int dbg = 0;
     a.dbg = dbg;
     a.trace = nullptr;
     // diagnostics (tools/bench_conv3.py): per-workgroup phase timeline of one launch, printed to stderr
-    static const int trace_on = xknob_i("SEG_CONV3_TRACE", 0);
+    static const int trace_on = 0;
     static unsigned long long* tbuf = nullptr;
     const size_t tmax = 1 << 18;
     if (trace_on) {
@@ -1179,15 +1056,15 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, 
     // One box, every BASELINE config (profiles/r03_wgrad_policy_configs_ab.log), total / total16 = 256/256, 512/1024, 256/1024, 512/256:
     // C3 4.15 / 4.20 / 4.18 / 4.15 ms, C4 4.58 / 4.55 / 4.43 / 4.68, C5 4.55 / 4.61 / 4.57 / 4.58, C2 (2-D) 6.65 / 6.40 / 6.68 / 6.37 -> the
     // 2-D boxes keep 512 workgroups
-    static const int total_env = xknob_i("SEG_W3_TOTAL", 0);
+    static const int total_env = 0;
     const int total = total_env > 0 ? total_env : (ndim == 3 ? 256 : 512);
-    static const int minbox = xknob_i("SEG_W3_MINBOX", 6);
+    static const int minbox = 6;
     // 16 -> 16 channels (the finest level): four workgroups fit a CU (23 KB LDS, 113 VGPRs) and the partial tile is 27 KB, so the
     // staging latency of one workgroup can hide behind the others
     // round 2 (no prefetch), standalone 4x96^3: 512 -> 168 us, 1024 -> 123 us, 2048 -> 137 us (r02_wgrad16_ab.log), step unchanged.  With the
     // prefetching kernel inside the step (profiles/r03_wgrad_policy_ab3.log): 128 -> 947, 256 -> 967 / 967, 384 -> 961, 1024 -> 956-958
     // volumes/s - one workgroup per CU leaves the bandwidth-bound 96^3 GroupNorm passes of the main stream the rest of the machine
-    static const int total16 = xknob_i("SEG_W3_TOTAL16", 256);
+    static const int total16 = 256;
     long long nb = (P == 16 && Q == 16 ? total16 : total) / combos;
     if (nb < 1) nb = 1;
     const long long nbox = boxes_for(ndim, N, D, H, W);
@@ -1208,45 +1085,14 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) 
 }
 
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1, int C0, const float* xscale, const float* xshift, int qreal) {
+                   int dtype, hipStream_t s, const void* x1, int C0, int qreal) {
     const int T = ndim == 3 ? 27 : 9;
     if (qreal <= 0 || qreal > Q) qreal = Q;
-#ifdef SEG_EXPERIMENTS
-    // 16-bit tensors, opt-in (SEG_WGRAD3X=1, read per call): double-buffered kernel (wgrad3x.hip), same partial-tile layout and
-    // reduce.  Measured on MI355X (profiles/r02_wgrad3x_ab.log): op-level 67 vs 67 us at 32ch@48^3, 62 vs 52 us at 64ch@24^3, train
-    // step 689 vs 712 volumes/s - one box in flight per CU is still latency-bound and its 112 KB / 512-thread workgroups crowd the
-    // main stream's kernels out of the CU, so wgrad3_kernel (three 44 KB workgroups per CU) stays the default.
-    const char* envx = xenv("SEG_WGRAD3X");
-    const bool use_x = envx && atoi(envx) != 0 && !xscale && qreal == Q;      // the double-buffered variant copies x straight into LDS: no activation on the way
-    if (use_x && wgrad3x_supported(dtype, N, ndim == 3 ? D : 1, H, W, P, Q, C0, x1 != nullptr)) {
-        int CP, CQ;
-        wgrad3x_tiles(P, Q, C0, x1 != nullptr, &CP, &CQ);
-        const int combos = (P / CP) * (Q / CQ);
-        // one resident round of workgroups (one 512-thread workgroup per CU); at least `minbox` boxes per workgroup. The scratch
-        // sized by wgrad3_partial_bytes (512 tiles of 32 x taps x 32) covers every choice below
-        static const int total = xknob_i("SEG_W3X_TOTAL", 256);
-        static const int minbox = xknob_i("SEG_W3X_MINBOX", 4);
-        const long long nbox = boxes_for(ndim, N, D, H, W);
-        long long nb = total / combos;
-        if (nb > (nbox + minbox - 1) / minbox) nb = (nbox + minbox - 1) / minbox;
-        const long long cap = (long long)(wgrad3_partial_bytes(ndim, N, D, H, W, P, Q) / ((size_t)combos * CP * T * CQ * sizeof(float)));
-        if (nb > cap) nb = cap;
-        if (nb < 1) nb = 1;
-        launch_wgrad3x(dr, x, x1, C0, partial, (int)nb, N, D, H, W, P, Q, ndim, dtype, wide_box(W), s);
-        const long long tot = (long long)P * Q * T;
-        int blocks = (int)((tot + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, ((int)nb + 31) / 32), dim3(256), 0, s, (const float*)partial, dw, P, Q, CP, CQ, T, (int)nb,
-                           (long long)Q * T, (long long)T, Q);
-        return;
-    }
-#endif
     Wgrad3Args a;
     a.x1 = x1; a.C0 = C0;
     a.dr = dr; a.x = x; a.partial = partial;
     a.N = N; a.D = D; a.H = H; a.W = W; a.P = P; a.Q = Q;
     a.nb = wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q, dtype == DT_F32 ? 4 : 2);
-    a.xsc = xscale; a.xsh = xshift;
 #ifdef SEG_W3_TRACE
     static unsigned long long* tbuf = nullptr;
     const size_t tmax = 8192;

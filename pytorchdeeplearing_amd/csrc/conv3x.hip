@@ -7,8 +7,7 @@ namespace seg {
 namespace {
 using c3x::Conv3xArgs;
 
-struct Cfg { int id, ndim, td, th, tw, bn, nres; const char* name; int cin16 = 0; int cin32 = 0; };   // cin16: the Cin == 16 kernel (two taps per
-                                                                                                        // MFMA step); cin32: the persistent Cin == 32 kernel
+struct Cfg { int id, ndim, td, th, tw, bn, nres; const char* name; int cin16 = 0; };   // cin16: the Cin == 16 kernel (two taps per MFMA step)
 
 // id, ndim, box, BN, resident chunks — kept in sync with SEG_C3X_3D_BODY / SEG_C3X_2D_BODY (conv3x_impl.h)
 const Cfg kCfgs[] = {
@@ -44,21 +43,10 @@ const Cfg kCfgs[] = {
     {48, 3, 4, 4, 12, 32, 4, "4x4x12 t4 2x2 waves 6x1 tiles, 26-deep B ring"},
     {49, 3, 2, 4, 12, 64, 4, "2x4x12 t4 1x4 waves 6x1 tiles (every wave its own weight columns)"},
     {50, 3, 2, 4, 12, 64, 4, "2x4x12 t4 1x4 waves 6x1 tiles, 26-deep B ring"},
-#ifdef SEG_EXPERIMENTS
-    {51, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, next halo copied under the epilogue, weights streamed from L2", 0, 1},
-    {18, 3, 4, 8, 8, 32, 1, "Cin32 persistent: 4x8x8 t8 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
-    {19, 3, 2, 8, 8, 32, 1, "Cin32 persistent: 2x8x8 t8 4x1 waves 2x2 tiles, weights in LDS, double-buffered halo", 0, 1},
-#endif
     {24, 3, 2, 8, 16, 16, 1, "Cin16: 2x8x16 t16 4x1 waves 4x1 tiles", 1},
     {25, 3, 4, 8, 16, 16, 1, "Cin16: 4x8x16 t16 4x1 waves 8x1 tiles", 1},
     {26, 3, 2, 8, 16, 32, 1, "Cin16: 2x8x16 t16 4x1 waves 4x2 tiles", 1},
     {27, 3, 4, 8, 16, 32, 1, "Cin16: 4x8x16 t16 4x1 waves 8x2 tiles", 1},
-#ifdef SEG_EXPERIMENTS
-    {52, 3, 4, 8, 16, 16, 1, "Cin16 persistent: 4x8x16 t16 4x1 waves 8x1 tiles, next halo copied under the epilogue", 1},
-    {53, 3, 2, 8, 16, 16, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x1 tiles, next halo copied under the epilogue", 1},
-    {28, 3, 2, 8, 16, 16, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x1 tiles, weights in LDS, double-buffered halo", 1},
-    {29, 3, 2, 8, 16, 32, 1, "Cin16 persistent: 2x8x16 t16 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 1},
-#endif
     // 2-D
     {32, 2, 1, 16, 16, 32, 1, "16x16 t16 4x1 waves 4x2 tiles"},
     {33, 2, 1, 16, 16, 64, 2, "16x16 t16 2x2 waves 8x2 tiles"},
@@ -68,15 +56,8 @@ const Cfg kCfgs[] = {
     {37, 2, 1, 16, 16, 16, 1, "16x16 t16 4x1 waves 4x1 tiles"},
     {38, 2, 1, 8, 8, 64, 4, "8x8 t8 2x2 waves 2x2 tiles, 4 resident chunks"},
     {39, 2, 1, 8, 16, 32, 2, "8x16 t16 4x1 waves 2x2 tiles, 2 resident chunks"},
-#ifdef SEG_EXPERIMENTS
-    {40, 2, 1, 16, 16, 32, 1, "Cin32 persistent: 16x16 t16 4x1 waves 4x2 tiles, weights in LDS, double-buffered halo", 0, 1},
-#endif
     {56, 2, 1, 16, 16, 16, 1, "Cin16: 16x16 t16 4x1 waves 4x1 tiles", 1},
     {57, 2, 1, 16, 16, 32, 1, "Cin16: 16x16 t16 4x1 waves 4x2 tiles", 1},
-#ifdef SEG_EXPERIMENTS
-    {59, 2, 1, 16, 16, 16, 1, "Cin16 persistent: 16x16 t16 4x1 waves 4x1 tiles, next halo copied under the epilogue", 1},
-    {58, 2, 1, 16, 16, 16, 1, "Cin16 persistent: 16x16 t16 4x1 waves 4x1 tiles, weights in LDS, double-buffered halo", 1},
-#endif
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -87,7 +68,7 @@ const Cfg* find_cfg(int id) {
 }
 
 bool cfg_fits(const Cfg& c, int ndim, int Cin, int Cout) {
-    return c.ndim == ndim && Cout % c.bn == 0 && (c.cin16 != 0) == (Cin == 16) && (!c.cin32 || Cin == 32);
+    return c.ndim == ndim && Cout % c.bn == 0 && (c.cin16 != 0) == (Cin == 16);
 }
 
 }  // namespace
@@ -104,28 +85,15 @@ bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, 
     return true;
 }
 
-// the FUSE instantiations: one source tensor, 32-channel chunks, per-sample fold of <= 256 channels by 256 threads
-#ifdef SEG_EXPERIMENTS
-bool conv3x_gn_supported(int Cin, bool has_in1) { return !has_in1 && Cin % 32 == 0 && Cin <= 256 && 256 % Cin == 0; }
-#else
-bool conv3x_gn_supported(int, bool) { return false; }
-#endif
-
-// default tiling per problem.  Overrides: SEG_C3X_CFG=<id> (one tiling wherever it fits), SEG_C3X_MAP="cin:cout:w=id,..."
-// (per layer shape; tools/tune_conv3x.py prints the measured table).
+// default tiling per problem.  Override: SEG_C3X_MAP="cin:cout:w=id,..." (per layer shape; tools/tune_conv3x.py prints the measured table).
 int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool has_in1) {
-    static const int force = xknob_i("SEG_C3X_CFG", -1);
-    if (force >= 0) {
-        const Cfg* c = find_cfg(force);
-        if (c && cfg_fits(*c, ndim, Cin, Cout) && !(c->cin32 && has_in1)) return force;
-    }
     static const char* map = knob_s("SEG_C3X_MAP");
     if (map) {
         for (const char* p = map; *p;) {
             int ci = 0, co = 0, w = 0, id = -1;
             if (sscanf(p, "%d:%d:%d=%d", &ci, &co, &w, &id) == 4 && ci == Cin && co == Cout && w == W) {
                 const Cfg* c = find_cfg(id);
-                if (c && cfg_fits(*c, ndim, Cin, Cout) && !(c->cin32 && has_in1)) return id;
+                if (c && cfg_fits(*c, ndim, Cin, Cout)) return id;
             }
             while (*p && *p != ',') ++p;
             if (*p == ',') ++p;
@@ -171,7 +139,7 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool ha
     const Cfg* c = find_cfg(id);
     if (c && cfg_fits(*c, ndim, Cin, Cout)) return id;
     for (int i = 0; i < kNumCfgs; ++i)
-        if (cfg_fits(kCfgs[i], ndim, Cin, Cout) && !kCfgs[i].cin32) return kCfgs[i].id;
+        if (cfg_fits(kCfgs[i], ndim, Cin, Cout)) return kCfgs[i].id;
     return -1;
 }
 
@@ -189,28 +157,12 @@ int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres
 }
 
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep, const GnFinArgs* gn, ForkSig sg, const Conv3xReduce* rq) {
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep) {
     const Cfg* c = find_cfg(cfg);
     if (!c || !cfg_fits(*c, ndim, Cin, Cout) || !conv3x_supported(dtype, ndim, N, D, H, W, Cin, Cout, C0, in1 != nullptr)) return false;
-    if (gn && (!conv3x_gn_supported(Cin, in1 != nullptr) || c->cin32)) return false;
-    if (c->cin32 && in1) return false;
     Conv3xArgs a;
-    a.fuse = gn ? 1 : 0;
-    a.gn = gn ? *gn : GnFinArgs{};
-    a.sig = sg;
     a.in0 = in0; a.in1 = in1; a.C0 = in1 ? C0 : Cin; a.w = w; a.bias = bias; a.out = out; a.stats = stats;
     a.stat_rep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
-    a.rq_y = nullptr; a.rq_scale = nullptr; a.rq_shift = nullptr; a.rq_Q = nullptr;
-    if (rq && rq->Q && !stats) {          // (a launch produces forward statistics OR backward sums, never both)
-        a.rq_y = rq->y; a.rq_scale = rq->scale; a.rq_shift = rq->shift; a.rq_Q = rq->Q;
-        a.stat_rep = (rq->rep > 0 && rq->rep <= STAT_REP) ? rq->rep : STAT_REP;
-    }
-#ifdef SEG_DIAG
-    // diagnostic builds only (python tools/build_variant.py diag conv3x.hip -DSEG_DIAG; WRONG results): SEG_DIAG_NOSTATS=1 drops the GroupNorm
-    // statistics epilogue, to time what it costs inside a step.  Not compiled into the product library.
-    static const bool nostats = xknob_i("SEG_DIAG_NOSTATS", 0) != 0;
-    if (nostats) a.stats = nullptr;
-#endif
     a.N = N; a.D = ndim == 3 ? D : 1; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
 #ifdef SEG_C3X_TRACE
     // diagnostic build only (python tools/build_variant.py c3xtrace conv3x.hip,conv3x_f16_3d.hip -DSEG_C3X_TRACE; tools/trace_conv3x.py): per-workgroup phase stamps,
@@ -249,26 +201,7 @@ bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void
         }
     } dump{tbuf, tmax, s, cfg, N, a.D, H, W, Cin, Cout};
 #endif
-    static const int remap = xknob_i("SEG_C3X_REMAP", 1);      // XCD-aware box order (c3x_box_of_block)
-    a.remap = remap;
-#ifdef SEG_DIAG
-    // diagnostic builds only (tools/trace_gaps.py): SEG_C3X_TWICE=1 launches every conv twice without statistics first, so a kernel trace shows
-    // the same launch with cold and with warm operands
-    static const bool twice = xknob_i("SEG_C3X_TWICE", 0) != 0;
-    if (twice) {
-        Conv3xArgs w = a; w.stats = nullptr;
-        if (ndim == 3) { if (dtype == DT_F16) c3x::launch_3d<f16>(cfg, w, s); else c3x::launch_3d<bf16>(cfg, w, s); }
-        else { if (dtype == DT_F16) c3x::launch_2d<f16>(cfg, w, s); else c3x::launch_2d<bf16>(cfg, w, s); }
-    }
-#endif
-    if (a.fuse) {
-#ifdef SEG_EXPERIMENTS      // the FUSE instantiations (conv3x_*_gn.hip: GroupNorm applied by the consumer, bit-exact and 2.3 % slower) are not in the product library
-        if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d_gn<f16>(cfg, a, s) : c3x::launch_3d_gn<bf16>(cfg, a, s);
-        return dtype == DT_F16 ? c3x::launch_2d_gn<f16>(cfg, a, s) : c3x::launch_2d_gn<bf16>(cfg, a, s);
-#else
-        return false;
-#endif
-    }
+    a.remap = 1;                     // XCD-aware box order (c3x_box_of_block)
     if (ndim == 3) return dtype == DT_F16 ? c3x::launch_3d<f16>(cfg, a, s) : c3x::launch_3d<bf16>(cfg, a, s);
     return dtype == DT_F16 ? c3x::launch_2d<f16>(cfg, a, s) : c3x::launch_2d<bf16>(cfg, a, s);
 }

@@ -5,7 +5,6 @@ namespace seg {
 namespace c3x {
 template <> bool launch_2d<bf16>(int id, const Conv3xArgs& a, hipStream_t s) {
     typedef bf16 T;
-    constexpr bool FUSE = false;
     SEG_C3X_2D_BODY
 }
 }  // namespace c3x

@@ -19,7 +19,6 @@
 #include <cstdlib>
 
 #include "kernels.h"
-#include "gn_fold.h"
 
 namespace seg {
 namespace c3x {
@@ -47,34 +46,12 @@ template <int TD_, int TH_, int TW_, int KD_, int TX_> struct XBox {
     }
 };
 
-#ifdef SEG_EXPERIMENTS
-#define SEG_C3X_RQ(a) ((a).rq_Q != nullptr)
-#define SEG_C3X_RQ_LDS 3
-#else
-#define SEG_C3X_RQ(a) false
-#define SEG_C3X_RQ_LDS 1
-#endif
 struct Conv3xArgs {
     const void* in0; const void* in1; int C0;     // in1: second source of a virtual channel concat (channels C0..Cin-1), or null
     const void* w;                                // fragment-major weights [Cin/32][taps][Cout/16][64 lanes][8]
     const float* bias; void* out; double* stats; int stat_rep;   // stat_rep: replicas of `stats` the workgroups spread over (<= STAT_REP)
     int N, D, H, W, Cin, Cout;
     int remap;                                    // 1: XCD-aware box order (grid.x rounded up to a multiple of 8)
-    // forward launches only (FUSE instantiations): `in0` is the RAW output of the producer's convolution and the producer's GroupNorm +
-    // channel dropout + ReLU (reference op chain networks/VNet3d.py:13-15, networks/Unet3d.py:66-80) is applied while the halo sits in LDS:
-    // every workgroup folds the producer's statistics of its sample (gn_fold_block: scale / shift per channel), the first workgroup of a
-    // sample publishes them (plus mean / rstd) for the backward pass, and each lane rewrites the 16-B pieces it copied as
-    // relu(scale * x + shift); padding voxels stay zero.  The activated tensor is never written to HBM (the gn_act launch is gone).
-    int fuse; GnFinArgs gn;
-    ForkSig sig;                                  // a flag fork carried by this launch (its first thread stores the number)
-    // EXPERIMENTS BUILD (measured in round 5, profiles/r05_reduce_fold_ab.log: the epilogue grows by what the reduce launches cost at the 24^3 / 12^3 levels where
-    // the fold applies, and the forward kernels lose 0.6 % to the extra prologue work - the product keeps the separate reduce pass).
-    // Data-gradient launches only: the GroupNorm-backward REDUCE pass of the unit that consumes this gradient, folded into
-    // the epilogue.  The tensor written here is d loss / d activation of a [conv -> GroupNorm -> dropout -> ReLU] unit whose ONLY gradient source it is;
-    // rq_y = that unit's raw conv output (same extent as `out`), rq_scale / rq_shift its forward coefficients [N][Cout].  The epilogue adds sum dz and
-    // sum dz * y (dz = dy where scale * y + shift > 0, dy as stored) per (sample, channel) into rq_Q [stat_rep][N][Cout][2] - what gn_bwd_reduce_kernel
-    // computes from two more reads of the tensors, and one launch less.
-    const void* rq_y; const float* rq_scale; const float* rq_shift; double* rq_Q;
 #ifdef SEG_C3X_TRACE
     unsigned long long* trace;                    // diagnostic build (tools/trace_conv3x.py): 8 wall_clock64 stamps per workgroup - 0 start, 4 copies issued, 5 copies landed,
                                                   // 1 barrier passed, 2 tap loops done, 6 tile stored, 7 statistics folded per wave, 3 end
@@ -109,7 +86,7 @@ __device__ __forceinline__ int c3x_box_of_block(int b, int nbox, int remap) {
 // dependent L2 round trips in front of the first store)
 template <class T, class B, int TM, int TN, int WM, int WN>
 __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, const Conv3xArgs& a, int n, int x0, int y0, int z0, int co0,
-                                             const float* bias_lds = nullptr, bool stamp = true, const float* rq_lds = nullptr) {
+                                             const float* bias_lds = nullptr, bool stamp = true) {
     (void)stamp;                                           // (trace builds: whether this call records its phase stamps)
     constexpr int BN = WN * TN * 16;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -123,23 +100,6 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
             bs[j][r] = bias_lds ? bias_lds[(wn * TN + j) * 16 + 4 * q + r] : (a.bias ? a.bias[co0 + (wn * TN + j) * 16 + 4 * q + r] : 0.f);
             cs[j][r] = 0.f; css[j][r] = 0.f;
         }
-    // folded GroupNorm-backward reduce: this lane's pieces of the consuming unit's raw output and its forward coefficients are requested FIRST and used
-    // after the tile has been converted and stored (their latency hides behind the store phase)
-    const bool rq = SEG_C3X_RQ(a);
-    vec<T, 4> ry[TM][TN];
-    if (rq) {
-        const T* yb = (const T*)a.rq_y;
-#pragma unroll
-        for (int m = 0; m < TM; ++m) {
-            int vz, vy, vx;
-            B::vox((wm * TM + m) * 16 + l15, vz, vy, vx);
-            const int x = x0 + vx, y = y0 + vy, z = z0 + vz;
-            const bool ok = x < a.W && y < a.H && z < a.D;
-            const T* yrow = yb + ((((long long)n * a.D + (ok ? z : 0)) * a.H + (ok ? y : 0)) * a.W + (ok ? x : 0)) * a.Cout + co0 + wn * TN * 16;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) ry[m][j] = *(const vec<T, 4>*)(yrow + j * 16 + 4 * q);
-        }
-    }
     const bool odd = q & 1;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
@@ -156,7 +116,6 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
                 const T tv = from_f<T>(acc[m][j][r] + bs[j][r]);
                 o4[j][r] = tv;
                 if (a.stats && ok) { const float f = to_f(tv); cs[j][r] += f; css[j][r] = fmaf(f, f, css[j][r]); }
-                if (rq) acc[m][j][r] = ok ? to_f(tv) : 0.f;          // the gradient AS STORED, kept for the sums below (the accumulator is done)
             }
         if (TN % 2 == 0) {
 #pragma unroll
@@ -180,26 +139,7 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
         }
     }
     if (stamp) SEG_C3XT(6);
-    if (rq) {
-        // the unit's forward coefficients of this workgroup's channels: parked in LDS by the kernel prologue ([scale BN][shift BN]) or read here
-        constexpr int BN_ = WN * TN * 16;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int cl = (wn * TN + j) * 16 + 4 * q;
-            const vec<float, 4> rsc = rq_lds ? *(const vec<float, 4>*)(rq_lds + cl) : *(const vec<float, 4>*)(a.rq_scale + (long long)n * a.Cout + co0 + cl);
-            const vec<float, 4> rsh = rq_lds ? *(const vec<float, 4>*)(rq_lds + BN_ + cl) : *(const vec<float, 4>*)(a.rq_shift + (long long)n * a.Cout + co0 + cl);
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float yf = to_f(ry[m][j][r]);
-                    const float dz = (fmaf(rsc[r], yf, rsh[r]) > 0.f) ? acc[m][j][r] : 0.f;
-                    cs[j][r] += dz;
-                    css[j][r] = fmaf(dz, yf, css[j][r]);
-                }
-        }
-    }
-    if (a.stats || rq) {
+    if (a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -213,20 +153,17 @@ __device__ __forceinline__ void c3x_epilogue(f32x4 (&acc)[TM][TN], float* red, c
             double ts = 0.0, tss = 0.0;
 #pragma unroll
             for (int k = 0; k < WM; ++k) { ts += (double)red[(k * BN + tid) * 2]; tss += (double)red[(k * BN + tid) * 2 + 1]; }
-            double* dst = (rq ? a.rq_Q : a.stats) + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + tid) * 2;
+            double* dst = a.stats + ((long long)(blockIdx.x % a.stat_rep) * a.N * a.Cout + (long long)n * a.Cout + co0 + tid) * 2;
             atomicAdd(dst, ts);
             atomicAdd(dst + 1, tss);
         }
     }
 }
 
-template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC, bool FUSE>
+template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
-    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
     SEG_C3XT(0);
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
-    __shared__ double gn_part[FUSE ? 256 : 1][2];
-    __shared__ __attribute__((aligned(16))) float gn_coef[2][FUSE ? 256 : 8];
     static_assert(WM * WN == 4 && WM * TM == B::NTILE, "wave grid must cover the box");
     static_assert(B::NTAP % (PF + 1) == 0, "register ring must divide the tap count");
     constexpr int BN = WN * TN * 16;
@@ -234,7 +171,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
     // resident chunk images; the epilogue stores straight from the accumulators and only needs the small statistics exchange array
     __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
     __shared__ float red_s[WM * BN * 2];
-    __shared__ __attribute__((aligned(16))) float bias_s[SEG_C3X_RQ_LDS * BN];       // bias (| scale, shift of a folded GroupNorm-backward reduce, Conv3xArgs::rq_*)
+    __shared__ __attribute__((aligned(16))) float bias_s[BN];
     constexpr int NI = (B::NINSTR + 3) / 4;               // copy instructions per wave and chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -344,43 +281,13 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
         for (int s = 0; s < PF; ++s)
 #pragma unroll
             for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, wg + s * wstep);
-        if (FUSE && g0 == 0)      // the producer's statistics -> scale / shift of this sample, while the first copies are in flight
-            gn_fold_block(a.gn, n, x0 == 0 && y0 == 0 && z0 == 0 && blockIdx.y == 0, gn_part, gn_coef[0], gn_coef[1]);
         // the bias of this workgroup's channels travels with the first copies and is parked in LDS for the epilogue
         float bias_v = 0.f;
         if (g0 == 0 && a.bias && threadIdx.x < BN) bias_v = a.bias[co0 + threadIdx.x];
-        float rq_sc = 0.f, rq_sh = 0.f;
-        if (g0 == 0 && SEG_C3X_RQ(a) && threadIdx.x < BN) {
-            rq_sc = a.rq_scale[(long long)n * a.Cout + co0 + threadIdx.x];
-            rq_sh = a.rq_shift[(long long)n * a.Cout + co0 + threadIdx.x];
-        }
         if (g0 == 0) SEG_C3XT(4);
         wait_vmem();
         if (g0 == 0 && threadIdx.x < BN) bias_s[threadIdx.x] = bias_v;
-        if (g0 == 0 && SEG_C3X_RQ(a) && threadIdx.x < BN) { bias_s[(SEG_C3X_RQ_LDS / 3) * BN + threadIdx.x] = rq_sc; bias_s[(SEG_C3X_RQ_LDS / 3) * 2 * BN + threadIdx.x] = rq_sh; }
         if (g0 == 0) SEG_C3XT(5);
-        if (FUSE) {
-            // each lane activates the pieces it copied itself (lane-linear image: no other lane touches them before the barrier)
-#pragma unroll
-            for (int b = 0; b < NRES; ++b) {
-                if (b < nres) {
-#pragma unroll
-                    for (int u = 0; u < NI; ++u) {
-                        const int i = u * 4 + wv;
-                        if (i < B::NINSTR && src[u] >= 0) {
-                            T* pz = Xs + b * B::CHUNK_ELEMS + i * 512 + lane * 8;
-                            const int ch = (g0 + b) * 32 + (src[u] & 3) * 8;
-                            const vec<float, 8> sc = *(const vec<float, 8>*)&gn_coef[0][ch];
-                            const vec<float, 8> sh = *(const vec<float, 8>*)&gn_coef[1][ch];
-                            vec<T, 8> v = load8(pz);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = from_f<T>(fmaxf(fmaf(sc[j], to_f(v[j]), sh[j]), 0.f));
-                            store8(pz, v);
-                        }
-                    }
-                }
-            }
-        }
         __syncthreads();
         if (g0 == 0) SEG_C3XT(1);
         unsigned wo = wg + PF * wstep;                     // byte offset of the step being prefetched
@@ -415,348 +322,20 @@ __global__ __launch_bounds__(256, OCC) void conv3x_kernel(Conv3xArgs a) {
         }
     }
     SEG_C3XT(2);
-    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s, true, bias_s + (SEG_C3X_RQ_LDS / 3) * BN);      // no barrier: nothing of the halo buffer is reused
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s);      // no barrier: nothing of the halo buffer is reused
     SEG_C3XT(3);
 }
 
 
-template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC, bool FUSE>
+template <class T, class B, int TM, int TN, int WM, int WN, int NRES, int PF, int OCC>
 void launch_cfg(const Conv3xArgs& a, hipStream_t s) {
     constexpr int BN = WN * TN * 16;
     const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
     dim3 grid(a.remap ? (unsigned)((nbox + 7) / 8 * 8) : (unsigned)nbox, a.Cout / BN);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x_kernel<T, B, TM, TN, WM, WN, NRES, PF, OCC, FUSE>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x_kernel<T, B, TM, TN, WM, WN, NRES, PF, OCC>), grid, dim3(256), 0, s, a);
 }
 
-#ifdef SEG_EXPERIMENTS
-// ------------------------------------------------------------------------------------------------
-// Cin == 32 (one resident chunk per box): PERSISTENT workgroups whose next halo is copied UNDER THE EPILOGUE (round 5).
-// The phase trace of conv3x_kernel (profiles/r05_conv3x_phase_trace_*.log) says a 48^3 x 32-channel workgroup lives 9.7 us of which 3.6 us are its PROLOGUE -
-// ~1400 instructions of per-lane index arithmetic, descriptors and copy issue in front of the first MFMA (the copies themselves land 0.3 us after the last one is
-// issued) - 3.0 us the 27 taps and 2.5 us the epilogue; 1728 such workgroups take 38.7 us.  Here a workgroup pays that prologue ONCE and then walks the boxes of its
-// XCD's range with ONE halo buffer: barrier -> taps -> barrier (every wave is done reading the halo) -> the copies of the NEXT box are issued into the same buffer
-// (dma16_async, ~0.3 us) -> epilogue of the current box (bias, statistics, stores: ~2.3 us, which is what hides the copy latency) -> weight-ring prefetch, wait,
-// next box.  No second halo buffer (two of them are 92 KB: one workgroup per CU, which is what made round 3's conv3p_kernel lose, together with its LDS-resident
-// weights); 46 KB of LDS and <= 256 registers keep two workgroups per CU, the weights keep streaming from L2 through the register ring.
-// MEASURED (profiles/r05_conv3q_persistent_*): bit-exact, a box costs 8.2 us in the steady state against the 10.0 us life of a conv3x_kernel workgroup - and the launch
-// takes the same 37-38 us (4 x 48^3: 37.9 vs 36.9 us standalone, step 1031-1033 vs 1030 volumes/s), because 1728 boxes on 512 workgroups leave a quarter of them a
-// fourth box (the hardware's own dispatch of 1728 short workgroups balances better) and because the per-box tail - coordinate divisions, the extra barrier behind the
-// taps, twelve LDS-copy issues - still costs 2.6 us.  The tap loop itself cannot get faster: with TM x TN = 4 x 2 tiles per wave one tap-round of the eight resident
-// waves needs 256 clk of LDS reads (128 B/clk), 256 clk of weight loads through the vector L1 (64 B/clk) and 272 clk of MFMA issue per SIMD - three pipes co-critical,
-// which is why the family sits at 0.22-0.25 of MFMA peak whatever wraps the loop.  Experiments build only (tiling 51).
-// ------------------------------------------------------------------------------------------------
-template <class T, class B, int TM, int TN, int PF>
-__global__ __launch_bounds__(256, 2) void conv3q_kernel(Conv3xArgs a) {
-    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
-    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
-    static_assert(4 * TM == B::NTILE, "four waves cover the box");
-    static_assert(B::NTAP % (PF + 1) == 0, "register ring must divide the tap count");
-    constexpr int WM = 4, WN = 1, BN = TN * 16;
-    constexpr int NI = (B::NINSTR + 3) / 4;
-    __shared__ __attribute__((aligned(16))) T Xs[B::CHUNK_ELEMS];
-    __shared__ float red_s[WM * BN * 2];
-    __shared__ float bias_s[BN];
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
-    const int nbox = a.N * nbz * nby * nbx;
-    const int nvb = a.remap ? (nbox + 7) / 8 * 8 : nbox;           // virtual block ids of the non-persistent launch (c3x_box_of_block: XCD-aware order)
-    const int co0 = blockIdx.y * BN;
-    const int NT_total = a.Cout >> 4;
-    const long long vol = (long long)a.D * a.H * a.W;
-    if (tid < BN) bias_s[tid] = a.bias ? a.bias[co0 + tid] : 0.f;  // visible after the first barrier of the box loop
-
-    // virtual block ids of this workgroup: blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so it stays on its XCD's contiguous box range)
-    auto next_valid = [&](int vb, int& box) {
-        for (; vb < nvb; vb += (int)gridDim.x) {
-            box = c3x_box_of_block(vb, nbox, a.remap);
-            if (box >= 0) return vb;
-        }
-        box = -1;
-        return nvb;
-    };
-    struct Pos { int x0, y0, z0, n; };
-    auto pos_of = [&](int b) {
-        Pos p;
-        p.x0 = (b % nbx) * B::TW; b /= nbx;
-        p.y0 = (b % nby) * B::TH; b /= nby;
-        p.z0 = (b % nbz) * B::TD;
-        p.n = b / nbz;
-        return p;
-    };
-    // Copy pieces of this lane (instruction u of a box: 16 B): what does not depend on the box is computed ONCE - the halo coordinates (packed), the voxel
-    // offset relative to the box origin and the swizzled channel piece - so that a box costs ~13 vector instructions per piece instead of the ~35 of the full
-    // decomposition (the phase trace of the first version of this kernel: the per-box index arithmetic was what kept it at conv3x_kernel's speed)
-    int pk[NI], rel[NI];
-#pragma unroll
-    for (int u = 0; u < NI; ++u) {
-        const int i = u * 4 + wv;
-        const int g = i * 64 + lane;
-        const int row = g / (B::HWP * 4), rem = g % (B::HWP * 4);
-        const int hx = rem >> 2, slot = rem & 3;
-        const int hz = row / B::HH, hy = row % B::HH;
-        const bool valid = i < B::NINSTR && row < B::ROWS && hx < B::HW;
-        pk[u] = valid ? ((hz << 16) | (hy << 8) | hx) : -1;
-        rel[u] = (((hz - B::PD) * a.H + (hy - 1)) * a.W + (hx - 1)) * 64 + (slot ^ halo_swz_x(row, hx)) * 16;       // bytes (64 per voxel: Cin == 32)
-    }
-    // copy the halo of box p into Xs: zero padding from the buffer's out-of-range rule, swizzle on the source side (conv3x_kernel)
-    auto issue_box = [&](const Pos& p) {
-        const i32x4 rs = make_rsrc((const T*)a.in0 + (long long)p.n * vol * 32, (unsigned)(vol * 64));
-        const int org = ((p.z0 * a.H + p.y0) * a.W + p.x0) * 64;
-        const int zlo = B::PD - p.z0, ylo = 1 - p.y0, xlo = 1 - p.x0;      // halo coordinate of the first in-volume plane / row / column (<= 0: all)
-        const int zhi = a.D + B::PD - p.z0, yhi = a.H + 1 - p.y0, xhi = a.W + 1 - p.x0;
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int i = u * 4 + wv;
-            if (i < B::NINSTR) {
-                const int hz = pk[u] >> 16, hy = (pk[u] >> 8) & 255, hx = pk[u] & 255;
-                const bool ok = pk[u] >= 0 && hz >= zlo && hz < zhi && hy >= ylo && hy < yhi && hx >= xlo && hx < xhi;
-                dma16_async(rs, Xs + i * 512, ok ? (unsigned)(org + rel[u]) : DMA_OOB);
-            }
-        }
-    };
-    // ---- A-fragment addressing (conv3x_kernel)
-    int ab[TM][3];
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-        int vz, vy, vx;
-        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
-        const int row = vz * B::HH + vy;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) ab[m][kw] = (row * B::HWP + vx) * 32 + ((q ^ halo_swz_x(row, vx + kw)) << 3);
-    }
-    const unsigned wstep = (unsigned)NT_total * 1024u;
-    const i32x4 wr = make_rsrc(a.w, (unsigned)B::NTAP * wstep);
-    const unsigned wl = ((unsigned)(blockIdx.y * TN) * 64u + lane) * 16u;
-
-    int box, nbox_id;
-    int vb = next_valid((int)blockIdx.x, box);
-    if (box < 0) return;
-    Pos p = pos_of(box);
-    issue_box(p);
-#ifdef SEG_C3X_TRACE
-    int kb = 0;                                            // trace builds: the stamps are those of a workgroup's SECOND box (steady state: both resident workgroups busy)
-#define SEG_C3QT(k) do { if (kb == 1) SEG_C3XT(k); } while (0)
-#else
-#define SEG_C3QT(k)
-#endif
-    for (;;) {
-        SEG_C3QT(0);
-        // the first PF weight steps of this box travel while the halo lands
-        typename Mma<T>::frag bq[PF + 1][TN];
-#pragma unroll
-        for (int s = 0; s < PF; ++s)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, s * wstep);
-        SEG_C3QT(4);
-        wait_vmem();                                       // this wave's copies into Xs have landed ...
-        SEG_C3QT(5);
-        __syncthreads();                                   // ... everybody's (and the statistics slots of the previous box have been read)
-        SEG_C3QT(1);
-        f32x4 acc[TM][TN];
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned wo = PF * wstep;
-        typename Mma<T>::frag af[2][TM];
-#pragma unroll
-        for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xs[ab[m][0]]);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-#pragma unroll
-        for (int t = 0; t < B::NTAP; ++t) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bq[(t + PF) % (PF + 1)][j] = buffer_load8<T>(wr, wl + j * 1024, wo);
-            wo += wstep;
-            if (t + 1 < B::NTAP) {
-                const int t1 = t + 1, kw = t1 % 3, srow = (t1 / 9) * B::HH + (t1 / 3) % 3;
-                const int toff = (srow * B::HWP + kw) * 32, flip = (srow & 1) << 4;
-#pragma unroll
-                for (int m = 0; m < TM; ++m) af[t1 & 1][m] = load8(&Xs[toff + (ab[m][kw] ^ flip)]);
-            }
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bq[t % (PF + 1)][j], af[t & 1][m], acc[m][j]);
-            __builtin_amdgcn_sched_group_barrier(0x020, TN, 0);
-            if (t + 1 < B::NTAP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-        }
-        SEG_C3QT(2);
-        // every wave is done reading the halo: the next box's copies go into the same buffer and land while this box's epilogue runs
-        const int nvb_id = next_valid(vb + (int)gridDim.x, nbox_id);
-        Pos pn = p;
-        __syncthreads();
-        if (nbox_id >= 0) { pn = pos_of(nbox_id); issue_box(pn); }
-#ifdef SEG_C3X_TRACE
-        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0, bias_s, kb == 1);
-#else
-        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0, bias_s);
-#endif
-        SEG_C3QT(3);
-#ifdef SEG_C3X_TRACE
-        ++kb;
-#endif
-        if (nbox_id < 0) break;
-        p = pn; vb = nvb_id;
-    }
-}
-
-template <class T, class B, int TM, int TN, int PF>
-void launch_cfgq(const Conv3xArgs& a, hipStream_t s) {
-    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
-    // two workgroups per CU of the 256 (46 KB of LDS each); fewer when there are fewer boxes; grid.x a multiple of 8 (workgroups per XCD x 8 XCDs)
-    static const int wgs = xknob_i("SEG_C3Q_WGS", 512);             // (tests: 16 makes every workgroup of a small volume walk several boxes)
-    long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
-    const long long per = (nbox + 7) / 8;
-    if (per_xcd > per) per_xcd = per;
-    dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3q_kernel<T, B, TM, TN, PF>), grid, dim3(256), 0, s, a);
-}
-
-#endif  // SEG_EXPERIMENTS (conv3q_kernel)
-
-#ifdef SEG_EXPERIMENTS      // persistent halo convs (round 3): measured slower than conv3x_kernel standalone and in the step (profiles/r03_persistent_conv_ab.log)
-// ------------------------------------------------------------------------------------------------
-// Cin == 32, 32 output channels per workgroup: PERSISTENT workgroups with LDS-RESIDENT weights and a DOUBLE-BUFFERED halo
-// (the 48^3 x 32-channel LUConv level of VNet3d, networks/VNet3d.py:117-125 down_tr32 / up_tr64: 8 launches per train step).
-// conv3x_kernel spends 3-5 us of a box's ~8 us staging its halo and streams 54 KB of B fragments per wave and box from L2 (the
-// round-2 roofline_mfma kernel: 0.16 of MFMA peak).  Here a workgroup
-//   * copies the [27][2][64 lanes][8] fragment-major weight slab (54 KB) into LDS ONCE and reads its B fragments from there:
-//     the tap loop issues no vector-memory instruction at all, so
-//   * the halo of the NEXT box travels global -> LDS (dma16_async: untracked buffer_load ... lds) while the MFMAs of the current
-//     box run out of the other buffer; one s_waitcnt vmcnt(0) + barrier per box publishes it;
-//   * walks the boxes of ONE XCD's contiguous range (block b -> XCD b % 8), stride = workgroups per XCD.
-// One workgroup per CU (2 x 45 KB halo + 54 KB weights); the epilogue (shared with conv3x_kernel) aliases the consumed buffer.
-// ------------------------------------------------------------------------------------------------
-template <class T, class B, int TM, int TN>
-__global__ __launch_bounds__(256, 1) void conv3p_kernel(Conv3xArgs a) {
-    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
-    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
-    static_assert(4 * TM == B::NTILE, "four waves cover the box");
-    constexpr int WM = 4, WN = 1, BN = TN * 16;
-    constexpr int BUF = B::CHUNK_ELEMS;
-    constexpr int NW = B::NTAP * TN;                       // 1 KB weight fragments resident in LDS
-    __shared__ float red_s[WM * BN * 2];
-    __shared__ __attribute__((aligned(16))) T Ws[NW * 512];
-    __shared__ __attribute__((aligned(16))) T Xs[2][BUF];
-    constexpr int NI = (B::NINSTR + 3) / 4;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
-    const int nbox = a.N * nbz * nby * nbx;
-    // this workgroup's boxes: XCD k = blockIdx.x % 8 owns [k * per, (k + 1) * per), its workgroups stride through it
-    const int per = (nbox + 7) >> 3, xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
-    const int b_end = (xcd + 1) * per < nbox ? (xcd + 1) * per : nbox;
-    int box = xcd * per + (int)(blockIdx.x >> 3);
-    if (box >= b_end) return;
-    const int co0 = blockIdx.y * BN;
-    const int NT_total = a.Cout >> 4;
-    const long long vol = (long long)a.D * a.H * a.W;
-
-    // ---- weights -> LDS (tracked copies; waited for together with the first halo)
-    {
-        const i32x4 wr = make_rsrc(a.w, (unsigned)B::NTAP * (unsigned)NT_total * 1024u);
-        for (int i = wv; i < NW; i += 4) {
-            const int tap = i / TN, j = i % TN;
-            dma16(wr, Ws + i * 512, ((unsigned)(tap * NT_total + blockIdx.y * TN + j) * 64u + lane) * 16u);
-        }
-    }
-    struct Pos { int x0, y0, z0, n; };
-    auto pos_of = [&](int b) {
-        Pos p;
-        p.x0 = (b % nbx) * B::TW; b /= nbx;
-        p.y0 = (b % nby) * B::TH; b /= nby;
-        p.z0 = (b % nbz) * B::TD;
-        p.n = b / nbz;
-        return p;
-    };
-    auto issue_box = [&](const Pos& p, int buf) {
-        const i32x4 rs = make_rsrc((const T*)a.in0 + (long long)p.n * vol * 32, (unsigned)(vol * 64));
-        T* dst = Xs[buf];
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int i = u * 4 + wv;                      // instruction index inside the chunk image (wave-uniform)
-            if (i < B::NINSTR) {
-                const int g = i * 64 + lane;
-                const int row = g / (B::HWP * 4), rem = g % (B::HWP * 4);
-                const int hx = rem >> 2, slot = rem & 3;
-                const int hz = row / B::HH, hy = row % B::HH;
-                const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
-                const bool ok = row < B::ROWS && hx < B::HW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H &&
-                                (unsigned)x < (unsigned)a.W;
-                const unsigned off = ok ? (unsigned)((z * a.H + y) * a.W + x) * 64u + (unsigned)(slot ^ halo_swz_x(row, hx)) * 16u : DMA_OOB;
-                dma16_async(rs, dst + i * 512, off);
-            }
-        }
-    };
-    // ---- A-fragment addressing (as conv3x_kernel)
-    int ab[TM][3];
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-        int vz, vy, vx;
-        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
-        const int row = vz * B::HH + vy;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) ab[m][kw] = (row * B::HWP + vx) * 32 + ((q ^ halo_swz_x(row, vx + kw)) << 3);
-    }
-    Pos p = pos_of(box);
-    issue_box(p, 0);
-    int cur = 0;
-    for (; box < b_end; box += stride) {
-        wait_vmem();                                       // this wave's copies into Xs[cur] (and, the first time, the weights) have landed
-        __syncthreads();                                   // ... everybody's; the other buffer's epilogue scratch is free
-        const int nxt = box + stride;
-        Pos pn = p;
-        if (nxt < b_end) { pn = pos_of(nxt); issue_box(pn, cur ^ 1); }
-        f32x4 acc[TM][TN];
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const T* Xc = Xs[cur];
-        typename Mma<T>::frag af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xc[ab[m][0]]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = load8(&Ws[j * 512 + lane * 8]);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-        for (int t = 0; t < B::NTAP; ++t) {
-            if (t + 1 < B::NTAP) {
-                const int t1 = t + 1, kw = t1 % 3, srow = (t1 / 9) * B::HH + (t1 / 3) % 3;
-                const int toff = (srow * B::HWP + kw) * 32, flip = (srow & 1) << 4;
-#pragma unroll
-                for (int m = 0; m < TM; ++m) af[t1 & 1][m] = load8(&Xc[toff + (ab[m][kw] ^ flip)]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[t1 & 1][j] = load8(&Ws[(t1 * TN + j) * 512 + lane * 8]);
-            }
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bf[t & 1][j], af[t & 1][m], acc[m][j]);
-            if (t + 1 < B::NTAP) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS reads of tap t + 1 ...
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                        // ... ahead of the MFMAs of tap t
-        }
-        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0);
-        p = pn;
-        cur ^= 1;
-    }
-}
-
-template <class T, class B, int TM, int TN>
-void launch_cfgp(const Conv3xArgs& a, hipStream_t s) {
-    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
-    // one workgroup per CU of the 256; fewer when there are fewer boxes (grid.x a multiple of 8: workgroups per XCD x 8 XCDs)
-    static const int wgs = xknob_i("SEG_C3P_WGS", 256);
-    long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
-    const long long per = (nbox + 7) / 8;
-    if (per_xcd > per) per_xcd = per;
-    dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3p_kernel<T, B, TM, TN>), grid, dim3(256), 0, s, a);
-}
-
-#endif  // SEG_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------------
 // Cin == 16 (the full-resolution LUConv / _block layers: networks/VNet3d.py:117-125 up_tr32.ops, networks/Unet3d.py enc1 / dec1).
@@ -768,7 +347,6 @@ void launch_cfgp(const Conv3xArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <class T, class B, int TM, int TN, int PF, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
-    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
     static_assert(sizeof(T) == 2, "16-bit run dtypes only");
     static_assert(B::TX == 16, "x rows of 16 voxels");
     static_assert(4 * TM == B::NTILE, "four waves cover the box");
@@ -778,7 +356,7 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
     constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
     __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
     __shared__ float red_s[WM * BN * 2];
-    __shared__ __attribute__((aligned(16))) float bias_s[SEG_C3X_RQ_LDS * BN];       // (see conv3x_kernel)
+    __shared__ __attribute__((aligned(16))) float bias_s[BN];
     constexpr int NI = (NINSTR + 3) / 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -836,11 +414,8 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float bias_v = (a.bias && tid < BN) ? a.bias[co0 + tid] : 0.f;      // parked in LDS for the epilogue (see conv3x_kernel)
-    float rq_sc = 0.f, rq_sh = 0.f;
-    if (SEG_C3X_RQ(a) && tid < BN) { rq_sc = a.rq_scale[(long long)n * a.Cout + co0 + tid]; rq_sh = a.rq_shift[(long long)n * a.Cout + co0 + tid]; }
     wait_vmem();
     if (tid < BN) bias_s[tid] = bias_v;
-    if (SEG_C3X_RQ(a) && tid < BN) { bias_s[(SEG_C3X_RQ_LDS / 3) * BN + tid] = rq_sc; bias_s[(SEG_C3X_RQ_LDS / 3) * 2 * BN + tid] = rq_sh; }
     __syncthreads();
 
     unsigned wo = PF * wstep;
@@ -873,312 +448,10 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
         if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
-    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s, true, bias_s + (SEG_C3X_RQ_LDS / 3) * BN);
+    c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, n, x0, y0, z0, co0, bias_s);
 }
 
-#ifdef SEG_EXPERIMENTS
-// ------------------------------------------------------------------------------------------------
-// Cin == 16, PERSISTENT (round 5): conv3x16_kernel's arithmetic in the box loop of conv3q_kernel.  The 96^3 x 16-channel launches are byte-bound by design (226 MB in
-// and out) yet ran at 2.9 TB/s alone against the 4.7-5.0 TB/s a copy reaches, because a 512-voxel box is only 112 MFMAs per wave and a workgroup's ~8 us life is
-// mostly its ~3.5 us instruction-bound prologue plus an exposed copy wait; 6912 workgroups pay it 6912 times.  Here 512 workgroups pay it once, then per box:
-// (copies of this box landed under the previous epilogue) barrier -> 14 two-tap MFMA steps -> barrier -> next box's copies issued (per-piece addresses: 13
-// instructions from the precomputed halo coordinates) -> epilogue.  Unlike the 32-channel case (conv3q_kernel: neutral, its tap loop is what binds) there is no
-// tap-loop ceiling here: what is left per box is the memory system.
-// MEASURED (profiles/r05_conv3q16_persistent_*): bit-exact; 4 x 96^3 without statistics 72.5 vs 79.1 us (tiling 25), WITH the GroupNorm statistics 103 vs 87 us (the per-box
-// barrier + fp64 atomics sit on the persistent loop's critical path instead of overlapping with another workgroup's start); 768 workgroups beat 512 and 1024;
-// C4 / C5 shapes 78.6 / 75.4 vs 80.2 / 82.5 us; in the step 1044-1047 vs 1041-1049 volumes/s: neutral.  Experiments build only (tilings 52 / 53 / 59).
-// ------------------------------------------------------------------------------------------------
-template <class T, class B, int TM, int TN, int PF>
-__global__ __launch_bounds__(256, 2) void conv3q16_kernel(Conv3xArgs a) {
-    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
-    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
-    static_assert(B::TX == 16, "x rows of 16 voxels");
-    static_assert(4 * TM == B::NTILE, "four waves cover the box");
-    constexpr int WM = 4, WN = 1, BN = TN * 16;
-    constexpr int NSTEP = (B::NTAP + 1) / 2;
-    static_assert(NSTEP >= PF + 1, "ring deeper than the loop");
-    constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
-    constexpr int NI = (NINSTR + 3) / 4;
-    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
-    __shared__ float red_s[WM * BN * 2];
-    __shared__ float bias_s[BN];
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
-    const int nbox = a.N * nbz * nby * nbx;
-    const int nvb = a.remap ? (nbox + 7) / 8 * 8 : nbox;
-    const int co0 = blockIdx.y * BN;
-    const long long vol = (long long)a.D * a.H * a.W;
-    if (tid < BN) bias_s[tid] = a.bias ? a.bias[co0 + tid] : 0.f;
-
-    auto next_valid = [&](int vb, int& box) {
-        for (; vb < nvb; vb += (int)gridDim.x) {
-            box = c3x_box_of_block(vb, nbox, a.remap);
-            if (box >= 0) return vb;
-        }
-        box = -1;
-        return nvb;
-    };
-    struct Pos { int x0, y0, z0, n; };
-    auto pos_of = [&](int b) {
-        Pos p;
-        p.x0 = (b % nbx) * B::TW; b /= nbx;
-        p.y0 = (b % nby) * B::TH; b /= nby;
-        p.z0 = (b % nbz) * B::TD;
-        p.n = b / nbz;
-        return p;
-    };
-    // copy pieces of this lane, box-independent part (see conv3q_kernel): halo coordinates packed, byte offset relative to the box origin (32 B per voxel)
-    int pk[NI], rel[NI];
-#pragma unroll
-    for (int u = 0; u < NI; ++u) {
-        const int i = u * 4 + wv;
-        const int g = i * 64 + lane;
-        const int row = g / (B::HWP * 2), rem = g % (B::HWP * 2);
-        const int hx = rem >> 1, piece = rem & 1;
-        const int hz = row / B::HH, hy = row % B::HH;
-        const bool valid = i < NINSTR && row < B::ROWS && hx < B::HW;
-        pk[u] = valid ? ((hz << 16) | (hy << 8) | hx) : -1;
-        rel[u] = (((hz - B::PD) * a.H + (hy - 1)) * a.W + (hx - 1)) * 32 + piece * 16;
-    }
-    auto issue_box = [&](const Pos& p) {
-        const i32x4 rs = make_rsrc((const T*)a.in0 + (long long)p.n * vol * 16, (unsigned)(vol * 32));
-        const int org = ((p.z0 * a.H + p.y0) * a.W + p.x0) * 32;
-        const int zlo = B::PD - p.z0, ylo = 1 - p.y0, xlo = 1 - p.x0;
-        const int zhi = a.D + B::PD - p.z0, yhi = a.H + 1 - p.y0, xhi = a.W + 1 - p.x0;
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int i = u * 4 + wv;
-            if (i < NINSTR) {
-                const int hz = pk[u] >> 16, hy = (pk[u] >> 8) & 255, hx = pk[u] & 255;
-                const bool ok = pk[u] >= 0 && hz >= zlo && hz < zhi && hy >= ylo && hy < yhi && hx >= xlo && hx < xhi;
-                dma16_async(rs, Xs + i * 512, ok ? (unsigned)(org + rel[u]) : DMA_OOB);
-            }
-        }
-    };
-    // ---- weights through the register ring, A addressing: conv3x16_kernel
-    const unsigned wstep = (unsigned)(a.Cout >> 4) * 1024u;
-    const i32x4 wr = make_rsrc(a.w, (unsigned)NSTEP * wstep);
-    const unsigned wl = ((unsigned)(blockIdx.y * TN) * 64u + lane) * 16u;
-    constexpr int D_KW = 16, D_KH = (B::HWP - 2) * 16, D_KD = ((B::HH - 2) * B::HWP - 2) * 16;    // elements
-    const int hi = q >> 1, piece = q & 1;
-    int ab[TM][3];
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-        int vz, vy, vx;
-        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
-        const int base = ((vz * B::HH + vy) * B::HWP + vx) * 16 + piece * 8;
-        ab[m][0] = base + (hi ? D_KW : 0);
-        ab[m][1] = base + (hi ? D_KH : 0);
-        ab[m][2] = base + (hi ? D_KD : 0);
-    }
-    auto tap_off = [](int t) { return ((t / 9) * B::HH + (t / 3) % 3) * B::HWP + t % 3; };       // halo voxels
-
-    int box, nbox_id;
-    int vb = next_valid((int)blockIdx.x, box);
-    if (box < 0) return;
-    Pos p = pos_of(box);
-    issue_box(p);
-    for (;;) {
-        typename Mma<T>::frag bq[PF + 1][TN];
-#pragma unroll
-        for (int s = 0; s < PF; ++s)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bq[s][j] = buffer_load8<T>(wr, wl + j * 1024, s * wstep);
-        wait_vmem();
-        __syncthreads();
-        f32x4 acc[TM][TN];
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned wo = PF * wstep;
-        typename Mma<T>::frag af[2][TM];
-#pragma unroll
-        for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xs[ab[m][0] + tap_off(0) * 16]);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bq[(s + PF) % (PF + 1)][j] = buffer_load8<T>(wr, wl + j * 1024, wo);
-            wo += wstep;
-            if (s + 1 < NSTEP) {
-                const int t0 = 2 * (s + 1), t1 = t0 + 1;
-                const int d = t1 >= B::NTAP ? -1 : (tap_off(t1) - tap_off(t0) == 1 ? 0 : (t1 % 9 == 0 ? 2 : 1));
-#pragma unroll
-                for (int m = 0; m < TM; ++m) {
-                    const int basev = d < 0 ? ab[m][0] - (hi ? D_KW : 0) : ab[m][d];
-                    af[(s + 1) & 1][m] = load8(&Xs[basev + tap_off(t0) * 16]);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bq[s % (PF + 1)][j], af[s & 1][m], acc[m][j]);
-            __builtin_amdgcn_sched_group_barrier(0x020, TN, 0);
-            if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-        }
-        // every wave is done reading the halo: the next box's copies go into the same buffer and land while this box's epilogue runs
-        const int nvb_id = next_valid(vb + (int)gridDim.x, nbox_id);
-        Pos pn = p;
-        __syncthreads();
-        if (nbox_id >= 0) { pn = pos_of(nbox_id); issue_box(pn); }
-        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0, bias_s);
-        if (nbox_id < 0) break;
-        p = pn; vb = nvb_id;
-    }
-}
-
-template <class T, class B, int TM, int TN, int PF>
-void launch_cfgq16(const Conv3xArgs& a, hipStream_t s) {
-    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
-    static const int wgs = xknob_i("SEG_C3Q16_WGS", 768);          // three workgroups per CU (155 VGPRs, 39 KB LDS); tests: 16 makes every workgroup of a small volume walk several boxes
-    long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
-    const long long per = (nbox + 7) / 8;
-    if (per_xcd > per) per_xcd = per;
-    dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3q16_kernel<T, B, TM, TN, PF>), grid, dim3(256), 0, s, a);
-}
-
-#endif  // SEG_EXPERIMENTS (conv3q16_kernel)
-
-#ifdef SEG_EXPERIMENTS
-// The same persistent scheme for Cin == 16 (conv3x16_kernel's two-taps-per-step arithmetic): the [14 steps][TN][64][8] weight slab (14 / 28 KB)
-// lives in LDS, the 25 KB halo is double-buffered, two workgroups per CU.  These launches are HBM-bound (226 MB at 4 x 96^3):
-// what the double buffer buys is that the copy of box i + 1 streams while box i is multiplied and written back.
-template <class T, class B, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void conv3p16_kernel(Conv3xArgs a) {
-    if (a.sig.flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) fork_signal_store(a.sig.flag, a.sig.seq);
-    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
-    static_assert(B::TX == 16, "x rows of 16 voxels");
-    static_assert(4 * TM == B::NTILE, "four waves cover the box");
-    constexpr int WM = 4, WN = 1, BN = TN * 16;
-    constexpr int NSTEP = (B::NTAP + 1) / 2;
-    constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
-    constexpr int BUF = XS_ELEMS;
-    __shared__ float red_s[WM * BN * 2];
-    constexpr int NW = NSTEP * TN;
-    __shared__ __attribute__((aligned(16))) T Ws[NW * 512];
-    __shared__ __attribute__((aligned(16))) T Xs[2][BUF];
-    constexpr int NI = (NINSTR + 3) / 4;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
-    const int nbox = a.N * nbz * nby * nbx;
-    const int per = (nbox + 7) >> 3, xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
-    const int b_end = (xcd + 1) * per < nbox ? (xcd + 1) * per : nbox;
-    int box = xcd * per + (int)(blockIdx.x >> 3);
-    if (box >= b_end) return;
-    const int co0 = blockIdx.y * BN;
-    const long long vol = (long long)a.D * a.H * a.W;
-    {
-        const unsigned wstep = (unsigned)(a.Cout >> 4) * 1024u;
-        const i32x4 wr = make_rsrc(a.w, (unsigned)NSTEP * wstep);
-        for (int i = wv; i < NW; i += 4) {
-            const int st = i / TN, j = i % TN;
-            dma16(wr, Ws + i * 512, (unsigned)st * wstep + ((unsigned)(blockIdx.y * TN + j) * 64u + lane) * 16u);
-        }
-    }
-    struct Pos { int x0, y0, z0, n; };
-    auto pos_of = [&](int b) {
-        Pos p;
-        p.x0 = (b % nbx) * B::TW; b /= nbx;
-        p.y0 = (b % nby) * B::TH; b /= nby;
-        p.z0 = (b % nbz) * B::TD;
-        p.n = b / nbz;
-        return p;
-    };
-    auto issue_box = [&](const Pos& p, int buf) {
-        const i32x4 rs = make_rsrc((const T*)a.in0 + (long long)p.n * vol * 16, (unsigned)(vol * 32));
-        T* dst = Xs[buf];
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int i = u * 4 + wv;
-            if (i < NINSTR) {
-                const int g = i * 64 + lane;
-                const int row = g / (B::HWP * 2), rem = g % (B::HWP * 2);
-                const int hx = rem >> 1, piece = rem & 1;
-                const int hz = row / B::HH, hy = row % B::HH;
-                const int z = p.z0 + hz - B::PD, y = p.y0 + hy - 1, x = p.x0 + hx - 1;
-                const bool ok = row < B::ROWS && hx < B::HW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                dma16_async(rs, dst + i * 512, ok ? (unsigned)(((z * a.H + y) * a.W + x) * 32 + piece * 16) : DMA_OOB);
-            }
-        }
-    };
-    // ---- A addressing (conv3x16_kernel): lanes q < 2 read tap 2s, lanes q >= 2 tap 2s + 1
-    constexpr int D_KW = 16, D_KH = (B::HWP - 2) * 16, D_KD = ((B::HH - 2) * B::HWP - 2) * 16;    // elements
-    const int hi = q >> 1, piece = q & 1;
-    int ab[TM][3];
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-        int vz, vy, vx;
-        B::vox((wv * TM + m) * 16 + l15, vz, vy, vx);
-        const int base = ((vz * B::HH + vy) * B::HWP + vx) * 16 + piece * 8;
-        ab[m][0] = base + (hi ? D_KW : 0);
-        ab[m][1] = base + (hi ? D_KH : 0);
-        ab[m][2] = base + (hi ? D_KD : 0);
-    }
-    auto tap_off = [](int t) { return ((t / 9) * B::HH + (t / 3) % 3) * B::HWP + t % 3; };       // halo voxels
-    Pos p = pos_of(box);
-    issue_box(p, 0);
-    int cur = 0;
-    for (; box < b_end; box += stride) {
-        wait_vmem();
-        __syncthreads();
-        const int nxt = box + stride;
-        Pos pn = p;
-        if (nxt < b_end) { pn = pos_of(nxt); issue_box(pn, cur ^ 1); }
-        f32x4 acc[TM][TN];
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const T* Xc = Xs[cur];
-        typename Mma<T>::frag af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int m = 0; m < TM; ++m) af[0][m] = load8(&Xc[ab[m][0] + tap_off(0) * 16]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = load8(&Ws[j * 512 + lane * 8]);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) {
-                const int t0 = 2 * (s + 1), t1 = t0 + 1;
-                const int d = t1 >= B::NTAP ? -1 : (tap_off(t1) - tap_off(t0) == 1 ? 0 : (t1 % 9 == 0 ? 2 : 1));
-#pragma unroll
-                for (int m = 0; m < TM; ++m) {
-                    const int basev = d < 0 ? ab[m][0] - (hi ? D_KW : 0) : ab[m][d];
-                    af[(s + 1) & 1][m] = load8(&Xc[basev + tap_off(t0) * 16]);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[(s + 1) & 1][j] = load8(&Ws[((s + 1) * TN + j) * 512 + lane * 8]);
-            }
-#pragma unroll
-            for (int m = 0; m < TM; ++m)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(bf[s & 1][j], af[s & 1][m], acc[m][j]);
-            if (s + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-        }
-        c3x_epilogue<T, B, TM, TN, WM, WN>(acc, red_s, a, p.n, p.x0, p.y0, p.z0, co0);
-        p = pn;
-        cur ^= 1;
-    }
-}
-
-template <class T, class B, int TM, int TN>
-void launch_cfgp16(const Conv3xArgs& a, hipStream_t s) {
-    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
-    static const int wgs = xknob_i("SEG_C3P16_WGS", 512);      // two workgroups per CU
-    long long per_xcd = (wgs > 8 ? wgs : 8) / 8;
-    const long long per = (nbox + 7) / 8;
-    if (per_xcd > per) per_xcd = per;
-    dim3 grid((unsigned)(per_xcd * 8), a.Cout / (TN * 16));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3p16_kernel<T, B, TM, TN>), grid, dim3(256), 0, s, a);
-}
-
-#endif  // SEG_EXPERIMENTS
 
 template <class T, class B, int TM, int TN, int PF, int OCC>
 void launch_cfg16(const Conv3xArgs& a, hipStream_t s) {
@@ -1190,88 +463,59 @@ void launch_cfg16(const Conv3xArgs& a, hipStream_t s) {
 // one translation unit per (dtype, ndim): the tap loops are fully unrolled and each instantiation takes ~10 s to compile
 template <class T> bool launch_3d(int id, const Conv3xArgs& a, hipStream_t s);
 template <class T> bool launch_2d(int id, const Conv3xArgs& a, hipStream_t s);
-// the FUSE = true instantiations (conv3x_<dtype>_<nd>_gn.hip)
-template <class T> bool launch_3d_gn(int id, const Conv3xArgs& a, hipStream_t s);
-template <class T> bool launch_2d_gn(int id, const Conv3xArgs& a, hipStream_t s);
 
-/* halo-conv tilings; FUSE (a constexpr bool in scope) selects the instantiation that applies the producer GroupNorm while staging */
+/* halo-conv tilings:                  box              TM TN WM WN NRES PF OCC */
 #define SEG_C3X_3D_CONV_CASES                                                                                         \
-        case 0: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 2, 2, FUSE>(a, s); return true;                   \
-        case 1: launch_cfg<T, XBox<4, 8, 16, 3, 16>, 8, 2, 4, 1, 1, 2, 1, FUSE>(a, s); return true;                   \
-        case 2: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 8, 2, 2, 2, 2, 8, 1, FUSE>(a, s); return true;                   \
-        case 3: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 2, 8, 2, FUSE>(a, s); return true;                     \
-        case 4: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 8, 2, 2, 2, 2, 8, 1, FUSE>(a, s); return true;                     \
-        case 5: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 4, 4, 1, 2, 2, 1, FUSE>(a, s); return true;                     \
-        case 6: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 4, 4, 1, 2, 2, 2, FUSE>(a, s); return true;                     \
-        case 7: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 2, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
-        case 8: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 2, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
-        case 9: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 4, 2, 2, 4, 2, 1, FUSE>(a, s); return true;                    \
-        case 10: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 1, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                  \
-        case 11: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
-        case 12: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 4, 2, 2, 4, 2, 1, FUSE>(a, s); return true;                    \
-        case 13: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 2, 8, 2, FUSE>(a, s); return true;                    \
-        case 14: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 2, FUSE>(a, s); return true;                    \
-        case 15: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 2, 8, 1, FUSE>(a, s); return true;                  \
-        case 16: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                  \
-        case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                    \
-        case 20: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 3, FUSE>(a, s); return true;                    \
-        case 21: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 1, 2, 4, FUSE>(a, s); return true;                    \
-        case 22: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 1, 8, 3, FUSE>(a, s); return true;                    \
-        case 23: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 3, FUSE>(a, s); return true;                    \
-        case 44: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 2, 2, 2, 4, 26, 1, FUSE>(a, s); return true;                   \
-        case 45: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 1, 2, 2, 4, 26, 1, FUSE>(a, s); return true;                   \
-        case 46: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 1, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
-        case 47: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 1, 2, 2, 4, 8, 1, FUSE>(a, s); return true;                    \
-        case 48: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 1, 2, 2, 4, 26, 1, FUSE>(a, s); return true;                   \
-        case 49: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 8, 1, FUSE>(a, s); return true;                    \
-        case 50: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 26, 1, FUSE>(a, s); return true;
-/* Cin == 32, no concat, no FUSE: persistent form of tiling 17 (conv3q_kernel; experiments build) */
-#ifdef SEG_EXPERIMENTS
-#define SEG_C3X_3D_Q_CASES                                                                                            \
-        case 51: launch_cfgq<T, XBox<4, 8, 8, 3, 8>, 4, 2, 8>(a, s); return true;
-#else
-#define SEG_C3X_3D_Q_CASES
-#endif
-/* Cin == 32 persistent tilings (conv3p_kernel):   box                  TM TN */
-#ifdef SEG_EXPERIMENTS
-#define SEG_C3X_3D_P_CASES                                                                                            \
-        case 18: launch_cfgp<T, XBox<4, 8, 8, 3, 8>, 4, 2>(a, s); return true;                                       \
-        case 19: launch_cfgp<T, XBox<2, 8, 8, 3, 8>, 2, 2>(a, s); return true;                                       \
-        case 28: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 1>(a, s); return true;                                    \
-        case 29: launch_cfgp16<T, XBox<2, 8, 16, 3, 16>, 4, 2>(a, s); return true;                                    \
-        case 52: launch_cfgq16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2>(a, s); return true;                                 \
-        case 53: launch_cfgq16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2>(a, s); return true;
-#define SEG_C3X_2D_P_CASES                                                                                            \
-        case 40: launch_cfgp<T, XBox<1, 16, 16, 1, 16>, 4, 2>(a, s); return true;                                    \
-        case 58: launch_cfgp16<T, XBox<1, 16, 16, 1, 16>, 4, 1>(a, s); return true;                                   \
-        case 59: launch_cfgq16<T, XBox<1, 16, 16, 1, 16>, 4, 1, 2>(a, s); return true;
-#else
-#define SEG_C3X_3D_P_CASES
-#define SEG_C3X_2D_P_CASES
-#endif
+        case 0: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 2, 2>(a, s); return true;                         \
+        case 1: launch_cfg<T, XBox<4, 8, 16, 3, 16>, 8, 2, 4, 1, 1, 2, 1>(a, s); return true;                         \
+        case 2: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 8, 2, 2, 2, 2, 8, 1>(a, s); return true;                         \
+        case 3: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 2, 8, 2>(a, s); return true;                           \
+        case 4: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 8, 2, 2, 2, 2, 8, 1>(a, s); return true;                           \
+        case 5: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 4, 4, 1, 2, 2, 1>(a, s); return true;                           \
+        case 6: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 4, 4, 1, 2, 2, 2>(a, s); return true;                           \
+        case 7: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 2, 2, 2, 4, 8, 1>(a, s); return true;                          \
+        case 8: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 2, 2, 2, 4, 8, 1>(a, s); return true;                          \
+        case 9: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 4, 2, 2, 4, 2, 1>(a, s); return true;                          \
+        case 10: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 1, 4, 1, 1, 8, 2>(a, s); return true;                        \
+        case 11: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 2, 2, 2, 4, 8, 1>(a, s); return true;                          \
+        case 12: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 4, 4, 2, 2, 4, 2, 1>(a, s); return true;                          \
+        case 13: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 2, 8, 2>(a, s); return true;                          \
+        case 14: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 2>(a, s); return true;                          \
+        case 15: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 2, 8, 1>(a, s); return true;                        \
+        case 16: launch_cfg<T, XBox<2, 8, 16, 3, 16>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;                        \
+        case 17: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;                          \
+        case 20: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 2, 3>(a, s); return true;                          \
+        case 21: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 1, 2, 4>(a, s); return true;                          \
+        case 22: launch_cfg<T, XBox<2, 8, 8, 3, 8>, 2, 2, 4, 1, 1, 8, 3>(a, s); return true;                          \
+        case 23: launch_cfg<T, XBox<4, 8, 8, 3, 8>, 4, 2, 4, 1, 1, 8, 3>(a, s); return true;                          \
+        case 44: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 2, 2, 2, 4, 26, 1>(a, s); return true;                         \
+        case 45: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 1, 2, 2, 4, 26, 1>(a, s); return true;                         \
+        case 46: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 3, 1, 2, 2, 4, 8, 1>(a, s); return true;                          \
+        case 47: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 1, 2, 2, 4, 8, 1>(a, s); return true;                          \
+        case 48: launch_cfg<T, XBox<4, 4, 12, 3, 4>, 6, 1, 2, 2, 4, 26, 1>(a, s); return true;                         \
+        case 49: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 8, 1>(a, s); return true;                          \
+        case 50: launch_cfg<T, XBox<2, 4, 12, 3, 4>, 6, 1, 1, 4, 4, 26, 1>(a, s); return true;      
+/* Cin == 16 tilings (conv3x16_kernel): box             TM TN PF OCC */
 #define SEG_C3X_3D_C16_CASES                                                                                          \
         case 24: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2, 4>(a, s); return true;                               \
         case 25: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2, 3>(a, s); return true;                               \
         case 26: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 2, 2, 3>(a, s); return true;                               \
         case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;
-#define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_Q_CASES SEG_C3X_3D_P_CASES SEG_C3X_3D_C16_CASES default: return false; }
-#define SEG_C3X_3D_GN_BODY switch (id) { SEG_C3X_3D_CONV_CASES default: return false; }
+#define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_C16_CASES default: return false; }
 
-/* halo-conv tilings; FUSE (a constexpr bool in scope) selects the instantiation that applies the producer GroupNorm while staging */
 #define SEG_C3X_2D_CONV_CASES                                                                                         \
-        case 32: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 2, 4, 1, 1, 8, 2, FUSE>(a, s); return true;                 \
-        case 33: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 8, 2, 2, 2, 2, 2, 2, FUSE>(a, s); return true;                 \
-        case 34: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 2, 8, 2, FUSE>(a, s); return true;                  \
-        case 35: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 4, 8, 2, FUSE>(a, s); return true;                  \
-        case 36: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 4, 2, 2, 4, 2, 2, FUSE>(a, s); return true;                  \
-        case 37: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 1, 4, 1, 1, 8, 3, FUSE>(a, s); return true;                 \
-        case 38: launch_cfg<T, XBox<1, 8, 8, 1, 8>, 2, 2, 2, 2, 4, 8, 2, FUSE>(a, s); return true;                    \
-        case 39: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 2, 2, 4, 1, 2, 8, 2, FUSE>(a, s); return true;
+        case 32: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 2, 4, 1, 1, 8, 2>(a, s); return true;                       \
+        case 33: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 8, 2, 2, 2, 2, 2, 2>(a, s); return true;                       \
+        case 34: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 2, 8, 2>(a, s); return true;                        \
+        case 35: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 2, 2, 2, 4, 8, 2>(a, s); return true;                        \
+        case 36: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 4, 4, 2, 2, 4, 2, 2>(a, s); return true;                        \
+        case 37: launch_cfg<T, XBox<1, 16, 16, 1, 16>, 4, 1, 4, 1, 1, 8, 3>(a, s); return true;                       \
+        case 38: launch_cfg<T, XBox<1, 8, 8, 1, 8>, 2, 2, 2, 2, 4, 8, 2>(a, s); return true;                          \
+        case 39: launch_cfg<T, XBox<1, 8, 16, 1, 16>, 2, 2, 4, 1, 2, 8, 2>(a, s); return true;      
 #define SEG_C3X_2D_C16_CASES                                                                                          \
         case 56: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 1, 2, 4>(a, s); return true;                              \
         case 57: launch_cfg16<T, XBox<1, 16, 16, 1, 16>, 4, 2, 2, 4>(a, s); return true;
-#define SEG_C3X_2D_BODY switch (id) { SEG_C3X_2D_CONV_CASES SEG_C3X_2D_P_CASES SEG_C3X_2D_C16_CASES default: return false; }
-#define SEG_C3X_2D_GN_BODY switch (id) { SEG_C3X_2D_CONV_CASES default: return false; }
+#define SEG_C3X_2D_BODY switch (id) { SEG_C3X_2D_CONV_CASES SEG_C3X_2D_C16_CASES default: return false; }
 
 
 }  // namespace c3x

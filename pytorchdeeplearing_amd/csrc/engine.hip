@@ -33,23 +33,8 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->use_stemx = knob_i("SEG_STEMX", e->use_stemx) != 0;
     e->pack_split = knob_i("SEG_PACK_SPLIT", e->pack_split) != 0;
     e->use_fold = knob_i("SEG_GN_FOLD", e->use_fold) != 0;
-    e->use_rfuse = xknob_i("SEG_GN_RFUSE", 0) != 0;       // experiments build only (measured slower, profiles/r05_reduce_fold_ab.log)
     e->use_vhead = knob_i("SEG_VHEAD", e->use_vhead) != 0;
     e->dual_gn_bwd = knob_i("SEG_DUAL_GN", e->dual_gn_bwd) != 0;
-    // experiment knobs: their defaults in the product library, environment variables only in a -DSEG_EXPERIMENTS build (profiles/HISTORY.md says what
-    // each one measured)
-    e->use_vact = xknob_i("SEG_GN_VACT", e->use_vact) != 0;
-    e->tail_wgrads = xknob_i("SEG_TAIL_WGRADS", e->tail_wgrads);
-    e->fork_heavy_bytes = xknob_f("SEG_FORK_HEAVY_MB", e->fork_heavy_bytes / 1e6) * 1e6;
-    e->flush_late = xknob_i("SEG_FLUSH_LATE", e->flush_late) != 0;
-    e->hold_lvl = xknob_i("SEG_HOLD_HEAVY_LVL", e->hold_lvl);
-    e->hold_bytes = xknob_f("SEG_HOLD_HEAVY_MB", e->hold_bytes / 1e6) * 1e6;
-    e->stem_on_main = xknob_i("SEG_STEM_MAIN", e->stem_on_main) != 0;
-    e->side_prio = xknob_i("SEG_SIDE_PRIO", e->side_prio);
-    e->n_side = xknob_i("SEG_WGRAD_STREAMS", 1) >= 2 ? 2 : 1;
-    if (xknob_i("SEG_FORK_BATCH", 0) > 0) e->fork_batch = xknob_i("SEG_FORK_BATCH", 0);
-    e->sub_mb = xknob_f("SEG_SUB_MB", e->sub_mb);
-    e->sub_lvl = xknob_i("SEG_SUB_LVL", e->sub_lvl);
     build_network(*e, net_kind);
     *out = e;
     return 0;
@@ -64,11 +49,8 @@ void seg_destroy(seg_handle h) {
     if (h->pack_done) (void)hipEventDestroy(h->pack_done);
     if (h->side_done) (void)hipEventDestroy(h->side_done);
     if (h->ar_ev) (void)hipEventDestroy(h->ar_ev);
-    h->release_waiters();
+    if (h->xchg) (void)hipStreamDestroy(h->xchg);
     if (h->side) (void)hipStreamDestroy(h->side);
-    if (h->side2_done) (void)hipEventDestroy(h->side2_done);
-    if (h->side2) (void)hipStreamDestroy(h->side2);
-    if (h->fork_flag) { (void)hipDeviceSynchronize(); (void)hipFree(h->fork_flag); }
     delete h;
 }
 
@@ -97,7 +79,6 @@ int seg_set_dropout_draws(seg_handle h, long long draws) {
     if (draws < 0 || draws > 0x7fffffffll) return fail("seg_set_dropout_draws: counter out of range");
     h->draws = (int)draws;
     if (h->ws) {          // bound: the device-side counter follows (seg_bind restores it from the host copy otherwise)
-        h->release_waiters();
         if (h->side) (void)hipStreamSynchronize(h->side);
         if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h->ws + h->off_step, &h->draws, sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
             return fail("seg_set_dropout_draws: counter upload failed");
@@ -113,11 +94,9 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
         return fail("seg_plan: spatial dims must be multiples of 16 (four 2x down-samplings)");
     // a backward-only weight pack of the previous step may still be running on the (non-blocking) side stream into the workspace the
     // caller is about to replace
-    h->release_waiters();
     if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }
-    if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->drop_graph();
-    h->N = n; h->Nplan = n; h->D = d; h->H = hgt; h->W = wid;
+    h->N = n; h->D = d; h->H = hgt; h->W = wid;
     g_err.clear();
     plan_engine(*h);
     if (!g_err.empty()) return -1;
@@ -127,26 +106,9 @@ int seg_plan(seg_handle h, int n, int d, int hgt, int wid) {
 int seg_plan_count(seg_handle h, int what) {
     if (!h || !h->planned) return -1;
     if (what == 2) return h->n_event_forks;             // last backward pass: fork events recorded on the main stream
-    if (what == 3) return h->n_flag_forks;              // ... flag forks (the weight-gradient queue's command processor waits on a word the main queue's next kernel stores)
-    if (what == 7) return h->n_sig_taken;               // ... of which the next kernel of the main stream stored the number itself
-    if (what == 8) return h->n_sig_kernels;             // ... and one-wave kernels that stored it
-    if (what == 9) {                                    // 1: no released batch is left waiting (the host checker also reads the flag word itself)
-#ifdef SEG_EMU
-        if (h->fork_flag && *h->fork_flag != h->fork_seq) return 0;
-#endif
-        return h->sig_pending == 0;
-    }
-    if (what == 4) return h->sub_nb;                    // samples per group of the sub-batched finest level (0: whole-batch launches)
-    if (what == 5 || what == 6) {                       // forward / backward ops that run group by group
-        int n = 0;
-        for (auto& c : (what == 5 ? h->fwd_chains : h->bwd_chains)) n += c.second - c.first;
-        return n;
-    }
     int n = 0;
     for (auto& s : h->steps) {
-        if (what == 0) n += s.type == ST_ACT && s.vact;                                   // activations applied by their consumer (never written)
-        else if (what == 1) n += s.type == ST_UNIT;                                       // convolution units
-        else if (what == 10) n += s.type == ST_UNIT && s.rfused;                          // GroupNorm-backward reduce passes done by a data-gradient epilogue
+        if (what == 1) n += s.type == ST_UNIT;                                            // convolution units
         else return -1;
     }
     return n;
@@ -158,9 +120,7 @@ int seg_bind(seg_handle h, float* params, float* grads, void* workspace) {
     if (!h->planned) return fail("seg_bind: call seg_plan first");
     if (!params || !workspace) return fail("seg_bind: params/workspace must not be null");
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)workspace) & 255) return fail("seg_bind: buffers must be 256-byte aligned");
-    h->release_waiters();
     if (h->side) { (void)hipStreamSynchronize(h->side); h->pack_bwd_pending = false; }     // see seg_plan
-    if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->drop_graph();
     h->p = params; h->g = grads; h->ws = (char*)workspace;
     // resolve and upload the weight re-layout descriptors; reset the device-side step counter
@@ -218,7 +178,7 @@ int seg_forward(seg_handle h, const float* x, int mask_mode, const float* masks,
         ++h->draws;
     }
     h->cur_x = x; h->cur_logits = logits; h->cur_probs = probs;
-    h->run_ops(h->fwd_ops, h->fwd_chains, 0, (int)h->fwd_ops.size(), st, false);
+    h->run_ops(h->fwd_ops, 0, (int)h->fwd_ops.size(), st);
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_forward: ") + hipGetErrorString(hipGetLastError()));
 }
 
@@ -232,11 +192,7 @@ int seg_backward_slice(seg_handle h, const float* dlogits, int zero_grads, int o
 int seg_side_wait(seg_handle h, void* stream) {
     if (check_handle(h)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    h->emit_sig(st);
-    if (h->use_side && h->side) {
-        (void)hipEventRecord(h->side_done, h->side); (void)hipStreamWaitEvent(st, h->side_done, 0);
-        if (h->side2) { (void)hipEventRecord(h->side2_done, h->side2); (void)hipStreamWaitEvent(st, h->side2_done, 0); }
-    }
+    if (h->use_side && h->side) { (void)hipEventRecord(h->side_done, h->side); (void)hipStreamWaitEvent(st, h->side_done, 0); }
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_side_wait: event error");
 }
 static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, int op_begin, int op_end, int join, void* stream) {
@@ -248,11 +204,11 @@ static int backward_slice(seg_handle h, const float* dlogits, int zero_grads, in
     hipStream_t st = (hipStream_t)stream;
     if (zero_grads && op_begin == 0) (void)hipMemsetAsync(h->g, 0, (size_t)h->nparam * 4, st);
     h->cur_dlogits = dlogits;
-    if (op_begin == 0) { h->wgrad_seq = 0; h->ready_used = 0; h->hold_open = false; h->n_event_forks = 0; h->n_flag_forks = 0; h->n_sig_kernels = 0; h->n_sig_taken = 0; }
+    if (op_begin == 0) { h->ready_used = 0; h->hold_open = false; h->n_event_forks = 0; }
     if (h->pack_bwd_pending) { (void)hipStreamWaitEvent(st, h->pack_done, 0); h->pack_bwd_pending = false; }
-    h->run_ops(h->bwd_ops, h->bwd_chains, op_begin, op_end, st, true);
+    h->run_ops(h->bwd_ops, op_begin, op_end, st);
     if (join) h->join_side(st);
-    else { h->flush_side(st); h->emit_sig(st); }         // the queued weight gradients of this slice are released; `stream` does not wait for them
+    else h->flush_side(st);                              // the queued weight gradients of this slice are released; `stream` does not wait for them
     return hipGetLastError() == hipSuccess ? 0 : fail(std::string("seg_backward: ") + hipGetErrorString(hipGetLastError()));
 }
 int seg_backward(seg_handle h, const float* dlogits, int zero_grads, void* stream) {
@@ -302,8 +258,7 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
     if (!a->packed && seg_pack_weights(h, stream)) return -1;
     // Serial section at the step boundary (profiles/r04_trace_timeline.txt: fill, overflow check, Adam, counter, re-pack, masks, counter, fill,
     // ingest - nothing overlaps them): the one-wave bookkeeping launches ride on their neighbours.  SEG_STEP_RIDERS=0: separate launches.
-    const bool riders_env = knob_i("SEG_STEP_RIDERS", 1) != 0;
-    const bool riders = riders_env && h->sub_nb == 0;
+    const bool riders = knob_i("SEG_STEP_RIDERS", 1) != 0;
     const long long v = h->vol(0);
     struct RideGuard { seg_engine* e; ~RideGuard() { e->ride_on = false; e->ride_zero = nullptr; } } ride_guard{h};      // every way out of the step
     h->ride_on = riders; h->head_zeroed = false;
@@ -338,14 +293,26 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
     if (seg_loss_backward(a->logits, a->target, a->label_type, h->N, h->ncls, v, a->loss_kind, a->focal_alpha, a->focal_gamma, a->loss_ws,
                           h->loss_scale, a->dlogits, stream)) return -1;
     h->prof_end(st, pi);
-    if (a->bucket_cb) {
-        // bucketed gradient exchange: every finished suffix of the flat gradient buffer is handed to the caller's hook while the finer levels
-        // still run.  On the GPU the hook runs behind an auxiliary stream that waits for the caller's stream and the
+    const bool native = !a->bucket_cb && h->rccl_comm && h->rccl_allreduce;
+    if (a->bucket_cb || native) {
+        // bucketed gradient exchange: every finished suffix of the flat gradient buffer is exchanged while the finer levels still run (DESIGN.md
+        // section 6) - by the caller's hook, or by the library itself (seg_set_rccl_comm: ncclAllReduce on the exchange stream, no host callback).
+        // On the GPU the exchange of every bucket but the last is ordered behind an auxiliary stream that waits for the caller's stream and the
         // weight-gradient stream, so the backward pass itself never stalls at a bucket boundary.
         if (a->nfrac < 0 || a->nfrac > 4) return fail("seg_train_step: nfrac must be 0..4");
         const int nops = (int)h->bwd_ops.size();
         hipStream_t aux = (hipStream_t)a->aux_stream;
+#ifndef SEG_EMU
+        if (native && !aux) {
+            if (!h->xchg && hipStreamCreateWithFlags(&h->xchg, hipStreamNonBlocking) != hipSuccess) return fail("seg_train_step: cannot create the exchange stream");
+            aux = h->xchg;
+        }
+#endif
         if (aux && !h->ar_ev) (void)hipEventCreateWithFlags(&h->ar_ev, hipEventDisableTiming);
+        auto exchange = [&](int idx, long long off, long long cnt, hipStream_t on) -> int {
+            if (!native) return a->bucket_cb(a->cb_user, idx, off, cnt);
+            return cnt > 0 ? h->rccl_allreduce(h->g + off, h->g + off, (size_t)cnt, 7 /* ncclFloat */, 0 /* ncclSum */, h->rccl_comm, on) : 0;
+        };
         int prev_k = 0, idx = 0;
         long long prev_off = h->nparam;
         for (int f = 0; f < a->nfrac; ++f) {
@@ -357,12 +324,13 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
                 (void)hipEventRecord(h->ar_ev, st); (void)hipStreamWaitEvent(aux, h->ar_ev, 0);
                 if (seg_side_wait(h, aux)) return -1;
             }
-            if (a->bucket_cb(a->cb_user, idx++, off, prev_off - off)) return fail("seg_train_step: the gradient exchange hook failed");
+            if (exchange(idx++, off, prev_off - off, aux ? aux : st)) return fail("seg_train_step: the gradient exchange failed");
             prev_k = k; prev_off = off;
         }
         if (backward_slice(h, a->dlogits, 1, prev_k, nops, 1, stream)) return -1;
-        if (aux && idx) { (void)hipEventRecord(h->ar_ev, aux); (void)hipStreamWaitEvent(st, h->ar_ev, 0); }     // whatever the hooks queued on the auxiliary stream itself
-        if (a->bucket_cb(a->cb_user, idx, 0, prev_off) || a->bucket_cb(a->cb_user, -1, 0, 0)) return fail("seg_train_step: the gradient exchange hook failed");
+        if (aux && idx) { (void)hipEventRecord(h->ar_ev, aux); (void)hipStreamWaitEvent(st, h->ar_ev, 0); }     // whatever was queued on the auxiliary stream itself
+        if (exchange(idx, 0, prev_off, st)) return fail("seg_train_step: the gradient exchange failed");
+        if (!native && a->bucket_cb(a->cb_user, -1, 0, 0)) return fail("seg_train_step: the gradient exchange hook failed");
     } else
     if (seg_backward(h, a->dlogits, 1, stream)) return -1;
     // fused optimiser: p, m, v read + written, g read (+ once more by the overflow check); re-pack: fp32 masters read, run-dtype layouts written
@@ -378,6 +346,15 @@ int seg_train_step(seg_handle h, const seg_train_args* a, void* stream) {
     return rc;
 }
 
+int seg_set_rccl_comm(seg_handle h, void* comm, void* allreduce_fn) {
+    if (check_handle(h)) return -1;
+    if (comm && !allreduce_fn) return fail("seg_set_rccl_comm: the ncclAllReduce of the library that created the communicator must be given");
+    h->drop_graph();
+    h->rccl_comm = comm;
+    h->rccl_allreduce = comm ? (seg_engine::rccl_allreduce_t)allreduce_fn : nullptr;
+    return 0;
+}
+
 // The same step captured once as a HIP graph and replayed: ~250 launches + ~60 event operations become one hipGraphLaunch on the host.  For
 // hosts that cannot enqueue a step as fast as the GPU runs it (BENCH_r02: 4.2 ms of host time per 5.5 ms step on the driver's box against
 // 0.9 ms on the builder's); on a fast host the stream launches are as fast or faster (the graph orders the weight-gradient branch less
@@ -388,14 +365,13 @@ int seg_train_graph_capture(seg_handle h, const seg_train_args* a, void* stream)
     if (!a) return fail("seg_train_graph_capture: args is null");
     if (!a->packed) return fail("seg_train_graph_capture: run one ordinary step first (the captured step starts from packed weights)");
     if (a->bucket_cb || a->loss_cb) return fail("seg_train_graph_capture: a step with exchange hooks cannot be captured (host callbacks)");
+    if (h->rccl_comm) return fail("seg_train_graph_capture: a step with an RCCL communicator (seg_set_rccl_comm) is not captured");
     if (h->prof_mask) return fail("seg_train_graph_capture: switch seg_profile_enable off first");
     hipStream_t st = (hipStream_t)stream;
     h->drop_graph();
     // nothing un-captured may be pending on the streams the capture forks to
     (void)hipStreamSynchronize(st);
-    h->release_waiters();
     if (h->side) (void)hipStreamSynchronize(h->side);
-    if (h->side2) (void)hipStreamSynchronize(h->side2);
     h->pack_bwd_pending = false;
     h->ensure_side();
     if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return fail("seg_train_graph_capture: hipStreamBeginCapture failed"); }
@@ -461,11 +437,7 @@ const char* seg_last_error(void) { return g_err.c_str(); }
 
 const char* seg_build_info(void) {
 #ifdef SEG_EMU
-#ifdef SEG_EXPERIMENTS
-    return "segengine host-checker build (tests only) +experiments";
-#else
     return "segengine host-checker build (tests only)";
-#endif
 #else
 #ifdef SEG_BUILD_ID
     return "segengine gfx950 " SEG_BUILD_ID;          // build.py: sha256 over the sources + flags (which binary a profile was taken from)

@@ -287,13 +287,12 @@ struct Planner {
     void plan() {
         seg_engine& E = e;
         const int N = E.N, dt = E.dtype;
-        E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_is_bwd.clear(); E.pack_max = 0; E.n_deferred = 0;
-        E.bwd_sub.clear(); E.bwd_sig.clear(); E.fwd_chains.clear(); E.bwd_chains.clear();
+        E.fwd_ops.clear(); E.bwd_ops.clear(); E.bwd_writes.clear(); E.packdescs.clear(); E.pack_is_bwd.clear(); E.pack_max = 0;
         // drop gradient tensors of a previous plan
         size_t nfw = 0;
         for (auto& s : E.steps) {
             nfw = std::max<size_t>(nfw, std::max(s.raw, s.out) + 1);
-            s.draw = -1; s.vact = false; s.vact_prod = -1; s.rq_unit[0] = s.rq_unit[1] = -1; s.rfused = false;
+            s.draw = -1;
         }
         E.tens.resize(std::max<size_t>(nfw, (size_t)E.image_ten + 1));
         for (auto& t : E.tens) t.grads.clear();
@@ -394,29 +393,6 @@ struct Planner {
                     break;
             }
         }
-        // ---- virtual activations: an ACT (one branch, no residual) whose output feeds exactly ONE 3^d conv that runs on conv3x is
-        // never written: the consumer applies relu(scale * raw + shift) while it stages its halo, and so does the consumer's weight
-        // gradient (LUConv chains of networks/VNet3d.py:5-23, the two convs of networks/Unet3d.py:64-86 _block)
-        if (E.use_vact && dt != DT_F32 && !(xknob_i("SEG_WGRAD3X", 0) != 0))
-            for (size_t ai = 0; ai < E.steps.size(); ++ai) {
-                Step& act = E.steps[ai];
-                if (act.type != ST_ACT || act.ub >= 0 || act.res >= 0) continue;
-                const Step& prod = E.steps[act.ua];
-                if (prod.fused_stem || prod.gn_w < 0 || prod.Cout > 256) continue;
-                int users = 0, cons = -1;
-                for (size_t ci = 0; ci < E.steps.size(); ++ci) {
-                    const Step& c = E.steps[ci];
-                    if (c.type == ST_UNIT && (c.in0 == act.out || c.in1 == act.out)) { ++users; cons = (int)ci; }
-                    if (c.type == ST_ACT && c.res == act.out) ++users;
-                    if ((c.type == ST_POOL || c.type == ST_HEAD) && c.in == act.out) ++users;
-                }
-                if (users != 1 || cons < 0) continue;
-                Step& c = E.steps[cons];
-                if (c.ck != CK_K3 || c.in0 != act.out || c.in1 >= 0 || c.x_fwd < 0 || !conv3x_gn_supported(c.Cin, false)) continue;
-                act.vact = true;
-                c.vact_prod = act.ua;
-                E.steps[act.ua].fold_fin = true;       // no finalize launch either: the consumer folds the statistics itself
-            }
         {   // forward layouts first, backward-only layouts behind them: the second range is packed on the weight-gradient stream
             std::vector<PackDesc> fw, bw;
             for (size_t i = 0; i < E.packdescs.size(); ++i) (E.pack_is_bwd[i] ? bw : fw).push_back(E.packdescs[i]);
@@ -443,8 +419,6 @@ struct Planner {
                 }
             }
         E.off_partial = alloc(pmax);
-        E.off_partial2 = E.n_side > 1 ? alloc(pmax) : E.off_partial;
-        E.off_partial_main = alloc(pmax);
         E.off_partial_stemx = alloc(stemx_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), E.in_ch));
         E.off_partial_stem1 = alloc(stem_wgrad_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), 16 * ((E.feat + 15) / 16)));
 
@@ -484,19 +458,7 @@ struct Planner {
                                                     2.0 * E.N * E.vol(l) * (E.ndim == 3 ? 27 : 9) * s.Cin * s.Cout);
                         // replicas this producer spreads the statistics over (read back by the folded finalize of the consumers)
                         E.steps[si].stat_rep = (s.x_fwd >= 0 && E.use_fold) ? stat_rep_for(E.vol(l)) : STAT_REP;
-                        if (s.x_fwd >= 0 && s.vact_prod >= 0) {
-                            const Step& u = E.steps[s.vact_prod];        // the producer: its raw output is this launch's input
-                            GnFinArgs f{};
-                            f.stats = (double*)(E.ws + u.stats); f.gamma = E.p + E.params[u.gn_w].off; f.beta = E.p + E.params[u.gn_b].off;
-                            f.mask = E.mask_mode == SEG_MASKS_EVAL ? nullptr
-                                     : E.mask_base(u.mask_slot);
-                            f.mask_ld = E.ld_mask();
-                            f.scale = (float*)(E.ws + u.scale); f.shift = (float*)(E.ws + u.shift);
-                            f.mean = (float*)(E.ws + u.mean); f.rstd = (float*)(E.ws + u.rstd);
-                            f.N = E.N; f.C = u.Cout; f.V = E.vol(E.tens[u.raw].lvl); f.eps = 1e-5f; f.rep = u.stat_rep;
-                            launch_conv3x(s.x_fwd, E.ws + E.tens[u.raw].off, nullptr, i0.C, E.ws + s.wp_fwd, bias, E.ws + ro.off, stats, E.N,
-                                          E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st, s.stat_rep, &f);
-                        } else if (s.x_fwd >= 0)
+                        if (s.x_fwd >= 0)
                             launch_conv3x(s.x_fwd, E.ws + i0.off, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, E.ws + s.wp_fwd, bias,
                                           E.ws + ro.off, stats, E.N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cin, s.Cout, E.ndim, E.dtype, st,
                                           s.stat_rep);
@@ -554,7 +516,6 @@ struct Planner {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
                     const Step& ua = E.steps[s.ua];
-                    if (s.vact) return;                    // applied by the consuming conv while it stages its halo (Step::vact_prod)
                     if (ua.fused_stem) {
                         // fused input block: statistics of both branches from the image, finalize, then recompute + normalise + add
                         seg_stemx_args x = stemx_args(E, s);
@@ -655,17 +616,8 @@ struct Planner {
             }
         }
 
-        // a unit whose statistics live in the per-group layout while chains run (seg_engine::run_chain): finest level(s), real kernels
-        auto unit_sub = [&E](int ui) {
-            if (ui < 0) return false;
-            const Step& u = E.steps[ui];
-            if (u.type != ST_UNIT || E.tens[u.raw].lvl > E.sub_lvl || u.vact_prod >= 0) return false;
-            return (u.ck != CK_STEM3 && u.ck != CK_STEM1) || u.fused_stem;
-        };
         // ------------------------------------------------------------------ backward schedule
         E.bwd_writes.push_back({});
-        E.bwd_sub.push_back(0);
-        E.bwd_sig.push_back(0);
         E.bwd_ops.push_back([this_ = &E](hipStream_t st) {
             seg_engine& E = *this_;
             if (!E.q_clean) (void)hipMemsetAsync(E.ws + E.off_Q, 0, E.Q_bytes, st);
@@ -680,8 +632,6 @@ struct Planner {
                 E.head_step = si;
                 E.tens[s.in].grads.push_back(gin);
                 E.bwd_writes.push_back({s.w, s.b});
-                E.bwd_sub.push_back(1);
-                E.bwd_sig.push_back(0);
                 E.bwd_ops.push_back([this_ = &E, si, gin](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -703,8 +653,6 @@ struct Planner {
                 E.tens[s.in].grads.push_back(gin);
                 const int gout = gl[0];
                 E.bwd_writes.push_back({});
-                E.bwd_sub.push_back(E.tens[s.in].lvl <= E.sub_lvl ? 1 : 0);
-                E.bwd_sig.push_back(0);
                 E.bwd_ops.push_back([this_ = &E, si, gin, gout](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -763,8 +711,6 @@ struct Planner {
                     for (int ui : {s.ua, s.ub})
                         if (ui >= 0) { const Step& u = E.steps[ui]; wr.push_back(u.gn_w); wr.push_back(u.gn_b); wr.push_back(u.b); wr.push_back(u.w); }
                     E.bwd_writes.push_back(wr);
-                    E.bwd_sub.push_back((unit_sub(s.ua) && (s.ub < 0 || unit_sub(s.ub))) ? 1 : 0);
-                    E.bwd_sig.push_back(0);
                     E.bwd_ops.push_back([this_ = &E, si, gl](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& s = E.steps[si];
@@ -812,15 +758,12 @@ struct Planner {
                     ua.draw = new_grad(ua.raw);
                     ub.draw = new_grad(ub.raw);
                     E.bwd_writes.push_back({ua.gn_w, ua.gn_b, ua.b, ub.gn_w, ub.gn_b, ub.b});
-                    E.bwd_sub.push_back((unit_sub(s.ua) && unit_sub(s.ub)) ? 1 : 0);
-                    E.bwd_sig.push_back(1);
                     E.bwd_ops.push_back([this_ = &E, uia = s.ua, uib = s.ub, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
                         GnBwdArgs a, b;
                         GnBwdFinArgs fa{}, fb{};
                         fill(E, uia, gl, a, fa);
                         fill(E, uib, gl, b, fb);
-                        a.sig_flag = E.take_sig(a.sig_seq);        // the reduce pass is the first kernel behind a released batch of weight gradients
                         a.r2 = b.r; a.scale2 = b.scale; a.shift2 = b.shift; a.Q2 = b.Q; a.coef2 = b.coef; a.dr2 = b.dr;
                         const double tb = E.tbytes(E.steps[uia].raw);
                         int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, tb * (a.ndy + 2), 0.0);
@@ -837,15 +780,7 @@ struct Planner {
                     if (ui < 0) continue;
                     Step& u = E.steps[ui];
                     u.draw = new_grad(u.raw);
-                    // the reduce pass rides on the conv that produces this unit's only gradient (c3x_epilogue, Conv3xArgs::rq_*)
-                    if (E.use_rfuse && s.ub < 0 && gl.size() == 1 && E.tens[gl[0]].prod_step >= 0 && !E.tens[gl[0]].virt &&
-                        !gn_bwd_group_eligible(E.tens[u.raw].C, E.vol(E.tens[u.raw].lvl), (int)E.esz())) {
-                        u.rfused = true;
-                        E.steps[E.tens[gl[0]].prod_step].rq_unit[E.tens[gl[0]].prod_which] = ui;
-                    }
                     E.bwd_writes.push_back({u.gn_w, u.gn_b, u.b});      // gamma/beta and (analytically) the conv bias
-                    E.bwd_sub.push_back(unit_sub(ui) ? 1 : 0);
-                    E.bwd_sig.push_back(1);
                     E.bwd_ops.push_back([this_ = &E, ui, gl, fill](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& u = E.steps[ui];
@@ -853,19 +788,15 @@ struct Planner {
                         GnBwdArgs a;
                         GnBwdFinArgs f{};
                         fill(E, ui, gl, a, f);
-                        a.sig_flag = E.take_sig(a.sig_seq);        // (see the dual-branch op)
                         if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
                             const int pg = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
                             launch_gn_bwd_group(a, f, E.dtype, st);
                             E.prof_end(st, pg);
                             return;
                         }
-                        int pi = -1;
-                        if (!u.rfused) {
-                            pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
-                            launch_gn_bwd_reduce(a, E.dtype, st);
-                            E.prof_end(st, pi);
-                        }
+                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
+                        launch_gn_bwd_reduce(a, E.dtype, st);
+                        E.prof_end(st, pi);
                         const bool fold = E.use_fold && a.C <= 256;
                         if (!fold) launch_gn_bwd_finalize(f, st);
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
@@ -888,14 +819,7 @@ struct Planner {
                 int g0 = -1, g1 = -1;
                 if (need_dg0) { g0 = new_grad(s.in0); E.tens[s.in0].grads.push_back(g0); }
                 if (s.in1 >= 0) { g1 = new_grad(s.in1); E.tens[s.in1].grads.push_back(g1); }
-                if (s.ck == CK_K3) {      // halo-tile data gradients can carry the GroupNorm-backward reduce of the unit they feed (ACT branch above)
-                    if (g0 >= 0 && s.x_dg0 >= 0) { E.tens[g0].prod_step = (int)si; E.tens[g0].prod_which = 0; }
-                    if (g1 >= 0 && s.x_dg1 >= 0) { E.tens[g1].prod_step = (int)si; E.tens[g1].prod_which = 1; }
-                }
                 E.bwd_writes.push_back({s.w, s.gn_w < 0 ? s.b : -1});
-                E.bwd_sub.push_back(unit_sub((int)si) ? 1 : 0);
-                E.bwd_sig.push_back(0);
-                if (s.ck != CK_STEM3 && s.ck != CK_STEM1) ++E.n_deferred;
                 E.bwd_ops.push_back([this_ = &E, si, draw, g0, g1](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
@@ -916,41 +840,29 @@ struct Planner {
                             const Step& s = E.steps[si];
                             const Ten& i0 = E.tens[s.in0];
                             const int pi = E.prof_begin(ws_, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), fl);
-                            if (s.vact_prod >= 0) {     // the input tensor was never written: raw producer output + its published scale / shift
-                                const Step& u = E.steps[s.vact_prod];
-                                launch_wgrad3(E.ws + E.tens[draw].off, E.ws + E.tens[u.raw].off, (float*)(E.ws + E.cur_partial),
-                                              E.g + E.params[s.w].off, E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
-                                              nullptr, i0.C, (const float*)(E.ws + u.scale), (const float*)(E.ws + u.shift));
-                            } else
                             launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.cur_partial), E.g + E.params[s.w].off,
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
-                                          s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, nullptr, nullptr, s.cin_par);
+                                          s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, s.cin_par);
                             E.prof_end(ws_, pi);
-                        }, E.tbytes(draw), lo, s.gn_w >= 0 ? si : -1, g0 >= 0 ? s.x_dg0 >= 0 : (g1 >= 0 && s.x_dg1 >= 0));
+                        }, E.tbytes(draw), lo);
                         int pi;
-                        ForkSig sg;                               // a batch released just now: the first data-gradient kernel stores its number
                         if (g0 >= 0) {
-                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0) * (s.rq_unit[0] >= 0 ? 2 : 1), fl * i0.C / s.Cin);
-                            if (s.x_dg0 >= 0) {
-                                sg.flag = E.take_sig(sg.seq);
-                                const Conv3xReduce rq = E.reduce_args(s.rq_unit[0]);
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g0), fl * i0.C / s.Cin);
+                            if (s.x_dg0 >= 0)
                                 launch_conv3x(s.x_dg0, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr,
-                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st, STAT_REP, nullptr, sg, &rq);
-                            } else
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
+                            else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg0, nullptr, E.ws + E.tens[g0].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, i0.C, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);
                         }
                         if (g1 >= 0) {
                             const int C1 = E.tens[s.in1].C;
-                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g1) * (s.rq_unit[1] >= 0 ? 2 : 1), fl * C1 / s.Cin);
-                            if (s.x_dg1 >= 0) {
-                                sg = ForkSig{};
-                                sg.flag = E.take_sig(sg.seq);     // (null when the first data-gradient took it)
-                                const Conv3xReduce rq = E.reduce_args(s.rq_unit[1]);
+                            pi = E.prof_begin(st, conv3_class(E.dim_w(lo), s.Cout), E.tbytes(draw) + E.tbytes(g1), fl * C1 / s.Cin);
+                            if (s.x_dg1 >= 0)
                                 launch_conv3x(s.x_dg1, E.ws + E.tens[draw].off, nullptr, 0, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr,
-                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st, STAT_REP, nullptr, sg, &rq);
-                            } else
+                                              E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);
+                            else
                             launch_conv3(E.ws + E.tens[draw].off, E.ws + s.wp_dg1, nullptr, E.ws + E.tens[g1].off, nullptr, E.N,
                                          E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, C1, E.ndim, E.dtype, st);
                             E.prof_end(st, pi);
@@ -964,9 +876,9 @@ struct Planner {
                             seg_engine& E = *this_;
                             const Step& s = E.steps[si];
                             const Ten& i0 = E.tens[s.in0];
-                            // both stems use the stem scratch when they run on the main stream (in order there); the shared
-                            // partial buffer belongs to whatever the side stream is still reducing
-                            const size_t scratch = (s.ck == CK_STEM1 || E.stem_on_main) ? E.off_partial_stem1 : E.cur_partial;
+                            // the stems run on the main stream (in order there) with their own scratch; the shared partial buffer belongs to
+                            // whatever the weight-gradient stream is still reducing
+                            const size_t scratch = E.off_partial_stem1;
                             const int pi = E.prof_begin(ws_, SEG_K_STEM, E.tbytes(draw) + E.tbytes(s.in0), 0.0);
                             launch_stem_wgrad(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + scratch), E.g + E.params[s.w].off,
                                               E.N, E.dim_d(0), E.dim_h(0), E.dim_w(0), i0.C, s.Cout, s.ck == CK_STEM1, E.ndim, E.dtype, ws_);
@@ -974,8 +886,8 @@ struct Planner {
                         };
                         // step-24 trace: with the 3^d stem on the side stream the main stream idled 256 us at the end of every step
                         // behind wgrad3(16ch@96^3) + the 1^d concat wgrad + this kernel; both stems now run on the main stream
-                        if (s.ck == CK_STEM1 || E.stem_on_main) { E.flush_side(st); run(st); }
-                        else { E.defer_wgrad(st, run); E.flush_side(st); }
+                        E.flush_side(st);
+                        run(st);
                         return;
                     }
                     // ---- weight gradient
@@ -987,11 +899,9 @@ struct Planner {
                                                     E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), 0.0);
                         launch_wgrad(w, (float*)(E.ws + E.cur_partial), E.dtype, ws_, s.cin_par);
                         E.prof_end(ws_, pi);
-                    }, E.tbytes(draw), lo < li ? lo : li, s.gn_w >= 0 ? si : -1, g0 >= 0 || g1 >= 0);
+                    }, E.tbytes(draw), lo < li ? lo : li);
                     // ---- data gradient(s)
                     if (g0 < 0 && g1 < 0) return;
-                    ForkSig sg;                                   // a batch released just now: the first data-gradient kernel stores its number
-                    sg.flag = E.take_sig(sg.seq);
                     ConvArgs a{};
                     a.in0 = E.ws + E.tens[draw].off; a.C0 = s.Cout; a.in1 = nullptr; a.C1 = 0;
                     a.bias = nullptr; a.stats = nullptr; a.N = E.N;
@@ -1003,7 +913,7 @@ struct Planner {
                         a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
                         a.taps = make_taps(E.ndim, 2, 0);
                         a.Cout = s.Cin; a.K = s.Cout; a.Ngemm = a.taps.n * s.Cin; a.Kpad = (a.K + 31) / 32 * 32;
-                        { launch_conv_igemm(a, E.dtype, st, STAT_REP, sg); sg = ForkSig{}; }
+                        launch_conv_igemm(a, E.dtype, st, STAT_REP);
                     } else if (s.ck == CK_KT) {
                         // d_X[i][ci] = sum_{a,co} dY[2i+a][co] Wt[ci][co][a] : gather, stride 2 over the fine gradient
                         a.scatter = 0; a.w = E.ws + s.wp_dg0; a.out = E.ws + E.tens[g0].off;
@@ -1012,7 +922,7 @@ struct Planner {
                         a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
                         a.taps = make_taps(E.ndim, 2, 0);
                         a.Cout = s.Cin; a.Ngemm = s.Cin; a.K = a.taps.n * s.Cout; a.Kpad = (a.K + 31) / 32 * 32;
-                        { launch_conv_igemm(a, E.dtype, st, STAT_REP, sg); sg = ForkSig{}; }
+                        launch_conv_igemm(a, E.dtype, st, STAT_REP);
                     } else {
                         // conv 3^d / 1^d: gather conv of d(raw) with flipped taps, once per concat source
                         a.scatter = 0;
@@ -1023,49 +933,15 @@ struct Planner {
                         a.K = a.taps.n * s.Cout; a.Kpad = (a.K + 31) / 32 * 32;
                         if (g0 >= 0) {
                             a.w = E.ws + s.wp_dg0; a.out = E.ws + E.tens[g0].off; a.Cout = a.Ngemm = E.tens[s.in0].C;
-                            { launch_conv_igemm(a, E.dtype, st, STAT_REP, sg); sg = ForkSig{}; }
+                            launch_conv_igemm(a, E.dtype, st, STAT_REP);
                         }
                         if (g1 >= 0) {
                             a.w = E.ws + s.wp_dg1; a.out = E.ws + E.tens[g1].off; a.Cout = a.Ngemm = E.tens[s.in1].C;
-                            { launch_conv_igemm(a, E.dtype, st, STAT_REP, sg); sg = ForkSig{}; }
+                            launch_conv_igemm(a, E.dtype, st, STAT_REP);
                         }
                     }
                 });
             }
-        }
-        // ---- chains of finest-level ops that run group of samples by group of samples (seg_engine::run_chain)
-        {
-            double mb = E.sub_mb;
-            if (mb < 0.0) mb = SEG_SUB_MB_DEFAULT;
-            E.sub_nb = 0;
-            const double per_sample_mb = (double)E.vol(0) * 16.0 * (double)E.esz() / 1e6;          // one 16-channel finest-level tensor
-            if (mb > 0.0 && !E.use_vact && N > 1) {
-                int nb = (int)(mb / per_sample_mb);
-                if (nb < 1) nb = 1;
-                while (nb > 1 && N % nb) --nb;                    // equal groups only (a unit's replica count is remembered per launch)
-                if (nb < N) E.sub_nb = nb;
-            }
-            auto runs = [](const std::vector<char>& ok, std::vector<std::pair<int, int>>& out) {
-                for (int i = 0; i < (int)ok.size();) {
-                    if (!ok[i]) { ++i; continue; }
-                    int j = i;
-                    while (j < (int)ok.size() && ok[j]) ++j;
-                    out.push_back({i, j});
-                    i = j;
-                }
-            };
-            std::vector<char> fok(E.fwd_ops.size(), 0);           // fwd_ops[0] = fill + ingest, fwd_ops[1 + si] = step si
-            for (size_t si = 0; si < E.steps.size(); ++si) {
-                const Step& s = E.steps[si];
-                bool ok;
-                if (s.type == ST_UNIT) ok = unit_sub((int)si);
-                else if (s.type == ST_ACT) ok = unit_sub(s.ua) && (s.ub < 0 || unit_sub(s.ub));
-                else if (s.type == ST_POOL) ok = E.tens[s.in].lvl <= E.sub_lvl;
-                else ok = true;
-                fok[1 + si] = ok ? 1 : 0;
-            }
-            runs(fok, E.fwd_chains);
-            runs(E.bwd_sub, E.bwd_chains);
         }
         E.ws_bytes = align_up(cur, 4096);
         E.planned = true;

@@ -19,9 +19,7 @@ __device__ __forceinline__ void step_rider_run(const StepRider& r) {
     if (r.bump) { if (!(r.gate && *r.gate)) *r.bump += 1; else if (r.tally) *r.tally += 1; }
     if (r.clear) *r.clear = 0;
 }
-// A flag fork carried by a launch (engine_internal.h, seg_engine::flush_side_full): the kernel's first thread stores `seq` to `flag` (fork_signal_store below)
-struct ForkSig { unsigned* flag = nullptr; unsigned seq = 0; };
-void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep = STAT_REP, ForkSig sg = ForkSig{});   // stat_rep: LDS-staged kernel only
+void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep = STAT_REP);   // stat_rep: LDS-staged kernel only
 bool conv_uses_stream_kernel(const ConvArgs& a);   // true: register-resident streaming kernel, false: LDS-staged implicit GEMM
 
 // LDS halo-tile kernels for 3^d stride-1 pad-1 convs (conv3.hip): forward / data-gradient and weight gradient
@@ -32,16 +30,8 @@ bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, 
 int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool has_in1 = false);    // tiling id for the shape, -1: none
 int conv3x_num_cfgs();
 int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name);
-struct GnFinArgs;
-// gn != null: in0 is the RAW conv output of the producer unit; its GroupNorm + dropout + ReLU is applied while the halo is staged
-// (Conv3xArgs::fuse, conv3x_impl.h).  conv3x_gn_supported: which inputs that variant takes.
-bool conv3x_gn_supported(int Cin, bool has_in1);
-// GroupNorm-backward REDUCE of the consuming unit folded into a data-gradient launch (Conv3xArgs::rq_*, conv3x_impl.h): y = that unit's raw conv output,
-// scale / shift its forward coefficients [N][Cout], Q its backward sums [rep][N][Cout][2]
-struct Conv3xReduce { const void* y; const float* scale; const float* shift; double* Q; int rep; };
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,
-                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep = STAT_REP, const GnFinArgs* gn = nullptr,
-                   ForkSig sg = ForkSig{}, const Conv3xReduce* rq = nullptr);
+                   int H, int W, int Cin, int Cout, int ndim, int dtype, hipStream_t s, int stat_rep = STAT_REP);
 // replicas a statistics producer spreads its atomics over, by voxels per sample: enough to keep same-address fp64 atomics apart,
 // few enough that the consumer-side fold (gn_fold_block) reads ~8 KB
 inline int stat_rep_for(long long V) { return V >= 262144 ? 32 : V >= 65536 ? 16 : V >= 8192 ? 8 : 4; }
@@ -49,16 +39,10 @@ inline int stat_rep_for(long long V) { return V >= 262144 ? 32 : V >= 65536 ? 16
 int stemx_workgroups(int ndim, int N, int D, int H, int W);
 size_t stemx_partial_bytes(int ndim, int N, int D, int H, int W, int Cimg);
 void launch_stemx(const seg_stemx_args& a, int mode, int ndim, int dtype, float* dw3, float* dw1, hipStream_t s);
-// double-buffered weight gradient for 16-bit tensors (wgrad3x.hip); partial tiles in the layout wgrad3_reduce_kernel sums
-bool wgrad3x_supported(int dtype, int N, int D, int H, int W, int P, int Q, int C0, bool has_x1);
-void wgrad3x_tiles(int P, int Q, int C0, bool has_x1, int* CP, int* CQ);
-bool launch_wgrad3x(const void* dr, const void* x0, const void* x1, int C0, float* partial, int nb, int N, int D, int H, int W, int P, int Q,
-                    int ndim, int dtype, bool wide, hipStream_t s);
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, int esz = 2);
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, const float* xscale = nullptr, const float* xshift = nullptr,
-                   int qreal = 0);      // qreal in (0, Q): x carries zero-padded channels, dw is [P][qreal][taps] (the channels beyond qreal are not written)
+                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, int qreal = 0);      // qreal in (0, Q): x carries zero-padded channels, dw is [P][qreal][taps] (the channels beyond qreal are not written)
 
 // MFMA image stem (K = taps*Cimg <= 32): forward and weight gradient on box tiles (conv3.hip)
 void launch_stem_fwd(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cimg,
@@ -152,20 +136,7 @@ struct GnBwdArgs {
     // the fly from the loss gradient (planar fp32) and the head weights instead of being written as a 16-channel tensor and read
     // back by every GroupNorm-backward pass it feeds
     const float* vdl; const float* vw; int vK;    int rep_q;                                  // replicas of Q the reduce pass spreads over; 0 = STAT_REP
-    // flag fork (engine_internal.h, seg_engine::flush_side_full): the reduce pass / the one-launch pass is the first main-stream kernel behind a batch of
-    // weight gradients released to the second queue; its first thread stores `sig_seq` to the flag that queue's command processor waits on
-    unsigned* sig_flag = nullptr; unsigned sig_seq = 0;
 };
-// One store to a flag in signal memory (hipMallocSignalMemory) that another queue waits on with hipStreamWaitValue32.  In-order queue: the kernel
-// that executes it starts after everything launched before it has completed and released its writes.
-__device__ __forceinline__ void fork_signal_store(unsigned* flag, unsigned seq) {
-#ifdef SEG_EMU
-    *flag = seq;
-#else
-    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
-}
-void launch_fork_signal(unsigned* flag, unsigned seq, hipStream_t s);      // the same store from a one-wave kernel of its own (misc.hip)
 void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s);
 struct GnBwdFinArgs;
 // fa != null: the backward finalize of the branch(es) runs as a prologue of this launch (no gn_bwd_finalize launch before it)

@@ -757,7 +757,7 @@ void launch_pack(const PackDesc* descs_dev, int ndesc, int max_elems, int dtype,
     (void)max_elems;
     // rows are strided over `wgs` workgroups per descriptor.  The 256-channel levels hold most of the bytes in descriptors of 256
     // rows: at 64 workgroups each one walked four 27 KB rows back to back (67 us per step, latency-bound)
-    static const int wgs = xknob_i("SEG_PACK_WGS", 256);
+    static const int wgs = 256;
     dim3 grid(wgs, ndesc);
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<float>), grid, dim3(256), 0, s, descs_dev, rd);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_kernel<f16>), grid, dim3(256), 0, s, descs_dev, rd);
@@ -821,8 +821,6 @@ void launch_adam(const AdamArgs& a, hipStream_t s, bool bump) {
     if (bump) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(64), 0, s, a.step, a.found_inf, 1);
 }
 
-namespace { __global__ __launch_bounds__(64) void fork_signal_kernel(unsigned* flag, unsigned seq) { if (threadIdx.x == 0) fork_signal_store(flag, seq); } }
-void launch_fork_signal(unsigned* flag, unsigned seq, hipStream_t s) { hipLaunchKernelGGL(fork_signal_kernel, dim3(1), dim3(64), 0, s, flag, seq); }
 
 void launch_dropout_masks(float* masks, int L, int N, int ld, float p, unsigned long long seed, const int* step, hipStream_t s, bool bump) {
     const long long total = (long long)L * N * ld;

@@ -200,7 +200,6 @@ template <class T, bool DUAL, int NDY>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs a, int GNB_ROWS) {
     __shared__ float red[256 * 16];
     const int tid = threadIdx.x, n = blockIdx.y;
-    if (a.sig_flag && tid == 0 && blockIdx.x == 0 && n == 0) fork_signal_store(a.sig_flag, a.sig_seq);
     const int CPR = a.C / 8;                  // 2..32 (power of two)
     const int G = 256 / CPR;
     const int cc = tid % CPR, g = tid / CPR;
@@ -500,7 +499,6 @@ __global__ __launch_bounds__(1024) void gn_bwd_group_kernel(GnBwdGroupArgs a) {
     __shared__ double chan[32][3];           // per channel of the group: Q1, Q2, R1
     __shared__ float coef[32][3];
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (a.e.sig_flag && tid == 0 && g == 0 && n == 0) fork_signal_store(a.e.sig_flag, a.e.sig_seq);
     const int C = a.e.C, cpg = C / GN_GROUPS, CG = cpg / 8, CPR = C / 8;     // CG = 16-B chunks per voxel in this group: 1, 2 or 4
     const long long V = a.e.V;
     const int cg = tid % CG, c0 = g * cpg + cg * 8;
@@ -682,7 +680,7 @@ void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
     int bx = ew_blocks(a.V * (a.C / 8));
     if (a.fold) {
         // every workgroup repeats the fold: fewer, longer-running workgroups on the big levels
-        static const int cap = xknob_i("SEG_FOLD_WGS", 2048);
+        static const int cap = 2048;
         const int per_n = cap / a.N > 0 ? cap / a.N : 1;
         if (bx > per_n) bx = per_n;
     }
@@ -703,7 +701,7 @@ void launch_gn_bwd_reduce(const GnBwdArgs& a, int dtype, hipStream_t s) {
     long long rows = ((long long)a.N * a.V + 2047) / 2048;
     rows = (rows + G - 1) / G * G;
     if (rows < 2 * G) rows = 2 * G;
-    static const int max_rows = xknob_i("SEG_GNB_MAXROWS", 1024);   // measured: 256 -> 686, 512 -> 688, 1024..4096 -> 690.5 volumes/s
+    static const int max_rows = 1024;   // measured: 256 -> 686, 512 -> 688, 1024..4096 -> 690.5 volumes/s
     if (rows > max_rows) rows = max_rows / G * G;
     const int GNB_ROWS = (int)rows;
     dim3 grid(cdiv(a.V, GNB_ROWS), a.N);
@@ -746,7 +744,7 @@ void launch_gn_bwd_apply(const GnBwdArgs& a, int dtype, hipStream_t s, const GnB
     int bx = ew_blocks(a.V * (a.C / 8));
     const bool fold = fa != nullptr;
     if (fold) {
-        static const int cap = xknob_i("SEG_FOLD_WGS", 2048);
+        static const int cap = 2048;
         const int per_n = cap / a.N > 0 ? cap / a.N : 1;
         if (bx > per_n) bx = per_n;
     }

@@ -440,7 +440,7 @@ inline long long sx_boxes(int ndim, int N, int D, int H, int W) {
 
 int stemx_workgroups(int ndim, int N, int D, int H, int W) {
     const long long nb = sx_boxes(ndim, N, ndim == 3 ? D : 1, H, W);
-    static const int cap = xknob_i("SEG_STEMX_WGS", 2048);
+    static const int cap = 2048;
     return (int)(nb < cap ? nb : cap);
 }
 size_t stemx_partial_bytes(int ndim, int N, int D, int H, int W, int Cimg) {

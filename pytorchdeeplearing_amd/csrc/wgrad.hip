@@ -401,8 +401,8 @@ WgPlan make_plan(const WgradArgs& a) {
     pl.ntg = (T + pl.TB - 1) / pl.TB;
     const int bx = pl.ntg * pl.ntile;
     // voxel-axis split: ~2048 workgroups in total, at most 1024 slices and 16 MB of partial tiles
-    static const long long total = xknob_ll("SEG_WG_TOTAL", 2048);        // tuning knobs
-    static const long long pcap = xknob_ll("SEG_WG_CAP", (4ll << 20));
+    static const long long total = 2048;        // tuning knobs
+    static const long long pcap = ((4ll << 20));
     long long parts = total / bx;
     if (parts < 1) parts = 1;
     if (parts > 1024) parts = 1024;

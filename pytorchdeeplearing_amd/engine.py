@@ -299,7 +299,9 @@ class SegEngine:
     def cldice_term(self, probs, target, weight=1.0, width=10, dlogits=None, grad_scale=None):
         """Binary soft-clDice (model/lossescldice.py:37-59) on the head's probabilities as one library call (seg_cldice_binary): returns a
         1-element device tensor with the loss; when `dlogits` is given, weight * loss scale * d loss / d logit is ADDED to it (call after
-        loss_backward of the companion loss).  The workspace is planned once per shape and kept."""
+        loss_backward of the companion loss).  The workspace is planned once per shape and kept.
+        The target is read as the binary mask (label != 0) whatever `binarize_labels` says - what the reference's train loop hands to every loss
+        (model/modelVNet.py:576); soft targets go through `lossescldice.soft_skeletonize` and the plane operators instead (include/segengine.h)."""
         if probs.shape[1] != 1:
             raise ValueError("cldice_term: the binary clDice term needs a one-channel head (numclass == 1)")
         n = probs.shape[0]
@@ -382,14 +384,17 @@ class SegEngine:
         once per (buffers, hyper-parameters) as a HIP graph and replayed - for hosts that cannot enqueue ~250 launches per step as fast as
         the GPU runs them (the tensors must then stay at the same addresses from step to step); falls back to "stream" where a capture is
         not possible."""
-        if allreduce is not None and not hasattr(allreduce, "world"):
-            # an exchange object without a world size would be dropped silently (world = 1) and the ranks would train unsynchronised
-            import torch.distributed as dist
-            if not (dist.is_available() and dist.is_initialized()):
-                raise TypeError("train_step: `allreduce` has no `.world` attribute and no torch.distributed process group is initialised; "
-                                "pass parallel.GradAllReduce / BucketedGradAllReduce or set `.world` on the callable")
-            allreduce.world = dist.get_world_size()
-        world = getattr(allreduce, "world", 1) if allreduce is not None else 1
+        world = 1
+        if allreduce is not None:
+            world = getattr(allreduce, "world", None)
+            if world is None:
+                # an exchange object without a world size would be dropped silently (world = 1) and the ranks would train unsynchronised; the size of the
+                # default process group is taken for it (kept in a local: the callable may be a bound method, a partial, a builtin - nothing is set on it)
+                import torch.distributed as dist
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise TypeError("train_step: `allreduce` has no `.world` attribute and no torch.distributed process group is initialised; "
+                                    "pass parallel.GradAllReduce / BucketedGradAllReduce or give the callable a `.world`")
+                world = dist.get_world_size()
         xworld = loss_exchange.world if loss_exchange is not None else 1
         if cldice_weight and xworld > 1:
             # the clDice term is a rank-local ratio: under GlobalBatchLoss the summed (not averaged) gradients would carry it `world` times
@@ -400,7 +405,8 @@ class SegEngine:
             # schedule where a collective belongs (gradient buckets, the loss sums) and this side enqueues it (torch.distributed)
             return self._train_step_one_call(x, target, loss_name, lr, weight_decay, decoupled, focal_alpha, focal_gamma, class_alpha,
                                              mask_mode, masks, logits, probs, launch,
-                                             allreduce if world > 1 else None, loss_exchange if xworld > 1 else None)
+                                             allreduce if (world > 1 or getattr(allreduce, "native", False)) else None,
+                                             loss_exchange if xworld > 1 else None)
         if cldice_weight:
             self.cldice_prepare_target(target, x.shape[0], tuple(x.shape[2:]), cldice_width)     # overlaps the forward pass
         logits, probs = self.forward(x, mask_mode, masks, logits, probs)
@@ -520,7 +526,29 @@ class SegEngine:
         a.lr, a.weight_decay, a.decoupled = float(lr), float(weight_decay), 1 if decoupled else 0
         a.check_finite = 1 if self.dtype in ("f16", "fp16", "float16") else 0
         a.packed = 1 if self.packed else 0
-        hooked = allreduce is not None or loss_exchange is not None
+        native = allreduce is not None and getattr(allreduce, "native", False) and loss_exchange is None
+        want = allreduce if native else None
+        if getattr(self, "_rccl_on", None) is not want:
+            # the in-library exchange is a property of the handle: set when a step runs with a NativeRcclAllReduce, removed when one runs without it
+            comm, fn = want.handles(self.device) if want is not None else (None, None)
+            self.lib.check(self.lib.seg_set_rccl_comm(self.h, comm, fn), "seg_set_rccl_comm")
+            self._rccl_on = want
+        hooked = (allreduce is not None and not native) or loss_exchange is not None
+        if native:
+            fr = getattr(allreduce, "fractions", None) or (allreduce.tail_fraction,)
+            a.bucket_cb, a.loss_cb, a.aux_stream = None, None, None
+            a.nfrac = min(len(fr), 4)
+            for i in range(4):
+                a.fractions[i] = float(fr[i]) if i < a.nfrac else 0.0
+            a.grad_div = float(getattr(allreduce, "world", 1))
+            self.lib.check(self.lib.seg_train_step(self.h, C.byref(a), self.stream()), "seg_train_step")
+            self.packed = True
+            self._pack_pending = True
+            self._keep = (x, mt)
+            self._keep_loss = (target, class_alpha)
+            self._last_probs = probs
+            self._after_step()
+            return self._out3
         if hooked:
             bucket_cb, loss_cb = self._exchange_hooks()
             on_gpu = self.device.type == "cuda"

@@ -104,14 +104,20 @@ class DevicePrefetcher:
             labs = [np.load(ds.labels[i], mmap_mode="r") for i in indices]
 
             def fits_u8(l):                                # class ids after the reference's `.long()` (truncation): 0..255?
-                return l.dtype.kind in "bu" and l.dtype.itemsize == 1 or (int(l.min()) >= 0 and int(l.max()) < 256)
+                if l.dtype.kind in "bu" and l.dtype.itemsize == 1:
+                    return True
+                lo, hi = l.min(), l.max()
+                if l.dtype.kind == "f" and not (np.isfinite(lo) and np.isfinite(hi)):
+                    raise ValueError("label file with NaN / inf values: %r" % (getattr(l, "filename", None),))
+                return int(lo) >= 0 and int(hi) < 256
             if self.binary:
                 y = self.pool.take((n, d, h, w), torch.uint8)
             else:
-                if self._u8_ok is None:                    # class ids: one byte when they fit (decided on the first batch)
+                # class ids: one byte while they fit.  The label dtype is decided per DATA SET, not per batch: the first batch whose ids do not fit
+                # switches every following batch to int64 (the captured-graph launch mode needs tensors that keep their dtype)
+                if self._u8_ok is not False:
                     self._u8_ok = all(fits_u8(l) for l in labs)
-                # a later batch whose ids do not fit takes an int64 buffer for itself (what the generic path yields for it)
-                y = self.pool.take((n, d, h, w), torch.uint8 if (self._u8_ok and all(fits_u8(l) for l in labs)) else torch.int64)
+                y = self.pool.take((n, d, h, w), torch.uint8 if self._u8_ok else torch.int64)
             yn = y.numpy()
             for k, i in enumerate(indices):
                 img = np.load(ds.images[i], mmap_mode="r")

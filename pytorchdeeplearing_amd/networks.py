@@ -58,7 +58,7 @@ class _SegNet(nn.Module):
         self._dtype = dtype or _default_dtype()
         self._in_channels, self._numclass = in_channels, numclass
         self._engines = {}
-        lib = _capi._injected if _capi._injected is not None else _capi.product_library()
+        lib = _capi.host_library()
         table = _read_table(lib, self._kind, self._ndim, in_channels, numclass, init_features)
         self._param_names = list(table.keys())
         nd = self._ndim

@@ -55,6 +55,44 @@ class BucketedGradAllReduce(GradAllReduce):
                 w.wait()                      # current stream waits for the collective; no host block on GPU backends
 
 
+class NativeRcclAllReduce(BucketedGradAllReduce):
+    """The same buckets with NO Python between the slices of the backward pass: the process group's RCCL communicator and the
+    `ncclAllReduce` of the RCCL library torch loaded are handed to the engine once (seg_set_rccl_comm); seg_train_step then issues the in-place
+    SUM all-reduces itself, on its own exchange stream, where `BucketedGradAllReduce` is called back into `torch.distributed`.  GPU ranks with the
+    "nccl" backend only; `comm` / `allreduce_fn` may also be given explicitly (a caller that owns its communicator, or a test double)."""
+    native = True
+
+    def __init__(self, world_size=None, group=None, tail_fraction=0.5, fractions=None, comm=None, allreduce_fn=None):
+        super().__init__(world_size, group, tail_fraction, fractions)
+        self.comm, self.allreduce_fn = comm, allreduce_fn
+        self._keep = None
+
+    def handles(self, device):
+        """(ncclComm_t, address of ncclAllReduce) as integers"""
+        if self.comm is None:
+            pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
+            backend = pg._get_backend(torch.device(device))
+            if not hasattr(backend, "_comm_ptr"):
+                raise RuntimeError("NativeRcclAllReduce needs the 'nccl' (RCCL) backend; this process group is %r" % (dist.get_backend(pg),))
+            # a communicator is created lazily by the first collective on the device
+            t = torch.zeros(1, device=device)
+            dist.all_reduce(t, group=self.group)
+            torch.cuda.synchronize(device)
+            self.comm = int(backend._comm_ptr())
+        if self.allreduce_fn is None:
+            import ctypes
+            import os
+            lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))      # the library torch itself loaded (same handle)
+            self._keep = lib
+            self.allreduce_fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+        fn = self.allreduce_fn
+        if not isinstance(fn, int):                    # a ctypes callback object (tests): keep it alive, pass its address
+            import ctypes
+            self._keep = fn
+            fn = ctypes.cast(fn, ctypes.c_void_p).value
+        return int(self.comm), int(fn)
+
+
 class GlobalBatchLoss:
     """Exact global-batch loss across ranks (SURVEY.md section 8e mode ii): the reference losses are ratios of sums over
     the WHOLE batch (model/losses.py:50-51, 259, 315-325), so the loss of N volumes split over R ranks needs the sums of

@@ -7,7 +7,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
-os.environ.setdefault("GPU_STREAMOPS_CP_WAIT", "1")      # SEG_FORK=flag (test_flag_forks_equal_event_forks): hipStreamWaitValue32 as a command-processor wait; read when the HIP runtime starts
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -25,30 +24,32 @@ _emu_lib = None
 
 
 def emu_library():
-    """Host-side wave64 checker build of the UNMODIFIED HIP sources (tests/emu) — CPU tests only."""
+    """Host-side wave64 checker build of the product's HIP sources (tests/emu) - CPU tests only.  The product package has no hook for it: this function
+    REPLACES `_capi.lib_for` / `_capi.host_library` in the test process so that CPU tensors reach the checker library (GPU tensors keep reaching the
+    product library)."""
     global _emu_lib
     if _emu_lib is None:
         sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
         import build_emu
         from pytorchdeeplearing_amd import _capi
-        # SEG_TEST_EXPERIMENTS=1: the -DSEG_EXPERIMENTS twin of the checker (the measured-slower paths of rounds 2-4 and every tuning knob);
-        # the default is the product's source list and flags
-        _emu_lib = _capi.SegLib(build_emu.build(experiments=EXPERIMENTS))
-        _capi.inject_library(_emu_lib)
+        if hasattr(_capi, "product_lib_for"):          # this file imported twice (`conftest` and `tests.conftest`): the routing is already in place
+            _emu_lib = _capi.host_library()
+            return _emu_lib
+        _emu_lib = _capi.SegLib(build_emu.build())
+        product_lib_for = _capi.lib_for
+
+        def lib_for(device):
+            import torch
+            return _emu_lib if torch.device(device).type == "cpu" else product_lib_for(device)
+
+        _capi.product_lib_for = product_lib_for        # (tests of the "CPU tensors raise" behaviour call the original)
+        _capi.lib_for = lib_for
+        _capi.host_library = lambda: _emu_lib
     return _emu_lib
 
 
-EXPERIMENTS = bool(os.environ.get("SEG_TEST_EXPERIMENTS"))
-PERSISTENT_CFGS = (18, 19, 28, 29, 40, 58, 51, 52, 53, 59)      # conv3p / conv3p16 / conv3q / conv3q16 tilings: experiments build only
-
-
-def needs_experiments(dev):
-    """Tests of paths that are not in the product library (wgrad3x, GroupNorm in the consumer conv, persistent halo convs, flag forks, sub-batched levels,
-    two weight-gradient streams): they run against the experiments build only - SEG_TEST_EXPERIMENTS=1 on the host checker, and on the GPU additionally
-    SEGENGINE_LIB=pytorchdeeplearing_amd/lib/libsegengine_exp.so (python -m pytorchdeeplearing_amd.build --experiments)."""
-    from pytorchdeeplearing_amd import _capi
-    if "+experiments" not in _capi.lib_for(dev).build_info():
-        pytest.skip("experiments build only (SEG_TEST_EXPERIMENTS=1; on the GPU also SEGENGINE_LIB=.../libsegengine_exp.so)")
+def emu_active():
+    return _emu_lib is not None
 
 
 @pytest.fixture(params=[pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)])

@@ -227,6 +227,29 @@ def test_module_tree_matches_live_reference():
         assert ta == tb
 
 
+@pytest.mark.skipif(not ref_loader.available(), reason="reference tree only exists in the build container")
+def test_initialize_weights_draws_the_reference_values():
+    """A9 (networks/__init__.py:11-26) at the VALUE level: the same seed followed by `apply(initialize_weights)` gives the live reference
+    module and this package's module identical state_dicts (same leaf order, same fan computation, same RNG consumption) - what makes a
+    training run started here reproduce a run started on the reference."""
+    nets, _, _ = ref_loader.load()
+    from tests.conftest import emu_library
+    emu_library()
+    for seed, (ours, theirs) in enumerate(((networks.VNet3d(1, 1, dtype="f32"), nets.VNet3d(1, 1)), (networks.UNet3d(1, 4, dtype="f32"), nets.UNet3d(1, 4)),
+                                           (networks.VNet2d(3, 2, dtype="f32"), nets.VNet2d(3, 2)), (networks.UNet2d(1, 1, dtype="f32"), nets.UNet2d(1, 1)))):
+        torch.manual_seed(100 + seed)
+        theirs.apply(nets.initialize_weights)
+        torch.manual_seed(100 + seed)
+        ours.apply(networks.initialize_weights)
+        a, b = ours.state_dict(), theirs.state_dict()
+        assert list(a.keys()) == list(b.keys())
+        for k in a:
+            assert torch.equal(a[k].cpu(), b[k]), k
+        # and the values really are in the engine's flat buffer (the views alias it), not in detached copies
+        w0 = next(iter(a))
+        assert torch.equal(ours.engine.param_view(w0).cpu().reshape(b[w0].shape), b[w0])
+
+
 @pytest.mark.parametrize("shape,c", [((2, 1, 5, 6, 7), 1), ((3, 4, 9, 11), 4), ((1, 3, 4, 4, 6), 3)])
 def test_predict_mask_exact(dev, shape, c):
     """device threshold / argmax (predict post-processing) == numpy on the same probabilities, ties included."""

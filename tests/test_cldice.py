@@ -143,10 +143,13 @@ def test_engine_train_step_with_cldice_term(dev):
 
 def test_cldice_cpu_tensors_raise():
     from pytorchdeeplearing_amd import _capi
-    if _capi._injected is not None:
-        pytest.skip("checker library injected in this process")
-    with pytest.raises(RuntimeError):
-        cl.soft_skeletonize(torch.rand(1, 1, 8, 8))
+    saved = _capi.lib_for
+    _capi.lib_for = getattr(_capi, "product_lib_for", saved)          # the package's own routing (the test suite's checker routing put aside)
+    try:
+        with pytest.raises(RuntimeError):
+            cl.soft_skeletonize(torch.rand(1, 1, 8, 8))
+    finally:
+        _capi.lib_for = saved
 
 
 @pytest.mark.parametrize("shape,nd", [((2, 5, 9, 11), 3), ((3, 4, 10, 13), 2), ((1, 6, 20, 40), 3)])
@@ -177,7 +180,10 @@ def test_skel_iter_kernels_agree_with_two_kernel_forms(dev, shape, nd):
 
 
 @pytest.mark.parametrize("shape,nd,width", [((1, 5, 9, 33), 3, 10), ((2, 4, 6, 64), 3, 3), ((1, 3, 7, 65), 3, 10), ((1, 6, 12, 31), 3, 4),
-                                            ((2, 3, 10, 70), 2, 10), ((1, 1, 16, 160), 2, 2)])
+                                            ((2, 3, 10, 70), 2, 10), ((1, 1, 16, 160), 2, 2),
+                                            # volumes whose three bit images do not fit the fp32 scratch volume (rows of <= 2 voxels, a few hundred
+                                            # voxels) take the fp32 iteration instead of spilling into the neighbouring volumes
+                                            ((2, 4, 4, 4), 3, 3), ((1, 2, 8, 8), 3, 3), ((3, 5, 6, 2), 3, 2), ((1, 1, 9, 1), 2, 2)])
 def test_target_skeleton_on_bits_equals_the_fp32_iteration(dev, shape, nd, width):
     """round 5: the label-only half of the one-call clDice term (seg_cldice_target) computes the skeleton of the BINARY mask (label != 0) on a bit
     image - erosion / dilation as AND / OR of shifted words, 32 voxels per word - and expands it to fp32 once.  It must equal, bit for bit, `width`
@@ -211,4 +217,4 @@ def test_target_skeleton_on_bits_equals_the_fp32_iteration(dev, shape, nd, width
             lib.check(lib.seg_op_skel_iter(cur.data_ptr(), e.data_ptr(), nx.data_ptr(), planes, d, h, w, nd, st), "iter")
             cur = nx
         assert torch.equal(got, cur)
-        assert 0 < int(cur.sum()) < n
+        assert 0 < int(cur.sum()) < n or w <= 2

@@ -13,12 +13,6 @@ from pytorchdeeplearing_amd import ops
 from test_ops import cl, ncdhw, ints, to_dev
 
 # ndim, N, spatial, Cin (list = concat sources), Cout, tiling ids to run (None: the default pick)
-# the persistent Cin == 32 kernel launches one workgroup per CU; 16 workgroups make every workgroup of these small volumes walk several boxes
-os.environ.setdefault("SEG_C3Q16_WGS", "16")     # conv3q16_kernel (tilings 52 / 53 / 59, experiments build): 16 persistent workgroups, so each walks several boxes of these small volumes
-os.environ.setdefault("SEG_C3Q_WGS", "16")       # conv3q_kernel (tiling 51, experiments build): 16 persistent workgroups, so each walks several boxes of these small volumes
-os.environ.setdefault("SEG_C3P_WGS", "16")
-os.environ.setdefault("SEG_C3P16_WGS", "16")
-
 CASES = [
     (3, 1, (3, 9, 18), [32], 32, [0, 1, 13, 14, 20, 21, 22, 23]),          # partial boxes in every direction
     (3, 2, (2, 8, 16), [64], 64, [2, 15]),
@@ -31,21 +25,11 @@ CASES = [
     (3, 1, (2, 4, 8), [64, 64], 64, [None]),
     (3, 1, (3, 9, 18), [16], 16, [24, 25]),                 # Cin == 16: two taps per MFMA step, flat-K weights
     (3, 2, (2, 8, 32), [16], 32, [26, 27]),
-    (3, 2, (5, 17, 34), [16], 16, [28]),
-    (3, 2, (9, 17, 34), [16], 16, [52, 53]),                # Cin == 16 persistent tilings of round 5 (next halo copied under the epilogue; experiments build): ragged boxes, several per workgroup
-    (3, 1, (4, 16, 48), [16], 32, [52]),                    # two output-channel slabs (grid.y = 2)
-    (2, 2, (33, 40), [16], 16, [59]),                    # Cin == 16 persistent tilings, several boxes per workgroup (SEG_C3P16_WGS)
-    (3, 1, (4, 16, 48), [16], 32, [29]),
-    (2, 2, (33, 40), [16], 16, [58]),
     (2, 1, (19, 24), [16], 16, [56]),
     (2, 2, (16, 16), [16], 32, [57, None]),
     (2, 2, (17, 20), [32], 32, [32, 39]),
     (2, 1, (16, 32), [64], 64, [33, 34, 35, 38]),
     (2, 1, (9, 16), [128], 128, [36]),
-    (3, 2, (9, 17, 18), [32], 32, [18, 19]),               # Cin == 32 persistent tilings: several boxes per workgroup (SEG_C3P_WGS below), both halo buffers
-    (2, 2, (33, 40), [32], 32, [40]),
-    (3, 2, (9, 17, 18), [32], 32, [51]),                   # persistent Cin == 32 tiling of round 5 (next halo copied under the epilogue; experiments build): 54 boxes on 16 workgroups
-    (3, 1, (5, 9, 20), [32], 64, [51]),                    # two output-channel slabs (grid.y = 2), ragged boxes on every axis
     (2, 1, (8, 16), [32], 16, [37]),
     (2, 1, (12, 24), [16, 16], 64, [38]),
 ]
@@ -76,8 +60,6 @@ def test_conv3x_exact(dev, dtype, case):
     wf = ops.pack(w.to(dev), "conv_fwd", dtype, frag=True)
     rs = torch.stack([ref.detach().double().flatten(2).sum(2), (ref.detach().double() ** 2).flatten(2).sum(2)], dim=2)
     known = {c["id"]: c for c in ops.conv3x_cfgs(dev)}
-    if any(c in conftest.PERSISTENT_CFGS for c in cfgs if c is not None):
-        conftest.needs_experiments(dev)               # conv3p / conv3p16 (measured slower, round 3) are not in the product library
     for cfg in cfgs:
         if cfg is not None:
             assert cfg in known and known[cfg]["ndim"] == ndim and cout % known[cfg]["bn"] == 0, (cfg, known.get(cfg))

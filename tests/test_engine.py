@@ -262,14 +262,14 @@ def test_errors_are_reported(dev):
 
 
 def test_cpu_tensors_fail_loudly_without_the_gpu_library():
-    """No CPU fallback in the product path: with nothing injected, CPU devices are refused."""
-    saved = _capi._injected
-    _capi._injected = None
+    """No CPU fallback in the product path: the package's own `lib_for` (the test suite's checker routing put aside) refuses CPU devices."""
+    saved = _capi.lib_for
+    _capi.lib_for = getattr(_capi, "product_lib_for", saved)
     try:
         with pytest.raises(RuntimeError, match="MI355X"):
             SegEngine("vnet", 3, 1, 1, device="cpu")
     finally:
-        _capi._injected = saved
+        _capi.lib_for = saved
 
 
 def test_backward_op_ranges_equal_full_backward(dev):
@@ -346,6 +346,58 @@ def test_bucketed_train_step_equals_plain_step(dev):
     assert bad <= 0.002 * tot
 
 
+def test_in_library_exchange_calls_the_given_allreduce_over_every_suffix(dev):
+    """seg_set_rccl_comm: with a communicator set, seg_train_step issues the all-reduce of every finished suffix of the flat
+    gradient buffer ITSELF - no bucket hook, no Python between the slices.  The `ncclAllReduce` it is handed here is a test double with the RCCL
+    signature (send, recv, count, ncclFloat = 7, ncclSum = 0, comm, stream) that records its calls: in place, fp32 SUM, on the given communicator,
+    suffixes in descending order that tile the buffer exactly once.  On the host checker the double also DOUBLES the slice (two identical ranks
+    summing): with grad_div = world = 2 the step must equal the plain step bit for bit (x2 then /2 is exact).  (The real RCCL function runs in
+    tests/test_parallel.py::test_bucketed_exchange_on_rccl_single_rank_communicator.)"""
+    import ctypes
+    from pytorchdeeplearing_amd.parallel import NativeRcclAllReduce
+    tag = "unet2d_s" if dev.type == "cpu" else "vnet3d"
+    calls = []
+    COMM = 0x5E6C0DE
+
+    def fake_allreduce(send, recv, count, dtype, op, comm, stream):
+        calls.append((send, recv, int(count), dtype, op, comm))
+        if dev.type == "cpu":
+            buf = (ctypes.c_float * count).from_address(recv)
+            t = torch.frombuffer(buf, dtype=torch.float32)
+            t.mul_(2.0)
+        return 0
+    res = []
+    for native in (False, True):
+        e, params, x, y, masks, alpha, loss = build(tag, "f32", dev, True)
+        ar = None
+        if native:
+            ar = NativeRcclAllReduce(world_size=2 if dev.type == "cpu" else 1, comm=COMM, allreduce_fn=_capi.NCCL_ALLREDUCE(fake_allreduce))
+        for _ in range(2):
+            e.train_step(x.to(dev), y.to(dev), loss, lr=1e-3, class_alpha=alpha.to(dev), mask_mode=_capi.MASKS_GIVEN, masks=masks, allreduce=ar)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        res.append({k: v.cpu().clone() for k, v in e.state_dict().items()})
+        if native:
+            g0 = e.grads.data_ptr()
+            per_step = len(calls) // 2
+            assert len(calls) == 2 * per_step and 2 <= per_step <= 4, calls
+            for step in range(2):
+                cs = calls[step * per_step:(step + 1) * per_step]
+                assert all(c[0] == c[1] and c[3] == 7 and c[4] == 0 and c[5] == COMM for c in cs)        # in place, ncclFloat, ncclSum, our communicator
+                offs = [(c[0] - g0) // 4 for c in cs]
+                assert offs == sorted(offs, reverse=True) and offs[-1] == 0                                # suffixes, the head of the buffer last
+                assert sum(c[2] for c in cs) == e.numel and all(o + c[2] == (offs[i - 1] if i else e.numel) for i, (o, c) in enumerate(zip(offs, cs)))
+            # the communicator is a property of the handle: a later step without the exchange object removes it (no stale all-reduce)
+            n = len(calls)
+            e.train_step(x.to(dev), y.to(dev), loss, lr=1e-3, class_alpha=alpha.to(dev), mask_mode=_capi.MASKS_GIVEN, masks=masks)
+            assert len(calls) == n
+    for k in res[0]:
+        if dev.type == "cpu":
+            assert torch.equal(res[0][k], res[1][k]), k
+        else:            # run-to-run order of the fp32 / fp64 atomics on the GPU: same bound as test_bucketed_train_step_equals_plain_step
+            assert float((res[0][k] - res[1][k]).abs().max()) < 4.2e-3, k
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,dtype", [("unet3d_32", "f16"), ("vnet3d_48", "bf16")])
 def test_conv3x_path_matches_conv3_kernel_path_gpu(monkeypatch, tag, dtype):
@@ -356,40 +408,6 @@ def test_conv3x_path_matches_conv3_kernel_path_gpu(monkeypatch, tag, dtype):
 def test_conv3x_path_matches_conv3_kernel_path(dev, monkeypatch, tag, dtype):
     conftest.checker_slow(dev, "two whole 16-bit train steps per case: 2-3 min on the host checker")
     check_conv3x_path(dev, monkeypatch, tag, dtype)
-
-
-def check_reduce_fold(dev, monkeypatch, tag, dtype):
-    """GroupNorm-backward reduce inside the conv3x data-gradient epilogue (SEG_GN_RFUSE, read when the engine is created; Conv3xArgs::rq_*) against
-    the reduce kernel: the forward pass is untouched (identical logits / loss), the sums are the same values added in another order (fp32 partials per
-    workgroup, fp64 atomics), so every gradient tensor agrees to summation noise."""
-    conftest.needs_experiments(dev)
-    res = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("SEG_GN_RFUSE", flag)
-        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
-        logits, probs, out3, grads = run_engine(e, x, y, masks, alpha, loss, dev)
-        res.append((logits, out3, grads, e.lib.seg_plan_count(e.h, 10)))
-    assert torch.equal(res[0][0], res[1][0]) and float(res[0][1][0]) == float(res[1][1][0])
-    assert res[0][3] > 0 and res[1][3] == 0, "no reduce pass was folded: the test would compare a path with itself"
-    for k in res[0][2]:
-        a, b = res[0][2][k].double(), res[1][2][k].double()
-        if float(b.norm()) < 1e-12:
-            continue
-        # 16-bit storage of d(raw) rounds the other way when a coefficient moves in its last bit; nothing systematic survives 1e-2
-        assert float((a - b).norm()) / float(b.norm()) < 1e-2, (k, float((a - b).norm()) / float(b.norm()))
-
-
-@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16"), ("unet2d_s", "bf16"), ("vnet3d", "f16")])
-def test_reduce_folded_into_data_gradient_equals_reduce_kernel(dev, monkeypatch, tag, dtype):
-    if tag != "vnet2d_s":
-        conftest.checker_slow(dev, "two whole 16-bit train steps per case: 1-3 min each on the host checker (one small case runs there)")
-    check_reduce_fold(dev, monkeypatch, tag, dtype)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("tag,dtype", [("unet3d_32", "bf16"), ("vnet3d_48", "f16")])
-def test_reduce_folded_into_data_gradient_equals_reduce_kernel_gpu(monkeypatch, tag, dtype):
-    check_reduce_fold(torch.device("cuda:0"), monkeypatch, tag, dtype)
 
 
 def check_conv3x_path(dev, monkeypatch, tag, dtype):
@@ -416,35 +434,6 @@ def check_conv3x_path(dev, monkeypatch, tag, dtype):
         assert float((a - b).norm()) / float(b.norm()) < (0.2 if dtype == "f16" else 0.6), k
 
 
-@pytest.mark.parametrize("tag,dtype", [("vnet3d", "f16"), ("unet3d", "bf16"), ("vnet2d", "f16")])
-def test_virtual_activation_equals_materialised(dev, tag, dtype, monkeypatch):
-    """The activation of a [conv -> GroupNorm -> dropout -> ReLU] unit whose only consumer is a halo conv is applied by that consumer
-    while it stages its input (and by the consumer's weight gradient) instead of being written by an elementwise launch
-    (Step::vact_prod, conv3x FUSE instantiations; reference chain networks/VNet3d.py:13-15).  Same arithmetic on the same values:
-    logits, loss and every gradient must equal the materialised path (SEG_GN_VACT=0) - bit for bit on the sequential host checker, to
-    rounding on the GPU (the statistics are accumulated with fp64 atomics whose order varies from launch to launch)."""
-    conftest.needs_experiments(dev)          # not in the product library (profiles/HISTORY.md): runs against the -DSEG_EXPERIMENTS build
-    if tag != "vnet2d":       # one 2-D case keeps the fused path on the host checker (~1 min); the 3-D twins take 3-4 min each there
-        conftest.checker_slow(dev, "two 3-D forward+backward passes on the host checker")
-    res = []
-    for vact in ("0", "1"):
-        monkeypatch.setenv("SEG_GN_VACT", vact)             # opt-in since the A/B of round 3 (slower on the GPU); kept bit-exact
-        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
-        res.append(run_engine(e, x, y, masks, alpha, loss, dev))
-        nv = e.lib.seg_plan_count(e.h, 0)
-        assert nv == (0 if vact == "0" else {"vnet3d": 12, "unet3d": 7, "vnet2d": 12}[tag]), nv      # LUConv chains / second conv of a _block
-        del e
-    (l0, p0, o0, g0), (l1, p1, o1, g1) = res
-    exact = dev.type == "cpu"
-    tol = 0.0 if exact else 2e-3
-    assert float((l0 - l1).abs().max()) <= tol * max(1.0, float(l0.abs().max()))
-    assert abs(float(o0[0]) - float(o1[0])) <= (0.0 if exact else 1e-5)
-    for k in g0:
-        d = float((g0[k] - g1[k]).norm())
-        # fp32 atomics of the weight-gradient reduce order differently from run to run on the GPU
-        assert d <= (0.0 if exact else 2e-3 * float(g0[k].norm()) + 1e-12), k
-
-
 @pytest.mark.parametrize("tag", ["vnet2d_s", "unet2d"])
 def test_virtual_head_gradient_equals_materialised(dev, tag, monkeypatch):
     """One-class heads (networks/VNet3d.py:83-99): the data-gradient of the 1^d head is never written - the GroupNorm-backward passes of the
@@ -464,69 +453,6 @@ def test_virtual_head_gradient_equals_materialised(dev, tag, monkeypatch):
     assert abs(float(o0[0]) - float(o1[0])) <= (0.0 if exact else 1e-6)
     for k in g0:
         assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-5) * float(g1[k].norm()) + 1e-12, k
-
-
-@pytest.mark.parametrize("tag,dtype,mb", [("vnet2d_s", "f32", 0.005), ("unet2d", "f32", 0.04), ("vnet2d", "f16", 0.04),
-                                          pytest.param("vnet3d_48", "f16", 4.0, marks=pytest.mark.gpu),
-                                          pytest.param("unet3d_32", "bf16", 1.1, marks=pytest.mark.gpu)])
-def test_sub_batched_finest_level_equals_whole_batch_launches(dev, tag, dtype, mb, monkeypatch):
-    """SEG_SUB_MB (seg_engine::run_chain): the finest-level op chains (decoder top, input block, and their backward twins) run group of samples
-    by group of samples so that a consumer finds its producer's output in the memory-side cache; GroupNorm statistics and dropout masks are per
-    sample (networks/VNet3d.py:9, 13-15), so every value is computed by the same arithmetic on the same data.  Logits, loss and every gradient
-    must equal the whole-batch launches: bit for bit on the sequential host checker for logits / loss (each statistic is one sample's sum in both
-    modes), to accumulation order for the parameter gradients (the per-group launches add their gamma / beta / bias / head partial sums one after
-    the other).  `mb` picks one- or two-sample groups for the case's volume."""
-    conftest.needs_experiments(dev)          # not in the product library (profiles/HISTORY.md): runs against the -DSEG_EXPERIMENTS build
-    if dtype != "f32":
-        conftest.checker_slow(dev, "four 16-bit forward+backward passes on the host checker (the f32 cases run there)")
-    res, groups = [], []
-    for sub in ("0", str(mb)):
-        monkeypatch.setenv("SEG_SUB_MB", sub)
-        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
-        run_engine(e, x, y, masks, alpha, loss, dev)              # twice: the second pass starts from the buffers the first one left
-        res.append(run_engine(e, x, y, masks, alpha, loss, dev))
-        groups.append((e.lib.seg_plan_count(e.h, 4), e.lib.seg_plan_count(e.h, 5), e.lib.seg_plan_count(e.h, 6)))
-        del e
-    (l0, p0, o0, g0), (l1, p1, o1, g1) = res
-    n = CASES[tag][2][0]
-    assert groups[0][0] == 0 and 1 <= groups[1][0] < n and groups[1][1] >= 4 and groups[1][2] >= 4, groups
-    exact = dev.type == "cpu"
-    assert float((l0 - l1).abs().max()) <= (0.0 if exact else 2e-3 * max(1.0, float(l0.abs().max())))
-    assert abs(float(o0[0]) - float(o1[0])) <= (0.0 if exact else 1e-5)
-    for k in g0:
-        assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-3) * float(g0[k].norm()) + 1e-12, k
-
-
-@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f32"), ("unet2d_s", "f32"), pytest.param("vnet3d_48", "f16", marks=pytest.mark.gpu),
-                                       pytest.param("unet3d_32", "bf16", marks=pytest.mark.gpu)])
-def test_flag_forks_equal_event_forks(dev, tag, dtype, monkeypatch):
-    """Releasing weight gradients to the second queue without an event (seg_engine::flush_side_full): that queue's command processor waits on a
-    word in signal memory (hipStreamWaitValue32) and the word is stored by the first thread of the next kernel the caller's stream runs anyway -
-    the GroupNorm-backward reduce / one-launch pass (GnBwdArgs::sig_flag) - or by a one-wave kernel where another kernel follows.  Same
-    launches, same data: the gradients equal the event-fork engine's (SEG_FORK=event).  Bookkeeping checked on both boxes: every released
-    batch got its number stored (nothing is left waiting: a forgotten store would hang the weight-gradient queue), most of them by the next
-    kernel itself; the host checker also reads the flag word."""
-    conftest.needs_experiments(dev)          # not in the product library (profiles/HISTORY.md): runs against the -DSEG_EXPERIMENTS build
-    if tag in ("vnet3d_48", "unet3d_32"):
-        conftest.checker_slow(dev, "four 3-D 16-bit forward+backward passes on the host checker")
-    res, counts = [], []
-    for mode in ("event", "flag"):
-        monkeypatch.setenv("SEG_FORK", mode)
-        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
-        run_engine(e, x, y, masks, alpha, loss, dev)              # twice: the sequence numbers keep growing across passes
-        res.append(run_engine(e, x, y, masks, alpha, loss, dev))
-        counts.append([e.lib.seg_plan_count(e.h, w) for w in (2, 3, 7, 8, 9)])
-        del e
-    (l0, p0, o0, g0), (l1, p1, o1, g1) = res
-    ev, fl = counts
-    assert ev[0] >= 2 and ev[1] == 0 and ev[4] == 1, counts
-    assert fl[0] == 0 and fl[1] == ev[0] and 1 <= fl[2] + fl[3] <= fl[1] and fl[2] >= 1 and fl[4] == 1, counts
-    if dtype != "f32":          # the 16-bit kernels behind a release (halo / generic data-gradients, GroupNorm-backward reduce) all carry the number
-        assert fl[2] >= fl[1] // 2, counts
-    exact = dev.type == "cpu"
-    assert float((l0 - l1).abs().max()) <= (0.0 if exact else 2e-3 * max(1.0, float(l0.abs().max())))
-    for k in g0:
-        assert float((g0[k] - g1[k]).norm()) <= (0.0 if exact else 2e-3) * float(g0[k].norm()) + 1e-12, k
 
 
 @pytest.mark.gpu

@@ -180,10 +180,19 @@ def test_oracle_forward_full_size_f32(tag):
     # integer masks: the Dice metric thresholds every class probability at 0.5 (metric.py:146-181)
     flip = (probs > 0.5) != (ref_probs > 0.5)
     nflip = int(flip.sum())
+    tie = float((ref_probs[flip] - 0.5).abs().max()) if nflip else 0.0
+    ref_dice = seg.dice_coeff(ref_probs, y) if ncls == 1 else seg.multiclass_dice_coeff(ref_probs, y)
+    # north_star: "Dice metric bit-identical at integer mask level" - the flip count per config is printed and kept (profiles/rNN_fullsize_report.txt);
+    # a flipped voxel is only tolerated where the ORACLE's own probability is within 5e-5 of the threshold (a numerical tie between two fp32 evaluations)
+    line = "forward %s f32 vs the fp32 oracle: logits max|d| %.3e, integer-mask flips %d of %d (largest |p_oracle - 0.5| among them %.1e), Dice %.7f vs %.7f" % (
+        tag, err, nflip, flip.numel(), tie, float(out3[1]), float(ref_dice))
+    print(line)
+    if os.environ.get("SEG_FULLSIZE_REPORT"):
+        with open(os.environ["SEG_FULLSIZE_REPORT"], "a") as f:
+            f.write(line + "\n")
     assert nflip <= 2e-5 * flip.numel(), nflip
     if nflip:
-        assert float((ref_probs[flip] - 0.5).abs().max()) < 5e-5                 # only numerically tied voxels may differ
-    ref_dice = seg.dice_coeff(ref_probs, y) if ncls == 1 else seg.multiclass_dice_coeff(ref_probs, y)
+        assert tie < 5e-5                                                         # only numerically tied voxels may differ
     assert abs(float(out3[1]) - float(ref_dice)) < (1e-6 if nflip == 0 else 1e-4)
     ref_loss = seg.loss_fn(loss, torch.ones(ncls))(ref_logits, y)
     assert abs(float(out3[0]) - float(ref_loss)) < 2e-5
@@ -217,6 +226,7 @@ GRAD_CASES = {
     "C4_unet3d_1x128": ("unet", 3, (1, 1, 128, 128, 128), 4, "MutilDiceLoss"),
 }
 _GRAD_CACHE = {}
+LOWP_CAL = 1.25          # engine-vs-autocast bound of test_low_precision_gradients_calibrated_against_autocast (SEG_LOWP_CAL overrides: measurement runs)
 
 
 def oracle_grads(tag):
@@ -354,6 +364,55 @@ def test_oracle_gradients_full_size_low_precision(tag, dtype, tol, med_tol, cos_
     assert rows[0][0] < tol, rows[0]
     assert med < med_tol, med
     assert min(c for _, _, _, c in rows) > cos_tol
+
+
+def _autocast_grads(tag, dt, scale):
+    """the oracle's own functions on the GPU under torch.autocast(dt) - the standard mixed-precision path (conv operands 16-bit, GroupNorm / losses in
+    fp32 by autocast's policy, fp32 master weights), with the same static loss scale the engine uses"""
+    from collections import OrderedDict
+    kind, ndim, shape, ncls, loss = GRAD_CASES[tag]
+    params, x, y, _ = oracle_grads(tag)
+    P = OrderedDict((k, v.to(DEV).clone().requires_grad_(True)) for k, v in params.items())
+    with torch.autocast("cuda", dtype=dt):
+        logits, _ = seg.net_forward(kind, P, x.to(DEV), None)
+    l = seg.loss_fn(loss, torch.ones(ncls, device=DEV))(logits.float(), y.to(DEV))
+    (l * scale).backward()
+    torch.cuda.synchronize()
+    return OrderedDict((k, (v.grad / scale).cpu().double()) for k, v in P.items())
+
+
+@pytest.mark.parametrize("tag", list(GRAD_CASES))
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_low_precision_gradients_calibrated_against_autocast(tag, dtype):
+    """is the 16-bit run dtypes' gradient error 'what 16-bit storage costs' or the engine's own loss?  Three columns, ALL against
+    the float64 oracle, per parameter tensor (relative L2): the engine in the 16-bit run dtype, the oracle's functions under torch.autocast of
+    the same dtype on the same GPU (MIOpen / rocBLAS kernels; activations between GroupNorm and the next conv stay fp32 there, so it stores MORE
+    precision than the engine's 16-bit activations), and the fp32 torch-CPU oracle.  Gate: engine median and worst <= CAL x autocast's."""
+    kind, ndim, shape, ncls, loss = GRAD_CASES[tag]
+    params, x, y, r32 = oracle_grads(tag)
+    r64 = oracle_grads_fp64(tag)
+    e = SegEngine(kind, ndim, shape[1], ncls, dtype=dtype, device=DEV)
+    e.load_state_dict(params)
+    logits, probs = e.forward(x.to(DEV))
+    e.loss_forward(logits, y.to(DEV), loss, class_alpha=torch.ones(ncls, device=DEV))
+    e.backward(e.loss_backward(logits, y.to(DEV), loss))
+    scale = float(e.loss_scale)
+    ga = _autocast_grads(tag, torch.float16 if dtype == "f16" else torch.bfloat16, scale)
+    rows = []
+    for k, g in e.grad_dict().items():
+        ref = r64["grads"][k]
+        nrm = float(ref.norm()) + 1e-30
+        rows.append((float((g.cpu().double() - ref).norm()) / nrm, float((ga[k] - ref).norm()) / nrm, float((r32["grads"][k].double() - ref).norm()) / nrm, k))
+    med = lambda i: sorted(r[i] for r in rows)[len(rows) // 2]
+    worst = lambda i: max(r[i] for r in rows)
+    line = "%s %s vs the fp64 oracle, per-tensor rel-L2 median / worst: engine %.3e / %.3e | autocast %.3e / %.3e | fp32 oracle %.3e / %.3e  (engine : autocast = %.2f / %.2f)" % (
+        tag, dtype, med(0), worst(0), med(1), worst(1), med(2), worst(2), med(0) / med(1), worst(0) / worst(1))
+    print(line)
+    if os.environ.get("SEG_FULLSIZE_REPORT"):
+        with open(os.environ["SEG_FULLSIZE_REPORT"], "a") as f:
+            f.write("calibration " + line + "\n")
+    cal = float(os.environ.get("SEG_LOWP_CAL", LOWP_CAL))
+    assert med(0) <= cal * med(1) and worst(0) <= cal * worst(1), line
 
 
 def test_c5_with_cldice_term_full_size():

@@ -251,20 +251,34 @@ def test_conv3_halo_exact(dev, dtype, case):
     assert torch.equal(ncdhw(got.float().cpu(), ndim), xr.grad)
 
 
-@pytest.fixture(params=["wgrad3_kernel", "wgrad3x_kernel"])
-def wgrad3_impl(request, monkeypatch):
-    """both halo weight-gradient kernels: wgrad3_kernel (default) and the double-buffered 16-bit wgrad3x_kernel (SEG_WGRAD3X=1)"""
-    monkeypatch.setenv("SEG_WGRAD3X", "1" if request.param == "wgrad3x_kernel" else "0")
-    if request.param == "wgrad3x_kernel" and not conftest.EXPERIMENTS:
-        pytest.skip("wgrad3x_kernel (measured slower inside the step, round 2) is in the experiments build only (SEG_TEST_EXPERIMENTS=1)")
-    return request.param
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3_halo_exact(dev, dtype, case):
+    ndim, N, sp, cin, cout = case
+    g = torch.Generator().manual_seed(sum(sp) + cin)
+    x = ints((N, cin) + sp, -2, 2, g)
+    w = ints((cout, cin) + (3,) * ndim, -1, 1, g, density=0.15)
+    b = ints((cout,), -3, 3, g)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    xr = x.clone().requires_grad_(True)
+    ref = conv(xr, w, b, padding=1)
+    assert float(ref.abs().max()) <= 256
+    out, stats = ops.conv3(to_dev(cl(x), dtype, dev), ops.pack(w.to(dev), "conv_fwd", dtype), dtype, ndim, cout,
+                           bias=ops.aligned_like(b.to(dev)), want_stats=True)
+    assert torch.equal(ncdhw(out.float().cpu(), ndim), ref.detach())
+    rs = torch.stack([ref.detach().double().flatten(2).sum(2), (ref.detach().double() ** 2).flatten(2).sum(2)], dim=2)
+    assert torch.equal(stats.cpu(), rs)
+    # data-gradient through the same kernel with the flipped layout
+    dy = ints(tuple(ref.shape), -1, 1, g, density=0.4)
+    ref.backward(dy)
+    assert float(xr.grad.abs().max()) <= 256
+    got = ops.conv3(to_dev(cl(dy), dtype, dev), ops.pack(w.to(dev), "conv_dgrad", dtype), dtype, ndim, cin)
+    assert torch.equal(ncdhw(got.float().cpu(), ndim), xr.grad)
 
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", HALO_CASES)
-def test_wgrad3_halo_exact(dev, dtype, case, wgrad3_impl):
-    if wgrad3_impl == "wgrad3x_kernel" and dtype == "f32":
-        pytest.skip("the double-buffered kernel is 16-bit only")
+def test_wgrad3_halo_exact(dev, dtype, case):
     ndim, N, sp, cin, cout = case
     g = torch.Generator().manual_seed(sum(sp) + cout)
     x = ints((N, cin) + sp, -2, 2, g)
@@ -309,11 +323,9 @@ def test_wgrad3_big_box_16_channels_exact(dev, dtype, sp, N, monkeypatch):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", [(3, 1, (3, 8, 16), [16, 16], 16), (3, 2, (4, 6, 8), [32, 32], 32), (2, 1, (8, 16), [64, 64], 64),
                                   (3, 1, (7, 9, 17), [32, 32], 64), (2, 2, (11, 13), [16, 16], 32)])
-def test_wgrad3_concat_exact(dev, dtype, case, wgrad3_impl):
+def test_wgrad3_concat_exact(dev, dtype, case):
     """x = virtual concat of two tensors (UNet decoder blocks): q-tiles never straddle the sources; partial boxes; several
-    boxes per workgroup on the double-buffered 16-bit kernel."""
-    if wgrad3_impl == "wgrad3x_kernel" and dtype == "f32":
-        pytest.skip("the double-buffered kernel is 16-bit only")
+    boxes per workgroup."""
     ndim, N, sp, cins, cout = case
     if dtype == "bf16" and N * sp[0] * sp[1] * (sp[2] if ndim == 3 else 1) * sum(cins) * cout > 2_000_000:
         conftest.checker_slow(dev, "big bf16 case: 20 s per kernel on the host checker (the f16 twin runs there)")

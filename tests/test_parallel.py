@@ -381,16 +381,17 @@ def _nccl_single_rank_body(port, q):
     th.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
     from pytorchdeeplearing_amd import SegEngine, synthetic
-    from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GradAllReduce
+    from pytorchdeeplearing_amd.parallel import BucketedGradAllReduce, GradAllReduce, NativeRcclAllReduce
     dev = th.device("cuda:0")
     x, y = synthetic.synthetic_batch(2, (32, 32, 32), 1, 1, seed=3)
     x, y = x.to(dev), y.to(dev)
     out = []
-    for bucketed in (False, True):
+    for kind in ("blocking", "bucketed", "native"):
         e = SegEngine("vnet", 3, 1, 1, dtype="f32", device=dev)
         synthetic.init_engine(e, seed=0)
-        # world = 2 on the one-rank communicator: train_step takes its N > 1 paths, SUM = own gradient, the optimiser divides by 2 in BOTH runs
-        ar = BucketedGradAllReduce(world_size=1) if bucketed else GradAllReduce(world_size=1)
+        # world = 2 on the one-rank communicator: train_step takes its N > 1 paths, SUM = own gradient, the optimiser divides by 2 in ALL runs
+        # "native": the library issues ncclAllReduce itself on torch's communicator (seg_set_rccl_comm) - no Python between the backward slices
+        ar = {"blocking": GradAllReduce, "bucketed": BucketedGradAllReduce, "native": NativeRcclAllReduce}[kind](world_size=1)
         ar.world = 2
         losses = [float(e.train_step(x, y, "BinaryDiceLoss", mask_mode=0, allreduce=ar)[0])]
         th.cuda.synchronize()
@@ -413,13 +414,14 @@ def test_bucketed_exchange_on_rccl_single_rank_communicator():
     p.start()
     got = q.get(timeout=170)
     assert not (isinstance(got, tuple) and got and got[0] == "error"), got[1]
-    (l0, p0), (l1, p1) = got
+    (l0, p0), (l1, p1), (l2, p2) = got
     p.join(timeout=60)
     assert p.exitcode == 0
-    assert all(abs(a - b) < 1e-3 for a, b in zip(l0, l1)), (l0, l1)
-    d = (p0 - p1).abs()
-    # one Adam step moves a weight by <= lr; the order of the fp32 gradient atomics flips the sign of a few ~0 gradients (same bound as
-    # test_bucketed_train_step_equals_plain_step, x5); a stale or partial bucket would move most weights
-    bad = float((d > 1e-5).float().mean())
-    print("bucketed vs blocking exchange after one step: max|d| %.2e, fraction above 1e-5: %.4f; losses %s / %s" % (float(d.max()), bad, l0, l1))
-    assert float(d.max()) < 2.1e-3 and bad < 0.01, (float(d.max()), bad)
+    for name, lk, pk in (("bucketed (torch.distributed hooks)", l1, p1), ("in-library ncclAllReduce (seg_set_rccl_comm)", l2, p2)):
+        assert all(abs(a - b) < 1e-3 for a, b in zip(l0, lk)), (name, l0, lk)
+        d = (p0 - pk).abs()
+        # one Adam step moves a weight by <= lr; the order of the fp32 gradient atomics flips the sign of a few ~0 gradients (same bound as
+        # test_bucketed_train_step_equals_plain_step, x5); a stale or partial bucket would move most weights
+        bad = float((d > 1e-5).float().mean())
+        print("%s vs blocking exchange after one step: max|d| %.2e, fraction above 1e-5: %.4f; losses %s / %s" % (name, float(d.max()), bad, l0, lk))
+        assert float(d.max()) < 2.1e-3 and bad < 0.01, (name, float(d.max()), bad)

@@ -6,8 +6,11 @@ The file text is compiled and run unmodified with `__name__ == "__main__"`.  Wha
 hard-code: `pandas.read_csv` answers the three CSV paths from a temporary data set, `SimpleITK` is a small stand-in (not installable in this
 image), `file_name_path` maps the author's F:\\ drive to a temporary directory, and the wrapper class is entered through a shim that binds the
 script's constructor / method arguments against THIS repo's signatures (a keyword the wrappers do not take raises TypeError) and then
-shrinks the volume (128 x 112 x 112 -> 16^3), the epoch count and the device (host checker) so the run fits the GPU-less build box.
-Needs the reference tree: skipped where /root/reference does not exist (the GPU box)."""
+shrinks the volume (128 x 112 x 112 -> 16^3) and the epoch count so the run fits the GPU-less build box.
+Every test takes the `dev` fixture (round 6): its "emu" leg runs the files against the host checker, its "gpu" leg (`-m gpu`) runs the
+same files with `use_cuda=True` on cuda:0 against the product library.  Needs the reference tree (SEG_REFERENCE_ROOT, default /root/reference): both legs
+are skipped where it does not exist - the driver's GPU box carries no reference files (they may not be copied into this repo), so the GPU leg runs
+wherever a maintainer has the reference checked out next to a GPU."""
 import inspect
 import os
 import sys
@@ -19,18 +22,18 @@ import torch
 
 import conftest
 
-REF = "/root/reference"
+REF = os.environ.get("SEG_REFERENCE_ROOT", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "train.py")), reason="the reference tree is not present on this box")
 
 
-def _shim(real_cls, record, small=(16, 16, 16), model_path=None):
-    """enter `real_cls` the way the script does, check the call against the real signatures, run it small on the host checker"""
+def _shim(real_cls, record, small=(16, 16, 16), model_path=None, use_cuda=False):
+    """enter `real_cls` the way the script does, check the call against the real signatures, run it small on the host checker (or cuda:0)"""
     class Shim(real_cls):
         def __init__(self, *args, **kw):
             bound = inspect.signature(real_cls.__init__).bind(self, *args, **kw)        # TypeError: the script passes something the wrapper lacks
             record["ctor"] = dict(bound.arguments)
             kw = dict(kw)
-            kw.update(image_depth=small[0], image_height=small[1], image_width=small[2], use_cuda=False)
+            kw.update(image_depth=small[0], image_height=small[1], image_width=small[2], use_cuda=use_cuda)
             if kw.get("inference"):
                 kw["model_path"] = model_path
             real_cls.__init__(self, *args, **kw)
@@ -60,8 +63,8 @@ def _run_file(name, monkeypatch):
     return ns
 
 
-def test_train_py_file_runs_against_this_package(tmp_path, monkeypatch):
-    conftest.emu_library()
+def test_train_py_file_runs_against_this_package(dev, tmp_path, monkeypatch):
+    cuda = dev.type == "cuda"
     import pandas as pd
     import model
     from pytorchdeeplearing_amd.model import seg_models
@@ -84,7 +87,7 @@ def test_train_py_file_runs_against_this_package(tmp_path, monkeypatch):
         return rows[os.path.splitext(os.path.basename(str(p).replace("\\", "/")))[0]]
     monkeypatch.setattr(pd, "read_csv", read_csv)
     record = {}
-    monkeypatch.setattr(model, "MutilUNet3dModel", _shim(seg_models.MutilUNet3dModel, record))
+    monkeypatch.setattr(model, "MutilUNet3dModel", _shim(seg_models.MutilUNet3dModel, record, use_cuda=cuda))
     ns = _run_file("train.py", monkeypatch)
     assert [os.path.basename(str(p).replace("\\", "/")) for p in asked] == ["traindata.csv", "trainaugdata.csv", "validata.csv"]
     # the arguments are the file's own (train.py:34-37) ...
@@ -112,8 +115,8 @@ class _FakeImage:
     def SetDirection(self, d): self.direction = tuple(d)
 
 
-def test_inference_py_file_runs_against_this_package(tmp_path, monkeypatch):
-    conftest.emu_library()
+def test_inference_py_file_runs_against_this_package(dev, tmp_path, monkeypatch):
+    cuda = dev.type == "cuda"
     import model
     import dataprocess.utils as DU
     from pytorchdeeplearing_amd import networks
@@ -141,7 +144,7 @@ def test_inference_py_file_runs_against_this_package(tmp_path, monkeypatch):
     pth = str(tmp_path / "unet3d.pth")
     torch.save(networks.UNet3d(1, 1).state_dict(), pth)
     record = {}
-    monkeypatch.setattr(model, "MutilUNet3dModel", _shim(seg_models.MutilUNet3dModel, record, model_path=pth))
+    monkeypatch.setattr(model, "MutilUNet3dModel", _shim(seg_models.MutilUNet3dModel, record, model_path=pth, use_cuda=cuda))
     # the script concatenates "F:\..." + "/" + file name: reads and writes go to the temporary directory instead
     real_read = sitk.ReadImage
     sitk.ReadImage = lambda p: real_read(str(data / os.path.basename(str(p).replace("\\", "/"))))
@@ -156,13 +159,13 @@ def test_inference_py_file_runs_against_this_package(tmp_path, monkeypatch):
         assert img.GetSpacing() == (0.8, 0.8, 1.5) and img.GetOrigin() == (1.0, 2.0, 3.0)      # ... carrying the source geometry (modelUnet.py:990-997)
 
 
-def test_flask_app_py_file_serves_predictions_from_this_package(tmp_path, monkeypatch):
+def test_flask_app_py_file_serves_predictions_from_this_package(dev, tmp_path, monkeypatch):
     """north_star names flask_app.py beside train.py / inference.py: the file text is executed unmodified as a module
     (not as __main__, so the server is not started), then driven through `app.test_client()`: POST /predict with a volume file, GET /getresult
     for the mask.  The harness supplies only the outside world of /root/reference/flask_app.py:16-18,30-41: SimpleITK (stand-in, as above), the
     `D:/` upload directories (created relative to a temporary cwd), the checkpoint path, and `send_file`'s `attachment_filename` keyword that
     Flask >= 2.2 renamed to `download_name`.  Two requests are in flight at once to exercise the lock around the shared model object."""
-    conftest.emu_library()
+    cuda = dev.type == "cuda"
     flask = pytest.importorskip("flask")
     import io
     import threading
@@ -189,7 +192,7 @@ def test_flask_app_py_file_serves_predictions_from_this_package(tmp_path, monkey
     torch.save(networks.UNet3d(1, 1).state_dict(), pth)
     record = {}
     active, peak = [0], [0]
-    Base = _shim(seg_models.MutilUNet3dModel, record, model_path=pth)
+    Base = _shim(seg_models.MutilUNet3dModel, record, model_path=pth, use_cuda=cuda)
 
     class Counting(Base):                              # how many request threads are inside the network at once (must be 1: the lock)
         def _predict_device(self, *a, **k):
