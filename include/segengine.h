@@ -17,6 +17,8 @@
  *   SEG_STEMX=0          separate image-stem / GroupNorm / stem weight-gradient kernels instead of the fused input block
  *   SEG_VHEAD=0          the head writes its data-gradient tensor instead of the on-the-fly form
  *   SEG_GN_FOLD=0        GroupNorm finalize as launches of its own;  SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
+ *   SEG_GN_COOP=0        (read per seg_create) GroupNorm backward of the >= 64-channel levels as reduce + apply launches instead of the one-launch
+ *                        kernel whose workgroups exchange their partial sums inside the launch
  *   SEG_STEP_RIDERS=0    (read per step) step counters / flag clears as launches of their own instead of riding on neighbouring kernels
  *   SEG_PACK_SPLIT=0     the weight re-layout as one launch on the caller's stream
  *   SEG_CONV_STREAM=0    the generic implicit-GEMM kernel also where the register-resident streaming conv applies

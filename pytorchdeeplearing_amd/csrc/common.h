@@ -117,10 +117,23 @@ __device__ __forceinline__ float row_sum16(float v) {
     v += dpp_take<0x140>(v);      // row_mirror
     return v;
 }
+// Sum over the lanes of a DPP row that are congruent modulo CG (1, 2 or 4): quad_perm xor 1 (CG = 1), xor 2 (CG <= 2), then row_ror 4 and 8
+template <int CG> __device__ __forceinline__ float row_sum_mod(float v) {
+    if (CG <= 1) v += dpp_take<0xB1>(v);
+    if (CG <= 2) v += dpp_take<0x4E>(v);
+    v += dpp_take<0x124>(v);      // row_ror:4
+    v += dpp_take<0x128>(v);      // row_ror:8
+    return v;
+}
 #else
 __device__ __forceinline__ float row_sum16(float v) {
 #pragma unroll
     for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+template <int CG> __device__ __forceinline__ float row_sum_mod(float v) {
+#pragma unroll
+    for (int m = CG; m < 16; m <<= 1) v += __shfl_xor(v, m);
     return v;
 }
 #endif
@@ -190,6 +203,20 @@ __device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
 #else
 __device__ __forceinline__ void settle(int&) {}
 __device__ __forceinline__ void settle(float&) {}
+#endif
+
+// ---- one 8-byte word handed from one workgroup to others INSIDE a kernel (gn_bwd_coop_kernel) ----------------------------------------------
+// Agent-scope relaxed atomics: the store goes to the memory side (sc1), the polling load misses every L2, so workgroups on different XCDs (whose L2s are
+// not coherent with each other) see the word without a fence - a release fence would write back whatever the co-running weight-gradient kernels have
+// dirty in this XCD's L2 (round 3 measured that: the step went from 6 to 13 ms).  The host checker runs workgroups one after another: plain accesses.
+#ifndef SEG_EMU
+__device__ __forceinline__ void xwg_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long xwg_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xwg_pause() { __builtin_amdgcn_s_sleep(1); }
+#else
+__device__ __forceinline__ void xwg_store(unsigned long long* p, unsigned long long v) { *p = v; }
+__device__ __forceinline__ unsigned long long xwg_load(const unsigned long long* p) { return *p; }
+__device__ __forceinline__ void xwg_pause() {}
 #endif
 
 // labels arrive as u8 / i32 / i64 / f32 class ids (the reference's datasets hand out int64)

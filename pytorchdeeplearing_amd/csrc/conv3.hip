@@ -698,10 +698,19 @@ __global__ __launch_bounds__(256, SEG_W3_OCC) SEG_W3_WAVES void wgrad3_kernel(Wg
 }
 
 // dw[p][q][tap] += sum_b partial[combo][b][p'][tap][q']   (one thread per dw element: coalesced read-modify-write of
-// the master gradient, partial tiles gathered through L1/L2)
-__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial, float* dw, int P, int Q, int CP, int CQ, int ntap, int nb,
-                                                            long long sP, long long sQ, int qreal) {
-    // grid.y slices the partial list (32 partial tiles per slice); slices meet in dw through one atomic each
+// the master gradient, partial tiles gathered through L1/L2).  One launch reduces up to W3_BATCH layers (blockIdx.z): the engine runs the reduce of
+// every layer of a level visit in ONE launch behind the last weight-gradient kernel of the visit (round 6: 20 latency-bound reduce launches per VNet3d
+// step - 7-8 us each for a few MB, 256 us in all - became 8).  The order of the sum per element is unchanged: it does not depend on the batching.
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(Wgrad3ReduceBatch bt) {
+    const Wgrad3Reduce& r = bt.r[blockIdx.z];
+    const float* partial = r.partial;
+    float* dw = r.dw;
+    const int P = r.P, Q = r.Q, CP = r.CP, CQ = r.CQ, ntap = r.ntap, nb = r.nb, qreal = r.qreal;
+    const long long sP = r.sP, sQ = r.sQ;
+    // grid.y slices the partial list (32 partial tiles per slice); slices meet in dw through one atomic each.  The grid is sized for the largest
+    // layer of the batch: the slices / blocks a smaller layer does not need leave at once
+    const int nslice = (nb + 31) / 32;
+    if ((int)blockIdx.y >= nslice) return;
     const long long total = (long long)P * Q * ntap;
     const int tile = CP * ntap * CQ, nqt = Q / CQ;
     const int b0 = blockIdx.y * 32, b1 = (b0 + 32 < nb) ? b0 + 32 : nb;
@@ -728,13 +737,18 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* partial
         const float tot = (s0 + s1) + (s2 + s3);
         const int p = (combo / nqt) * CP + pp, qc = (combo % nqt) * CQ + qq;
         if (qc >= qreal) continue;                      // zero-padded input channels (multi-channel image tensor): no such weight
-        if (gridDim.y == 1) dw[p * sP + qc * sQ + tap] += tot;
+        if (nslice == 1) dw[p * sP + qc * sQ + tap] += tot;
         else atomicAdd(&dw[p * sP + qc * sQ + tap], tot);
     }
 }
+inline Wgrad3Reduce wgrad3_reduce_desc(const float* partial, float* dw, int P, int Q, int CP, int CQ, int ntap, int nb, long long sP, long long sQ, int qreal) {
+    Wgrad3Reduce r;
+    r.partial = partial; r.dw = dw; r.P = P; r.Q = Q; r.CP = CP; r.CQ = CQ; r.ntap = ntap; r.nb = nb; r.sP = sP; r.sQ = sQ; r.qreal = qreal;
+    return r;
+}
 
 template <class T, int TD, int TH, int TW, int KD>
-void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
+Wgrad3Reduce wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
     Wgrad3Args a = a0;
     int CP, CQ;
     wgrad3_tile(a.P, a.Q, (int)sizeof(T), KD == 3 ? 3 : 2, &CP, &CQ);
@@ -746,11 +760,7 @@ void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long lon
     else if (CQ == 32) SEG_W3(16, 32);
     else SEG_W3(16, 16);
 #undef SEG_W3
-    const int ntap = KD * 9;
-    const long long total = (long long)a.P * a.Q * ntap;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(blocks, (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, CP, CQ, ntap, a.nb, sP, sQ, qreal);
+    return wgrad3_reduce_desc(a.partial, dw, a.P, a.Q, CP, CQ, KD * 9, a.nb, sP, sQ, qreal);
 }
 
 // 16 -> 16 channels on a large volume (the finest level of the 3-D nets: the longest single launch of the step, 313 us for 226 MB at 4 x 96^3,
@@ -758,7 +768,7 @@ void wgrad3_launch_shape(const Wgrad3Args& a0, float* dw, long long sP, long lon
 // bytes per round trip and barriers per voxel: 50 KB instead of 23 KB per trip, 2.7x fewer barrier pairs per voxel, and the halo re-read of x
 // drops from 2.8x to 2.1x (PMC round 3: 349 MB fetched for 226 MB algorithmic).  50.5 KB of LDS; 16-bit tensors only (an f32 box would need 127 KB).
 template <class T> struct Wgrad3Big16 {
-    static bool launch(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
+    static bool launch(const Wgrad3Args& a0, float* dw, long long sP, long long sQ, hipStream_t s, int qreal, Wgrad3Reduce* rd) {
         const char* env = knob_s("SEG_W3_BOX16");          // 0: off; 1 (default): where the volume holds enough boxes; 2: wherever the shape fits (tests)
         const int on = env ? atoi(env) : 1;
         int CP, CQ;
@@ -772,26 +782,20 @@ template <class T> struct Wgrad3Big16 {
         Wgrad3Args a = a0;
         if (a.nb > nbox) a.nb = (int)nbox;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3_kernel<T, 4, 8, 16, 3, 16, 16>), dim3(a.nb, combos), dim3(256), 0, s, a);
-        const long long total = 16ll * a.Q * 27;
-        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total + 255) / 256), (a.nb + 31) / 32), dim3(256), 0, s, (const float*)a.partial, dw, a.P, a.Q, 16, 16, 27,
-                           a.nb, sP, sQ, qreal);
+        *rd = wgrad3_reduce_desc(a.partial, dw, a.P, a.Q, 16, 16, 27, a.nb, sP, sQ, qreal);
         return true;
     }
 };
 template <> struct Wgrad3Big16<float> {
-    static bool launch(const Wgrad3Args&, float*, long long, long long, hipStream_t, int) { return false; }
+    static bool launch(const Wgrad3Args&, float*, long long, long long, hipStream_t, int, Wgrad3Reduce*) { return false; }
 };
 
 template <class T>
-void wgrad3_dispatch(const Wgrad3Args& a, int ndim, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
-    if (ndim == 3 && Wgrad3Big16<T>::launch(a, dw, sP, sQ, s, qreal)) return;
-    if (ndim == 3) {
-        if (wide_box(a.W)) wgrad3_launch_shape<T, 3, 4, 16, 3>(a, dw, sP, sQ, s, qreal);
-        else wgrad3_launch_shape<T, 3, 8, 8, 3>(a, dw, sP, sQ, s, qreal);
-    } else {
-        if (wide_box(a.W)) wgrad3_launch_shape<T, 1, 8, 16, 1>(a, dw, sP, sQ, s, qreal);
-        else wgrad3_launch_shape<T, 1, 8, 8, 1>(a, dw, sP, sQ, s, qreal);
-    }
+Wgrad3Reduce wgrad3_dispatch(const Wgrad3Args& a, int ndim, float* dw, long long sP, long long sQ, hipStream_t s, int qreal) {
+    Wgrad3Reduce rd;
+    if (ndim == 3 && Wgrad3Big16<T>::launch(a, dw, sP, sQ, s, qreal, &rd)) return rd;
+    if (ndim == 3) return wide_box(a.W) ? wgrad3_launch_shape<T, 3, 4, 16, 3>(a, dw, sP, sQ, s, qreal) : wgrad3_launch_shape<T, 3, 8, 8, 3>(a, dw, sP, sQ, s, qreal);
+    return wide_box(a.W) ? wgrad3_launch_shape<T, 1, 8, 16, 1>(a, dw, sP, sQ, s, qreal) : wgrad3_launch_shape<T, 1, 8, 8, 1>(a, dw, sP, sQ, s, qreal);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1056,9 +1060,12 @@ int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, 
     // One box, every BASELINE config (profiles/r03_wgrad_policy_configs_ab.log), total / total16 = 256/256, 512/1024, 256/1024, 512/256:
     // C3 4.15 / 4.20 / 4.18 / 4.15 ms, C4 4.58 / 4.55 / 4.43 / 4.68, C5 4.55 / 4.61 / 4.57 / 4.58, C2 (2-D) 6.65 / 6.40 / 6.68 / 6.37 -> the
     // 2-D boxes keep 512 workgroups
-    static const int total_env = 0;
+#ifdef SEG_DIAG
+    static const int total_env = knob_i("SEG_W3_TOTAL", 0), minbox = knob_i("SEG_W3_MINBOX", 6);      // diagnostic variant builds only (tools/build_variant.py)
+#else
+    static const int total_env = 0, minbox = 6;
+#endif
     const int total = total_env > 0 ? total_env : (ndim == 3 ? 256 : 512);
-    static const int minbox = 6;
     // 16 -> 16 channels (the finest level): four workgroups fit a CU (23 KB LDS, 113 VGPRs) and the partial tile is 27 KB, so the
     // staging latency of one workgroup can hide behind the others
     // round 2 (no prefetch), standalone 4x96^3: 512 -> 168 us, 1024 -> 123 us, 2048 -> 137 us (r02_wgrad16_ab.log), step unchanged.  With the
@@ -1084,8 +1091,27 @@ size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q) 
     return (size_t)combos * wgrad3_blocks_per_combo(ndim, N, D, H, W, P, Q, 4) * CP * (ndim == 3 ? 27 : 9) * CQ * sizeof(float);
 }
 
+void launch_wgrad3_reduce(const Wgrad3Reduce* list, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += W3_BATCH) {
+        Wgrad3ReduceBatch bt;
+        const int m = n - i0 < W3_BATCH ? n - i0 : W3_BATCH;
+        unsigned gx = 1, gy = 1;
+        for (int i = 0; i < m; ++i) {
+            bt.r[i] = list[i0 + i];
+            const long long total = (long long)list[i0 + i].P * list[i0 + i].Q * list[i0 + i].ntap;
+            long long blocks = (total + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            gx = blocks > gx ? (unsigned)blocks : gx;
+            const unsigned sl = (unsigned)((list[i0 + i].nb + 31) / 32);
+            gy = sl > gy ? sl : gy;
+        }
+        for (int i = m; i < W3_BATCH; ++i) bt.r[i] = bt.r[0];
+        hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3(gx, gy, (unsigned)m), dim3(256), 0, s, bt);
+    }
+}
+
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1, int C0, int qreal) {
+                   int dtype, hipStream_t s, const void* x1, int C0, int qreal, Wgrad3Reduce* defer) {
     const int T = ndim == 3 ? 27 : 9;
     if (qreal <= 0 || qreal > Q) qreal = Q;
     Wgrad3Args a;
@@ -1100,9 +1126,11 @@ void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int
     (void)hipMemsetAsync(tbuf, 0, tmax * 8 * sizeof(unsigned long long), s);
     a.trace = tbuf;
 #endif
-    if (dtype == DT_F32) wgrad3_dispatch<float>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
-    else if (dtype == DT_F16) wgrad3_dispatch<f16>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
-    else wgrad3_dispatch<bf16>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
+    const Wgrad3Reduce rd = dtype == DT_F32 ? wgrad3_dispatch<float>(a, ndim, dw, (long long)qreal * T, T, s, qreal)
+                            : dtype == DT_F16 ? wgrad3_dispatch<f16>(a, ndim, dw, (long long)qreal * T, T, s, qreal)
+                                              : wgrad3_dispatch<bf16>(a, ndim, dw, (long long)qreal * T, T, s, qreal);
+    if (defer) *defer = rd;                      // the caller batches the reduce (launch_wgrad3_reduce) behind further weight-gradient kernels
+    else launch_wgrad3_reduce(&rd, 1, s);
 #ifdef SEG_W3_TRACE
     {
         (void)hipStreamSynchronize(s);

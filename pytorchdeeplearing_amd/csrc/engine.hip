@@ -35,6 +35,10 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->use_fold = knob_i("SEG_GN_FOLD", e->use_fold) != 0;
     e->use_vhead = knob_i("SEG_VHEAD", e->use_vhead) != 0;
     e->dual_gn_bwd = knob_i("SEG_DUAL_GN", e->dual_gn_bwd) != 0;
+    e->use_coop = knob_i("SEG_GN_COOP", e->use_coop) != 0;
+#ifdef SEG_DIAG
+    e->w3_mode = knob_i("SEG_DIAG_W3_MODE", e->w3_mode);
+#endif
     build_network(*e, net_kind);
     *out = e;
     return 0;
@@ -192,6 +196,7 @@ int seg_backward_slice(seg_handle h, const float* dlogits, int zero_grads, int o
 int seg_side_wait(seg_handle h, void* stream) {
     if (check_handle(h)) return -1;
     hipStream_t st = (hipStream_t)stream;
+    h->finish_wgrads();
     if (h->use_side && h->side) { (void)hipEventRecord(h->side_done, h->side); (void)hipStreamWaitEvent(st, h->side_done, 0); }
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_side_wait: event error");
 }

@@ -115,6 +115,7 @@ struct seg_engine {
     size_t off_partial_stemx = 0;
     bool use_conv3x = true;     // SEG_CONV3X=0: conv3_kernel for every halo conv (round-1 path)
     bool dual_gn_bwd = true;    // SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
+    bool use_coop = true;       // SEG_GN_COOP=0: the deep levels' GroupNorm backward as reduce + apply launches (one-workgroup-per-group launch at 6^3)
     std::vector<hipEvent_t> ready_ev;
     hipEvent_t side_done = nullptr;
     hipEvent_t ar_ev = nullptr;          // orders the gradient-exchange stream behind / in front of the caller's stream (seg_train_step hooks)
@@ -136,6 +137,29 @@ struct seg_engine {
     int fork_batch = 3;      // weight gradients per fork event; measured on MI355X (VNet3d 4x96^3): 2 / 3 / 4 / 6 / 9 -> 1032 / 1031-1035 / 1025 / 1015 / 994
                              // volumes/s (profiles/r05_release_schedule_sweep.log)
     size_t cur_partial = 0;  // partial-tile scratch of the weight-gradient launch being issued
+    // Halo weight gradients: the ordered reduce of the partial tiles (second stage) of every layer of a level visit runs as ONE launch behind the
+    // visit's last weight-gradient kernel (launch_wgrad3_reduce; 8 reduce launches per VNet3d step instead of 20).  Each pending layer keeps a
+    // partial-tile slot of its own until then.
+    std::vector<Wgrad3Reduce> w3_pending;
+    int w3_mode = 2;         // which launches share a reduce: 0 none (one reduce per layer), 1 a level visit, 2 the layers released to the queue together
+    int w3_lvl = -1;
+    hipStream_t w3_stream = nullptr;
+    size_t off_partial3 = 0, partial3_stride = 0;
+    void flush_w3() {
+        if (w3_pending.empty()) return;
+        double bytes = 0.0;
+        for (auto& r : w3_pending) bytes += (double)(r.P / r.CP) * (r.Q / r.CQ) * r.nb * r.CP * r.ntap * r.CQ * 4.0 + 2.0 * (double)r.P * r.Q * r.ntap * 4.0;
+        const int pi = prof_begin(w3_stream, SEG_K_WGRAD3, bytes, 0.0);
+        launch_wgrad3_reduce(w3_pending.data(), (int)w3_pending.size(), w3_stream);
+        prof_end(w3_stream, pi);
+        w3_pending.clear();
+    }
+    // the partial-tile slot of the next halo weight gradient on level `lvl`, issued on stream `st`
+    float* w3_slot(int lvl, hipStream_t st) {
+        if (!w3_pending.empty() && (w3_lvl != lvl || w3_stream != st || (int)w3_pending.size() == W3_BATCH)) flush_w3();
+        w3_lvl = lvl; w3_stream = st;
+        return (float*)(ws + off_partial3 + w3_pending.size() * partial3_stride);
+    }
     hipStream_t make_side() {
         // lowest priority: the weight gradients only have to finish before the optimiser, the main stream carries the critical
         // path.  At equal priority the command processor kept serving the side queue's back-to-back launches while the main
@@ -193,13 +217,17 @@ struct seg_engine {
         (void)hipEventRecord(e, main);          // everything the queued weight gradients read has been produced on `main`
         (void)hipStreamWaitEvent(side, e, 0);
         for (auto& f : pending) { cur_partial = off_partial; f.f(side); }
+        if (w3_mode == 2) flush_w3();
         side_used = true;
         pending.clear();
     }
+    // every weight gradient issued so far is complete behind this point of its stream (joins, bucket boundaries)
+    void finish_wgrads() { flush_w3(); }
     void join_side(hipStream_t main) {
         for (auto& h : held) pending.push_back(std::move(h));      // (a network without deep levels never reached the release level)
         held.clear();
         flush_side(main);
+        finish_wgrads();
         if (use_side && side && (ready_used || side_used)) { (void)hipEventRecord(side_done, side); (void)hipStreamWaitEvent(main, side_done, 0); }
         ready_used = 0;
         side_used = false;

@@ -419,6 +419,16 @@ struct Planner {
                 }
             }
         E.off_partial = alloc(pmax);
+        {   // halo weight gradients keep one partial-tile slot per layer until the reduce of their level visit (seg_engine::w3_slot)
+            size_t p3 = 0;
+            for (auto& s : E.steps)
+                if (s.type == ST_UNIT && s.ck == CK_K3) {
+                    const int l = E.tens[s.raw].lvl;
+                    p3 = std::max(p3, wgrad3_partial_bytes(E.ndim, N, E.dim_d(l), E.dim_h(l), E.dim_w(l), s.Cout, s.Cin));
+                }
+            E.partial3_stride = align_up(p3);
+            E.off_partial3 = alloc(E.partial3_stride * W3_BATCH);
+        }
         E.off_partial_stemx = alloc(stemx_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), E.in_ch));
         E.off_partial_stem1 = alloc(stem_wgrad_partial_bytes(E.ndim, N, E.dim_d(0), E.dim_h(0), E.dim_w(0), 16 * ((E.feat + 15) / 16)));
 
@@ -788,6 +798,13 @@ struct Planner {
                         GnBwdArgs a;
                         GnBwdFinArgs f{};
                         fill(E, ui, gl, a, f);
+                        if (E.use_coop && gn_bwd_coop_eligible(a, (int)E.esz())) {
+                            // 24^3 ... 6^3 levels: reduce + finalize + apply in one launch on ~one workgroup per CU (each tensor read once)
+                            const int pg = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
+                            launch_gn_bwd_coop(a, f, E.dtype, st);
+                            E.prof_end(st, pg);
+                            return;
+                        }
                         if (gn_bwd_group_eligible(r.C, a.V, (int)E.esz())) {
                             const int pg = E.prof_begin(st, SEG_K_GN_GROUP, E.tbytes(u.raw) * (2 * a.ndy + 3), 0.0);
                             launch_gn_bwd_group(a, f, E.dtype, st);
@@ -840,9 +857,13 @@ struct Planner {
                             const Step& s = E.steps[si];
                             const Ten& i0 = E.tens[s.in0];
                             const int pi = E.prof_begin(ws_, SEG_K_WGRAD3, E.tbytes(draw) + E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0), fl);
-                            launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, (float*)(E.ws + E.cur_partial), E.g + E.params[s.w].off,
+                            Wgrad3Reduce rd;
+                            float* slot = E.w3_slot(lo, ws_);
+                            launch_wgrad3(E.ws + E.tens[draw].off, E.ws + i0.off, slot, E.g + E.params[s.w].off,
                                           E.N, E.dim_d(lo), E.dim_h(lo), E.dim_w(lo), s.Cout, s.Cin, E.ndim, E.dtype, ws_,
-                                          s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, s.cin_par);
+                                          s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C, s.cin_par, &rd);
+                            E.w3_pending.push_back(rd);
+                            if (E.w3_mode == 0 || !E.use_side) E.flush_w3();
                             E.prof_end(ws_, pi);
                         }, E.tbytes(draw), lo);
                         int pi;

@@ -41,8 +41,14 @@ size_t stemx_partial_bytes(int ndim, int N, int D, int H, int W, int Cimg);
 void launch_stemx(const seg_stemx_args& a, int mode, int ndim, int dtype, float* dw3, float* dw1, hipStream_t s);
 int wgrad3_blocks_per_combo(int ndim, int N, int D, int H, int W, int P, int Q, int esz = 2);
 size_t wgrad3_partial_bytes(int ndim, int N, int D, int H, int W, int P, int Q);
+// second stage of the halo weight gradient: dw += the ordered sum of a layer's partial tiles.  launch_wgrad3 runs it itself, or - `defer` given - hands
+// back its descriptor for a later launch_wgrad3_reduce over several layers (one launch; the partial buffers must stay untouched until then)
+struct Wgrad3Reduce { const float* partial; float* dw; int P, Q, CP, CQ, ntap, nb; long long sP, sQ; int qreal; };
+constexpr int W3_BATCH = 4;
+struct Wgrad3ReduceBatch { Wgrad3Reduce r[W3_BATCH]; };
+void launch_wgrad3_reduce(const Wgrad3Reduce* list, int n, hipStream_t s);
 void launch_wgrad3(const void* dr, const void* x, float* partial, float* dw, int N, int D, int H, int W, int P, int Q, int ndim,
-                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, int qreal = 0);      // qreal in (0, Q): x carries zero-padded channels, dw is [P][qreal][taps] (the channels beyond qreal are not written)
+                   int dtype, hipStream_t s, const void* x1 = nullptr, int C0 = 0, int qreal = 0, Wgrad3Reduce* defer = nullptr);      // qreal in (0, Q): x carries zero-padded channels, dw is [P][qreal][taps] (the channels beyond qreal are not written)
 
 // MFMA image stem (K = taps*Cimg <= 32): forward and weight gradient on box tiles (conv3.hip)
 void launch_stem_fwd(const void* in, const void* w, const float* bias, void* out, double* stats, int N, int D, int H, int W, int Cimg,
@@ -160,6 +166,11 @@ void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s, const GnBwdFin
 bool gn_bwd_group_eligible(int C, long long V, int esz);
 void launch_gn_fwd_group(const GnFinArgs& f, const void* r, const void* res, void* out, int dtype, hipStream_t s);
 void launch_gn_bwd_group(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, hipStream_t s);
+// the same in one launch on S workgroups per (sample, group) that exchange their partial sums inside the kernel (norm.hip: gn_bwd_coop_kernel); uses the
+// unit's Q region (zero at launch) as the exchange area
+bool gn_bwd_coop_plan(int C, long long V, int N, int esz, int* S, int* ku);
+bool gn_bwd_coop_eligible(const GnBwdArgs& e, int esz);
+void launch_gn_bwd_coop(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, hipStream_t s);
 
 // Weight gradient: see seg_wgrad_args in include/segengine.h
 typedef seg_wgrad_args WgradArgs;

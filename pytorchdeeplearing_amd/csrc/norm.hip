@@ -665,6 +665,185 @@ __global__ __launch_bounds__(1024) void gn_fwd_group_kernel(GnFwdGroupArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Deep-level GroupNorm backward in ONE launch on MANY workgroups (C >= 64: the 24^3 / 12^3 / 6^3 levels).  The two-pass form costs two latency-bound
+// launches per unit there (5 - 10 us each for a tensor of <= 7 MB), the one-workgroup-per-group form above pulls a group through 1024 threads (32
+// workgroups: 11 - 14 us at 6^3, 4x slower than two passes at 24^3).  Here the S workgroups of a (sample, group) each load a slice ONCE and keep it in
+// registers (<= K chunks of 8 channels per thread), hand their partial sums (sum dz, sum dz*r per channel: two floats in one 8-byte word) to one another
+// through memory (xwg_store / xwg_load: no fence, no atomics on data), every workgroup folds the S partials in slot order (deterministic) into the
+// group's coefficients and applies them to the registers it kept.  A word is "there" when it is non-zero (+0.0 is stored as -0.0); the slot area is the
+// unit's Q region, which every backward pass starts with zeros.  Workgroups of a group have consecutive ids and the dispatcher hands out ids in order, so
+// the earliest unfinished group is always resident as a whole: the wait cannot starve as long as S workgroups fit on the device at once (S <= 32).
+// The poll gives up after ~0.3 s and poisons the output with NaN (the gradient check of the step then reports it) instead of hanging the queue.
+// PH: 0 = the kernel; 1 / 2 = its two halves as separate launches (host checker: workgroups run one after another there).
+// ------------------------------------------------------------------------------------------------
+struct GnBwdCoopArgs {
+    GnBwdArgs e;
+    GnBwdFinArgs f;
+    unsigned long long* slots;      // [N][8][S][cpg] words, zero at launch
+    int S, ku;                      // workgroups per (sample, group); chunks per thread (<= K)
+};
+
+template <class T, int NDY, int K, int PH>
+__global__ __launch_bounds__(256) void gn_bwd_coop_kernel(GnBwdCoopArgs a) {
+    __shared__ float wsum[16][4][16];        // [DPP row of the workgroup][chunk-in-group][q1 0..7 | q2 0..7]
+    __shared__ float part[256][2];           // [slot * cpg + channel]: the partial sums of every workgroup of the group
+    __shared__ double chan[32][3];           // per channel of the group: Q1, Q2, R1
+    __shared__ float coef[32][3];
+    const int S = a.S;
+    const int g = blockIdx.x / S, sl = blockIdx.x - g * S, n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C = a.e.C, cpg = C / GN_GROUPS, CG = cpg / 8, CPR = C / 8;     // CG = 16-B chunks per voxel in this group: 1, 2 or 4
+    const int V = (int)a.e.V;
+    const int cg = tid % CG, c0 = g * cpg + cg * 8;
+    const int items = V * CG, it0 = sl * a.ku * 256;       // (a slice starts at a multiple of 256: a thread keeps its chunk column cg)
+    const T* r = (const T*)a.e.r;
+    T* dr = (T*)a.e.dr;
+    unsigned long long* slot = a.slots + (long long)((n * GN_GROUPS + g) * S) * cpg;
+    const vec<float, 8> sc = *(const vec<float, 8>*)(a.e.scale + (long long)n * C + c0);
+    const vec<float, 8> sh = *(const vec<float, 8>*)(a.e.shift + (long long)n * C + c0);
+    // the slice: every load in front of the first use (slots past the slice re-read a valid chunk and contribute / store nothing)
+    int iu[K];
+    unsigned okm = 0u;
+    DySrc<T, NDY> src[K];
+    vec<T, 8> x[K];
+    vec<float, 8> vw8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vw8[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int it = it0 + tid + k * 256;
+        const bool ok = k < a.ku && it < items;
+        okm |= ok ? (1u << k) : 0u;
+        const int itc = ok ? it : cg;
+        iu[k] = (n * V + itc / CG) * CPR + g * CG + cg;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        src[k].issue(a.e, iu[k], n, 0, c0);
+        x[k] = load8(r + (long long)iu[k] * 8);
+    }
+    // what the coefficient math needs besides the sums travels with the slice (not as a round trip of its own behind the exchange)
+    double f_mu = 0.0, f_rs = 0.0, f_mk = 0.0, f_ga = 0.0;
+    if (wv == 0 && PH != 1) {
+        const int c = g * cpg + (lane < cpg ? lane : 0);
+        f_mu = a.f.mean[n * GN_GROUPS + g]; f_rs = a.f.rstd[n * GN_GROUPS + g];
+        if (lane < cpg) {
+            f_mk = a.f.mask ? (double)a.f.mask[(long long)n * a.f.mask_ld + c] : 1.0;
+            f_ga = (double)a.f.gamma[c];
+        }
+    }
+    // forward sum(r) of the group's channels (conv-bias gradient): only the publishing workgroup needs it
+    double r1 = 0.0;
+    if (sl == 0 && tid < cpg && PH != 1) {
+        const int nrep = a.f.rep_s > 0 ? a.f.rep_s : STAT_REP;
+        for (int rep = 0; rep < nrep; rep += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = a.f.stats[(((long long)(rep + u < nrep ? rep + u : 0) * a.f.N + n) * C + g * cpg + tid) * 2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (rep + u < nrep) r1 += v[u];
+        }
+    }
+    if (PH != 2) {
+        float q1[8], q2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q1[j] = 0.f; q2[j] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float dy[8];
+            src[k].sum(dy, vw8);
+            const bool ok = (okm >> k) & 1u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = to_f(x[k][j]);
+                const float d = (ok && fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
+                q1[j] += d;
+                q2[j] = fmaf(d, xv, q2[j]);
+            }
+        }
+        // lanes with equal (lane % CG) hold the same channels: DPP sums inside the 16-lane rows, the 16 rows of the workgroup meet in LDS
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (CG == 1) { q1[j] = row_sum_mod<1>(q1[j]); q2[j] = row_sum_mod<1>(q2[j]); }
+            else if (CG == 2) { q1[j] = row_sum_mod<2>(q1[j]); q2[j] = row_sum_mod<2>(q2[j]); }
+            else { q1[j] = row_sum_mod<4>(q1[j]); q2[j] = row_sum_mod<4>(q2[j]); }
+        }
+        if ((lane & 15) < CG) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { wsum[tid >> 4][lane & 15][j] = q1[j]; wsum[tid >> 4][lane & 15][8 + j] = q2[j]; }
+        }
+        __syncthreads();
+        if (tid < cpg) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { s1 += wsum[w][tid >> 3][tid & 7]; s2 += wsum[w][tid >> 3][8 + (tid & 7)]; }
+            unsigned long long w = ((unsigned long long)__builtin_bit_cast(unsigned, s2) << 32) | (unsigned long long)__builtin_bit_cast(unsigned, s1);
+            if (w == 0ull) w = 0x80000000ull;                 // "there": +0.0 travels as -0.0
+            xwg_store(slot + sl * cpg + tid, w);
+        }
+        if (PH == 1) return;
+    }
+    // every thread fetches one (workgroup, channel) word of the group (S * cpg <= 256)
+    {
+        const int lc = 31 - __builtin_clz(cpg);
+        const int ps = tid >> lc, pc = tid & (cpg - 1);
+        float v1 = 0.f, v2 = 0.f;
+        if (ps < S) {
+            unsigned long long w = xwg_load(slot + ps * cpg + pc);
+            for (int spin = 0; w == 0ull && spin < (1 << 18); ++spin) { xwg_pause(); w = xwg_load(slot + ps * cpg + pc); }
+            v1 = __builtin_bit_cast(float, (unsigned)(w & 0xffffffffull));
+            v2 = __builtin_bit_cast(float, (unsigned)(w >> 32));
+            if (w == 0ull) { v1 = __builtin_nanf(""); v2 = v1; }
+        }
+        part[tid][0] = v1; part[tid][1] = v2;
+    }
+    __syncthreads();
+    if (tid < cpg) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int s = 0; s < S; ++s) { s1 += (double)part[s * cpg + tid][0]; s2 += (double)part[s * cpg + tid][1]; }
+        chan[tid][0] = s1; chan[tid][1] = s2; chan[tid][2] = r1;
+    }
+    __syncthreads();
+    if (wv == 0) {                                       // one wave finishes the group: cpg <= 32 channels (same formulas as gn_bwd_finalize_kernel)
+        const int c = g * cpg + (lane < cpg ? lane : 0);
+        const bool act = lane < cpg;
+        const bool publish = sl == 0;
+        const double mu = f_mu, rs = f_rs, mk = act ? f_mk : 0.0, ga = act ? f_ga : 0.0;
+        const double Q1 = act ? chan[lane][0] : 0.0, Q2 = act ? chan[lane][1] : 0.0, R1 = act ? chan[lane][2] : 0.0;
+        const double q1d = mk * Q1, qx = (mk * Q2 - mu * q1d) * rs;
+        const double S1 = wave_sum_d(ga * q1d), S2 = wave_sum_d(ga * qx);
+        if (act) {
+            const double Mg = (double)cpg * (double)V;
+            const double A = rs * ga * mk, B = -rs * rs * S2 / Mg, Cc = -rs * S1 / Mg + rs * rs * S2 * mu / Mg;
+            coef[lane][0] = (float)A; coef[lane][1] = (float)B; coef[lane][2] = (float)Cc;
+            if (publish) {
+                atomicAdd(&a.f.dbeta[c], (float)q1d);
+                atomicAdd(&a.f.dgamma[c], (float)qx);
+                if (a.f.dbias) atomicAdd(&a.f.dbias[c], (float)(A * Q1 + B * R1 + Cc * (double)V));
+            }
+        }
+    }
+    __syncthreads();
+    float cA[8], cB[8], cC[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cA[j] = coef[cg * 8 + j][0]; cB[j] = coef[cg * 8 + j][1]; cC[j] = coef[cg * 8 + j][2]; }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float dy[8];
+        src[k].sum(dy, vw8);
+        vec<T, 8> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = to_f(x[k][j]);
+            const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
+            o[j] = from_f<T>(fmaf(cA[j], d, fmaf(cB[j], xv, cC[j])));
+        }
+        if ((okm >> k) & 1u) store8(dr + (long long)iu[k] * 8, o);
+    }
+}
+
 inline int ew_blocks(long long total_threads) {
     long long b = (total_threads + 255) / 256;
     return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
@@ -733,6 +912,57 @@ void launch_gn_bwd_group(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, h
     if (dtype == DT_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_group_kernel<float>), grid, dim3(1024), 0, s, a);
     else if (dtype == DT_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_group_kernel<f16>), grid, dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_group_kernel<bf16>), grid, dim3(1024), 0, s, a);
+}
+
+// S workgroups of 256 threads per (sample, group), ku <= K chunks per thread: about one workgroup per CU in all, more where a slice would not fit the
+// registers (K = 8 chunks of 16-bit data, 4 of f32), never more than 1024 workgroups or 32 per group, S * cpg <= 256 (one polled word per thread).
+// Only tensors of a few MB: the reduce + apply launches are latency-bound there; on a larger tensor they stream at the copy rate and one launch that holds the
+// tensor in registers is slower (MI355X, round 6, in-call A/B of VNet3d 4 x 96^3: every >= 64-channel level 1052 - 1055 volumes/s, only <= 4 MB 1048 - 1050, none
+// 1042 - 1044 - 7 MB at 24^3, 1.8 MB at 12^3 11 us against 13, 0.44 MB at 6^3 8 us against 12.5; 512 instead of 256 workgroups 1030 - 1044; VNet2d 16 x 512^2 with
+// its 8 - 34 MB tensors 6.58 ms with the one-launch form against 6.33 ms without)
+bool gn_bwd_coop_plan(int C, long long V, int N, int esz, int* S_out, int* ku_out) {
+    const int cpg = C / GN_GROUPS;
+    if (C % 64 || cpg < 8 || cpg > 32 || N < 1 || V < 1) return false;
+    constexpr long long max_bytes = 8000000;
+    constexpr int target = 256;
+    if ((long long)N * V * C * esz > max_bytes) return false;
+    const int CG = cpg / 8, kmax = esz == 2 ? 8 : 4;
+    const long long items = V * CG;
+    int smax = 256 / cpg;
+    if (smax > 32) smax = 32;
+    while (smax > 1 && GN_GROUPS * N * smax > 1024) smax >>= 1;
+    int S = target / (GN_GROUPS * N);
+    if (S < 1) S = 1;
+    if (S > smax) S = smax;
+    int ku = (int)((items + (long long)S * 256 - 1) / ((long long)S * 256));
+    while (ku > kmax && S < smax) { S *= 2; if (S > smax) S = smax; ku = (int)((items + (long long)S * 256 - 1) / ((long long)S * 256)); }
+    if (ku > kmax) return false;
+    S = (int)((items + (long long)ku * 256 - 1) / ((long long)ku * 256));      // (no empty slices)
+    if (S_out) *S_out = S;
+    if (ku_out) *ku_out = ku;
+    return true;
+}
+bool gn_bwd_coop_eligible(const GnBwdArgs& e, int esz) {
+    return !e.vdl && !e.r2 && e.ndy >= 1 && e.ndy <= 3 && gn_bwd_coop_plan(e.C, e.V, e.N, esz, nullptr, nullptr);
+}
+
+void launch_gn_bwd_coop(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, hipStream_t s) {
+    GnBwdCoopArgs a; a.e = e; a.f = f;
+    a.slots = (unsigned long long*)e.Q;
+    gn_bwd_coop_plan(e.C, e.V, e.N, dtype == DT_F32 ? 4 : 2, &a.S, &a.ku);
+    dim3 grid(GN_GROUPS * a.S, e.N);
+#ifdef SEG_EMU
+#define SEG_GNC2(T_, D_, K_) { hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_coop_kernel<T_, D_, K_, 1>), grid, dim3(256), 0, s, a); \
+                               hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_coop_kernel<T_, D_, K_, 2>), grid, dim3(256), 0, s, a); }
+#else
+#define SEG_GNC2(T_, D_, K_) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_bwd_coop_kernel<T_, D_, K_, 0>), grid, dim3(256), 0, s, a);
+#endif
+#define SEG_GNC1(T_, D_) { if (a.ku <= 2) SEG_GNC2(T_, D_, 2) else if (a.ku <= 4) SEG_GNC2(T_, D_, 4) else SEG_GNC2(T_, D_, (sizeof(T_) == 2 ? 8 : 4)) }
+#define SEG_GNC(T_) { if (e.ndy == 1) SEG_GNC1(T_, 1) else if (e.ndy == 2) SEG_GNC1(T_, 2) else SEG_GNC1(T_, 3) }
+    if (dtype == DT_F32) SEG_GNC(float) else if (dtype == DT_F16) SEG_GNC(f16) else SEG_GNC(bf16)
+#undef SEG_GNC
+#undef SEG_GNC1
+#undef SEG_GNC2
 }
 
 void launch_gn_bwd_finalize(const GnBwdFinArgs& a, hipStream_t s, const GnBwdFinArgs* b) {

@@ -28,6 +28,7 @@ CASES = {
     "vnet3d_48": ("vnet", 3, (2, 1, 48, 48, 48), 1, "BinaryDiceLoss"),
     "unet3d_32": ("unet", 3, (2, 1, 32, 32, 32), 4, "MutilDiceLoss"),
     "vnet2d_128": ("vnet", 2, (3, 1, 128, 128), 2, "MutilCrossEntropyLoss"),
+    "unet2d_96": ("unet", 2, (1, 1, 96, 96), 1, "BinaryDiceLoss"),          # 64 / 128 / 256 channels on 576 / 144 / 36 pixels: 3 / 2 / 1 workgroups per GroupNorm group
 }
 
 
@@ -453,6 +454,41 @@ def test_virtual_head_gradient_equals_materialised(dev, tag, monkeypatch):
     assert abs(float(o0[0]) - float(o1[0])) <= (0.0 if exact else 1e-6)
     for k in g0:
         assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-5) * float(g1[k].norm()) + 1e-12, k
+
+
+@pytest.mark.parametrize("tag,dtype", [("unet2d_96", "f32"), ("unet2d_96", "f16"), ("unet3d_32", "f32"), pytest.param("vnet3d_48", "f32", marks=pytest.mark.gpu), pytest.param("vnet3d_48", "f16", marks=pytest.mark.gpu),
+                                       pytest.param("unet3d_32", "bf16", marks=pytest.mark.gpu), pytest.param("vnet2d_128", "f16", marks=pytest.mark.gpu)])
+def test_one_launch_groupnorm_backward_equals_reduce_plus_apply(dev, tag, dtype, monkeypatch):
+    """GroupNorm backward of the >= 64-channel levels (networks/VNet3d.py:9 -> autograd): gn_bwd_coop_kernel - S workgroups per (sample, group) keep their slice in
+    registers and exchange partial sums inside the launch - against the reduce + apply launches (SEG_GN_COOP=0, read by seg_create).  Same products; the sums
+    are folded in another order, so fp32 agrees to rounding and the 16-bit run dtypes to one storage rounding of d(raw).  A slice / slot / channel mix-up would
+    show as an O(1) difference in the parameter gradients of the deep levels."""
+    if dev.type == "cpu" and (tag, dtype) != ("unet2d_96", "f32"):
+        conftest.checker_slow(dev, "1 - 5 min on the host checker (the 2-D fp32 case runs there)")
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SEG_GN_COOP", flag)
+        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
+        if dev.type != "cpu":
+            e.profile_enable(["gn_group", "gn_bwd_reduce"])
+        out = run_engine(e, x, y, masks, alpha, loss, dev)
+        calls = e.profile_read() if dev.type != "cpu" else {}
+        res.append((out, calls))
+        del e
+    (l0, p0, o0, g0), c0 = res[0]
+    (l1, p1, o1, g1), c1 = res[1]
+    if c0 or c1:          # the one-launch kernel really ran in the first engine and not in the second: it takes over reduce + apply launches, or (where the
+        # tensors are small enough for the one-workgroup-per-group launch of the same profile class) accounts for other bytes per launch
+        fewer = c0.get("gn_bwd_reduce", {}).get("calls", 0) < c1.get("gn_bwd_reduce", {}).get("calls", 0)
+        other = c0.get("gn_group", {}).get("bytes", 0.0) != c1.get("gn_group", {}).get("bytes", 0.0)
+        assert fewer or other, (c0, c1)
+    assert float((l0 - l1).abs().max()) == 0.0              # (the forward pass is the same code)
+    tol = {"f32": 2e-5, "f16": 2e-2, "bf16": 1e-1}[dtype]
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        if float(b.norm()) < 1e-12:
+            continue
+        assert float((a - b).norm()) / float(b.norm()) < tol, (k, float((a - b).norm()) / float(b.norm()))
 
 
 @pytest.mark.gpu
