@@ -19,6 +19,9 @@
  *   SEG_GN_FOLD=0        GroupNorm finalize as launches of its own;  SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
  *   SEG_GN_COOP=0        (read per seg_create) GroupNorm backward of the >= 64-channel levels as reduce + apply launches instead of the one-launch
  *                        kernel whose workgroups exchange their partial sums inside the launch
+ *   SEG_VACT=0|2         (read per seg_create) the activation between a VNet up-conv and the 1^d conv on the concat (networks/VNet3d.py:72-77): 0 = written as a
+ *                        tensor at every level, 2 = applied by its two readers on load at every level the kernels allow (default: on tensors >= 16 MB) -
+ *                        bit-identical results
  *   SEG_STEP_RIDERS=0    (read per step) step counters / flag clears as launches of their own instead of riding on neighbouring kernels
  *   SEG_PACK_SPLIT=0     the weight re-layout as one launch on the caller's stream
  *   SEG_CONV_STREAM=0    the generic implicit-GEMM kernel also where the register-resident streaming conv applies
@@ -304,6 +307,11 @@ typedef struct seg_conv_args {
     int sd, sh, sw;     /* gather: input stride; scatter: up-sampling factor */
     int scatter;
     seg_taps taps;
+    /* optional (null: off), gather form on the streaming kernel only (seg_op_conv_kernel == 1): in0 holds the RAW output r of a conv + GroupNorm unit and is read as
+     * a = relu(act_scale[n][c] * r + act_shift[n][c]) rounded to dtype - GroupNorm + channel dropout + ReLU of the producer (networks/VNet3d.py:72-74) applied on
+     * load, so that the activated tensor is never written; [N][C0] fp32 each */
+    const float* act_scale;
+    const float* act_shift;
 } seg_conv_args;
 int seg_op_conv(const seg_conv_args* a, int dtype, void* stream);
 /* which kernel seg_op_conv picks for these extents: 1 = register-resident streaming kernel (short reductions on large
@@ -325,6 +333,10 @@ typedef struct seg_wgrad_args {
     seg_taps taps;
     long long sP, sQ, sT;
     int stem;
+    /* optional (null: off), 1^d stride-1 convs on 16-bit tensors only (seg_op_wgrad fails otherwise): x0 holds the raw output of a conv + GroupNorm unit and is
+     * read as relu(act_scale[n][c] * r + act_shift[n][c]) rounded to dtype, like seg_conv_args.act_scale; [N][C0] fp32 each, C0 <= 64 */
+    const float* act_scale;
+    const float* act_shift;
 } seg_wgrad_args;
 long long seg_op_wgrad_partial_bytes(const seg_wgrad_args* a);
 int seg_op_wgrad(const seg_wgrad_args* a, float* partial_scratch, int dtype, void* stream);

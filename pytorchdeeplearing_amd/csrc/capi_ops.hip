@@ -201,6 +201,8 @@ int seg_op_conv(const seg_conv_args* a, int dtype, void* stream) {
     const int cin = a->C0 + a->C1;
     if (cin < 8 || (cin & (cin - 1)) || a->C0 % 8) return fail("seg_op_conv: channel counts must be powers of two >= 8");
     if (a->Cout % 16 || a->Ngemm % 16 || a->Kpad % 32 || a->Kpad < a->K) return fail("seg_op_conv: bad GEMM extents");
+    if ((a->act_scale || a->act_shift) && !(a->act_scale && a->act_shift && conv_uses_stream_kernel(*a)))
+        return fail("seg_op_conv: act_scale / act_shift need the streaming kernel (gather form, seg_op_conv_kernel == 1) and come as a pair");
     launch_conv_igemm(*a, dtype, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_conv: launch failed");
 }
@@ -210,6 +212,8 @@ int seg_op_wgrad(const seg_wgrad_args* a, float* partial_scratch, int dtype, voi
     if (!a || !a->dr || !a->x0 || !a->dw || !partial_scratch) return fail("seg_op_wgrad: null pointer");
     if (a->P % 16) return fail("seg_op_wgrad: P must be a multiple of 16");
     if (a->stem ? (a->Q > 32) : (a->Q % 16 != 0)) return fail("seg_op_wgrad: bad Q");
+    if ((a->act_scale || a->act_shift) && !(a->act_scale && a->act_shift && dtype != SEG_F32 && wgrad_act_supported(*a)))
+        return fail("seg_op_wgrad: act_scale / act_shift need a 1^d stride-1 conv on 16-bit tensors with C0 <= 64 and come as a pair");
     launch_wgrad(*a, partial_scratch, dtype, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_wgrad: launch failed");
 }

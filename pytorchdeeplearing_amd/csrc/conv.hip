@@ -279,8 +279,13 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep) {
 #else
 #define SEG_STREAM_WAVES(x)
 #endif
-template <class T, int KS, int NTL, int SC>
+// ACT (gather form): in0 holds the RAW output of a conv + GroupNorm unit; every piece loaded from it becomes relu(scale * r + shift) rounded to T - the
+// producer's GroupNorm + channel dropout + ReLU - in the registers of its reader, with the same fmaf / fmaxf / rounding as gn_act_kernel: the activated tensor
+// of the VNet up-conv (226 MB written and read again per pass at 4 x 96^3) is never materialised.  A lane's 8 channels are the same for every tile: the
+// coefficients are loop-invariant registers.
+template <class T, int KS, int NTL, int SC, bool ACT = false>
 __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) void conv_stream_kernel(ConvArgs a) {
+    static_assert(!ACT || SC == 0, "activation on load: gather form only");
     constexpr bool SCATTER = SC != 0;
     constexpr bool C16 = SC == 2;
     constexpr int NJ = C16 ? 1 : NTL;
@@ -340,6 +345,17 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
     // (vmcnt retires in order) also waited for the previous tile's load: the U loads "in flight" ran one after the other
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { settle(td[ks]); settle(th[ks]); settle(tw[ks]); settle(ci[ks]); }
+    vec<float, 8> asc[ACT ? KS : 1], ash[ACT ? KS : 1];
+    bool afrom0[ACT ? KS : 1];
+    if (ACT) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            afrom0[ks] = kin[ks] && ci[ks] < a.C0;
+            const int c = afrom0[ks] ? ci[ks] : 0;                       // (the other lanes load valid coefficients and ignore them)
+            asc[ks] = *(const vec<float, 8>*)(a.act_scale + (long long)n * a.C0 + c);
+            ash[ks] = *(const vec<float, 8>*)(a.act_shift + (long long)n * a.C0 + c);
+        }
+    }
     for (int t0 = blockIdx.x * 4 + wv; t0 < ntile; t0 += step * U) {
         typename Mma<T>::frag xf[U][KS];
         int d_[U], h_[U], w_[U];
@@ -368,6 +384,15 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
             f32x4 acc[NTL];
 #pragma unroll
             for (int j = 0; j < NTL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ACT) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    typename Mma<T>::frag v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = from_f<T>(fmaxf(fmaf(asc[ks][e], to_f(xf[u][ks][e]), ash[ks][e]), 0.f));
+                    if (afrom0[ks]) xf[u][ks] = v;
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -443,6 +468,7 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
 }
 
 bool stream_eligible(const ConvArgs& a) {
+    if (a.act_scale && (a.scatter || !a.act_shift || a.C0 % 8)) return false;
     static const bool off = knob_i("SEG_CONV_STREAM", 1) == 0;
     if (off) return false;
     const long long Vrow = (long long)a.OD * a.OH * a.OW;
@@ -477,6 +503,7 @@ bool launch_conv_stream(const ConvArgs& a, hipStream_t s) {
     if (ks == KS && ntl == NTL) {                                                                                            \
         if (a.scatter && a.Cout == 16 && NTL > 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 2>), grid, dim3(256), 0, s, a); \
         else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 1>), grid, dim3(256), 0, s, a); \
+        else if (a.act_scale) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 0, true>), grid, dim3(256), 0, s, a); \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 0>), grid, dim3(256), 0, s, a);               \
         return true;                                                                                                         \
     }
@@ -685,6 +712,7 @@ bool conv_uses_stream_kernel(const ConvArgs& a) { return stream_eligible(a); }
 
 void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep) {
     const int srep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
+    if (a.act_scale && !stream_eligible(a)) { fprintf(stderr, "segengine: activation on load needs the streaming conv kernel (internal error)\n"); abort(); }
     if (dtype == DT_F32) { if (!launch_conv_stream<float>(a, s)) conv_dispatch<float>(a, s, srep); }
     else if (dtype == DT_F16) { if (!launch_conv_stream<f16>(a, s)) conv_dispatch<f16>(a, s, srep); }
     else { if (!launch_conv_stream<bf16>(a, s)) conv_dispatch<bf16>(a, s, srep); }

@@ -56,8 +56,11 @@ struct Step {
     bool fold_fin = false;                    // statistics finalize folded into the consuming gn_act launch (no launch of its own)
     int x_fwd = -1, x_dg0 = -1, x_dg1 = -1;   // conv3x tiling of the forward / data-gradient launches (-1: conv3_kernel, row-major weights)
     int draw = -1;           // gradient wrt raw
+    int vact_unit = -1;      // >= 0: in0 is the (never written) activation of that UNIT step: this conv and its weight gradient read the unit's RAW output and apply
+                             // GroupNorm + dropout + ReLU on load (conv_stream_kernel / wgrad_direct_kernel <..., ACT>)
     // ACT
     int ua = -1, ub = -1, res = -1, out = -1;
+    bool vact = false;       // the output tensor is never written: its only reader applies the activation on load (Planner::plan)
     // POOL / HEAD
     int in = -1;
 };
@@ -115,6 +118,7 @@ struct seg_engine {
     size_t off_partial_stemx = 0;
     bool use_conv3x = true;     // SEG_CONV3X=0: conv3_kernel for every halo conv (round-1 path)
     bool dual_gn_bwd = true;    // SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
+    int use_vact = 1;           // SEG_VACT=0: the activation between a VNet up-conv and the 1^d conv on the concat is written as a tensor; 2: applied on load on small tensors too (tests)
     bool use_coop = true;       // SEG_GN_COOP=0: the deep levels' GroupNorm backward as reduce + apply launches (one-workgroup-per-group launch at 6^3)
     std::vector<hipEvent_t> ready_ev;
     hipEvent_t side_done = nullptr;

@@ -221,8 +221,55 @@ WgradArgs make_wgrad_args(const seg_engine& E, const Step& s, int draw) {
         w.taps = make_taps(E.ndim, k, k == 3 ? 1 : 0);
         w.sP = (long long)(s.cin_par ? s.cin_par : s.Cin) * T;
         if (s.ck == CK_STEM3 || s.ck == CK_STEM1) { w.stem = 1; w.Q = T * s.Cin; }
+        if (s.vact_unit >= 0) {          // x0 = the producer's raw output, activated on load
+            const Step& pu = E.steps[s.vact_unit];
+            w.x0 = P(E.tens[pu.raw].off);
+            w.act_scale = (const float*)P(pu.scale); w.act_shift = (const float*)P(pu.shift);
+            if (!ws) { w.act_scale = w.act_shift = (const float*)(uintptr_t)16; }      // (extents only: a non-null marker)
+        }
     }
     return w;
+}
+
+// arguments of the forward launch of a generic (non-halo) conv UNIT: 2^d stride-2, 1^d on a (virtual) concat, ConvTranspose
+ConvArgs make_fwd_conv_args(const seg_engine& E, const Step& s) {
+    const Ten& i0 = E.tens[s.in0];
+    const Ten& ro = E.tens[s.raw];
+    char* ws = E.ws;
+    auto P = [&](size_t off) -> char* { return ws ? ws + off : nullptr; };
+    ConvArgs a{};
+    a.in0 = P(i0.off); a.C0 = i0.C;
+    a.in1 = s.in1 >= 0 ? P(E.tens[s.in1].off) : nullptr;
+    a.C1 = s.in1 >= 0 ? E.tens[s.in1].C : 0;
+    a.w = P(s.wp_fwd); a.bias = (s.b >= 0 && E.p) ? E.p + E.params[s.b].off : nullptr; a.out = P(ro.off);
+    a.stats = s.gn_w >= 0 ? (double*)P(s.stats) : nullptr;
+    a.N = E.N; a.Cout = s.Cout;
+    const int li = i0.lvl, lo = ro.lvl;
+    a.ID = E.dim_d(li); a.IH = E.dim_h(li); a.IW = E.dim_w(li);
+    if (s.ck == CK_KT) {
+        a.scatter = 1;
+        a.OD = a.ID; a.OH = a.IH; a.OW = a.IW;
+        a.FD = E.dim_d(lo); a.FH = E.dim_h(lo); a.FW = E.dim_w(lo);
+        a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
+        a.taps = make_taps(E.ndim, 2, 0);
+        a.K = s.Cin; a.Ngemm = a.taps.n * s.Cout;
+    } else {
+        a.scatter = 0;
+        a.OD = E.dim_d(lo); a.OH = E.dim_h(lo); a.OW = E.dim_w(lo);
+        const int k = s.ck == CK_K3 ? 3 : s.ck == CK_K2S2 ? 2 : 1;
+        a.taps = make_taps(E.ndim, k, s.ck == CK_K3 ? 1 : 0);
+        const int str = s.ck == CK_K2S2 ? 2 : 1;
+        a.sd = E.ndim == 3 ? str : 1; a.sh = str; a.sw = str;
+        a.K = a.taps.n * s.Cin; a.Ngemm = s.Cout;
+    }
+    a.Kpad = (a.K + 31) / 32 * 32;
+    if (s.vact_unit >= 0) {              // in0 = the producer's raw output, activated on load
+        const Step& pu = E.steps[s.vact_unit];
+        a.in0 = P(E.tens[pu.raw].off);
+        a.act_scale = (const float*)P(pu.scale); a.act_shift = (const float*)P(pu.shift);
+        if (!ws) { a.act_scale = a.act_shift = (const float*)(uintptr_t)16; }          // (extents only: a non-null marker)
+    }
+    return a;
 }
 
 // arguments of the fused input block behind ACT step `s` (pointers valid once the engine is bound)
@@ -306,11 +353,38 @@ struct Planner {
                     E.steps[st_.ua].fused_stem = true;
                     if (st_.ub >= 0) E.steps[st_.ub].fused_stem = true;
                 }
+        // ---- activations that are never written: the output of a single-branch ACT step without residual whose ONLY reader is the first source of a 1^d conv on a
+        // (virtual) concat - the VNet up-conv -> concat -> conv chain, networks/VNet3d.py:72-77 - on tensors large enough for the two passes over it to cost
+        // bandwidth (>= 16 MB: the 96^3 and 48^3 decoder levels of the benchmark; below, the launches are latency and the generic conv kernel applies).  The
+        // reader's forward launch (streaming conv kernel) and its weight gradient (direct kernel) take the producer's raw output and apply scale / shift / ReLU on
+        // load; the unit's gradient flow is unchanged.  16-bit run dtypes.
+        for (auto& st_ : E.steps) { st_.vact = false; st_.vact_unit = -1; }
+        if (E.use_vact && dt != DT_F32)
+            for (size_t ai = 0; ai < E.steps.size(); ++ai) {
+                Step& A = E.steps[ai];
+                if (A.type != ST_ACT || A.ub >= 0 || A.res >= 0 || E.steps[A.ua].fused_stem || E.steps[A.ua].gn_w < 0) continue;
+                if (E.use_vact < 2 && (double)ten_bytes(E.tens[A.out]) < 16e6) continue;
+                int readers = 0, ci = -1;
+                for (size_t k = 0; k < E.steps.size(); ++k) {
+                    const Step& c = E.steps[k];
+                    if (c.type == ST_UNIT) { if (c.in0 == A.out) { ++readers; ci = (int)k; } if (c.in1 == A.out) readers += 2; }
+                    else if (c.type == ST_ACT) { if (c.res == A.out) readers += 2; }
+                    else if (c.in == A.out) readers += 2;
+                }
+                if (readers != 1) continue;
+                Step& c = E.steps[ci];
+                if (c.ck != CK_K1 || E.tens[c.in0].image) continue;
+                c.vact_unit = A.ua;
+                char* keep = E.ws; E.ws = nullptr;
+                const bool ok = conv_uses_stream_kernel(make_fwd_conv_args(E, c)) && wgrad_act_supported(make_wgrad_args(E, c, -1));
+                E.ws = keep;
+                if (ok) A.vact = true; else c.vact_unit = -1;
+            }
         // ---- statistics finalize folded into the elementwise consumer (not for the fused input block / one-launch small tensors)
         for (auto& st_ : E.steps) st_.fold_fin = false;
         if (E.use_fold)
             for (auto& st_ : E.steps) {
-                if (st_.type != ST_ACT || E.steps[st_.ua].fused_stem || E.steps[st_.ua].gn_w < 0) continue;
+                if (st_.type != ST_ACT || st_.vact || E.steps[st_.ua].fused_stem || E.steps[st_.ua].gn_w < 0) continue;
                 const Step& ua_ = E.steps[st_.ua];
                 if (st_.ub < 0 && gn_bwd_group_eligible(ua_.Cout, E.vol(E.tens[ua_.raw].lvl), (int)E.esz())) continue;
                 if (ua_.Cout > 256) continue;
@@ -477,36 +551,13 @@ struct Planner {
                                      s.Cin, s.Cout, E.ndim, E.dtype, st, s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr, i0.C);
                         E.prof_end(st, pi);
                     } else {
-                        ConvArgs a{};
-                        a.in0 = E.ws + i0.off; a.C0 = i0.C;
-                        a.in1 = s.in1 >= 0 ? E.ws + E.tens[s.in1].off : nullptr;
-                        a.C1 = s.in1 >= 0 ? E.tens[s.in1].C : 0;
-                        a.w = E.ws + s.wp_fwd; a.bias = bias; a.out = E.ws + ro.off; a.stats = stats;
-                        a.N = E.N; a.Cout = s.Cout;
+                        const ConvArgs a = make_fwd_conv_args(E, s);
                         const int li = i0.lvl, lo = ro.lvl;
-                        a.ID = E.dim_d(li); a.IH = E.dim_h(li); a.IW = E.dim_w(li);
-                        if (s.ck == CK_KT) {
-                            a.scatter = 1;
-                            a.OD = a.ID; a.OH = a.IH; a.OW = a.IW;
-                            a.FD = E.dim_d(lo); a.FH = E.dim_h(lo); a.FW = E.dim_w(lo);
-                            a.sd = E.ndim == 3 ? 2 : 1; a.sh = 2; a.sw = 2;
-                            a.taps = make_taps(E.ndim, 2, 0);
-                            a.K = s.Cin; a.Ngemm = a.taps.n * s.Cout;
-                        } else {
-                            a.scatter = 0;
-                            a.OD = E.dim_d(lo); a.OH = E.dim_h(lo); a.OW = E.dim_w(lo);
-                            const int k = s.ck == CK_K3 ? 3 : s.ck == CK_K2S2 ? 2 : 1;
-                            a.taps = make_taps(E.ndim, k, s.ck == CK_K3 ? 1 : 0);
-                            const int str = s.ck == CK_K2S2 ? 2 : 1;
-                            a.sd = E.ndim == 3 ? str : 1; a.sh = str; a.sw = str;
-                            a.K = a.taps.n * s.Cin; a.Ngemm = s.Cout;
-                        }
-                        a.Kpad = (a.K + 31) / 32 * 32;
                         const int pi = E.prof_begin(st, SEG_K_CONV_GENERIC,
                                                     E.tbytes(s.in0) + (s.in1 >= 0 ? E.tbytes(s.in1) : 0.0) + E.tbytes(s.raw),
                                                     2.0 * E.N * E.vol(s.ck == CK_KT ? li : lo) * (double)a.K * a.Ngemm);
                         E.steps[si].stat_rep = (E.use_fold && !conv_uses_stream_kernel(a)) ? stat_rep_for(E.vol(lo)) : STAT_REP;
-                        launch_conv_igemm(a, E.dtype, st, s.stat_rep);
+                        launch_conv_igemm(a, E.dtype, st, E.steps[si].stat_rep);
                         E.prof_end(st, pi);
                     }
                     if (s.gn_w >= 0 && !s.fold_fin && !gn_bwd_group_eligible(s.Cout, E.vol(ro.lvl), (int)E.esz())) {
@@ -526,6 +577,7 @@ struct Planner {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
                     const Step& ua = E.steps[s.ua];
+                    if (s.vact) return;                    // applied by the reader of the tensor on load (its unit's op launched the statistics finalize)
                     if (ua.fused_stem) {
                         // fused input block: statistics of both branches from the image, finalize, then recompute + normalise + add
                         seg_stemx_args x = stemx_args(E, s);

@@ -176,6 +176,7 @@ void launch_gn_bwd_coop(const GnBwdArgs& e, const GnBwdFinArgs& f, int dtype, hi
 typedef seg_wgrad_args WgradArgs;
 size_t wgrad_partial_bytes(const WgradArgs& a);   // scratch for the per-slice partial tiles
 void launch_wgrad(const WgradArgs& a, float* partial, int dtype, hipStream_t s, int qreal = 0);   // qreal in (0, Q): zero-padded input channels, see launch_wgrad3
+bool wgrad_act_supported(const WgradArgs& a);    // a.act_scale / act_shift (x0 activated on load) can be honoured for these extents (16-bit tensors)
 
 struct PoolArgs {
     const void* in; void* out;       // fwd: in fine, out coarse

@@ -255,12 +255,15 @@ __global__ __launch_bounds__(256) SEG_WG_WAVES(NTB == MAXTB && sizeof(T) == 2 ? 
 // its NPD + NPX 16-byte pieces, statically indexed (the step loop is unrolled DEPTH times), so the compiler's vmcnt waits for the OLDEST set
 // only.  Tile extents are template parameters (TP = 16 NPD, TQ = 16 NPX: exactly NPD / NPX pieces per thread and step).  Same partial-tile
 // layout, same order of the fp32 sums over the voxel axis as wgrad_kernel: bit-identical results.
-template <class T, int NPD, int NPX, int DEPTH>
+// ACT: x0 holds the RAW output of a conv + GroupNorm unit; its pieces become relu(scale * r + shift) rounded to T on their way into LDS (see
+// conv_stream_kernel<..., ACT>).  The coefficients of the (at most two) samples a workgroup's voxel slice touches are parked in LDS.
+template <class T, int NPD, int NPX, int DEPTH, bool ACT = false>
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradArgs a, WgPlan pl, float* partial) {
     constexpr int WMT = 128, TP = 16 * NPD, TQ = 16 * NPX;
     constexpr int cpr_p = TP / 8, cpr_q = TQ / 8;                // 16-byte pieces per row
     __shared__ T Ds[WMT * LDW];
     __shared__ T Xs[WMT * LDW];
+    __shared__ __attribute__((aligned(32))) float coef_s[ACT ? 2 : 1][2][ACT ? 64 : 8];       // [sample of the slice][scale | shift][channel of x0]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tile = (int)blockIdx.x;
     const int p0 = (tile / pl.ntq) * TP, q0 = (tile % pl.ntq) * TQ;
@@ -279,6 +282,19 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradArgs a, WgPlan p
     const T* dbase[NPD];
     const T* xbase[NPX];
     long long xstride[NPX];
+    int xact[NPX];                                               // ACT: channel offset of the piece inside x0, -1: a piece of x1
+    const long long Vs = (long long)a.OD * a.OH * a.OW;          // rows per sample
+    const long long nb = (mbeg / Vs + 1) * Vs;                   // first row of the slice's second sample
+    if (ACT) {
+        if (tid < 2 * a.C0) {
+            const int set = tid / a.C0, c = tid % a.C0;
+            long long n = mbeg / Vs + set;
+            if (n > a.N - 1) n = a.N - 1;
+            coef_s[set][0][c] = a.act_scale[n * a.C0 + c];
+            coef_s[set][1][c] = a.act_shift[n * a.C0 + c];
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < NPD; ++u) {
         const int pc = u * 256 + tid;
@@ -293,6 +309,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradArgs a, WgPlan p
         const bool from0 = qc < a.C0;
         xbase[u] = from0 ? (const T*)a.x0 + qc : (const T*)a.x1 + (qc - a.C0);
         xstride[u] = from0 ? a.C0 : a.C1;
+        xact[u] = from0 ? qc : -1;
     }
     vec<T, 8> dq[DEPTH][NPD], xq[DEPTH][NPX];
     unsigned okq[DEPTH];                                         // bit u: d piece u, bit 8 + u: x piece u of that set holds data
@@ -328,8 +345,19 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(WgradArgs a, WgPlan p
                 for (int u = 0; u < NPD; ++u)
                     store8(&Ds[drow[u] * LDW + ((u * 256 + tid) % cpr_p) * 8], ((okq[k] >> u) & 1u) ? dq[k][u] : zero8<T>());
 #pragma unroll
-                for (int u = 0; u < NPX; ++u)
-                    store8(&Xs[xrow[u] * LDW + ((u * 256 + tid) % cpr_q) * 8], ((okq[k] >> (8 + u)) & 1u) ? xq[k][u] : zero8<T>());
+                for (int u = 0; u < NPX; ++u) {
+                    vec<T, 8> xv = xq[k][u];
+                    if (ACT) {
+                        const int set = (m0 + xrow[u]) >= nb ? 1 : 0;
+                        const int c = xact[u] >= 0 ? xact[u] : 0;
+                        const vec<float, 8> sc = *(const vec<float, 8>*)&coef_s[set][0][c], sh = *(const vec<float, 8>*)&coef_s[set][1][c];
+                        vec<T, 8> av;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) av[e] = from_f<T>(fmaxf(fmaf(sc[e], to_f(xv[e]), sh[e]), 0.f));
+                        if (xact[u] >= 0) xv = av;
+                    }
+                    store8(&Xs[xrow[u] * LDW + ((u * 256 + tid) % cpr_q) * 8], ((okq[k] >> (8 + u)) & 1u) ? xv : zero8<T>());
+                }
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < MAXW; ++i) {
@@ -428,13 +456,16 @@ void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s, int qreal
     static const bool direct_on = (knob_i("SEG_WG_DIRECT", 1) != 0);       // A/B switch
     bool done = false;
     if constexpr (sizeof(T) == 2) {
-        if (direct_on && !a.stem && pl.TB == 1 && pl.direct && pl.ntg == 1 && a.C0 % 8 == 0) {
+        if ((direct_on || a.act_scale) && !a.stem && pl.TB == 1 && pl.direct && pl.ntg == 1 && a.C0 % 8 == 0) {
 #define SEG_WGD(ND, NX, DP) if (!done && pl.TP == 16 * ND && pl.TQ == 16 * NX) {                                                                     \
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_direct_kernel<T, ND, NX, DP>), grid, dim3(256), 0, s, a, pl, partial); done = true; }
+                if (a.act_scale) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_direct_kernel<T, ND, NX, DP, true>), grid, dim3(256), 0, s, a, pl, partial);  \
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_direct_kernel<T, ND, NX, DP>), grid, dim3(256), 0, s, a, pl, partial);                   \
+                done = true; }
             SEG_WGD(1, 2, 4) SEG_WGD(2, 4, 3) SEG_WGD(4, 4, 3) SEG_WGD(1, 1, 4) SEG_WGD(2, 2, 4)
 #undef SEG_WGD
         }
     }
+    if (a.act_scale && !done) { fprintf(stderr, "segengine: activation on load needs the direct weight-gradient kernel (internal error)\n"); abort(); }
     if (done) {}
     else if (a.stem) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, true, 1>), grid, dim3(256), 0, s, a, pl, partial);
     else if (pl.TB == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<T, false, 1>), grid, dim3(256), 0, s, a, pl, partial);
@@ -448,6 +479,18 @@ void wgrad_dispatch(const WgradArgs& a, float* partial, hipStream_t s, int qreal
 }
 
 }  // namespace
+
+// the direct kernel with activation on load applies: 16-bit tensors (checked by the caller), a 1^d stride-1 conv whose tile extents have an instantiation,
+// x0 of at most 64 channels, voxel slices that touch at most two samples
+bool wgrad_act_supported(const WgradArgs& a) {
+    if (a.stem || a.C0 % 8 || a.C0 > 64) return false;
+    const WgPlan pl = make_plan(a);
+    if (!(pl.TB == 1 && pl.direct && pl.ntg == 1)) return false;
+    if (pl.Mc > (long long)a.OD * a.OH * a.OW && a.N > 2) return false;       // (a slice may then touch more than two samples)
+    const int np = pl.TP / 16, nq = pl.TQ / 16;
+    return pl.TP % 16 == 0 && pl.TQ % 16 == 0 &&
+           ((np == 1 && nq == 2) || (np == 2 && nq == 4) || (np == 4 && nq == 4) || (np == 1 && nq == 1) || (np == 2 && nq == 2));
+}
 
 size_t wgrad_partial_bytes(const WgradArgs& a) {
     const WgPlan pl = make_plan(a);

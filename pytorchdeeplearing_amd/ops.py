@@ -24,7 +24,8 @@ class ConvArgs(C.Structure):
                 ("OD", C.c_int), ("OH", C.c_int), ("OW", C.c_int),
                 ("FD", C.c_int), ("FH", C.c_int), ("FW", C.c_int),
                 ("Cout", C.c_int), ("Ngemm", C.c_int), ("K", C.c_int), ("Kpad", C.c_int),
-                ("sd", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("scatter", C.c_int), ("taps", Taps)]
+                ("sd", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("scatter", C.c_int), ("taps", Taps),
+                ("act_scale", C.c_void_p), ("act_shift", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -33,7 +34,8 @@ class WgradArgs(C.Structure):
                 ("N", C.c_int), ("ID", C.c_int), ("IH", C.c_int), ("IW", C.c_int),
                 ("OD", C.c_int), ("OH", C.c_int), ("OW", C.c_int),
                 ("sd", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("taps", Taps),
-                ("sP", C.c_longlong), ("sQ", C.c_longlong), ("sT", C.c_longlong), ("stem", C.c_int)]
+                ("sP", C.c_longlong), ("sQ", C.c_longlong), ("sT", C.c_longlong), ("stem", C.c_int),
+                ("act_scale", C.c_void_p), ("act_shift", C.c_void_p)]
 
 
 class PackDesc(C.Structure):
@@ -140,9 +142,10 @@ def pack(w, layout, dtype, frag=False):
 last_conv_kernel = None
 
 
-def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=None, scatter=False, want_stats=False):
+def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=None, scatter=False, want_stats=False, act=None):
     """x0 (and optional concat source x1): [N,D,H,W,C] in dtype.  Gather conv (k, stride, pad) or, with
-    scatter=True, the k2-s2 transposed conv.  Returns out [N,OD,OH,OW,cout] (+ stats [N,cout,2] fp64)."""
+    scatter=True, the k2-s2 transposed conv.  Returns out [N,OD,OH,OW,cout] (+ stats [N,cout,2] fp64).
+    act = (scale, shift), fp32 [N, C0]: x0 is read as relu(scale * x0 + shift) rounded to dtype (streaming kernel only)."""
     lib = _capi.lib_for(x0.device)
     N, D, H, W, C0 = x0.shape
     a = ConvArgs()
@@ -151,6 +154,8 @@ def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=
     cin = a.C0 + a.C1
     a.w = wpacked.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
+    if act is not None:
+        a.act_scale, a.act_shift = act[0].data_ptr(), act[1].data_ptr()
     a.N, a.ID, a.IH, a.IW = N, D, H, W
     a.Cout = cout
     up = lambda v, dim3: v * 2 if (dim3 or ndim == 3) else v
@@ -184,8 +189,9 @@ def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=
     return (out, stats.sum(0)) if want_stats else out
 
 
-def wgrad(dr, x0, dtype, ndim, k, stride=1, pad=0, x1=None, stem=False):
-    """dW[p][q][tap] (PyTorch conv-weight layout (P, Q, k..)) = sum_m dr[m][p] * x[vox(m,tap)][q]."""
+def wgrad(dr, x0, dtype, ndim, k, stride=1, pad=0, x1=None, stem=False, act=None):
+    """dW[p][q][tap] (PyTorch conv-weight layout (P, Q, k..)) = sum_m dr[m][p] * x[vox(m,tap)][q].
+    act = (scale, shift), fp32 [N, C0]: x0 is read as relu(scale * x0 + shift) rounded to dtype (1^d convs on 16-bit tensors only)."""
     lib = _capi.lib_for(dr.device)
     N, OD, OH, OW, P = dr.shape
     _, D, H, W, C0 = x0.shape
@@ -200,6 +206,8 @@ def wgrad(dr, x0, dtype, ndim, k, stride=1, pad=0, x1=None, stem=False):
     a.sd, a.sh, a.sw = (stride if ndim == 3 else 1), stride, stride
     a.sP, a.sQ, a.sT = qc * T, T, 1
     a.stem = 1 if stem else 0
+    if act is not None:
+        a.act_scale, a.act_shift = act[0].data_ptr(), act[1].data_ptr()
     dw = _alloc((P, qc) + (k,) * ndim, torch.float32, dr.device, zero=True)
     a.dw = dw.data_ptr()
     scratch = aligned_empty(lib.seg_op_wgrad_partial_bytes(C.byref(a)), dr.device)

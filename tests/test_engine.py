@@ -491,6 +491,35 @@ def test_one_launch_groupnorm_backward_equals_reduce_plus_apply(dev, tag, dtype,
         assert float((a - b).norm()) / float(b.norm()) < tol, (k, float((a - b).norm()) / float(b.norm()))
 
 
+@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16"), pytest.param("vnet3d", "bf16", marks=pytest.mark.gpu), pytest.param("vnet3d_48", "f16", marks=pytest.mark.gpu),
+                                       pytest.param("vnet2d_128", "f16", marks=pytest.mark.gpu)])
+def test_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, dtype, monkeypatch):
+    """VNet UpTransition (networks/VNet3d.py:72-77): relu(drop(GN(up_conv(x)))) has ONE reader, the 1^d conv on the concat.  With SEG_VACT (default on tensors
+    >= 16 MB; 2 = wherever the kernels allow, as here) the tensor is never written: the conv's forward launch and its weight gradient read the up-conv's raw
+    output and apply scale / shift / ReLU / rounding on load - the same fmaf, fmaxf and rounding as gn_act_kernel, so logits, loss and every gradient must be
+    BIT-identical to the SEG_VACT=0 engine on the host checker (on the GPU the atomics of the statistics order differently from run to run)."""
+    res = []
+    for flag in ("2", "0"):
+        monkeypatch.setenv("SEG_VACT", flag)
+        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
+        e.profile_enable(["gn_act"])
+        out = run_engine(e, x, y, masks, alpha, loss, dev)
+        calls = e.profile_read().get("gn_act", {}).get("calls", 0)
+        res.append((out, calls))
+        del e
+    (l0, p0, o0, g0), c0 = res[0]
+    (l1, p1, o1, g1), c1 = res[1]
+    assert c0 < c1, (c0, c1)                          # fewer activation launches: the path is really taken
+    exact = dev.type == "cpu"
+    assert float((l0 - l1).abs().max()) <= (0.0 if exact else 2e-2 * max(1.0, float(l1.abs().max())))
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        if exact:
+            assert torch.equal(g0[k], g1[k]), k
+        elif float(b.norm()) > 1e-12:
+            assert float((a - b).norm()) / float(b.norm()) < (0.2 if dtype == "f16" else 0.6), k
+
+
 @pytest.mark.gpu
 def test_graph_replay_equals_stream_launches():
     """seg_train_graph_capture / _launch: the train step captured as a HIP graph (weight-gradient stream forked and joined inside the

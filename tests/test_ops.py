@@ -183,6 +183,49 @@ def test_wgrad_exact(dev, dtype, case):
     assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("case", [(3, 2, (2, 4, 6), [16, 16], 16), (3, 3, (4, 4, 8), [32, 32], 32), (2, 2, (8, 16), [16, 16], 16),
+                                  pytest.param((3, 2, (48, 48, 48), [32, 32], 32), marks=pytest.mark.gpu)])
+def test_activation_on_load_exact(dev, dtype, case):
+    """seg_conv_args / seg_wgrad_args act_scale, act_shift: the first concat source holds the RAW output r of a conv + GroupNorm unit and is read as
+    relu(scale[n][c] * r + shift[n][c]) rounded to the run dtype (GroupNorm + channel dropout + ReLU of networks/VNet3d.py:72-74 applied by the reader).  Integer
+    r, power-of-two scales (zero = a dropped channel) and small integer shifts: every product and sum is exact, so the 1^d conv and its weight gradient must
+    equal torch on the activated tensor bit for bit.  More than one sample: a voxel slice of the weight gradient may span a sample boundary."""
+    ndim, N, sp, cins, cout = case
+    g = torch.Generator().manual_seed(sum(sp) + cout)
+    r = ints((N, cins[0]) + sp, -4, 4, g)
+    skip = ints((N, cins[1]) + sp, 0, 3, g)
+    scale = torch.tensor([0.0, 0.5, 1.0, 2.0])[torch.randint(0, 4, (N, cins[0]), generator=g)]
+    shift = ints((N, cins[0]), -2, 2, g)
+    bc = (N, cins[0]) + (1,) * ndim
+    a0 = torch.relu(scale.reshape(bc) * r + shift.reshape(bc))
+    x = torch.cat([a0, skip], dim=1)
+    w = ints((cout, sum(cins)) + (1,) * ndim, -1, 1, g, density=0.3).requires_grad_(True)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    ref = conv(x, w)
+    assert float(ref.abs().max()) <= 512
+    dy = ints(tuple(ref.shape), -1, 1, g, density=0.5)
+    ref.backward(dy)
+    act = (ops.aligned_like(scale.to(dev)), ops.aligned_like(shift.to(dev)))
+    r0, x1 = to_dev(cl(r), dtype, dev), to_dev(cl(skip), dtype, dev)
+    out = ops.conv(r0, ops.pack(w.detach().to(dev), "conv_fwd", dtype), dtype, ndim, 1, x1=x1, cout=cout, act=act)
+    assert ops.last_conv_kernel == 1
+    assert torch.equal(ncdhw(out.float().cpu(), ndim), ref.detach())
+    got = ops.wgrad(to_dev(cl(dy), dtype, dev), r0, dtype, ndim, 1, x1=x1, act=act)
+    assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
+
+
+def test_activation_on_load_is_refused_where_no_kernel_applies_it(dev):
+    lib = _capi.lib_for(dev)
+    x = to_dev(torch.zeros(1, 3, 4, 6, 16), "f32", dev)                      # 72 voxel rows: not a multiple of 16 -> LDS-staged kernel
+    w = ops.pack(torch.zeros(16, 16, 1, 1, 1).to(dev), "conv_fwd", "f32")
+    act = (ops.aligned_like(torch.ones(1, 16).to(dev)), ops.aligned_like(torch.zeros(1, 16).to(dev)))
+    with pytest.raises(RuntimeError, match="act_scale"):
+        ops.conv(x, w, "f32", 3, 1, cout=16, act=act)
+    with pytest.raises(RuntimeError, match="act_scale"):                        # fp32 tensors: no direct weight-gradient kernel
+        ops.wgrad(to_dev(torch.zeros(1, 2, 4, 8, 16), "f32", dev), to_dev(torch.zeros(1, 2, 4, 8, 16), "f32", dev), "f32", 3, 1, act=act)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_wgrad_conv_transpose_and_stem_exact(dev, dtype):
     g = torch.Generator().manual_seed(3)
