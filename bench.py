@@ -58,9 +58,10 @@ FAMILIES = {
                           pmc=["gn_bwd_reduce_kernel"], count=None),
     "gn_bwd_apply": dict(classes=["gn_bwd_apply"], bound="hbm", queue="main", what="GroupNorm backward, elementwise pass (gn_bwd_apply_kernel)",
                          pmc=["gn_bwd_apply_kernel"], count=None),
-    "gn_small": dict(classes=["gn_group"], bound="hbm", queue="main", what="one-launch GroupNorm passes of the 6^3 level (gn_fwd/bwd_group_kernel)",
-                     pmc=["gn_fwd_group_kernel", "gn_bwd_group_kernel"], count=None),
-    "head": dict(classes=["head"], bound="hbm", queue="main", what="1^d head forward / backward (head_fwd_kernel, head_bwd_kernel)",
+    "gn_small": dict(classes=["gn_group"], bound="hbm", queue="main",
+                     what="one-launch GroupNorm passes of the >= 64-channel levels (gn_bwd_coop_kernel: 24^3 ... 6^3 backward; gn_fwd_group_kernel: 6^3 forward)",
+                     pmc=["gn_fwd_group_kernel", "gn_bwd_group_kernel", "gn_bwd_coop_kernel"], count=None),
+    "head": dict(classes=["head"], bound="hbm", queue="main", what="1^d head backward (head_bwd_kernel; the forward head runs inside the last gn_act launch)",
                  pmc=["head_fwd_kernel", "head_bwd_kernel"], count=None),
     "misc": dict(classes=["misc"], bound="hbm", queue="main", what="fill + ingest, loss, fused AdamW, weight re-pack",
                  pmc=["ingest", "loss_", "adam_kernel", "grad_check_kernel", "pack_kernel", "__amd_rocclr_fillBufferAligned", "dropout_mask_kernel"], count=None),

@@ -19,6 +19,8 @@
  *   SEG_GN_FOLD=0        GroupNorm finalize as launches of its own;  SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
  *   SEG_GN_COOP=0        (read per seg_create) GroupNorm backward of the >= 64-channel levels as reduce + apply launches instead of the one-launch
  *                        kernel whose workgroups exchange their partial sums inside the launch
+ *   SEG_HEAD_FUSE=0      (read per seg_create) the 1^d head (networks/VNet3d.py:83-99) as a launch of its own instead of inside the activation pass that produces its
+ *                        input (bit-identical results)
  *   SEG_VACT=0|2         (read per seg_create) the activation between a VNet up-conv and the 1^d conv on the concat (networks/VNet3d.py:72-77): 0 = written as a
  *                        tensor at every level, 2 = applied by its two readers on load at every level the kernels allow (default: on tensors >= 16 MB) -
  *                        bit-identical results
@@ -312,6 +314,10 @@ typedef struct seg_conv_args {
      * load, so that the activated tensor is never written; [N][C0] fp32 each */
     const float* act_scale;
     const float* act_shift;
+    /* optional (null: off), gather form on the streaming kernel only, no bias / stats: GEMM columns >= Cout0 (a multiple of 16) are written to out1 as rows of
+     * Ngemm - Cout0 channels, columns < Cout0 to out as rows of Cout0 channels - the data-gradients of BOTH sources of a virtual concat from one pass over d(raw) */
+    void* out1;
+    int Cout0;
 } seg_conv_args;
 int seg_op_conv(const seg_conv_args* a, int dtype, void* stream);
 /* which kernel seg_op_conv picks for these extents: 1 = register-resident streaming kernel (short reductions on large

@@ -414,7 +414,10 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
                     const long long orow = (((long long)n * a.FD + d_[u] * a.sd) * a.FH + h_[u] * a.sh) * a.FW + w_[u] * a.sw + toff[j];
                     return out + orow * a.Cout + (j * 16) % a.Cout;
                 }
-                return out + ((long long)n * Vrow + t * 16 + l15) * a.Cout + j * 16;
+                const long long orow = (long long)n * Vrow + t * 16 + l15;
+                if (a.out1)                             // two output tensors (both data-gradients of a virtual concat from one pass over d(raw)): a wave-uniform choice
+                    return j * 16 < a.Cout0 ? out + orow * a.Cout0 + j * 16 : (T*)a.out1 + orow * (a.Cout - a.Cout0) + (j * 16 - a.Cout0);
+                return out + orow * a.Cout + j * 16;
             };
             if (NTL % 2 == 0) {
                 // tiles in pairs (A, B): lanes q and q^1 swap one 4-channel piece so that even q stores 8 consecutive
@@ -469,6 +472,7 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
 
 bool stream_eligible(const ConvArgs& a) {
     if (a.act_scale && (a.scatter || !a.act_shift || a.C0 % 8)) return false;
+    if (a.out1 && (a.scatter || a.stats || a.bias || a.Cout0 <= 0 || a.Cout0 % 16 || a.Cout0 >= a.Ngemm || (a.Ngemm / 16) % 2)) return false;
     static const bool off = knob_i("SEG_CONV_STREAM", 1) == 0;
     if (off) return false;
     const long long Vrow = (long long)a.OD * a.OH * a.OW;
@@ -712,6 +716,7 @@ bool conv_uses_stream_kernel(const ConvArgs& a) { return stream_eligible(a); }
 
 void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep) {
     const int srep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
+    if (a.out1 && !stream_eligible(a)) { fprintf(stderr, "segengine: two output tensors need the streaming conv kernel (internal error)\n"); abort(); }
     if (a.act_scale && !stream_eligible(a)) { fprintf(stderr, "segengine: activation on load needs the streaming conv kernel (internal error)\n"); abort(); }
     if (dtype == DT_F32) { if (!launch_conv_stream<float>(a, s)) conv_dispatch<float>(a, s, srep); }
     else if (dtype == DT_F16) { if (!launch_conv_stream<f16>(a, s)) conv_dispatch<f16>(a, s, srep); }

@@ -37,6 +37,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->dual_gn_bwd = knob_i("SEG_DUAL_GN", e->dual_gn_bwd) != 0;
     e->use_coop = knob_i("SEG_GN_COOP", e->use_coop) != 0;
     e->use_vact = knob_i("SEG_VACT", e->use_vact);
+    e->use_head_fuse = knob_i("SEG_HEAD_FUSE", e->use_head_fuse) != 0;
 #ifdef SEG_DIAG
     e->w3_mode = knob_i("SEG_DIAG_W3_MODE", e->w3_mode);
 #endif

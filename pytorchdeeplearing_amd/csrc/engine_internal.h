@@ -61,6 +61,7 @@ struct Step {
     // ACT
     int ua = -1, ub = -1, res = -1, out = -1;
     bool vact = false;       // the output tensor is never written: its only reader applies the activation on load (Planner::plan)
+    bool head_fused = false; // ACT: this pass also evaluates the 1^d head that reads its output; HEAD: evaluated by that pass (no launch of its own)
     // POOL / HEAD
     int in = -1;
 };
@@ -118,6 +119,7 @@ struct seg_engine {
     size_t off_partial_stemx = 0;
     bool use_conv3x = true;     // SEG_CONV3X=0: conv3_kernel for every halo conv (round-1 path)
     bool dual_gn_bwd = true;    // SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
+    bool use_head_fuse = true;  // SEG_HEAD_FUSE=0: the 1^d head as a launch of its own
     int use_vact = 1;           // SEG_VACT=0: the activation between a VNet up-conv and the 1^d conv on the concat is written as a tensor; 2: applied on load on small tensors too (tests)
     bool use_coop = true;       // SEG_GN_COOP=0: the deep levels' GroupNorm backward as reduce + apply launches (one-workgroup-per-group launch at 6^3)
     std::vector<hipEvent_t> ready_ev;

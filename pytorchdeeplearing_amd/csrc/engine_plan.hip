@@ -380,6 +380,19 @@ struct Planner {
                 E.ws = keep;
                 if (ok) A.vact = true; else c.vact_unit = -1;
             }
+        // ---- the 1^d head evaluated by the activation pass that writes its input (16 channels, <= 4 classes)
+        for (auto& st_ : E.steps) st_.head_fused = false;
+        if (E.use_head_fuse)
+            for (auto& hs : E.steps) {
+                if (hs.type != ST_HEAD) continue;
+                for (auto& A : E.steps) {
+                    if (A.type != ST_ACT || A.out != hs.in || A.vact || A.ub >= 0 || E.steps[A.ua].fused_stem || E.steps[A.ua].gn_w < 0) continue;
+                    const Step& ua_ = E.steps[A.ua];
+                    if (gn_bwd_group_eligible(ua_.Cout, E.vol(E.tens[ua_.raw].lvl), (int)E.esz())) continue;      // (one-launch small-tensor pass)
+                    if (!gn_act_head_supported(E.tens[A.out].C, hs.Cout, false) || E.tens[A.out].lvl != 0) continue;
+                    A.head_fused = true; hs.head_fused = true;
+                }
+            }
         // ---- statistics finalize folded into the elementwise consumer (not for the fused input block / one-launch small tensors)
         for (auto& st_ : E.steps) st_.fold_fin = false;
         if (E.use_fold)
@@ -647,6 +660,12 @@ struct Planner {
                         fin(ua, a.fin1);
                         if (s.ub >= 0) fin(E.steps[s.ub], a.fin2);
                     }
+                    if (s.head_fused) {
+                        const Step& hs = E.steps[E.head_step];
+                        a.head_w = E.p + E.params[hs.w].off; a.head_b = E.p + E.params[hs.b].off;
+                        a.logits = E.cur_logits; a.probs = E.cur_probs; a.head_C = hs.Cout;
+                        if (E.ride_on && E.ride_zero) { a.zero_ptr = E.ride_zero; a.zero_n = E.ride_zero_n; E.head_zeroed = true; }
+                    }
                     const int pi = E.prof_begin(st, SEG_K_GN_ACT, E.tbytes(s.out) * (2 + (s.ub >= 0) + (s.res >= 0)), 0.0);
                     launch_gn_act(a, E.dtype, st);
                     E.prof_end(st, pi);
@@ -666,6 +685,7 @@ struct Planner {
                 E.fwd_ops.push_back([this_ = &E, si](hipStream_t st) {
                     seg_engine& E = *this_;
                     const Step& s = E.steps[si];
+                    if (s.head_fused) return;              // evaluated by the activation pass that wrote its input
                     HeadArgs a;
                     a.in = E.ws + E.tens[s.in].off; a.w = E.p + E.params[s.w].off; a.bias = E.p + E.params[s.b].off;
                     a.logits = E.cur_logits; a.probs = E.cur_probs;
@@ -1004,6 +1024,17 @@ struct Planner {
                         const int k = s.ck == CK_K3 ? 3 : 1;
                         a.taps = make_taps(E.ndim, k, k == 3 ? 1 : 0);
                         a.K = a.taps.n * s.Cout; a.Kpad = (a.K + 31) / 32 * 32;
+                        if (g0 >= 0 && g1 >= 0 && k == 1) {
+                            // 1^d conv on a concat: both data-gradients from ONE pass over d(raw) where the streaming kernel applies (their packed weights lie
+                            // back to back: one [C0 + C1][Kpad] matrix) - d(raw) of the 96^3 level is 113 MB
+                            const int C0 = E.tens[s.in0].C, C1 = E.tens[s.in1].C;
+                            ConvArgs b = a;
+                            b.w = E.ws + s.wp_dg0; b.out = E.ws + E.tens[g0].off; b.out1 = E.ws + E.tens[g1].off; b.Cout0 = C0; b.Cout = b.Ngemm = C0 + C1;
+                            if (s.wp_dg1 == s.wp_dg0 + (size_t)C0 * a.Kpad * E.esz() && conv_uses_stream_kernel(b)) {
+                                launch_conv_igemm(b, E.dtype, st, STAT_REP);
+                                return;
+                            }
+                        }
                         if (g0 >= 0) {
                             a.w = E.ws + s.wp_dg0; a.out = E.ws + E.tens[g0].off; a.Cout = a.Ngemm = E.tens[s.in0].C;
                             launch_conv_igemm(a, E.dtype, st, STAT_REP);

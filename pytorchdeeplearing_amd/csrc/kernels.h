@@ -122,8 +122,14 @@ struct ActArgs {
     // workgroup 0 of every sample publishes scale / shift / mean / rstd for the backward pass
     int fold;
     GnFinArgs fin1, fin2;
+    // optional (head_w != null; C == 16, head_C in {1, 2, 4}, no second branch): the 1^d head that reads this activation (networks/VNet3d.py:83-99) runs in the same pass -
+    // logits / probabilities are written next to `out` from the values just rounded to T, in head_fwd_kernel's order of operations (bit-identical), and the
+    // launch that would re-read the tensor (113 MB at 4 x 96^3) is gone.  Fields as in HeadArgs.
+    const float* head_w = nullptr; const float* head_b = nullptr; float* logits = nullptr; float* probs = nullptr; int head_C = 0;
+    double* zero_ptr = nullptr; long long zero_n = 0;
 };
 void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s);
+inline bool gn_act_head_supported(int C, int head_C, bool two_branches) { return C == 16 && !two_branches && (head_C == 1 || head_C == 2 || head_C == 4); }
 
 // GroupNorm+dropout+ReLU backward, pass 1: Q[n][c] = {sum dzr, sum dzr*r}, dzr = (sum_i dy_i)*[scale*r+shift>0]
 struct GnBwdArgs {

@@ -65,10 +65,15 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinArgs a0, GnFinArgs
 // loads of UNR chunks back to back and waits ONCE (with runtime `if (r2)` tests the compiler emitted load -> s_waitcnt vmcnt(0) ->
 // load -> ... : up to three serial HBM round trips per 16 bytes, memory-level parallelism left to occupancy alone - and next to the
 // weight-gradient stream's register-heavy workgroups a streaming kernel gets few waves per SIMD).
-template <class T, bool FOLD, bool R2, bool RES>
+// HC > 0 (C == 16: two neighbouring lanes hold a voxel): the 1^d head on this activation in the same pass.  The even lane starts head_fwd_kernel's fmaf chain
+// (bias, channels 0 .. 7) on the values as stored, the odd lane continues it (channels 8 .. 15) and writes the voxel's logits / probabilities: same operations
+// in the same order as the separate launch.
+template <class T, bool FOLD, bool R2, bool RES, int HC = 0>
 __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
     __shared__ double part[FOLD ? 256 : 1][2];
     __shared__ float coef_s[FOLD ? 4 : 1][256];
+    if (HC > 0 && a.zero_ptr && blockIdx.x == 0 && blockIdx.y == 0)
+        for (long long i = threadIdx.x; i < a.zero_n; i += 256) a.zero_ptr[i] = 0.0;
     // grid.y = sample; chunk index inside the sample in 32 bits, C/8 a power of two: no 64-bit division per element
     const int CPR = a.C / 8, n = blockIdx.y;
     const int per_n = (int)(a.V * CPR);
@@ -96,6 +101,15 @@ __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
     }
     constexpr int UNR = (R2 || RES) ? 2 : 4;
     const int stride = gridDim.x * 256;
+    float hw[HC > 0 ? HC : 1][8], hb[HC > 0 ? HC : 1];
+    if (HC > 0) {
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+            hb[c] = a.head_b ? a.head_b[c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hw[c][j] = a.head_w[c * 16 + c0 + j];
+        }
+    }
     for (int ii = blockIdx.x * 256 + threadIdx.x; ii < per_n; ii += stride * UNR) {
         long long iu[UNR];
         bool ok[UNR];
@@ -129,6 +143,43 @@ __global__ __launch_bounds__(256) void gn_act_kernel(ActArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = from_f<T>(y[j]);
             if (ok[u]) store8(out + iu[u] * 8, o);
+            if constexpr (HC > 0) {
+                // (per_n is even and the trip stride a multiple of 256: both lanes of a voxel take the same trips)
+                const bool hi = threadIdx.x & 1;
+                float z[HC > 0 ? HC : 1];
+#pragma unroll
+                for (int c = 0; c < HC; ++c) {
+                    float s = hb[c];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s = fmaf(to_f(o[j]), hw[c][j], s);          // even lane: bias + channels 0 .. 7
+                    const float lo = __shfl_xor(s, 1);                                    // odd lane: the even lane's partial chain
+                    float t = lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t = fmaf(to_f(o[j]), hw[c][j], t);          // ... continued with channels 8 .. 15
+                    z[c] = t;
+                }
+                if (hi && ok[u]) {
+                    const long long v = (long long)((ok[u] ? (int)(iu[u] - base) : 0) >> 1);
+                    if (HC == 1) {
+                        a.logits[(long long)n * a.V + v] = z[0];
+                        a.probs[(long long)n * a.V + v] = 1.f / (1.f + expf(-z[0]));
+                    } else {
+                        float mx = z[0];
+#pragma unroll
+                        for (int c = 1; c < HC; ++c) mx = fmaxf(mx, z[c]);
+                        float e[HC > 0 ? HC : 1], se = 0.f;
+#pragma unroll
+                        for (int c = 0; c < HC; ++c) { e[c] = expf(z[c] - mx); se += e[c]; }
+                        const float inv = 1.f / se;
+#pragma unroll
+                        for (int c = 0; c < HC; ++c) {
+                            const long long o2 = ((long long)n * HC + c) * a.V + v;
+                            a.logits[o2] = z[c];
+                            a.probs[o2] = e[c] * inv;
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -685,7 +736,7 @@ struct GnBwdCoopArgs {
 };
 
 template <class T, int NDY, int K, int PH>
-__global__ __launch_bounds__(256) void gn_bwd_coop_kernel(GnBwdCoopArgs a) {
+__global__ __launch_bounds__(256, 2) void gn_bwd_coop_kernel(GnBwdCoopArgs a) {      // (two waves per SIMD: left alone hipcc takes 258 registers for <f16, 1, 8>)
     __shared__ float wsum[16][4][16];        // [DPP row of the workgroup][chunk-in-group][q1 0..7 | q2 0..7]
     __shared__ float part[256][2];           // [slot * cpg + channel]: the partial sums of every workgroup of the group
     __shared__ double chan[32][3];           // per channel of the group: Q1, Q2, R1
@@ -703,25 +754,27 @@ __global__ __launch_bounds__(256) void gn_bwd_coop_kernel(GnBwdCoopArgs a) {
     const vec<float, 8> sc = *(const vec<float, 8>*)(a.e.scale + (long long)n * C + c0);
     const vec<float, 8> sh = *(const vec<float, 8>*)(a.e.shift + (long long)n * C + c0);
     // the slice: every load in front of the first use (slots past the slice re-read a valid chunk and contribute / store nothing)
-    int iu[K];
     unsigned okm = 0u;
     DySrc<T, NDY> src[K];
     vec<T, 8> x[K];
     vec<float, 8> vw8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) vw8[j] = 0.f;
+    // chunk index of slot k = i0 + k * dI (consecutive slots lie 256 items = 256 / CG voxels apart): two registers instead of K across the exchange
+    const int ifall = n * V * CPR + g * CG + cg;                       // (voxel 0: what a slot past the slice reads)
+    const int i0 = ifall + ((it0 + tid) / CG) * CPR, dI = (256 / CG) * CPR;
+    auto chunk_of = [&](int k) { return ((okm >> k) & 1u) ? i0 + k * dI : ifall; };
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int it = it0 + tid + k * 256;
         const bool ok = k < a.ku && it < items;
         okm |= ok ? (1u << k) : 0u;
-        const int itc = ok ? it : cg;
-        iu[k] = (n * V + itc / CG) * CPR + g * CG + cg;
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        src[k].issue(a.e, iu[k], n, 0, c0);
-        x[k] = load8(r + (long long)iu[k] * 8);
+        const int ic = chunk_of(k);
+        src[k].issue(a.e, ic, n, 0, c0);
+        x[k] = load8(r + (long long)ic * 8);
     }
     // what the coefficient math needs besides the sums travels with the slice (not as a round trip of its own behind the exchange)
     double f_mu = 0.0, f_rs = 0.0, f_mk = 0.0, f_ga = 0.0;
@@ -840,7 +893,7 @@ __global__ __launch_bounds__(256) void gn_bwd_coop_kernel(GnBwdCoopArgs a) {
             const float d = (fmaf(sc[j], xv, sh[j]) > 0.f) ? dy[j] : 0.f;
             o[j] = from_f<T>(fmaf(cA[j], d, fmaf(cB[j], xv, cC[j])));
         }
-        if ((okm >> k) & 1u) store8(dr + (long long)iu[k] * 8, o);
+        if ((okm >> k) & 1u) store8(dr + (long long)chunk_of(k) * 8, o);
     }
 }
 
@@ -866,10 +919,17 @@ void launch_gn_act(const ActArgs& a, int dtype, hipStream_t s) {
     dim3 grid(bx, a.N);
 #define SEG_ACT2(T_, R2_, RS_) { if (a.fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, true, R2_, RS_>), grid, dim3(256), 0, s, a); \
                                  else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, false, R2_, RS_>), grid, dim3(256), 0, s, a); }
-#define SEG_ACT(T_) { if (a.r2 && a.res) SEG_ACT2(T_, true, true) else if (a.r2) SEG_ACT2(T_, true, false) \
+#define SEG_ACTH(T_, RS_, HC_) { if (a.fold) hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, true, false, RS_, HC_>), grid, dim3(256), 0, s, a); \
+                                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(gn_act_kernel<T_, false, false, RS_, HC_>), grid, dim3(256), 0, s, a); }
+#define SEG_ACT(T_) { if (a.head_w && a.head_C == 1) { if (a.res) SEG_ACTH(T_, true, 1) else SEG_ACTH(T_, false, 1) }             \
+                      else if (a.head_w && a.head_C == 2) { if (a.res) SEG_ACTH(T_, true, 2) else SEG_ACTH(T_, false, 2) }        \
+                      else if (a.head_w) { if (a.res) SEG_ACTH(T_, true, 4) else SEG_ACTH(T_, false, 4) }                         \
+                      else if (a.r2 && a.res) SEG_ACT2(T_, true, true) else if (a.r2) SEG_ACT2(T_, true, false) \
                       else if (a.res) SEG_ACT2(T_, false, true) else SEG_ACT2(T_, false, false) }
+    if (a.head_w && !gn_act_head_supported(a.C, a.head_C, a.r2 != nullptr)) { fprintf(stderr, "segengine: head in the activation pass: unsupported shape (internal error)\n"); abort(); }
     if (dtype == DT_F32) SEG_ACT(float) else if (dtype == DT_F16) SEG_ACT(f16) else SEG_ACT(bf16)
 #undef SEG_ACT
+#undef SEG_ACTH
 #undef SEG_ACT2
 }
 

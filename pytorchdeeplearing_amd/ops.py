@@ -25,7 +25,7 @@ class ConvArgs(C.Structure):
                 ("FD", C.c_int), ("FH", C.c_int), ("FW", C.c_int),
                 ("Cout", C.c_int), ("Ngemm", C.c_int), ("K", C.c_int), ("Kpad", C.c_int),
                 ("sd", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("scatter", C.c_int), ("taps", Taps),
-                ("act_scale", C.c_void_p), ("act_shift", C.c_void_p)]
+                ("act_scale", C.c_void_p), ("act_shift", C.c_void_p), ("out1", C.c_void_p), ("Cout0", C.c_int)]
 
 
 class WgradArgs(C.Structure):
@@ -142,10 +142,11 @@ def pack(w, layout, dtype, frag=False):
 last_conv_kernel = None
 
 
-def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=None, scatter=False, want_stats=False, act=None):
+def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=None, scatter=False, want_stats=False, act=None, split=0):
     """x0 (and optional concat source x1): [N,D,H,W,C] in dtype.  Gather conv (k, stride, pad) or, with
     scatter=True, the k2-s2 transposed conv.  Returns out [N,OD,OH,OW,cout] (+ stats [N,cout,2] fp64).
-    act = (scale, shift), fp32 [N, C0]: x0 is read as relu(scale * x0 + shift) rounded to dtype (streaming kernel only)."""
+    act = (scale, shift), fp32 [N, C0]: x0 is read as relu(scale * x0 + shift) rounded to dtype (streaming kernel only).
+    split = c (a multiple of 16): returns (out[..., :c], out[..., c:]) written as two tensors by one launch (streaming kernel, gather form, no bias / stats)."""
     lib = _capi.lib_for(x0.device)
     N, D, H, W, C0 = x0.shape
     a = ConvArgs()
@@ -177,8 +178,12 @@ def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=
         oshape = (N, a.OD, a.OH, a.OW, cout)
     a.Kpad = _kpad(a.K)
     assert tuple(wpacked.shape) == (a.Ngemm, a.Kpad), (tuple(wpacked.shape), a.Ngemm, a.Kpad)
-    out = _alloc(oshape, TORCH_DTYPE[dtype], x0.device, zero=True)
+    out = _alloc(oshape if not split else oshape[:-1] + (split,), TORCH_DTYPE[dtype], x0.device, zero=True)
     a.out = out.data_ptr()
+    out1 = None
+    if split:
+        out1 = _alloc(oshape[:-1] + (cout - split,), TORCH_DTYPE[dtype], x0.device, zero=True)
+        a.out1, a.Cout0 = out1.data_ptr(), split
     stats = None
     if want_stats:
         stats = _alloc((32, N, cout, 2), torch.float64, x0.device, zero=True)
@@ -186,6 +191,8 @@ def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=
     global last_conv_kernel
     last_conv_kernel = lib.dll.seg_op_conv_kernel(C.byref(a))      # 1: streaming kernel, 0: LDS-staged implicit GEMM
     lib.check(lib.dll.seg_op_conv(C.byref(a), _capi.DTYPE[dtype], _capi.stream_for(x0.device)), "seg_op_conv")
+    if split:
+        return out, out1
     return (out, stats.sum(0)) if want_stats else out
 
 

@@ -498,6 +498,8 @@ def test_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, d
     >= 16 MB; 2 = wherever the kernels allow, as here) the tensor is never written: the conv's forward launch and its weight gradient read the up-conv's raw
     output and apply scale / shift / ReLU / rounding on load - the same fmaf, fmaxf and rounding as gn_act_kernel, so logits, loss and every gradient must be
     BIT-identical to the SEG_VACT=0 engine on the host checker (on the GPU the atomics of the statistics order differently from run to run)."""
+    if dev.type == "cpu" and tag != "vnet2d_s":
+        conftest.checker_slow(dev, "minutes on the host checker (the small 2-D case runs there)")
     res = []
     for flag in ("2", "0"):
         monkeypatch.setenv("SEG_VACT", flag)
@@ -518,6 +520,33 @@ def test_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, d
             assert torch.equal(g0[k], g1[k]), k
         elif float(b.norm()) > 1e-12:
             assert float((a - b).norm()) / float(b.norm()) < (0.2 if dtype == "f16" else 0.6), k
+
+
+@pytest.mark.parametrize("tag,dtype,train", [("vnet2d_s", "f16", True), ("unet2d_s", "f32", False), ("unet3d", "bf16", True),
+                                             pytest.param("vnet3d_48", "f16", True, marks=pytest.mark.gpu), pytest.param("vnet2d", "f32", True, marks=pytest.mark.gpu)])
+def test_head_inside_the_activation_pass_equals_the_head_launch(dev, tag, dtype, train, monkeypatch):
+    """OutputTransition (networks/VNet3d.py:83-99; UNet: networks/Unet3d.py:60-62): the 1^d head runs inside the activation pass that writes its 16-channel
+    input - the even lane of a voxel starts head_fwd_kernel's fmaf chain, the odd lane continues it - so logits and probabilities (1, 3 and 4 classes here;
+    sigmoid / softmax) must equal the separate launch BIT for bit, with fewer launches of the head class."""
+    if dev.type == "cpu" and tag in ("vnet3d_48", "vnet2d"):
+        conftest.checker_slow(dev, "minutes on the host checker (three small cases run there)")
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SEG_HEAD_FUSE", flag)
+        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, train)
+        e.profile_enable(["head"])
+        logits, probs, out3, grads = run_engine(e, x, y, masks, alpha, loss, dev)
+        res.append((logits, probs, out3, e.profile_read().get("head", {}).get("calls", 0)))
+        del e
+    ncls = CASES[tag][3]
+    if ncls in (1, 2, 4):
+        assert res[0][3] < res[1][3], (res[0][3], res[1][3])
+    else:
+        assert res[0][3] == res[1][3]              # three classes: no instantiation, the head keeps its launch
+    if dev.type == "cpu":                          # (on the GPU the statistics atomics order differently from run to run)
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    else:
+        assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-2 * max(1.0, float(res[1][0].abs().max()))
 
 
 @pytest.mark.gpu

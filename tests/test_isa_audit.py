@@ -24,7 +24,8 @@ def pick(res, part):
 def test_groupnorm_streaming_kernels_issue_their_loads_back_to_back():
     res = isa_audit.audit("norm.hip")
     # f16, no prologue fold: forward apply (plain / with residual), backward reduce and apply with one and two stored gradient sources
-    for part in ("gn_act_kernelIDF16_Lb0ELb0ELb0E", "gn_act_kernelIDF16_Lb0ELb0ELb1E", "gn_bwd_reduce_kernelIDF16_Lb0ELi1E",
+    # (gn_act: ... residual flag, classes of a fused 1^d head; ELi1E = the benchmark's last activation pass, which also writes logits and probabilities)
+    for part in ("gn_act_kernelIDF16_Lb0ELb0ELb0ELi0E", "gn_act_kernelIDF16_Lb0ELb0ELb1ELi0E", "gn_act_kernelIDF16_Lb1ELb0ELb1ELi1E", "gn_bwd_reduce_kernelIDF16_Lb0ELi1E",
                  "gn_bwd_reduce_kernelIDF16_Lb0ELi2E", "gn_bwd_apply_kernelIDF16_Lb0ELb0ELi1E", "gn_bwd_apply_kernelIDF16_Lb0ELb0ELi2E",
                  "gn_bwd_apply_kernelIDF16_Lb0ELb0ELi4E", "gn_bwd_reduce_kernelIDF16_Lb0ELi4E"):
         k = pick(res, part)
@@ -32,6 +33,15 @@ def test_groupnorm_streaming_kernels_issue_their_loads_back_to_back():
         # thread's channels once in their prologue: one such pair there)
         assert k["chains"] <= (1 if "ELi4E" in part else 0), (part, k)
         assert k["spill"] == 0 and k["waves"] >= 4, (part, k)
+
+
+def test_one_launch_groupnorm_backward_keeps_its_slice_in_registers_without_spills():
+    res = isa_audit.audit("norm.hip")
+    # (gradient sources, chunks per thread): the slice loads are issued together; the only load -> wait -> load sequences are the statistics fold of the publishing
+    # workgroup and the poll of the partial-sum words.  Two waves per SIMD even at eight chunks per thread: 256 workgroups fit the device at once.
+    for part in ("gn_bwd_coop_kernelIDF16_Li1ELi2ELi0E", "gn_bwd_coop_kernelIDF16_Li2ELi8ELi0E", "gn_bwd_coop_kernelIDF16_Li1ELi8ELi0E", "gn_bwd_coop_kernelIDF16bLi3ELi8ELi0E"):
+        k = pick(res, part)
+        assert k["chains"] <= 2 and k["spill"] == 0 and k["waves"] >= 2, (part, k)
 
 
 def test_generic_weight_gradient_kernel_stages_without_serial_loads_at_three_waves_per_simd():

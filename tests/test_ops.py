@@ -215,6 +215,22 @@ def test_activation_on_load_exact(dev, dtype, case):
     assert torch.equal(got.cpu(), w.grad), float((got.cpu() - w.grad).abs().max())
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(3, 2, (2, 4, 6), 16, [16, 16]), (3, 1, (4, 4, 8), 32, [32, 32]), (2, 2, (8, 16), 16, [16, 48])])
+def test_conv_two_outputs_exact(dev, dtype, case):
+    """seg_conv_args.out1 / Cout0: the data-gradients of BOTH sources of a virtual concat under a 1^d conv (networks/VNet3d.py:75-77 -> autograd) from one pass
+    over d(raw): GEMM columns below Cout0 go to the first tensor, the others to the second."""
+    ndim, N, sp, K, couts = case
+    g = torch.Generator().manual_seed(sum(sp) + K)
+    x = ints((N, K) + sp, -2, 2, g)
+    w = ints((sum(couts), K) + (1,) * ndim, -1, 1, g, density=0.4)
+    conv = F.conv3d if ndim == 3 else F.conv2d
+    ref = conv(x, w)
+    o0, o1 = ops.conv(to_dev(cl(x), dtype, dev), ops.pack(w.to(dev), "conv_fwd", dtype), dtype, ndim, 1, cout=sum(couts), split=couts[0])
+    assert ops.last_conv_kernel == 1
+    assert torch.equal(ncdhw(o0.float().cpu(), ndim), ref[:, :couts[0]]) and torch.equal(ncdhw(o1.float().cpu(), ndim), ref[:, couts[0]:])
+
+
 def test_activation_on_load_is_refused_where_no_kernel_applies_it(dev):
     lib = _capi.lib_for(dev)
     x = to_dev(torch.zeros(1, 3, 4, 6, 16), "f32", dev)                      # 72 voxel rows: not a multiple of 16 -> LDS-staged kernel

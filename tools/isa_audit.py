@@ -20,7 +20,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pytorchdeeplearing_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-munsafe-fp-atomics", "--cuda-device-only", "-S"]
+sys.path.insert(0, ROOT)
+from pytorchdeeplearing_amd.build import FLAGS as BUILD_FLAGS          # noqa: E402  (the product's own compiler flags: register counts depend on them)
+FLAGS = [f for f in BUILD_FLAGS if f != "-fPIC"] + ["--cuda-device-only", "-S"]
 
 
 def assembly(src):
