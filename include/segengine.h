@@ -21,6 +21,8 @@
  *                        kernel whose workgroups exchange their partial sums inside the launch
  *   SEG_HEAD_FUSE=0      (read per seg_create) the 1^d head (networks/VNet3d.py:83-99) as a launch of its own instead of inside the activation pass that produces its
  *                        input (bit-identical results)
+ *   SEG_RQ_FUSE=0        (read per seg_create) the GroupNorm-backward reduction of a VNet up-conv unit as a launch of its own instead of riding on the
+ *                        data-gradient launch of the 1^d conv that produces its gradient
  *   SEG_VACT=0|2         (read per seg_create) the activation between a VNet up-conv and the 1^d conv on the concat (networks/VNet3d.py:72-77): 0 = written as a
  *                        tensor at every level, 2 = applied by its two readers on load at every level the kernels allow (default: on tensors >= 16 MB) -
  *                        bit-identical results
@@ -318,6 +320,13 @@ typedef struct seg_conv_args {
      * Ngemm - Cout0 channels, columns < Cout0 to out as rows of Cout0 channels - the data-gradients of BOTH sources of a virtual concat from one pass over d(raw) */
     void* out1;
     int Cout0;
+    /* optional (null: off), with out1 only: `out` (the first Cout0 columns) is the gradient dz of an activation a = relu(rq_scale * r + rq_shift) whose raw tensor
+     * r is rq_r ([rows][Cout0] in dtype); the launch adds that unit's GroupNorm-backward sums - sum dz*[a > 0] and sum dz*[a > 0]*r per (sample, channel) - to
+     * rq_Q ([32][N][Cout0][2] fp64, replicas to be summed): the reduction pass over (dz, r) that would follow is not needed */
+    const void* rq_r;
+    const float* rq_scale;
+    const float* rq_shift;
+    double* rq_Q;
 } seg_conv_args;
 int seg_op_conv(const seg_conv_args* a, int dtype, void* stream);
 /* which kernel seg_op_conv picks for these extents: 1 = register-resident streaming kernel (short reductions on large

@@ -203,6 +203,7 @@ int seg_op_conv(const seg_conv_args* a, int dtype, void* stream) {
     if (a->Cout % 16 || a->Ngemm % 16 || a->Kpad % 32 || a->Kpad < a->K) return fail("seg_op_conv: bad GEMM extents");
     if ((a->act_scale || a->act_shift) && !(a->act_scale && a->act_shift && conv_uses_stream_kernel(*a)))
         return fail("seg_op_conv: act_scale / act_shift need the streaming kernel (gather form, seg_op_conv_kernel == 1) and come as a pair");
+    if (a->rq_Q && !(a->out1 && conv_uses_stream_kernel(*a))) return fail("seg_op_conv: rq_* need out1 / Cout0 on the streaming kernel and all of rq_r, rq_scale, rq_shift");
     if (a->out1 && !conv_uses_stream_kernel(*a)) return fail("seg_op_conv: out1 / Cout0 need the streaming kernel (gather form, no bias / stats, 16-channel tiles in pairs)");
     launch_conv_igemm(*a, dtype, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_conv: launch failed");

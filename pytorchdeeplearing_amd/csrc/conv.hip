@@ -283,9 +283,13 @@ void conv_dispatch(const ConvArgs& a, hipStream_t s, int srep) {
 // producer's GroupNorm + channel dropout + ReLU - in the registers of its reader, with the same fmaf / fmaxf / rounding as gn_act_kernel: the activated tensor
 // of the VNet up-conv (226 MB written and read again per pass at 4 x 96^3) is never materialised.  A lane's 8 channels are the same for every tile: the
 // coefficients are loop-invariant registers.
-template <class T, int KS, int NTL, int SC, bool ACT = false>
+// RQ (two output tensors): the first one is the gradient dz of an activation whose raw tensor r the lane reads for its own (voxel, 4 channels); the GroupNorm-backward
+// sums of that unit - sum dz * gate and sum dz * gate * r, gate = [scale * r + shift > 0], dz as stored (rounded) - ride on this launch through the statistics
+// epilogue (same per-lane accumulators, 16-lane sums, fp64 atomics), and gn_bwd_reduce_kernel's pass over (dz, r) is not launched: one tensor read instead of two.
+template <class T, int KS, int NTL, int SC, bool ACT = false, bool RQ = false>
 __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) void conv_stream_kernel(ConvArgs a) {
     static_assert(!ACT || SC == 0, "activation on load: gather form only");
+    static_assert(!RQ || (SC == 0 && !ACT), "GroupNorm-backward sums: gather form with two outputs");
     constexpr bool SCATTER = SC != 0;
     constexpr bool C16 = SC == 2;
     constexpr int NJ = C16 ? 1 : NTL;
@@ -345,6 +349,17 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
     // (vmcnt retires in order) also waited for the previous tile's load: the U loads "in flight" ran one after the other
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { settle(td[ks]); settle(th[ks]); settle(tw[ks]); settle(ci[ks]); }
+    constexpr int NT0 = (RQ && NTL >= 2) ? NTL / 2 : 1;                      // RQ: the first output holds half of the columns (both sources of the concat have the same width)
+    float rsc[NT0][4], rsh[NT0][4];
+    if (RQ) {
+#pragma unroll
+        for (int j = 0; j < NT0; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rsc[j][r] = a.rq_scale[(long long)n * a.Cout0 + j * 16 + 4 * q + r];
+                rsh[j][r] = a.rq_shift[(long long)n * a.Cout0 + j * 16 + 4 * q + r];
+            }
+    }
     vec<float, 8> asc[ACT ? KS : 1], ash[ACT ? KS : 1];
     bool afrom0[ACT ? KS : 1];
     if (ACT) {
@@ -384,6 +399,12 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
             f32x4 acc[NTL];
 #pragma unroll
             for (int j = 0; j < NTL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vec<T, 4> ry[NT0];
+            if (RQ) {                                   // this lane's (voxel, 4 channels) of the raw tensor, issued in front of the MFMAs
+                const long long orow = (long long)n * Vrow + t * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < NT0; ++j) ry[j] = *(const vec<T, 4>*)((const T*)a.rq_r + orow * a.Cout0 + j * 16 + 4 * q);
+            }
             if (ACT) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -405,8 +426,17 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
                 for (int r = 0; r < 4; ++r) {
                     o[j][r] = from_f<T>(acc[j][r] + bs[C16 ? 0 : j][r]);
                     const float f = to_f(o[j][r]);
-                    s1[C16 ? 0 : j][r] += f;
-                    s2[C16 ? 0 : j][r] = fmaf(f, f, s2[C16 ? 0 : j][r]);
+                    if (RQ) {
+                        if (j < NT0) {
+                            const float yv = to_f(ry[j < NT0 ? j : 0][r]);
+                            const float d = (fmaf(rsc[j < NT0 ? j : 0][r], yv, rsh[j < NT0 ? j : 0][r]) > 0.f) ? f : 0.f;
+                            s1[j][r] += d;
+                            s2[j][r] = fmaf(d, yv, s2[j][r]);
+                        }
+                    } else {
+                        s1[C16 ? 0 : j][r] += f;
+                        s2[C16 ? 0 : j][r] = fmaf(f, f, s2[C16 ? 0 : j][r]);
+                    }
                 }
             // address of the 16-channel group of tile j for this lane's voxel
             auto tile_ptr = [&](int j) -> T* {          // j: a compile-time constant at every call site
@@ -447,6 +477,26 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
             }
         }
     }
+    if (RQ) {
+        // the sums of the first output's channels (tiles below Cout0): 16 voxel lanes, then the four waves, then fp64 atomics into the unit's Q replicas
+#pragma unroll
+        for (int j = 0; j < NT0; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = s1[j][r], v = s2[j][r];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) { u += __shfl_xor(u, msk); v += __shfl_xor(v, msk); }
+                if (l15 == 0) { red[wv][j * 16 + 4 * q + r][0] = u; red[wv][j * 16 + 4 * q + r][1] = v; }
+            }
+        __syncthreads();
+        if (tid < a.Cout0) {
+            double ts = 0.0, tss = 0.0;
+            for (int k = 0; k < 4; ++k) { ts += red[k][tid][0]; tss += red[k][tid][1]; }
+            double* dst = a.rq_Q + (((long long)(blockIdx.x % STAT_REP) * a.N + n) * a.Cout0 + tid) * 2;
+            atomicAdd(dst, ts);
+            atomicAdd(dst + 1, tss);
+        }
+    } else
     if (a.stats) {
         // per-channel sums: over the 16 voxel lanes of the wave, then over waves (and taps for the scatter form)
 #pragma unroll
@@ -473,6 +523,7 @@ __global__ __launch_bounds__(256) SEG_STREAM_WAVES(SC == 2 && NTL == 8 ? 3 : 1) 
 bool stream_eligible(const ConvArgs& a) {
     if (a.act_scale && (a.scatter || !a.act_shift || a.C0 % 8)) return false;
     if (a.out1 && (a.scatter || a.stats || a.bias || a.Cout0 <= 0 || a.Cout0 % 16 || a.Cout0 >= a.Ngemm || (a.Ngemm / 16) % 2)) return false;
+    if (a.rq_Q && (!a.out1 || !a.rq_r || !a.rq_scale || !a.rq_shift || a.act_scale || a.Cout0 * 2 != a.Ngemm)) return false;
     static const bool off = knob_i("SEG_CONV_STREAM", 1) == 0;
     if (off) return false;
     const long long Vrow = (long long)a.OD * a.OH * a.OW;
@@ -508,6 +559,7 @@ bool launch_conv_stream(const ConvArgs& a, hipStream_t s) {
         if (a.scatter && a.Cout == 16 && NTL > 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 2>), grid, dim3(256), 0, s, a); \
         else if (a.scatter) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 1>), grid, dim3(256), 0, s, a); \
         else if (a.act_scale) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 0, true>), grid, dim3(256), 0, s, a); \
+        else if (a.rq_Q) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 0, false, true>), grid, dim3(256), 0, s, a); \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_stream_kernel<T, KS, NTL, 0>), grid, dim3(256), 0, s, a);               \
         return true;                                                                                                         \
     }
@@ -716,6 +768,7 @@ bool conv_uses_stream_kernel(const ConvArgs& a) { return stream_eligible(a); }
 
 void launch_conv_igemm(const ConvArgs& a, int dtype, hipStream_t s, int stat_rep) {
     const int srep = (stat_rep > 0 && stat_rep <= STAT_REP) ? stat_rep : STAT_REP;
+    if (a.rq_Q && !stream_eligible(a)) { fprintf(stderr, "segengine: GroupNorm-backward sums on a conv launch need the streaming kernel with two outputs (internal error)\n"); abort(); }
     if (a.out1 && !stream_eligible(a)) { fprintf(stderr, "segengine: two output tensors need the streaming conv kernel (internal error)\n"); abort(); }
     if (a.act_scale && !stream_eligible(a)) { fprintf(stderr, "segengine: activation on load needs the streaming conv kernel (internal error)\n"); abort(); }
     if (dtype == DT_F32) { if (!launch_conv_stream<float>(a, s)) conv_dispatch<float>(a, s, srep); }

@@ -38,6 +38,7 @@ int seg_create(int net_kind, int ndim, int in_channels, int num_class, int init_
     e->use_coop = knob_i("SEG_GN_COOP", e->use_coop) != 0;
     e->use_vact = knob_i("SEG_VACT", e->use_vact);
     e->use_head_fuse = knob_i("SEG_HEAD_FUSE", e->use_head_fuse) != 0;
+    e->use_rq_fuse = knob_i("SEG_RQ_FUSE", e->use_rq_fuse) != 0;
 #ifdef SEG_DIAG
     e->w3_mode = knob_i("SEG_DIAG_W3_MODE", e->w3_mode);
 #endif

@@ -56,11 +56,13 @@ struct Step {
     bool fold_fin = false;                    // statistics finalize folded into the consuming gn_act launch (no launch of its own)
     int x_fwd = -1, x_dg0 = -1, x_dg1 = -1;   // conv3x tiling of the forward / data-gradient launches (-1: conv3_kernel, row-major weights)
     int draw = -1;           // gradient wrt raw
+    bool dual_dg = false;    // 1^d conv on a concat: both data-gradients come from one streaming launch (seg_conv_args.out1)
     int vact_unit = -1;      // >= 0: in0 is the (never written) activation of that UNIT step: this conv and its weight gradient read the unit's RAW output and apply
                              // GroupNorm + dropout + ReLU on load (conv_stream_kernel / wgrad_direct_kernel <..., ACT>)
     // ACT
     int ua = -1, ub = -1, res = -1, out = -1;
     bool vact = false;       // the output tensor is never written: its only reader applies the activation on load (Planner::plan)
+    bool rq_fused = false;   // ACT (vact): the GroupNorm-backward sums of its unit ride on the data-gradient launch of the 1^d conv that reads it (no reduce launch)
     bool head_fused = false; // ACT: this pass also evaluates the 1^d head that reads its output; HEAD: evaluated by that pass (no launch of its own)
     // POOL / HEAD
     int in = -1;
@@ -119,6 +121,7 @@ struct seg_engine {
     size_t off_partial_stemx = 0;
     bool use_conv3x = true;     // SEG_CONV3X=0: conv3_kernel for every halo conv (round-1 path)
     bool dual_gn_bwd = true;    // SEG_DUAL_GN=0: one GroupNorm-backward pass per branch of the VNet input block
+    bool use_rq_fuse = true;    // SEG_RQ_FUSE=0: the GroupNorm-backward reduction of a VNet up-conv unit as a launch of its own
     bool use_head_fuse = true;  // SEG_HEAD_FUSE=0: the 1^d head as a launch of its own
     int use_vact = 1;           // SEG_VACT=0: the activation between a VNet up-conv and the 1^d conv on the concat is written as a tensor; 2: applied on load on small tensors too (tests)
     bool use_coop = true;       // SEG_GN_COOP=0: the deep levels' GroupNorm backward as reduce + apply launches (one-workgroup-per-group launch at 6^3)

@@ -292,6 +292,25 @@ seg_stemx_args stemx_args(const seg_engine& E, const Step& s) {
     return x;
 }
 
+// both data-gradients of a 1^d conv on a (virtual) concat as ONE streaming launch over d(raw) (their packed weights lie back to back: one [C0 + C1][Kpad]
+// matrix); `draw`, g0, g1: tensor ids or -1 (extents only).  Returns false where the launch does not apply.
+bool make_dual_dgrad_args(const seg_engine& E, const Step& s, int draw, int g0, int g1, ConvArgs& b) {
+    if (s.ck != CK_K1 || s.in1 < 0 || E.tens[s.in0].image) return false;
+    const int lo = E.tens[s.raw].lvl, C0 = E.tens[s.in0].C, C1 = E.tens[s.in1].C;
+    char* ws = E.ws;
+    auto P = [&](size_t off) -> char* { return ws ? ws + off : nullptr; };
+    b = ConvArgs{};
+    b.in0 = draw >= 0 ? P(E.tens[draw].off) : nullptr; b.C0 = s.Cout; b.N = E.N;
+    b.scatter = 0;
+    b.ID = b.OD = E.dim_d(lo); b.IH = b.OH = E.dim_h(lo); b.IW = b.OW = E.dim_w(lo);
+    b.sd = b.sh = b.sw = 1;
+    b.taps = make_taps(E.ndim, 1, 0);
+    b.K = s.Cout; b.Kpad = (b.K + 31) / 32 * 32;
+    b.w = P(s.wp_dg0); b.out = g0 >= 0 ? P(E.tens[g0].off) : nullptr; b.out1 = g1 >= 0 ? P(E.tens[g1].off) : (void*)(uintptr_t)16;
+    b.Cout0 = C0; b.Cout = b.Ngemm = C0 + C1;
+    return s.wp_dg1 == s.wp_dg0 + (size_t)C0 * b.Kpad * E.esz() && conv_uses_stream_kernel(b);
+}
+
 // ------------------------------------------------------------------------------------------------
 // planning: workspace layout + forward / backward schedules
 // ------------------------------------------------------------------------------------------------
@@ -490,6 +509,25 @@ struct Planner {
             for (size_t i = fw.size(); i < E.packdescs.size(); ++i) E.pack_is_bwd[i] = 1;
         }
         E.off_packdesc = alloc(E.packdescs.size() * sizeof(PackDesc));
+        // ---- 1^d convs on a concat: one data-gradient launch for both sources; where the first source is a never-written activation (vact) of equal width, that
+        // launch also carries the GroupNorm-backward sums of the activation's unit
+        for (auto& st_ : E.steps) { st_.dual_dg = false; st_.rq_fused = false; }
+        for (auto& c : E.steps) {
+            if (c.type != ST_UNIT) continue;
+            ConvArgs b;
+            char* keep = E.ws; E.ws = nullptr;
+            c.dual_dg = make_dual_dgrad_args(E, c, -1, -1, -1, b);
+            E.ws = keep;
+            if (!c.dual_dg || c.vact_unit < 0 || !E.use_rq_fuse || E.tens[c.in0].C != E.tens[c.in1].C) continue;
+            for (auto& A : E.steps)
+                if (A.type == ST_ACT && A.vact && A.ua == c.vact_unit) {
+                    const Step& pu = E.steps[A.ua];
+                    GnBwdArgs probe{}; probe.ndy = 1; probe.C = pu.Cout; probe.V = E.vol(E.tens[pu.raw].lvl); probe.N = N;
+                    if (E.use_coop && gn_bwd_coop_eligible(probe, (int)E.esz())) continue;
+                    if (gn_bwd_group_eligible(pu.Cout, probe.V, (int)E.esz())) continue;
+                    A.rq_fused = true;
+                }
+        }
         // partial-tile buffer of the halo weight-gradient kernel (largest K3 layer)
         size_t pmax = 0;
         for (auto& s : E.steps)
@@ -863,7 +901,7 @@ struct Planner {
                     Step& u = E.steps[ui];
                     u.draw = new_grad(u.raw);
                     E.bwd_writes.push_back({u.gn_w, u.gn_b, u.b});      // gamma/beta and (analytically) the conv bias
-                    E.bwd_ops.push_back([this_ = &E, ui, gl, fill](hipStream_t st) {
+                    E.bwd_ops.push_back([this_ = &E, ui, gl, fill, asi = si](hipStream_t st) {
                         seg_engine& E = *this_;
                         const Step& u = E.steps[ui];
                         const Ten& r = E.tens[u.raw];
@@ -883,9 +921,13 @@ struct Planner {
                             E.prof_end(st, pg);
                             return;
                         }
-                        int pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
-                        launch_gn_bwd_reduce(a, E.dtype, st);
-                        E.prof_end(st, pi);
+                        int pi;
+                        if (E.steps[asi].rq_fused) a.rep_q = f.rep_q = 0;      // the sums came with the data-gradient launch that wrote dy[0], spread over all STAT_REP replicas
+                        else {
+                            pi = E.prof_begin(st, SEG_K_GN_BWD_REDUCE, E.tbytes(u.raw) * (a.ndy + 1), 0.0);
+                            launch_gn_bwd_reduce(a, E.dtype, st);
+                            E.prof_end(st, pi);
+                        }
                         const bool fold = E.use_fold && a.C <= 256;
                         if (!fold) launch_gn_bwd_finalize(f, st);
                         pi = E.prof_begin(st, SEG_K_GN_BWD_APPLY, E.tbytes(u.raw) * (a.ndy + 2), 0.0);
@@ -1024,13 +1066,19 @@ struct Planner {
                         const int k = s.ck == CK_K3 ? 3 : 1;
                         a.taps = make_taps(E.ndim, k, k == 3 ? 1 : 0);
                         a.K = a.taps.n * s.Cout; a.Kpad = (a.K + 31) / 32 * 32;
-                        if (g0 >= 0 && g1 >= 0 && k == 1) {
-                            // 1^d conv on a concat: both data-gradients from ONE pass over d(raw) where the streaming kernel applies (their packed weights lie
-                            // back to back: one [C0 + C1][Kpad] matrix) - d(raw) of the 96^3 level is 113 MB
-                            const int C0 = E.tens[s.in0].C, C1 = E.tens[s.in1].C;
-                            ConvArgs b = a;
-                            b.w = E.ws + s.wp_dg0; b.out = E.ws + E.tens[g0].off; b.out1 = E.ws + E.tens[g1].off; b.Cout0 = C0; b.Cout = b.Ngemm = C0 + C1;
-                            if (s.wp_dg1 == s.wp_dg0 + (size_t)C0 * a.Kpad * E.esz() && conv_uses_stream_kernel(b)) {
+                        if (g0 >= 0 && g1 >= 0 && s.dual_dg) {
+                            // 1^d conv on a concat: both data-gradients from ONE pass over d(raw) (113 MB at the 96^3 level)
+                            ConvArgs b;
+                            if (make_dual_dgrad_args(E, s, draw, g0, g1, b)) {
+                                if (s.vact_unit >= 0) {
+                                    const Step& pu = E.steps[s.vact_unit];
+                                    bool rq = false;
+                                    for (const Step& A : E.steps) if (A.type == ST_ACT && A.vact && A.ua == s.vact_unit) rq = A.rq_fused;
+                                    if (rq) {        // ... and the GroupNorm-backward sums of the up-conv unit whose (virtual) activation is the first source
+                                        b.rq_r = E.ws + E.tens[pu.raw].off; b.rq_scale = (const float*)(E.ws + pu.scale); b.rq_shift = (const float*)(E.ws + pu.shift);
+                                        b.rq_Q = (double*)(E.ws + pu.Q);
+                                    }
+                                }
                                 launch_conv_igemm(b, E.dtype, st, STAT_REP);
                                 return;
                             }

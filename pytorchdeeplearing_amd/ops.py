@@ -25,7 +25,8 @@ class ConvArgs(C.Structure):
                 ("FD", C.c_int), ("FH", C.c_int), ("FW", C.c_int),
                 ("Cout", C.c_int), ("Ngemm", C.c_int), ("K", C.c_int), ("Kpad", C.c_int),
                 ("sd", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("scatter", C.c_int), ("taps", Taps),
-                ("act_scale", C.c_void_p), ("act_shift", C.c_void_p), ("out1", C.c_void_p), ("Cout0", C.c_int)]
+                ("act_scale", C.c_void_p), ("act_shift", C.c_void_p), ("out1", C.c_void_p), ("Cout0", C.c_int),
+                ("rq_r", C.c_void_p), ("rq_scale", C.c_void_p), ("rq_shift", C.c_void_p), ("rq_Q", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -142,11 +143,12 @@ def pack(w, layout, dtype, frag=False):
 last_conv_kernel = None
 
 
-def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=None, scatter=False, want_stats=False, act=None, split=0):
+def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=None, scatter=False, want_stats=False, act=None, split=0, rq=None):
     """x0 (and optional concat source x1): [N,D,H,W,C] in dtype.  Gather conv (k, stride, pad) or, with
     scatter=True, the k2-s2 transposed conv.  Returns out [N,OD,OH,OW,cout] (+ stats [N,cout,2] fp64).
     act = (scale, shift), fp32 [N, C0]: x0 is read as relu(scale * x0 + shift) rounded to dtype (streaming kernel only).
-    split = c (a multiple of 16): returns (out[..., :c], out[..., c:]) written as two tensors by one launch (streaming kernel, gather form, no bias / stats)."""
+    split = c (a multiple of 16): returns (out[..., :c], out[..., c:]) written as two tensors by one launch (streaming kernel, gather form, no bias / stats).
+    rq = (r, scale, shift) with split: also returns Q [N, c, 2] fp64 = sum of out0 * [scale * r + shift > 0] (* r) over the voxels (GroupNorm-backward sums)."""
     lib = _capi.lib_for(x0.device)
     N, D, H, W, C0 = x0.shape
     a = ConvArgs()
@@ -184,6 +186,10 @@ def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=
     if split:
         out1 = _alloc(oshape[:-1] + (cout - split,), TORCH_DTYPE[dtype], x0.device, zero=True)
         a.out1, a.Cout0 = out1.data_ptr(), split
+    q = None
+    if rq is not None:
+        q = _alloc((32, N, split, 2), torch.float64, x0.device, zero=True)
+        a.rq_r, a.rq_scale, a.rq_shift, a.rq_Q = rq[0].data_ptr(), rq[1].data_ptr(), rq[2].data_ptr(), q.data_ptr()
     stats = None
     if want_stats:
         stats = _alloc((32, N, cout, 2), torch.float64, x0.device, zero=True)
@@ -192,7 +198,7 @@ def conv(x0, wpacked, dtype, ndim, k, stride=1, pad=0, x1=None, bias=None, cout=
     last_conv_kernel = lib.dll.seg_op_conv_kernel(C.byref(a))      # 1: streaming kernel, 0: LDS-staged implicit GEMM
     lib.check(lib.dll.seg_op_conv(C.byref(a), _capi.DTYPE[dtype], _capi.stream_for(x0.device)), "seg_op_conv")
     if split:
-        return out, out1
+        return (out, out1, q.sum(0)) if q is not None else (out, out1)
     return (out, stats.sum(0)) if want_stats else out
 
 

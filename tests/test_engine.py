@@ -500,6 +500,7 @@ def test_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, d
     BIT-identical to the SEG_VACT=0 engine on the host checker (on the GPU the atomics of the statistics order differently from run to run)."""
     if dev.type == "cpu" and tag != "vnet2d_s":
         conftest.checker_slow(dev, "minutes on the host checker (the small 2-D case runs there)")
+    monkeypatch.setenv("SEG_RQ_FUSE", "0")          # (the sums that ride on the data-gradient launch of a virtual activation fold in another order: tested on their own)
     res = []
     for flag in ("2", "0"):
         monkeypatch.setenv("SEG_VACT", flag)
@@ -520,6 +521,32 @@ def test_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, d
             assert torch.equal(g0[k], g1[k]), k
         elif float(b.norm()) > 1e-12:
             assert float((a - b).norm()) / float(b.norm()) < (0.2 if dtype == "f16" else 0.6), k
+
+
+@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16"), pytest.param("vnet3d_48", "bf16", marks=pytest.mark.gpu), pytest.param("vnet2d_128", "f16", marks=pytest.mark.gpu)])
+def test_groupnorm_backward_sums_on_the_data_gradient_launch_equal_the_reduce_launch(dev, tag, dtype, monkeypatch):
+    """VNet UpTransition backward: the gradient of relu(drop(GN(up_conv))) is written by the data-gradient launch of the 1^d conv on the concat; with SEG_RQ_FUSE
+    that launch also delivers the GroupNorm-backward sums of the up-conv unit (sum dz*gate, sum dz*gate*r), read from the values it has just rounded, and
+    gn_bwd_reduce_kernel's pass over (dz, r) is not launched.  Same products, another order of the fp32 partial sums: gradients agree to rounding."""
+    if dev.type == "cpu" and tag != "vnet2d_s":
+        conftest.checker_slow(dev)
+    monkeypatch.setenv("SEG_VACT", "2")
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SEG_RQ_FUSE", flag)
+        e, params, x, y, masks, alpha, loss = build(tag, dtype, dev, True)
+        e.profile_enable(["gn_bwd_reduce"])
+        out = run_engine(e, x, y, masks, alpha, loss, dev)
+        res.append((out, e.profile_read().get("gn_bwd_reduce", {}).get("calls", 0)))
+        del e
+    (l0, p0, o0, g0), c0 = res[0]
+    (l1, p1, o1, g1), c1 = res[1]
+    assert c0 < c1, (c0, c1)
+    tol = 2e-2 if dtype == "f16" else 1e-1
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        if float(b.norm()) > 1e-12:
+            assert float((a - b).norm()) / float(b.norm()) < tol, (k, float((a - b).norm()) / float(b.norm()))
 
 
 @pytest.mark.parametrize("tag,dtype,train", [("vnet2d_s", "f16", True), ("unet2d_s", "f32", False), ("unet3d", "bf16", True),

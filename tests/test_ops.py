@@ -229,6 +229,20 @@ def test_conv_two_outputs_exact(dev, dtype, case):
     o0, o1 = ops.conv(to_dev(cl(x), dtype, dev), ops.pack(w.to(dev), "conv_fwd", dtype), dtype, ndim, 1, cout=sum(couts), split=couts[0])
     assert ops.last_conv_kernel == 1
     assert torch.equal(ncdhw(o0.float().cpu(), ndim), ref[:, :couts[0]]) and torch.equal(ncdhw(o1.float().cpu(), ndim), ref[:, couts[0]:])
+    if couts[0] == couts[1]:
+        # rq_*: the first output is the gradient dz of a = relu(scale * r + shift); the launch also delivers sum dz * [a > 0] and sum dz * [a > 0] * r per (n, c) -
+        # the GroupNorm-backward reduction over (dz, r) (gn_bwd_reduce_kernel) - exactly on integer data
+        r = ints((N, couts[0]) + sp, -3, 3, g)
+        scale = torch.tensor([0.0, 0.5, 1.0, 2.0])[torch.randint(0, 4, (N, couts[0]), generator=g)]
+        shift = ints((N, couts[0]), -2, 2, g)
+        bc = (N, couts[0]) + (1,) * ndim
+        gate = (scale.reshape(bc) * r + shift.reshape(bc) > 0).double()
+        dz = ref[:, :couts[0]].double()
+        want = torch.stack([(dz * gate).flatten(2).sum(2), (dz * gate * r.double()).flatten(2).sum(2)], dim=2)
+        o0b, o1b, q = ops.conv(to_dev(cl(x), dtype, dev), ops.pack(w.to(dev), "conv_fwd", dtype), dtype, ndim, 1, cout=sum(couts), split=couts[0],
+                               rq=(to_dev(cl(r), dtype, dev), ops.aligned_like(scale.to(dev)), ops.aligned_like(shift.to(dev))))
+        assert torch.equal(o0b, o0) and torch.equal(o1b, o1)
+        assert torch.equal(q.cpu(), want), float((q.cpu() - want).abs().max())
 
 
 def test_activation_on_load_is_refused_where_no_kernel_applies_it(dev):
