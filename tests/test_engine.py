@@ -456,15 +456,22 @@ def test_virtual_head_gradient_equals_materialised(dev, tag, monkeypatch):
         assert float((g0[k] - g1[k]).norm()) <= (2e-6 if exact else 2e-5) * float(g1[k].norm()) + 1e-12, k
 
 
-@pytest.mark.parametrize("tag,dtype", [("unet2d_96", "f32"), ("unet2d_96", "f16"), ("unet3d_32", "f32"), pytest.param("vnet3d_48", "f32", marks=pytest.mark.gpu), pytest.param("vnet3d_48", "f16", marks=pytest.mark.gpu),
-                                       pytest.param("unet3d_32", "bf16", marks=pytest.mark.gpu), pytest.param("vnet2d_128", "f16", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("tag,dtype", [("unet2d_96", "f32")])
 def test_one_launch_groupnorm_backward_equals_reduce_plus_apply(dev, tag, dtype, monkeypatch):
+    check_one_launch_groupnorm_backward(dev, tag, dtype, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dtype", [("unet2d_96", "f16"), ("unet3d_32", "f32"), ("vnet3d_48", "f32"), ("vnet3d_48", "f16"), ("unet3d_32", "bf16"), ("vnet2d_128", "f16")])
+def test_one_launch_groupnorm_backward_equals_reduce_plus_apply_gpu(tag, dtype, monkeypatch):
+    check_one_launch_groupnorm_backward(torch.device("cuda:0"), tag, dtype, monkeypatch)
+
+
+def check_one_launch_groupnorm_backward(dev, tag, dtype, monkeypatch):
     """GroupNorm backward of the >= 64-channel levels (networks/VNet3d.py:9 -> autograd): gn_bwd_coop_kernel - S workgroups per (sample, group) keep their slice in
     registers and exchange partial sums inside the launch - against the reduce + apply launches (SEG_GN_COOP=0, read by seg_create).  Same products; the sums
     are folded in another order, so fp32 agrees to rounding and the 16-bit run dtypes to one storage rounding of d(raw).  A slice / slot / channel mix-up would
     show as an O(1) difference in the parameter gradients of the deep levels."""
-    if dev.type == "cpu" and (tag, dtype) != ("unet2d_96", "f32"):
-        conftest.checker_slow(dev, "1 - 5 min on the host checker (the 2-D fp32 case runs there)")
     res = []
     for flag in ("1", "0"):
         monkeypatch.setenv("SEG_GN_COOP", flag)
@@ -491,15 +498,22 @@ def test_one_launch_groupnorm_backward_equals_reduce_plus_apply(dev, tag, dtype,
         assert float((a - b).norm()) / float(b.norm()) < tol, (k, float((a - b).norm()) / float(b.norm()))
 
 
-@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16"), pytest.param("vnet3d", "bf16", marks=pytest.mark.gpu), pytest.param("vnet3d_48", "f16", marks=pytest.mark.gpu),
-                                       pytest.param("vnet2d_128", "f16", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16")])
 def test_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, dtype, monkeypatch):
+    check_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, dtype, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dtype", [("vnet3d", "bf16"), ("vnet3d_48", "f16"), ("vnet2d_128", "f16")])
+def test_activation_applied_by_its_readers_equals_the_written_tensor_gpu(tag, dtype, monkeypatch):
+    check_activation_applied_by_its_readers_equals_the_written_tensor(torch.device("cuda:0"), tag, dtype, monkeypatch)
+
+
+def check_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, dtype, monkeypatch):
     """VNet UpTransition (networks/VNet3d.py:72-77): relu(drop(GN(up_conv(x)))) has ONE reader, the 1^d conv on the concat.  With SEG_VACT (default on tensors
     >= 16 MB; 2 = wherever the kernels allow, as here) the tensor is never written: the conv's forward launch and its weight gradient read the up-conv's raw
     output and apply scale / shift / ReLU / rounding on load - the same fmaf, fmaxf and rounding as gn_act_kernel, so logits, loss and every gradient must be
     BIT-identical to the SEG_VACT=0 engine on the host checker (on the GPU the atomics of the statistics order differently from run to run)."""
-    if dev.type == "cpu" and tag != "vnet2d_s":
-        conftest.checker_slow(dev, "minutes on the host checker (the small 2-D case runs there)")
     monkeypatch.setenv("SEG_RQ_FUSE", "0")          # (the sums that ride on the data-gradient launch of a virtual activation fold in another order: tested on their own)
     res = []
     for flag in ("2", "0"):
@@ -523,13 +537,21 @@ def test_activation_applied_by_its_readers_equals_the_written_tensor(dev, tag, d
             assert float((a - b).norm()) / float(b.norm()) < (0.2 if dtype == "f16" else 0.6), k
 
 
-@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16"), pytest.param("vnet3d_48", "bf16", marks=pytest.mark.gpu), pytest.param("vnet2d_128", "f16", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("tag,dtype", [("vnet2d_s", "f16")])
 def test_groupnorm_backward_sums_on_the_data_gradient_launch_equal_the_reduce_launch(dev, tag, dtype, monkeypatch):
+    check_groupnorm_backward_sums_on_the_data_gradient_launch_equal_the_reduce_launch(dev, tag, dtype, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dtype", [("vnet3d_48", "bf16"), ("vnet2d_128", "f16")])
+def test_groupnorm_backward_sums_on_the_data_gradient_launch_equal_the_reduce_launch_gpu(tag, dtype, monkeypatch):
+    check_groupnorm_backward_sums_on_the_data_gradient_launch_equal_the_reduce_launch(torch.device("cuda:0"), tag, dtype, monkeypatch)
+
+
+def check_groupnorm_backward_sums_on_the_data_gradient_launch_equal_the_reduce_launch(dev, tag, dtype, monkeypatch):
     """VNet UpTransition backward: the gradient of relu(drop(GN(up_conv))) is written by the data-gradient launch of the 1^d conv on the concat; with SEG_RQ_FUSE
     that launch also delivers the GroupNorm-backward sums of the up-conv unit (sum dz*gate, sum dz*gate*r), read from the values it has just rounded, and
     gn_bwd_reduce_kernel's pass over (dz, r) is not launched.  Same products, another order of the fp32 partial sums: gradients agree to rounding."""
-    if dev.type == "cpu" and tag != "vnet2d_s":
-        conftest.checker_slow(dev)
     monkeypatch.setenv("SEG_VACT", "2")
     res = []
     for flag in ("1", "0"):
@@ -549,14 +571,21 @@ def test_groupnorm_backward_sums_on_the_data_gradient_launch_equal_the_reduce_la
             assert float((a - b).norm()) / float(b.norm()) < tol, (k, float((a - b).norm()) / float(b.norm()))
 
 
-@pytest.mark.parametrize("tag,dtype,train", [("vnet2d_s", "f16", True), ("unet2d_s", "f32", False), ("unet3d", "bf16", True),
-                                             pytest.param("vnet3d_48", "f16", True, marks=pytest.mark.gpu), pytest.param("vnet2d", "f32", True, marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("tag,dtype,train", [("vnet2d_s", "f16", True), ("unet2d_s", "f32", False), ("unet3d", "bf16", True)])
 def test_head_inside_the_activation_pass_equals_the_head_launch(dev, tag, dtype, train, monkeypatch):
+    check_head_inside_the_activation_pass_equals_the_head_launch(dev, tag, dtype, train, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,dtype,train", [("vnet3d_48", "f16", True), ("vnet2d", "f32", True)])
+def test_head_inside_the_activation_pass_equals_the_head_launch_gpu(tag, dtype, train, monkeypatch):
+    check_head_inside_the_activation_pass_equals_the_head_launch(torch.device("cuda:0"), tag, dtype, train, monkeypatch)
+
+
+def check_head_inside_the_activation_pass_equals_the_head_launch(dev, tag, dtype, train, monkeypatch):
     """OutputTransition (networks/VNet3d.py:83-99; UNet: networks/Unet3d.py:60-62): the 1^d head runs inside the activation pass that writes its 16-channel
     input - the even lane of a voxel starts head_fwd_kernel's fmaf chain, the odd lane continues it - so logits and probabilities (1, 3 and 4 classes here;
     sigmoid / softmax) must equal the separate launch BIT for bit, with fewer launches of the head class."""
-    if dev.type == "cpu" and tag in ("vnet3d_48", "vnet2d"):
-        conftest.checker_slow(dev, "minutes on the host checker (three small cases run there)")
     res = []
     for flag in ("1", "0"):
         monkeypatch.setenv("SEG_HEAD_FUSE", flag)
