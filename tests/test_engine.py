@@ -347,6 +347,28 @@ def test_bucketed_train_step_equals_plain_step(dev):
     assert bad <= 0.002 * tot
 
 
+def test_bucketed_train_step_with_the_round_6_fusions_equals_plain_step(dev, monkeypatch):
+    """the same with everything round 6 fused into the VNet decoder active on a small net (SEG_VACT=2 lifts the 16 MB floor: up-conv activation on load, both
+    concat data-gradients and the up-conv unit's GroupNorm-backward sums from one launch, the head inside the last activation pass) in the f16 run dtype: the sums a
+    data-gradient launch leaves for a later backward op survive the slicing of the backward pass at the exchange points."""
+    monkeypatch.setenv("SEG_VACT", "2")
+    tag = "vnet2d_s" if dev.type == "cpu" else "vnet3d"
+    res = []
+    for ar in (None, _LoopbackBuckets()):
+        e, params, x, y, masks, alpha, loss = build(tag, "f16", dev, True)
+        e.train_step(x.to(dev), y.to(dev), loss, lr=1e-3, class_alpha=alpha.to(dev), mask_mode=_capi.MASKS_GIVEN, masks=masks, allreduce=ar)
+        res.append({k: v.cpu() for k, v in e.state_dict().items()})
+        if ar is not None:
+            assert len(ar.sizes) >= 2 and sum(ar.sizes) == e.numel
+    tot = bad = 0
+    for k in res[0]:
+        d = (res[0][k] - res[1][k]).abs()
+        assert float(d.max()) < 2.1e-3, k
+        tot += d.numel()
+        bad += int((d > 1e-5).sum())
+    assert bad <= 0.002 * tot
+
+
 def test_in_library_exchange_calls_the_given_allreduce_over_every_suffix(dev):
     """seg_set_rccl_comm: with a communicator set, seg_train_step issues the all-reduce of every finished suffix of the flat
     gradient buffer ITSELF - no bucket hook, no Python between the slices.  The `ncclAllReduce` it is handed here is a test double with the RCCL
@@ -606,11 +628,14 @@ def check_head_inside_the_activation_pass_equals_the_head_launch(dev, tag, dtype
 
 
 @pytest.mark.gpu
-def test_graph_replay_equals_stream_launches():
-    """seg_train_graph_capture / _launch: the train step captured as a HIP graph (weight-gradient stream forked and joined inside the
+@pytest.mark.parametrize("vact", ["1", "2"])
+def test_graph_replay_equals_stream_launches(vact, monkeypatch):
+    """(vact = "2": with the round-6 fusions of the VNet decoder active at this small size as well - SEG_VACT=2 lifts their 16 MB floor.)
+    seg_train_graph_capture / _launch: the train step captured as a HIP graph (weight-gradient stream forked and joined inside the
     capture) and replayed is the same sequence of launches as the stream path: five steps with engine-drawn dropout from the same
     weights give the same loss curve and the same parameters up to the run-to-run noise of the fp32 / fp64 atomics (Adam turns a
     rounding-level gradient difference into at most one lr-sized step per weight)."""
+    monkeypatch.setenv("SEG_VACT", vact)
     dev = torch.device("cuda:0")
     _capi.product_library()
     kind, ndim, shape, ncls, loss = CASES["vnet3d"]
