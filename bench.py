@@ -39,8 +39,8 @@ PEAK_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA
 # ("count": the symbols whose launches are one bracketed op of the family - a weight gradient is main kernel + partial-tile reduce).
 FAMILIES = {
     "halo_conv": dict(classes=["conv3", "conv3_smallbox"], bound="mfma", queue="main",
-                      what="3^d halo convolutions, forward + data-gradient (c3x::conv3x_kernel / conv3x16_kernel, all tilings)",
-                      pmc=["_ZN3seg3c3x13conv3x_kernel", "_ZN3seg3c3x15conv3x16_kernel", "conv3_kernel"], count=None),
+                      what="3^d halo convolutions, forward + data-gradient (c3x::conv3x_kernel / conv3x16_kernel / conv3x16r_kernel, all tilings)",
+                      pmc=["_ZN3seg3c3x13conv3x_kernel", "_ZN3seg3c3x15conv3x16_kernel", "_ZN3seg3c3x16conv3x16r_kernel", "conv3_kernel"], count=None),
     "halo_wgrad": dict(classes=["wgrad3"], bound="mfma", queue="weight-gradient stream",
                        what="weight gradients of the 3^d convolutions (wgrad3_kernel + wgrad3_reduce_kernel)",
                        pmc=["wgrad3_kernel", "wgrad3_reduce_kernel"], count=["wgrad3_kernel"]),

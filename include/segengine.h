@@ -32,6 +32,8 @@
  *   SEG_WG_DIRECT=0      1^d-conv weight gradients through wgrad_kernel instead of the multi-step streaming kernel
  *   SEG_W3_BOX16=0|2     the 4 x 8 x 16-box weight gradient of the 16-channel level: off / forced onto small volumes (operator tests)
  *   SEG_C3X_MAP="cin:cout:w=id,..."   per-shape halo-conv tiling override (tools/tune_conv3x.py)
+ *   SEG_C3X16_REUSE=0    the 16 -> 16 channel 3-D halo convs through conv3x16_kernel (one LDS fragment read per MFMA, weight layout 2) instead of
+ *                        conv3x16r_kernel (fragments reused across the kh taps, weight layout 3) - bit-identical on integer data
  * The tuning knobs and measured-slower paths of rounds 1-5 (double-buffered weight gradient, GroupNorm in the consumer conv, persistent halo convs, flag
  * forks, sub-batched levels, second weight-gradient stream) were removed from the sources in round 6; what each measured is in profiles/HISTORY.md.
  */
@@ -369,7 +371,9 @@ typedef struct seg_pack_desc {
                    multi-channel 3-D input, whose image tensor is zero-padded to 16 channels so that they run as ordinary 16-channel halo convs */
     int frag;   /* 0: rows [R1*R2][Kpad]; 1: MFMA-fragment-major [Cc/32][T][rows/16][64 lanes][8] (Cc % 32 == 0, rows % 16 == 0):
                    lane = 16*((c%32)/8) + row%16 holds k = c%8 .. — one 16x32 B fragment is one contiguous 1 KB line;
-                   2: the same over the flat k = t*Cc + c axis, [Kpad/32][rows/16][64 lanes][8] (Cc == 16: two taps per step) */
+                   2: the same over the flat k = t*Cc + c axis, [Kpad/32][rows/16][64 lanes][8] (Cc == 16: two taps per step);
+                   3: Cc == 16, T == 27, Kpad == 480: [15 steps = kh*5 + pair][rows/16][64 lanes][8], the two taps of a step differ in kd / kw only -
+                      pairs 0..2: (kd = pair, kw = 0 | 1), 3: (kd = 0 | 1, kw = 2), 4: (kd = 2, kw = 2 | zeros) (seg_op_conv3x_cfg_frag) */
 } seg_pack_desc;
 int seg_op_pack(const seg_pack_desc* descs, int ndesc, long long max_elems, int dtype, void* stream);
 /* LDS halo-tile kernels for the 3^d (ndim 3) / 3^2 (ndim 2, D = 1) stride-1 pad-1 convolutions.
@@ -411,7 +415,7 @@ typedef struct seg_stemx_args {
 long long seg_op_stemx_partial_bytes(int ndim, int n, int d, int h, int wid, int cimg);
 int seg_op_stemx(const seg_stemx_args* a, int mode, int ndim, int dtype, float* dw3, float* dw1, void* stream);
 /* Register-blocked halo conv for 16-bit tensors with Cin % 32 == 0 or Cin == 16 (csrc/conv3x.hip): same operator as seg_op_conv3, the
- * weights packed with seg_pack_desc.frag = 1 (Cin == 16: frag = 2) ("conv_fwd" / "conv_dgrad" element order), `in1` an optional second source of a
+ * weights packed with seg_pack_desc.frag = seg_op_conv3x_cfg_frag(cfg) (1; Cin == 16: 2 or 3) ("conv_fwd" / "conv_dgrad" element order), `in1` an optional second source of a
  * virtual channel concat (channels c0..cin-1).  cfg selects a tiling (seg_op_conv3x_cfg_info enumerates them; -1 = the
  * engine's default for the shape).  Returns <0 when the tiling does not fit the shape. */
 int seg_op_conv3x(int cfg, const void* in0, const void* in1, int c0, const void* w, const float* bias, void* out, double* stats,
@@ -420,6 +424,9 @@ int seg_op_conv3x_num_cfgs(void);
 /* index in [0, num_cfgs): tiling id, ndim, box {d,h,w}, output channels per workgroup, resident 32-channel chunks, description */
 int seg_op_conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, char* name, int name_cap);
 int seg_op_conv3x_default_cfg(int ndim, int n, int d, int h, int wid, int cin, int cout, int dtype);
+/* seg_pack_desc.frag of the weights tiling `cfg` reads: 1, 2 (Cin == 16) or 3 (Cin == 16, 3-D tilings 28 .. 31: the halo fragments are reused across
+ * the kh taps, csrc/conv3x_impl.h conv3x16r_kernel); 0 for an unknown id */
+int seg_op_conv3x_cfg_frag(int cfg);
 /* sizeof of the structs of this header as compiled into the library: 0 conv, 1 wgrad, 2 pack, 3 stemx, 4 train */
 int seg_abi_sizeof(int which);
 

@@ -84,6 +84,7 @@ SIGNATURES = {
     "seg_op_conv3x_num_cfgs": (_i, []),
     "seg_op_conv3x_cfg_info": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "seg_op_conv3x_default_cfg": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "seg_op_conv3x_cfg_frag": (_i, [_i]),
     "seg_op_wgrad3_partial_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
     "seg_op_wgrad3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "seg_op_wgrad3_cat": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -244,6 +244,7 @@ int seg_op_conv3x(int cfg, const void* in0, const void* in1, int c0, const void*
     return hipGetLastError() == hipSuccess ? 0 : fail("seg_op_conv3x: launch failed");
 }
 int seg_op_conv3x_num_cfgs(void) { return conv3x_num_cfgs(); }
+int seg_op_conv3x_cfg_frag(int cfg) { return conv3x_cfg_frag(cfg); }
 int seg_op_conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, char* name, int name_cap) {
     const char* nm = nullptr;
     if (conv3x_cfg_info(index, id, ndim, box3, bn, nres, &nm)) return fail("seg_op_conv3x_cfg_info: index out of range");

@@ -47,6 +47,9 @@ const Cfg kCfgs[] = {
     {25, 3, 4, 8, 16, 16, 1, "Cin16: 4x8x16 t16 4x1 waves 8x1 tiles", 1},
     {26, 3, 2, 8, 16, 32, 1, "Cin16: 2x8x16 t16 4x1 waves 4x2 tiles", 1},
     {27, 3, 4, 8, 16, 32, 1, "Cin16: 4x8x16 t16 4x1 waves 8x2 tiles", 1},
+    // Cin == 16, halo fragments reused across the kh taps (conv3x16r_kernel; weights packed with frag = 3: cin16 = 2)
+    {28, 3, 2, 8, 16, 16, 1, "Cin16 row reuse: 2x8x16 t16 4x1 waves 4x1 tiles", 2},
+    {29, 3, 4, 8, 16, 16, 1, "Cin16 row reuse: 4x8x16 t16 4x1 waves 8x1 tiles", 2},
     // 2-D
     {32, 2, 1, 16, 16, 32, 1, "16x16 t16 4x1 waves 4x2 tiles"},
     {33, 2, 1, 16, 16, 64, 2, "16x16 t16 2x2 waves 8x2 tiles"},
@@ -106,7 +109,11 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool ha
     const long long vox = (long long)N * D * H * W;
     int id;
     if (Cin == 16) {
-        id = ndim == 3 ? (Cout % 32 ? (vox >= (1ll << 21) ? 25 : 24) : 26) : (Cout % 32 ? 56 : 57);      // 25: 4x8x16 boxes, 67.6 vs 72.2 us at 4 x 96^3
+        // 3-D: the row-reuse kernel (28 .. 31 = 24 .. 27 with a third of the LDS fragment reads); SEG_C3X16_REUSE=0: the one-read-per-MFMA kernel
+        static const int reuse = knob_i("SEG_C3X16_REUSE", 1);
+        // (measured and not kept, profiles/r06_conv3x16_row_reuse_*: the row-reuse form with two output tiles per wave = 32 output channels, 175 / 162 vs
+        // 165 / 157 us at 2 x 128^3; four / five workgroups per CU instead of three / four: equal inside the step)
+        id = ndim == 3 ? (Cout % 32 ? (vox >= (1ll << 21) ? 25 : 24) + (reuse ? 4 : 0) : 26) : (Cout % 32 ? 56 : 57);      // 25: 4x8x16 boxes, 67.6 vs 72.2 us at 4 x 96^3
         // (the persistent double-buffered tilings 28 / 29 lose: 106 us against 73.7 us at 4 x 96^3 standalone, same log)
     }
     else if (ndim == 3) {
@@ -143,6 +150,11 @@ int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool ha
     return -1;
 }
 
+// weight layout a tiling reads (seg_pack_desc.frag): 1 fragment-major per (chunk, tap), 2 flat k axis (Cin == 16), 3 taps paired within a kh row (conv3x16r_kernel)
+int conv3x_cfg_frag(int cfg) {
+    const Cfg* c = find_cfg(cfg);
+    return !c ? 0 : (c->cin16 == 2 ? 3 : (c->cin16 ? 2 : 1));
+}
 int conv3x_num_cfgs() { return kNumCfgs; }
 int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name) {
     if (index < 0 || index >= kNumCfgs) return -1;

@@ -453,6 +453,110 @@ __global__ __launch_bounds__(256, OCC) void conv3x16_kernel(Conv3xArgs a) {
 
 
 
+// ------------------------------------------------------------------------------------------------
+// Cin == 16 with the halo fragments REUSED ACROSS THE kh TAPS (3-D; weights packed with seg_pack_desc.frag = 3).
+// conv3x16_kernel reads one 1 KB fragment from LDS per MFMA (one 16-channel output tile: nothing to share a fragment with) and the LDS pipe is its
+// busiest unit (SQ_ACTIVE_INST_LDS = 0.73 of the busy cycles at 4 x 96^3, MFMA 0.26: profiles/r06_mfma_util_per_kernel.json).  A wave's TM tiles are
+// TM consecutive y rows of ONE z plane, and the fragment of halo row r (16 x voxels, two taps that differ in kd / kw only) is what tile y = r - kh
+// needs for kh = 0, 1, 2 - the same lanes, no shift.  So the taps are paired WITHIN a kh row into five steps
+//     0..2: (kd, kw = 0 | kw = 1)     3: (kd = 0 | kd = 1, kw = 2)     4: (kd = 2, kw = 2 | zero weights)
+// = 15 MFMA steps per tile instead of 14, and every fragment read feeds up to three MFMAs on three accumulators:
+// 5 x (TM + 2) reads per wave instead of 14 x TM (TM = 8: 50 against 112).  The 15 weight fragments stay in registers for the whole box.
+// ------------------------------------------------------------------------------------------------
+template <class T, class B, int TM, int TN, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv3x16r_kernel(Conv3xArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit run dtypes only");
+    static_assert(B::TX == 16 && B::TW == 16 && B::KD == 3, "x rows of 16 voxels, 3-D taps");
+    static_assert(4 * TM == B::NTILE && B::TH % TM == 0, "a wave covers TM consecutive rows of one plane");
+    constexpr int WM = 4, BN = TN * 16, NS = 15;
+    constexpr int GRAN = B::ROWS * B::HWP * 2, NINSTR = (GRAN + 63) / 64, XS_ELEMS = NINSTR * 64 * 8;
+    __shared__ __attribute__((aligned(16))) T Xs[XS_ELEMS];
+    __shared__ float red_s[WM * BN * 2];
+    __shared__ __attribute__((aligned(16))) float bias_s[BN];
+    constexpr int NI = (NINSTR + 3) / 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int nbx = (a.W + B::TW - 1) / B::TW, nby = (a.H + B::TH - 1) / B::TH, nbz = (a.D + B::TD - 1) / B::TD;
+    int bb = c3x_box_of_block(blockIdx.x, a.N * nbz * nby * nbx, a.remap);
+    if (bb < 0) return;
+    const int x0 = (bb % nbx) * B::TW; bb /= nbx;
+    const int y0 = (bb % nby) * B::TH; bb /= nby;
+    const int z0 = (bb % nbz) * B::TD;
+    const int n = bb / nbz;
+    const int co0 = blockIdx.y * BN;
+    const long long vol = (long long)a.D * a.H * a.W;
+
+    // ---- halo: [row][HWP voxels][16 channels] (as conv3x16_kernel)
+    const i32x4 r0 = make_rsrc((const T*)a.in0 + (long long)n * vol * 16, (unsigned)(vol * 32));
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int i = u * 4 + wv;
+        if (i < NINSTR) {
+            const int g = i * 64 + lane;
+            const int row = g / (B::HWP * 2), rem = g % (B::HWP * 2);
+            const int hx = rem >> 1, piece = rem & 1;
+            const int hz = row / B::HH, hy = row % B::HH;
+            const int z = z0 + hz - B::PD, y = y0 + hy - 1, x = x0 + hx - 1;
+            const bool ok = row < B::ROWS && hx < B::HW && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            dma16(r0, Xs + i * 512, ok ? (unsigned)(((z * a.H + y) * a.W + x) * 32 + piece * 16) : DMA_OOB);
+        }
+    }
+    // ---- all 15 weight fragments per output tile: [step = kh * 5 + pair][Cout/16][64 lanes][8]
+    const unsigned wstep = (unsigned)(a.Cout >> 4) * 1024u;
+    const i32x4 wr = make_rsrc(a.w, (unsigned)NS * wstep);
+    const unsigned wl = ((unsigned)(blockIdx.y * TN) * 64u + lane) * 16u;
+    typename Mma<T>::frag wq[NS][TN];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wq[s][j] = buffer_load8<T>(wr, wl + j * 1024, s * wstep);
+
+    // ---- fragment addressing: lanes q < 2 read the first tap of a pair, lanes q >= 2 the second (+1 in kw, +1 in kd, or the same voxel again)
+    constexpr int ROWP = B::HWP * 16, PLANE = B::HH * ROWP;                 // elements per halo row / plane
+    const int hi = q >> 1, piece = q & 1;
+    const int t0 = wv * TM, vz = t0 / B::TH, vy0 = t0 % B::TH;
+    const int base = (vz * B::HH + vy0) * ROWP + l15 * 16 + piece * 8;
+    const int b_kw = base + (hi ? 16 : 0), b_kd = base + (hi ? PLANE : 0);
+    auto frag_of = [&](int r, int p) {                                    // halo row r of the wave's rows (0 .. TM + 1), pair p
+        const int off = r * ROWP + (p < 3 ? p * PLANE : (p == 3 ? 2 * 16 : 2 * PLANE + 2 * 16));
+        return load8(&Xs[(p < 3 ? b_kw : (p == 3 ? b_kd : base)) + off]);
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float bias_v = (a.bias && tid < BN) ? a.bias[co0 + tid] : 0.f;
+    wait_vmem();
+    if (tid < BN) bias_s[tid] = bias_v;
+    __syncthreads();
+
+    constexpr int NF = (TM + 2) * 5;
+    typename Mma<T>::frag af[2];
+    af[0] = frag_of(0, 0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int r = f / 5, p = f % 5;
+        if (f + 1 < NF) af[(f + 1) & 1] = frag_of((f + 1) / 5, (f + 1) % 5);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int m = r - kh;
+            if (m >= 0 && m < TM) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[m][j] = Mma<T>::run(wq[kh * 5 + p][j], af[f & 1], acc[m][j]);
+            }
+        }
+    }
+    c3x_epilogue<T, B, TM, TN, WM, 1>(acc, red_s, a, n, x0, y0, z0, co0, bias_s);
+}
+
+template <class T, class B, int TM, int TN, int OCC>
+void launch_cfg16r(const Conv3xArgs& a, hipStream_t s) {
+    const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
+    dim3 grid(a.remap ? (unsigned)((nbox + 7) / 8 * 8) : (unsigned)nbox, a.Cout / (TN * 16));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x16r_kernel<T, B, TM, TN, OCC>), grid, dim3(256), 0, s, a);
+}
+
 template <class T, class B, int TM, int TN, int PF, int OCC>
 void launch_cfg16(const Conv3xArgs& a, hipStream_t s) {
     const long long nbox = (long long)a.N * ((a.D + B::TD - 1) / B::TD) * ((a.H + B::TH - 1) / B::TH) * ((a.W + B::TW - 1) / B::TW);
@@ -500,7 +604,9 @@ template <class T> bool launch_2d(int id, const Conv3xArgs& a, hipStream_t s);
         case 24: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 1, 2, 4>(a, s); return true;                               \
         case 25: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 1, 2, 3>(a, s); return true;                               \
         case 26: launch_cfg16<T, XBox<2, 8, 16, 3, 16>, 4, 2, 2, 3>(a, s); return true;                               \
-        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;
+        case 27: launch_cfg16<T, XBox<4, 8, 16, 3, 16>, 8, 2, 2, 2>(a, s); return true;                               \
+        case 28: launch_cfg16r<T, XBox<2, 8, 16, 3, 16>, 4, 1, 4>(a, s); return true;                                 \
+        case 29: launch_cfg16r<T, XBox<4, 8, 16, 3, 16>, 8, 1, 3>(a, s); return true;
 #define SEG_C3X_3D_BODY switch (id) { SEG_C3X_3D_CONV_CASES SEG_C3X_3D_C16_CASES default: return false; }
 
 #define SEG_C3X_2D_CONV_CASES                                                                                         \

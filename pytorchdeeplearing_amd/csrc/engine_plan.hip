@@ -341,14 +341,14 @@ struct Planner {
         d.src = (const float*)(uintptr_t)src_off;   // offsets; resolved in seg_bind
         d.dst = (void*)(uintptr_t)dst;
         d.R1 = R1; d.R2 = R2; d.T = T; d.Cc = Cc;
-        d.Kpad = (T * Cc + 31) / 32 * 32;
+        d.Kpad = frag == 3 ? 480 : (T * Cc + 31) / 32 * 32;      // frag 3: 15 steps of two 16-channel taps (conv3x16r_kernel)
         d.s1 = s1; d.s2 = s2; d.sT = sT; d.sC = sC; d.flipT = flip;
         e.packdescs.push_back(d);
         e.pack_is_bwd.push_back(pack_bwd ? 1 : 0);
         const long long tot = (long long)R1 * R2 * d.Kpad;
         if (tot > e.pack_max) e.pack_max = tot;
     }
-    size_t alloc_pack(int rows, int K) { return alloc((size_t)rows * ((K + 31) / 32 * 32) * e.esz()); }
+    size_t alloc_pack(int rows, int K, int frag = 0) { return alloc((size_t)rows * (frag == 3 ? 480 : (K + 31) / 32 * 32) * e.esz()); }
 
     void plan() {
         seg_engine& E = e;
@@ -462,8 +462,8 @@ struct Planner {
                             s.x_dg0 = conv3x_pick(E.ndim, N, d_, h_, w_, Co, C0);
                         if (C1 && conv3x_supported(dt, E.ndim, N, d_, h_, w_, Co, C1, 0, false)) s.x_dg1 = conv3x_pick(E.ndim, N, d_, h_, w_, Co, C1);
                     }
-                    s.wp_fwd = alloc_pack(Co, T * Ci);
-                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)(s.cin_par ? s.cin_par : Ci) * T, 0, 1, T, 0, s.x_fwd >= 0 ? (Ci == 16 ? 2 : 1) : 0,
+                    s.wp_fwd = alloc_pack(Co, T * Ci, conv3x_cfg_frag(s.x_fwd));
+                    add_pack(s.wp_fwd, woff, Co, 1, T, Ci, (long long)(s.cin_par ? s.cin_par : Ci) * T, 0, 1, T, 0, s.x_fwd >= 0 ? conv3x_cfg_frag(s.x_fwd) : 0,
                              s.cin_par);                         // image convs on a zero-padded image tensor: the parameter has cin_par channels
                     if (s.ck == CK_K2S2) {       // data-gradient = scatter GEMM, rows (a, ci), K = Cout
                         s.wp_dg0 = alloc_pack(T * Ci, Co);
@@ -472,15 +472,15 @@ struct Planner {
                         pack_bwd = false;
                     } else {                     // data-gradient = gather conv with flipped taps, rows ci, k = (tap, co)
                         if (!E.tens[s.in0].image) {
-                            s.wp_dg0 = alloc_pack(C0, T * Co);
+                            s.wp_dg0 = alloc_pack(C0, T * Co, conv3x_cfg_frag(s.x_dg0));
                             pack_bwd = true;
-                            add_pack(s.wp_dg0, woff, C0, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg0 >= 0 ? (Co == 16 ? 2 : 1) : 0);
+                            add_pack(s.wp_dg0, woff, C0, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg0 >= 0 ? conv3x_cfg_frag(s.x_dg0) : 0);
                             pack_bwd = false;
                         }
                         if (C1) {
-                            s.wp_dg1 = alloc_pack(C1, T * Co);
+                            s.wp_dg1 = alloc_pack(C1, T * Co, conv3x_cfg_frag(s.x_dg1));
                             pack_bwd = true;
-                            add_pack(s.wp_dg1, woff + (long long)C0 * T, C1, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg1 >= 0 ? (Co == 16 ? 2 : 1) : 0);
+                            add_pack(s.wp_dg1, woff + (long long)C0 * T, C1, 1, T, Co, T, 0, 1, (long long)Ci * T, 1, s.x_dg1 >= 0 ? conv3x_cfg_frag(s.x_dg1) : 0);
                             pack_bwd = false;
                         }
                     }

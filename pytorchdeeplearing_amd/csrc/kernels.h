@@ -28,6 +28,7 @@ void launch_conv3(const void* in, const void* w, const float* bias, void* out, d
 // register-blocked variant for 16-bit tensors, Cin % 32 == 0 (conv3x.hip); weights fragment-major (PackDesc.frag = 1)
 bool conv3x_supported(int dtype, int ndim, int N, int D, int H, int W, int Cin, int Cout, int C0, bool has_in1);
 int conv3x_pick(int ndim, int N, int D, int H, int W, int Cin, int Cout, bool has_in1 = false);    // tiling id for the shape, -1: none
+int conv3x_cfg_frag(int cfg);      // seg_pack_desc.frag of the weights the tiling reads (0: unknown tiling)
 int conv3x_num_cfgs();
 int conv3x_cfg_info(int index, int* id, int* ndim, int* box3, int* bn, int* nres, const char** name);
 bool launch_conv3x(int cfg, const void* in0, const void* in1, int C0, const void* w, const float* bias, void* out, double* stats, int N, int D,

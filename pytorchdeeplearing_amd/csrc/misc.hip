@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackDesc* descs, StepRi
                 const long long f = (long long)(k8 >> 2) * (rows >> 4) + (row >> 4);
                 store8(dst + (f * 64 + (k8 & 3) * 16 + (row & 15)) * 8, v);
             }
+        } else if (d.frag == 3) {
+            // Cc == 16, T == 27 (conv3x16r_kernel): 15 steps = kh * 5 + pair, the two taps of a step differ in kd / kw only -
+            // pairs 0..2: (kd, kw = 0 | 1), 3: (kd = 0 | 1, kw = 2), 4: (kd = 2, kw = 2 | zeros); lanes as in frag 2
+            for (int k8 = threadIdx.x; k8 < 60; k8 += 256) {
+                const int step = k8 >> 2, qq = k8 & 3, second = qq >> 1, pc = qq & 1, kh = step / 5, p = step % 5;
+                const int kd = p < 3 ? p : (p == 3 ? second : 2), kw = p < 3 ? second : 2;
+                const int t = (p == 4 && second) ? -1 : kd * 9 + kh * 3 + kw;
+                vec<T, 8> v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = from_f<T>(t >= 0 ? row_s[t * 16 + pc * 8 + j] : 0.f);
+                const long long f = (long long)step * (rows >> 4) + (row >> 4);
+                store8(dst + (f * 64 + qq * 16 + (row & 15)) * 8, v);
+            }
         } else if (d.frag) {
             // fragment-major: the 8 consecutive channels (t, c8*8 ..) of this row are lane 16*(c8%4) + row%16 of the
             // (chunk c8/4, tap t, tile row/16) fragment

@@ -100,7 +100,15 @@ def pack(w, layout, dtype, frag=False):
     """Re-layout an fp32 PyTorch-layout conv / conv-transpose weight for the GEMM kernels.
     layouts: conv_fwd [co][(t,ci)] | conv_dgrad [ci][(flip t,co)] | k2s2_dgrad [(a,ci)][co] |
              convT_fwd [(a,co)][ci] | convT_dgrad [ci][(a,co)]
-    frag=True: the same elements in MFMA-fragment-major order (conv3x)."""
+    frag=True: the same elements in MFMA-fragment-major order (conv3x: layout 1, or 2 for 16 channels); frag=3: the row-reuse layout of the
+    16-channel 3-D tilings 28 .. 31 (seg_op_conv3x_cfg_frag); frag="all": a dict {layout: tensor} of every layout the shape has (conv3x picks by tiling)."""
+    if frag == "all":
+        out = {}
+        t = pack(w, layout, dtype, frag=True)
+        out[t._seg_frag] = t
+        if t._seg_frag == 2 and w.dim() == 5:
+            out[3] = pack(w, layout, dtype, frag=3)
+        return out
     lib = _capi.lib_for(w.device)
     w = aligned_like(w.float().contiguous())
     A, B = w.shape[0], w.shape[1]
@@ -127,9 +135,12 @@ def pack(w, layout, dtype, frag=False):
     else:
         raise ValueError(layout)
     d.Kpad = _kpad(d.T * d.Cc)
-    d.frag = (2 if d.Cc == 16 else 1) if frag else 0
+    d.frag = 3 if (frag == 3 and frag is not True) else ((2 if d.Cc == 16 else 1) if frag else 0)
     if frag:
         assert (d.Cc % 32 == 0 or d.Cc == 16) and rows % 16 == 0, "fragment-major packing needs Cc % 32 == 0 (or 16) and rows % 16 == 0"
+    if d.frag == 3:
+        assert d.Cc == 16 and d.T == 27, "layout 3 is the 16-channel 3-D layout"
+        d.Kpad = 480
     out = _alloc((rows, d.Kpad), TORCH_DTYPE[dtype], w.device)
     d.dst = out.data_ptr()
     raw = bytes(d)
@@ -137,6 +148,7 @@ def pack(w, layout, dtype, frag=False):
     dev.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
     lib.check(lib.dll.seg_op_pack(C.c_void_p(dev.data_ptr()), 1, C.c_longlong(rows * d.Kpad), _capi.DTYPE[dtype],
                                   _capi.stream_for(w.device)), "seg_op_pack")
+    out._seg_frag = int(d.frag)
     return out
 
 
@@ -275,10 +287,21 @@ def conv3x_cfgs(device):
 
 
 def conv3x(x, wfrag, dtype, ndim, cout, bias=None, want_stats=False, out=None, x1=None, cfg=-1):
-    """Register-blocked halo conv (16-bit, Cin % 32 == 0); wfrag = pack(..., frag=True).  x1: second concat source."""
+    """Register-blocked halo conv (16-bit, Cin % 32 == 0 or 16); wfrag = pack(..., frag=True / 3 / "all") in the layout the tiling reads
+    (seg_op_conv3x_cfg_frag; a dict from frag="all" is indexed by it).  x1: second concat source."""
     lib = _capi.lib_for(x.device)
     N, D, H, W, c0 = x.shape
     cin = c0 + (x1.shape[-1] if x1 is not None else 0)
+    if cfg < 0:
+        dflt = lib.dll.seg_op_conv3x_default_cfg(ndim, N, D, H, W, cin, cout, _capi.DTYPE[dtype])
+        cfg = dflt if dflt >= 0 else cfg
+    need = lib.dll.seg_op_conv3x_cfg_frag(cfg) if cfg >= 0 else 0
+    if isinstance(wfrag, dict):
+        if need not in wfrag:
+            raise RuntimeError("conv3x: tiling %d reads weight layout %d, packed: %s" % (cfg, need, sorted(wfrag)))
+        wfrag = wfrag[need]
+    elif need and getattr(wfrag, "_seg_frag", need) != need:
+        raise RuntimeError("conv3x: tiling %d reads weight layout %d, the weights are packed in layout %d" % (cfg, need, wfrag._seg_frag))
     if out is None:
         out = _alloc((N, D, H, W, cout), TORCH_DTYPE[dtype], x.device, zero=True)
     stats = _alloc((32, N, cout, 2), torch.float64, x.device, zero=True) if want_stats else None

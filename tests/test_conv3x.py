@@ -25,6 +25,8 @@ CASES = [
     (3, 1, (2, 4, 8), [64, 64], 64, [None]),
     (3, 1, (3, 9, 18), [16], 16, [24, 25]),                 # Cin == 16: two taps per MFMA step, flat-K weights
     (3, 2, (2, 8, 32), [16], 32, [26, 27]),
+    (3, 1, (3, 9, 18), [16], 16, [28, 29, None]),           # Cin == 16, halo fragments reused across the kh taps (weight layout 3); partial boxes
+    (3, 2, (5, 8, 32), [16], 16, [29, None]),
     (2, 1, (19, 24), [16], 16, [56]),
     (2, 2, (16, 16), [16], 32, [57, None]),
     (2, 2, (17, 20), [32], 32, [32, 39]),
@@ -57,7 +59,7 @@ def test_conv3x_exact(dev, dtype, case):
     xs = torch.split(x, cins, dim=1)
     x0 = to_dev(cl(xs[0]), dtype, dev)
     x1 = to_dev(cl(xs[1]), dtype, dev) if len(xs) > 1 else None
-    wf = ops.pack(w.to(dev), "conv_fwd", dtype, frag=True)
+    wf = ops.pack(w.to(dev), "conv_fwd", dtype, frag="all")          # every layout of the shape; conv3x picks the one the tiling reads
     rs = torch.stack([ref.detach().double().flatten(2).sum(2), (ref.detach().double() ** 2).flatten(2).sum(2)], dim=2)
     known = {c["id"]: c for c in ops.conv3x_cfgs(dev)}
     for cfg in cfgs:
@@ -75,7 +77,7 @@ def test_conv3x_exact(dev, dtype, case):
         for ci in cins:
             if ci % 16:
                 continue
-            wd = ops.pack(w[:, c_lo:c_lo + ci].contiguous().to(dev), "conv_dgrad", dtype, frag=True)
+            wd = ops.pack(w[:, c_lo:c_lo + ci].contiguous().to(dev), "conv_dgrad", dtype, frag="all")
             got = ops.conv3x(dyd, wd, dtype, ndim, ci)
             assert torch.equal(ncdhw(got.float().cpu(), ndim), xr.grad[:, c_lo:c_lo + ci]), ("dgrad", ci)
             c_lo += ci

@@ -31,7 +31,7 @@ nb = lib.seg_op_wgrad3_partial_bytes(3, N, S, S, S, C, C)
 partial = ops.aligned_empty(nb, dev).view(torch.float32)
 dw = torch.zeros(C, C, 3, 3, 3, device=dev)
 w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.1
-wfrag = ops.pack(w, "conv_fwd", "f16", frag=True)
+wfrag = ops.pack(w, "conv_fwd", "f16", frag="all")
 out = ops.aligned_like(torch.empty(N, S, S, S, C, device=dev).half())
 T_BYTES = 2.0 * N * S ** 3 * C * 2          # one operand in + one out / two operands in
 

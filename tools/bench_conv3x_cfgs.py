@@ -12,7 +12,7 @@ for spec in specs:
     N, S, Cin, Cout = (int(v) for v in shp.split(","))
     x = ops.aligned_like(torch.randn(N, S, S, S, Cin, device=dev).half())
     w = torch.randn(Cout, Cin, 3, 3, 3, device=dev) * 0.05
-    wf = ops.pack(w, "conv_fwd", "f16", frag=True)
+    wf = ops.pack(w, "conv_fwd", "f16", frag="all")
     out = ops.aligned_like(torch.empty(N, S, S, S, Cout, device=dev).half())
     res, ref = {}, None
     for cfg in (int(c) for c in cfgs.split(",")):

@@ -10,7 +10,7 @@ dev = torch.device("cuda")
 for (N, S, C, cfgs) in ((4, 48, 32, [17, 51]), (4, 24, 64, [-1]), (4, 12, 128, [-1]), (4, 6, 256, [-1])):
     x = ops.aligned_like(torch.randn(N, S, S, S, C, device=dev).half())
     w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
-    wf = ops.pack(w, "conv_fwd", "f16", frag=True)
+    wf = ops.pack(w, "conv_fwd", "f16", frag="all")
     out = ops.aligned_like(torch.empty(N, S, S, S, C, device=dev).half())
     for cfg in cfgs:
         for _ in range(3):

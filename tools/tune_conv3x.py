@@ -55,7 +55,7 @@ def main():
             x = ops.aligned_like((torch.randn((N,) + sp + (cin,), generator=g)).to(dev).to(tdt))
             w = (torch.randn((cout, cin) + (3,) * ndim, generator=g) * 0.05).to(dev)
             wr = ops.pack(w, "conv_fwd", dtype)
-            wf = ops.pack(w, "conv_fwd", dtype, frag=True)
+            wf = ops.pack(w, "conv_fwd", dtype, frag="all")
             out0 = torch.empty((N,) + sp + (cout,), dtype=tdt, device=dev)
             out0 = ops.aligned_like(out0)
             flops = 2.0 * N * (S ** ndim) * (27 if ndim == 3 else 9) * cin * cout
