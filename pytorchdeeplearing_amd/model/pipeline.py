@@ -114,10 +114,9 @@ class DevicePrefetcher:
                 y = self.pool.take((n, d, h, w), torch.uint8)
             else:
                 # class ids: one byte while they fit.  The label dtype is decided per DATA SET, not per batch: the first batch whose ids do not fit
-                # switches every following batch to int64 (the captured-graph launch mode needs tensors that keep their dtype)
-                if self._u8_ok is not False:
-                    self._u8_ok = all(fits_u8(l) for l in labs)
-                y = self.pool.take((n, d, h, w), torch.uint8 if self._u8_ok else torch.int64)
+                # switches every following batch to int64 (the captured-graph launch mode needs tensors that keep their dtype).  The reader
+                # threads run ahead of each other, so a thread only looks at its own batch here; the switch itself is applied in batch order (`in_order`)
+                y = self.pool.take((n, d, h, w), torch.uint8 if (self._u8_ok is not False and all(fits_u8(l) for l in labs)) else torch.int64)
             yn = y.numpy()
             for k, i in enumerate(indices):
                 img = np.load(ds.images[i], mmap_mode="r")
@@ -138,14 +137,28 @@ class DevicePrefetcher:
                 return fetch_direct(indices)
             return self._prepare(collate([ds[i] for i in indices]))
 
+        def in_order(item):
+            """the per-data-set label dtype, applied as the batches leave in order: after the first int64 batch every later one is int64"""
+            if not (direct and not self.binary):
+                return item
+            x, y, pooled = item
+            if y.dtype == torch.int64:
+                self._u8_ok = False
+            elif self._u8_ok is False:                       # a byte batch that a reader thread finished before the switch was known
+                wide = self.pool.take(tuple(y.shape), torch.int64)
+                wide.copy_(y)
+                self.pool.give(y, None)
+                y = wide
+            return x, y, pooled
+
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
             window = []
             for indices in ld.batch_sampler:                 # the sampler is walked once, in order: shuffling stays the loader's
                 window.append(pool.submit(fetch, list(indices)))
                 if len(window) > self.workers:
-                    yield window.pop(0).result()
+                    yield in_order(window.pop(0).result())
             while window:
-                yield window.pop(0).result()
+                yield in_order(window.pop(0).result())
 
     def _reader(self, q, stop):
         try:
