@@ -660,4 +660,8 @@ def test_graph_replay_equals_stream_launches(vact, monkeypatch):
     (c0, p0), (c1, p1) = runs["stream"], runs["graph"]
     assert max(abs(a - b) for a, b in zip(c0, c1)) < 2e-3, (c0, c1)
     d = (p0 - p1).abs()
-    assert float(d.max()) <= 5 * 1e-3 + 1e-6 and float((d > 1e-4).float().mean()) < 0.02
+    # Two outcomes exist run to run, for stream launches among themselves just as for graph against stream (profiles/r06_run_to_run_noise_stream_vs_graph.log:
+    # six repeats each): bit-identical parameters, or - one atomic sum folded in the other order somewhere in the five steps - a loss curve 3e-6 apart and
+    # 1.5 % (conv3x16_kernel) to 10 % (conv3x16r_kernel: another summation order, another set of weights whose Adam step hangs on a rounding) of the
+    # weights more than 1e-4 apart, none by more than the five lr-sized steps.  The fraction gate only has to catch a replay that runs OTHER launches.
+    assert float(d.max()) <= 5 * 1e-3 + 1e-6 and float((d > 1e-4).float().mean()) < 0.2
